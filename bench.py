@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- hyper-likelihood throughput on MI355X (BASELINE.json metric).
+
+A step = one full hyperposterior call (tables + det->src + weights + histogram/KDE + integrand + trapz + selection
+function + reduce) over the C3 workload: 1000 events x 32 pixels x 1000 z-bins x 4096 samples/event, 1e5 detected
+injections, PowerLaw+Peak + Madau-Dickinson + flat-LCDM, kind_p_gw3d='marginalized', binning(200), cut_grid=2 --
+with the inputs already resident in HBM.  Every step uses a different H0 (tables rebuilt every call, as in the
+reference's H0 scans, examples/test1dgalaxies.ipynb cell 11).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+N > 1: events and injections are sharded across ranks (strong scaling: the total workload is fixed), one RCCL
+all-reduce of 3 doubles per step inside chm_eval.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
+
+
+def algorithmic_bytes(E, S, P, Z, I, B, pixelated=True, full=False):
+  """every input read once, nothing materialised (fp64 values, int32 pixel index)."""
+  b = E * S * (4 * 8 + (4 if pixelated else 0)) + (E * S * 16 if full else 0)
+  b += (E * P * Z * 8 if pixelated else 0) + E * Z * 8 * 2 + E * P * 8 * 3 + I * 32 + E * 8
+  return b
+
+
+def kde_kernel_bytes(E, S, P, Z):
+  """Algorithmic bytes of ONE launch of the dominant kernel (k_kde_integrate): z, w (fp64) and the pixel index
+  (int32) of every sample once, p_cat once, the event grid and the three per-z factors once, per-pixel scalars."""
+  return E * S * (8 + 8 + 4) + E * P * Z * 8 + E * Z * 8 * 4 + E * P * 8 * 3
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=20)
+  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--config', default='C3')
+  ap.add_argument('--mode', default='marginalized')
+  ap.add_argument('--nbatch', type=int, default=1, help='hyper-parameter draws per call')
+  ap.add_argument('--events', type=int, default=None, help='shrink the number of events (debug)')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--cpu-events', type=int, default=24)
+  args = ap.parse_args()
+
+  rank = int(os.environ.get('RANK', 0))
+  world = int(os.environ.get('WORLD_SIZE', 1))
+  local_rank = int(os.environ.get('LOCAL_RANK', 0))
+  if world != args.gpus and world > 1:
+    raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+  os.environ.setdefault('CHIMERA_DEVICE', str(local_rank))
+
+  dist = None
+  if world > 1:
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)      # control plane only (barrier, max-of-times, id exchange)
+
+  import chimera_amd as CH
+  from chimera_amd import synth, _lib
+  from chimera_amd.catalog import dVdz_completeness, pixelated_catalog
+  from chimera_amd.parallel import Comm
+
+  t0 = time.time()
+  cfg, ev, inj = synth.make_config(args.config, E=args.events)
+  E, S, P, Z, I = cfg['E'], cfg['S'], cfg['P'], cfg['Z'], cfg['I']
+  pixelated = cfg['pixelated']
+  t_gen = time.time() - t0
+
+  comm = Comm(world, rank, local_rank) if world > 1 else None
+  cosmo = CH.cosmo.flrw(H0=70., Om0=0.25, z_max=5.)
+  mass = CH.mass.plp()
+  rate = CH.rate.madau_dickinson(gamma=2.7, kappa=3., zp=2.)
+  pe_fields = ('m1det', 'm2det', 'dL', 'ra', 'dec', 'pe_prior', 'pixels_opt_nsides', 'ra_pix', 'dec_pix',
+               'gw_loc2d_pdf', 'pixels_pe_opt_nside')
+  if pixelated:
+    th = CH.data.theta_pe_det(**{k: ev[k] for k in pe_fields})
+    gal_cat = pixelated_catalog(dVdz_completeness(z_range=[0.073, 1.3]), p_cat=ev['p_cat'], z_grids=ev['z_grids'],
+                                neff_pixels=ev['neff_pixels'])
+    kind = args.mode
+  else:
+    th = CH.data.theta_pe_det(**{k: ev[k] for k in ('m1det', 'm2det', 'dL', 'pe_prior')})
+    gal_cat, kind = None, None
+  pop = CH.population(cosmo, mass, rate, gal_cat=gal_cat, scale_free=True)
+  sel = CH.selection_function(CH.data.theta_inj_det(**{k: inj[k] for k in ('m1det', 'm2det', 'dL', 'p_draw')}),
+                              N_inj=inj['N_inj'], N_eff=5., comm=comm)
+  like = CH.hyperlikelihood(th, ev['z_grids'], pop, sel, kind_p_gw3d=kind, kernel='epan', bw_method=None, cut_grid=2,
+                            binning=True, num_bins=200, comm=comm)
+
+  nb = args.nbatch
+  H0s = np.linspace(55., 95., 4099)          # a different H0 for every draw of every step
+
+  def lambdas(step):
+    return [dict(H0=float(H0s[(step * nb + j) % len(H0s)])) for j in range(nb)]
+
+  def sync():
+    try:
+      import torch
+      if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    except ImportError:
+      pass
+    if dist is not None:
+      dist.barrier()
+
+  vals = []
+  for w in range(args.warmup):
+    vals.append(like.batch(lambdas(w)))
+  sync()
+  kt = np.zeros(8)
+  t1 = time.perf_counter()
+  for k in range(args.steps):
+    vals.append(like.batch(lambdas(args.warmup + k)))        # synchronous: returns after the HIP stream has drained
+    kt += like.last_timing()
+  sync()
+  dt = time.perf_counter() - t1
+  if dist is not None:
+    import torch
+    tt = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt[0])
+  kt /= max(args.steps, 1)
+
+  if rank == 0:
+    evals = args.steps * nb
+    value = evals / dt
+    El = like._e1 - like._e0
+    kb = kde_kernel_bytes(El, S, P if pixelated else 1, Z) * nb
+    kde_ms = kt[3]
+    ach = kb / (kde_ms * 1e-3) / 1e9 if kde_ms > 0 else 0.
+    path_bytes = algorithmic_bytes(E, S, P, Z, I, 200, pixelated, kind == 'full')
+    out = {
+      "metric": "log-likelihood evals/sec (full hyperposterior call), N_ev x N_pix x N_z",
+      "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+      "dtype": "f64", "data": "synthetic (seed 20250926; chimera_amd/synth.py)",
+      "config": {"workload": f"{args.config}: {E} events x {P} pixels x {Z} z-bins, {S} samples/event, {I} detected injections, "
+                             f"PLP + Madau-Dickinson + flat-LCDM, {kind or '1d'}, binning 200, cut_grid 2",
+                 "E": E, "P": P, "Z": Z, "S": S, "I": I, "kind_p_gw3d": kind, "nbatch": nb,
+                 "parallelism": f"events+injections sharded over {world} GPU(s)",
+                 "cells_per_s": value * E * max(P, 1) * Z},
+      "roofline": {"bound": "hbm", "kernel": "k_kde_integrate" if kind != 'full' else "k_full_kde",
+                   "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                   "traffic": None, "bytes_per_launch": kb, "kernel_ms": kde_ms,
+                   "path_bytes_per_eval": path_bytes,
+                   "path_frac": path_bytes * nb / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[0] > 0 else None,
+                   "stage_ms": {"eval": kt[0], "tables": kt[1], "samples": kt[2], "kde_integrate": kt[3],
+                                "selection": kt[4], "reduce": kt[5]}},
+      "setup_s": {"synthetic": t_gen},
+      "last_log_hyper": float(np.asarray(vals[-1]).ravel()[-1]),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      out["cpu_baseline"] = cpu_baseline(cfg, ev, inj, kind, args.cpu_events)
+    print(json.dumps(out), flush=True)
+  if dist is not None:
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, ev, inj, kind, n_ev):
+  """The oracle (NumPy restatement of the reference algorithm, one core) on a bounded sample of the same workload:
+  the first n_ev events + all injections, one evaluation; scaled linearly in the number of events."""
+  for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+    os.environ.setdefault(k, '1')
+  from oracle import chimera_oracle as O
+  E = cfg['E']
+  n_ev = min(n_ev, E)
+  sub = {k: (v[:n_ev] if hasattr(v, 'shape') and v.shape[:1] == (E,) else v) for k, v in ev.items()}
+  fields = ('m1det', 'm2det', 'dL', 'ra', 'dec', 'pe_prior', 'pixels_opt_nsides', 'ra_pix', 'dec_pix', 'gw_loc2d_pdf',
+            'pixels_pe_opt_nside')
+  th = O.theta_pe_det(**{k: sub[k] for k in fields if k in sub})
+  gc = O.pixelated_catalog(O.dVdz_completeness(), sub['p_cat'], sub['z_grids'], sub['neff_pixels']) if cfg['pixelated'] else None
+  pop = O.population(O.flrw(H0=70., Om0=0.25, z_max=5.), O.plp(), O.madau_dickinson(), gal_cat=gc)
+  sel = O.selection_function(O.theta_inj_det(**{k: inj[k] for k in ('m1det', 'm2det', 'dL', 'p_draw')}), inj['N_inj'])
+  like = O.hyperlikelihood(th, sub['z_grids'], pop, sel, kind_p_gw3d=kind)
+  popu = pop.update(H0=67.)
+  t0 = time.perf_counter(); like.compute_log_likenum(popu); t_ev = time.perf_counter() - t0
+  t0 = time.perf_counter(); sel.N_exp(popu); t_sel = time.perf_counter() - t0
+  t_full = t_ev * E / n_ev + t_sel
+  return {"value": 1.0 / t_full, "unit": "evals/s", "cores": 1, "kind": "port",
+          "sample": f"oracle (NumPy), first {n_ev} of {E} events ({t_ev:.2f} s) + all {cfg['I']} injections ({t_sel:.3f} s), "
+                    f"1 evaluation, event time scaled x{E / n_ev:.1f}",
+          "host_cpus": os.cpu_count()}
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,125 @@
+"""ctypes binding of libchimera_hip.so (include/chimera_hip.h).
+
+The library is the only compute backend of this package: there is no CPU fallback.  If it has not been built
+(``python -c 'import __graft_entry__ as g; g.build()'`` or ``make -C chimera_amd/csrc``) every entry point raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libchimera_hip.so')
+
+CHM_OK, CHM_E_ARG, CHM_E_HIP, CHM_E_NOMEM, CHM_E_RCCL = 0, -1, -2, -3, -4
+MODE = {'1d': 0, 'approximate': 1, 'marginalized': 2, 'full': 3}
+KERNEL = {'epan': 0, 'gauss': 1}
+NCOSMO, NMASS, NRATE = 8, 8, 4
+
+# function ids of chm_model_eval
+(F_E, F_INT_INVE, F_DCR, F_DCT, F_DL, F_DDLDZ, F_DVCDZ, F_VC, F_XI, F_Z_FROM_DGW, F_RATE, F_PM1M2, F_PRIMARY,
+ F_SECONDARY, F_SMOOTHING) = range(15)
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+
+
+class chm_params(C.Structure):
+  _fields_ = [('cosmo_model', C.c_int32), ('mass_model', C.c_int32), ('rate_model', C.c_int32),
+              ('z_grid_res', C.c_int32), ('mass_grid_res', C.c_int32), ('scale_free', C.c_int32),
+              ('has_catalog', C.c_int32), ('_pad', C.c_int32),
+              ('z_max', C.c_double), ('cosmo', C.c_double * NCOSMO), ('mass', C.c_double * NMASS),
+              ('rate', C.c_double * NRATE), ('R0', C.c_double), ('Tobs', C.c_double),
+              ('compl_z0', C.c_double), ('compl_z1', C.c_double)]
+
+
+class chm_like_desc(C.Structure):
+  _fields_ = [('E', C.c_int32), ('S', C.c_int32), ('Z', C.c_int32), ('P', C.c_int32),
+              ('ev_begin', C.c_int32), ('ev_end', C.c_int32),
+              ('dL', c_dp), ('m1det', c_dp), ('m2det', c_dp), ('pe_prior', c_dp), ('ra', c_dp), ('dec', c_dp),
+              ('pix_of_sample', c_ip), ('z_grids', c_dp), ('p_cat', c_dp), ('P_compl', c_dp),
+              ('gw_loc2d_pdf', c_dp), ('ra_pix', c_dp), ('dec_pix', c_dp), ('neff_pixels', c_ip),
+              ('mode', C.c_int32), ('kernel', C.c_int32), ('bw_method', C.c_int32), ('binning', C.c_int32),
+              ('num_bins', C.c_int32), ('device', C.c_int32),
+              ('bw_scalar', C.c_double), ('cut_grid', C.c_double), ('pe_neff', C.c_double)]
+
+
+class chm_sel_desc(C.Structure):
+  _fields_ = [('I', C.c_int64), ('inj_begin', C.c_int64), ('inj_end', C.c_int64),
+              ('dL', c_dp), ('m1det', c_dp), ('m2det', c_dp), ('p_draw', c_dp),
+              ('N_inj', C.c_double), ('N_eff', C.c_double), ('device', C.c_int32), ('_pad', C.c_int32)]
+
+
+class chm_out(C.Structure):
+  _fields_ = [('log_hyper', c_dp), ('log_num', c_dp), ('N_exp', c_dp), ('log_like_evs', c_dp),
+              ('numlike_evs', c_dp), ('p_gw', c_dp), ('partials', c_dp)]
+
+
+SYMBOLS = ['chm_version', 'chm_device_count', 'chm_last_error', 'chm_like_create', 'chm_like_destroy',
+           'chm_sel_create', 'chm_sel_destroy', 'chm_eval', 'chm_model_eval', 'chm_model_tables',
+           'chm_comm_unique_id', 'chm_comm_init_rank', 'chm_comm_destroy', 'chm_comm_allreduce_sum',
+           'chm_last_timing']
+
+_lib = None
+
+
+def lib():
+  """Load libchimera_hip.so once; raise (never fall back) if it is missing."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise RuntimeError(f"chimera_amd: HIP library not built ({LIB_PATH} missing). Build it with "
+                       "`python -c 'import __graft_entry__ as g; g.build()'`; there is no CPU fallback.")
+  L = C.CDLL(LIB_PATH)
+  vp = C.c_void_p
+  L.chm_version.restype = C.c_char_p
+  L.chm_last_error.restype = C.c_char_p
+  L.chm_device_count.restype = C.c_int
+  L.chm_like_create.argtypes = [C.POINTER(chm_like_desc), C.POINTER(vp)]
+  L.chm_like_destroy.argtypes = [vp]
+  L.chm_sel_create.argtypes = [C.POINTER(chm_sel_desc), C.POINTER(vp)]
+  L.chm_sel_destroy.argtypes = [vp]
+  L.chm_eval.argtypes = [vp, vp, vp, C.POINTER(chm_params), C.c_int32, C.c_int64, C.POINTER(chm_out)]
+  L.chm_model_eval.argtypes = [C.POINTER(chm_params), C.c_int32, c_dp, c_dp, C.c_int64, c_dp, C.c_int32]
+  L.chm_model_tables.argtypes = [C.POINTER(chm_params), c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int32]
+  L.chm_comm_unique_id.argtypes = [C.c_char_p]
+  L.chm_comm_init_rank.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+  L.chm_comm_destroy.argtypes = [vp]
+  L.chm_comm_allreduce_sum.argtypes = [vp, c_dp, C.c_int32]
+  L.chm_last_timing.argtypes = [vp, vp, c_dp]
+  for name in SYMBOLS:
+    if name not in ('chm_version', 'chm_last_error'):
+      getattr(L, name).restype = C.c_int
+  _lib = L
+  return L
+
+
+def check(rc):
+  """Map a CHM_E_* return code to the reference-side exception type (ValueError for arguments, RuntimeError else)."""
+  if rc == CHM_OK:
+    return
+  msg = lib().chm_last_error().decode()
+  if rc == CHM_E_ARG:
+    raise ValueError(msg)
+  if rc == CHM_E_NOMEM:
+    raise MemoryError(msg)
+  raise RuntimeError(msg)
+
+
+def default_device():
+  for k in ('CHIMERA_DEVICE', 'LOCAL_RANK'):
+    if k in os.environ:
+      return int(os.environ[k])
+  return 0
+
+
+def as_f64(a):
+  return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def dptr(a):
+  return None if a is None else a.ctypes.data_as(c_dp)
+
+
+def iptr(a):
+  return None if a is None else a.ctypes.data_as(c_ip)

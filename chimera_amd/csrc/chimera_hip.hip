@@ -1,0 +1,547 @@
+// chimera_hip.hip -- C ABI (include/chimera_hip.h) over the HIP kernels in chm_kernels.h.  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/chimera_hip.h"
+#include "chm_kernels.h"
+
+#define CHM_MAXP 1024
+static_assert(sizeof(chm_params) % 8 == 0, "chm_params layout");
+
+// ------------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+#define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { \
+  return fail(_e == hipErrorOutOfMemory ? CHM_E_NOMEM : CHM_E_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } } while (0)
+#define NCCLCHK(x) do { ncclResult_t _r = (x); if (_r != ncclSuccess) { \
+  return fail(CHM_E_RCCL, std::string(#x) + ": " + ncclGetErrorString(_r)); } } while (0)
+
+extern "C" const char* chm_version(void) { return "chimera_hip 0.1.0 (gfx950)"; }
+extern "C" const char* chm_last_error(void) { return g_err.c_str(); }
+extern "C" int chm_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+// ------------------------------------------------------------------------------------------------------
+// per-device evaluation context: stream, per-draw parameter block + tables, staging buffers
+// ------------------------------------------------------------------------------------------------------
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int nb_cap = 0, TcMax = 0, TmMax = 0;
+  DevParams* d_params = nullptr;
+  DevParams* h_params = nullptr;       // pinned
+  double *zt = nullptr, *It = nullptr, *dLt = nullptr, *mg = nullptr, *cdf = nullptr, *tmp = nullptr;
+  double* d_partials = nullptr;        // (nb,3)
+  double* d_out3 = nullptr;            // (nb,3)
+  double* h_out = nullptr;             // pinned (nb,6)
+  hipEvent_t ev[8] = {};
+  double ms[8] = {};
+  bool init = false;
+};
+
+static int ctx_init(Ctx& c, int device) {
+  c.device = device;
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c.ev[i]));
+  c.init = true;
+  return CHM_OK;
+}
+
+static void ctx_free_tables(Ctx& c) {
+  (void)hipFree(c.d_params); (void)hipHostFree(c.h_params);
+  (void)hipFree(c.zt); (void)hipFree(c.It); (void)hipFree(c.dLt); (void)hipFree(c.mg); (void)hipFree(c.cdf); (void)hipFree(c.tmp);
+  (void)hipFree(c.d_partials); (void)hipFree(c.d_out3); (void)hipHostFree(c.h_out);
+  c.d_params = nullptr; c.h_params = nullptr; c.zt = c.It = c.dLt = c.mg = c.cdf = c.tmp = nullptr;
+  c.d_partials = c.d_out3 = nullptr; c.h_out = nullptr;
+  c.nb_cap = c.TcMax = c.TmMax = 0;
+}
+
+static void ctx_destroy(Ctx& c) {
+  if (!c.init) return;
+  (void)hipSetDevice(c.device);
+  ctx_free_tables(c);
+  for (int i = 0; i < 8; i++) if (c.ev[i]) (void)hipEventDestroy(c.ev[i]);
+  if (c.stream) (void)hipStreamDestroy(c.stream);
+  c.init = false;
+}
+
+static int ctx_ensure(Ctx& c, int nb, int Tc, int Tm) {
+  if (nb <= c.nb_cap && Tc <= c.TcMax && Tm <= c.TmMax) return CHM_OK;
+  HIPCHK(hipStreamSynchronize(c.stream));
+  int nbn = nb > c.nb_cap ? nb : c.nb_cap, Tcn = Tc > c.TcMax ? Tc : c.TcMax, Tmn = Tm > c.TmMax ? Tm : c.TmMax;
+  ctx_free_tables(c);
+  size_t T = Tcn > Tmn ? Tcn : Tmn;
+  HIPCHK(hipMalloc(&c.d_params, sizeof(DevParams) * nbn));
+  HIPCHK(hipHostMalloc(&c.h_params, sizeof(DevParams) * nbn));
+  HIPCHK(hipMalloc(&c.zt, sizeof(double) * nbn * Tcn));
+  HIPCHK(hipMalloc(&c.It, sizeof(double) * nbn * Tcn));
+  HIPCHK(hipMalloc(&c.dLt, sizeof(double) * nbn * Tcn));
+  HIPCHK(hipMalloc(&c.mg, sizeof(double) * nbn * Tmn));
+  HIPCHK(hipMalloc(&c.cdf, sizeof(double) * nbn * Tmn));
+  HIPCHK(hipMalloc(&c.tmp, sizeof(double) * nbn * T));
+  HIPCHK(hipMalloc(&c.d_partials, sizeof(double) * nbn * 3));
+  HIPCHK(hipMalloc(&c.d_out3, sizeof(double) * nbn * 3));
+  HIPCHK(hipHostMalloc(&c.h_out, sizeof(double) * nbn * 6));
+  c.nb_cap = nbn; c.TcMax = Tcn; c.TmMax = Tmn;
+  return CHM_OK;
+}
+
+static int check_params(const chm_params* p) {
+  if (p->cosmo_model < 0 || p->cosmo_model > 1) return fail(CHM_E_ARG, "chm_params.cosmo_model out of range");
+  if (p->mass_model < 0 || p->mass_model > 2) return fail(CHM_E_ARG, "chm_params.mass_model out of range");
+  if (p->rate_model < 0 || p->rate_model > 3) return fail(CHM_E_ARG, "chm_params.rate_model out of range");
+  if (p->z_grid_res < 3 || p->z_grid_res > (1 << 22)) return fail(CHM_E_ARG, "chm_params.z_grid_res must be in [3, 2^22]");
+  if (p->mass_grid_res < 3 || p->mass_grid_res > (1 << 22)) return fail(CHM_E_ARG, "chm_params.mass_grid_res must be in [3, 2^22]");
+  return CHM_OK;
+}
+
+static void fill_dev_params(const chm_params* p, DevParams* d) {
+  memset(d, 0, sizeof(DevParams));
+  d->cosmo_model = p->cosmo_model; d->mass_model = p->mass_model; d->rate_model = p->rate_model;
+  d->Tc = p->z_grid_res; d->Tm = p->mass_grid_res; d->scale_free = p->scale_free; d->has_catalog = p->has_catalog;
+  d->z_max = p->z_max;
+  d->H0 = p->cosmo[CHM_C_H0]; d->Om0 = p->cosmo[CHM_C_OM0]; d->Ok0 = p->cosmo[CHM_C_OK0]; d->Or0 = p->cosmo[CHM_C_OR0];
+  d->w0 = p->cosmo[CHM_C_W0]; d->wa = p->cosmo[CHM_C_WA]; d->Xi0 = p->cosmo[CHM_C_XI0]; d->n_mg = p->cosmo[CHM_C_N];
+  d->Ode0 = 1.0 - d->Om0 - d->Or0 - d->Ok0;                 // cosmo.py:79-81
+  d->dH = 299792.458e-3 / d->H0;                            // cosmo.py:82-84
+  for (int i = 0; i < 8; i++) d->m[i] = p->mass[i];
+  for (int i = 0; i < 4; i++) d->r[i] = p->rate[i];
+  d->R0 = p->R0; d->Tobs = p->Tobs; d->zc0 = p->compl_z0; d->zc1 = p->compl_z1;
+}
+
+// upload nb draws and build their tables on c.stream
+static int ctx_tables(Ctx& c, const chm_params* params, int nb) {
+  int Tc = 0, Tm = 0;
+  for (int b = 0; b < nb; b++) {
+    int rc = check_params(&params[b]); if (rc) return rc;
+    Tc = params[b].z_grid_res > Tc ? params[b].z_grid_res : Tc;
+    Tm = params[b].mass_grid_res > Tm ? params[b].mass_grid_res : Tm;
+  }
+  int rc = ctx_ensure(c, nb, Tc, Tm); if (rc) return rc;
+  for (int b = 0; b < nb; b++) fill_dev_params(&params[b], &c.h_params[b]);
+  HIPCHK(hipMemcpyAsync(c.d_params, c.h_params, sizeof(DevParams) * nb, hipMemcpyHostToDevice, c.stream));
+  hipLaunchKernelGGL(k_tables, dim3(nb), dim3(256), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax);
+  HIPCHK(hipGetLastError());
+  return CHM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------------------------
+struct chm_like {
+  Ctx ctx;
+  LikeDev L;
+  std::vector<void*> owned;
+  int nb_ws = 0;
+  bool ws_dump = false;
+};
+struct chm_sel {
+  Ctx ctx;
+  SelDev S;
+  std::vector<void*> owned;
+  int nb_ws = 0;
+};
+struct chm_comm {
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0, device = 0;
+  hipStream_t stream = nullptr;
+  double* d_buf = nullptr; int cap = 0;
+};
+
+template <class T>
+static int upload(std::vector<void*>& owned, const T* host, size_t n, const T** dev, hipStream_t s) {
+  *dev = nullptr;
+  if (!host || n == 0) return CHM_OK;
+  T* d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(T) * n));
+  owned.push_back(d);
+  HIPCHK(hipMemcpyAsync(d, host, sizeof(T) * n, hipMemcpyHostToDevice, s));
+  *dev = d;
+  return CHM_OK;
+}
+
+extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
+  if (!d || !out) return fail(CHM_E_ARG, "chm_like_create: null argument");
+  *out = nullptr;
+  if (d->E <= 0 || d->S <= 0 || d->Z < 2) return fail(CHM_E_ARG, "chm_like_create: need E > 0, S > 0, Z >= 2");
+  if (d->mode < 0 || d->mode > 3) return fail(CHM_E_ARG, "chm_like_create: bad mode");
+  if (d->kernel < 0 || d->kernel > 1) return fail(CHM_E_ARG, "chm_like_create: bad kernel");
+  if (d->bw_method < 0 || d->bw_method > 2) return fail(CHM_E_ARG, "chm_like_create: bad bw_method");
+  if (!d->dL || !d->m1det || !d->m2det || !d->pe_prior || !d->z_grids) return fail(CHM_E_ARG, "chm_like_create: missing sample arrays / z_grids");
+  const bool pixelated = d->mode != CHM_MODE_1D;
+  if (pixelated) {
+    if (d->P <= 0 || d->P > CHM_MAXP) return fail(CHM_E_ARG, "chm_like_create: pixelated modes need 0 < P <= 1024");
+    if (!d->p_cat || !d->P_compl || !d->gw_loc2d_pdf || !d->neff_pixels) return fail(CHM_E_ARG, "chm_like_create: missing p_cat / P_compl / gw_loc2d_pdf / neff_pixels");
+    if (d->mode == CHM_MODE_MARG && !d->pix_of_sample) return fail(CHM_E_ARG, "chm_like_create: marginalized mode needs pix_of_sample");
+    if (d->mode == CHM_MODE_FULL && (!d->ra || !d->dec || !d->ra_pix || !d->dec_pix)) return fail(CHM_E_ARG, "chm_like_create: full mode needs ra, dec, ra_pix, dec_pix");
+    if (d->mode == CHM_MODE_FULL && std::isnan(d->cut_grid)) return fail(CHM_E_ARG, "chm_like_create: full mode needs cut_grid");
+  }
+  if (d->mode != CHM_MODE_FULL && d->binning && d->num_bins < 1) return fail(CHM_E_ARG, "chm_like_create: num_bins must be >= 1");
+  int e0 = d->ev_begin, e1 = d->ev_end;
+  if (e0 == 0 && e1 == 0) e1 = d->E;
+  if (e0 < 0 || e1 > d->E || e0 >= e1) return fail(CHM_E_ARG, "chm_like_create: bad event range");
+  int ndev = chm_device_count();
+  if (d->device < 0 || d->device >= ndev) return fail(CHM_E_HIP, "chm_like_create: no such HIP device (is a GPU visible?)");
+
+  chm_like* h = new chm_like();
+  int rc = ctx_init(h->ctx, d->device);
+  if (rc) { delete h; return rc; }
+  hipStream_t s = h->ctx.stream;
+  LikeDev& L = h->L;
+  memset(&L, 0, sizeof(L));
+  const size_t E = e1 - e0, S = d->S, Z = d->Z, P = pixelated ? d->P : 0;
+  L.E = (int)E; L.S = d->S; L.Z = d->Z; L.P = (int)P;
+  L.mode = d->mode; L.kernel = d->kernel; L.bw_method = d->bw_method; L.binning = d->binning ? 1 : 0; L.num_bins = d->num_bins;
+  L.has_cut = std::isnan(d->cut_grid) ? 0 : 1;
+  L.G = L.has_cut ? d->Z / 2 : d->Z;                         // likelihood.py:121,188
+  L.bw_scalar = d->bw_scalar; L.cut_grid = d->cut_grid; L.pe_neff = d->pe_neff;
+  if (L.mode != CHM_MODE_FULL && L.G < 2) { chm_like_destroy(h); return fail(CHM_E_ARG, "chm_like_create: Z//2 must be >= 2 when cut_grid is set"); }
+#define UP(field, src, n) do { rc = upload(h->owned, (src) ? (src) + (size_t)e0 * (n) : (src), (size_t)E * (n), &L.field, s); if (rc) { chm_like_destroy(h); return rc; } } while (0)
+  UP(dL, d->dL, S); UP(m1det, d->m1det, S); UP(m2det, d->m2det, S); UP(pe_prior, d->pe_prior, S);
+  if (d->mode == CHM_MODE_FULL) { UP(ra, d->ra, S); UP(dec, d->dec, S); }
+  if (pixelated && d->pix_of_sample) UP(pix, d->pix_of_sample, S);
+  UP(z_grids, d->z_grids, Z);
+  if (pixelated) {
+    UP(p_cat, d->p_cat, P * Z); UP(P_compl, d->P_compl, Z); UP(gw_pdf, d->gw_loc2d_pdf, P);
+    if (d->ra_pix) UP(ra_pix, d->ra_pix, P);
+    if (d->dec_pix) UP(dec_pix, d->dec_pix, P);
+    UP(neff_pixels, d->neff_pixels, 1);
+  }
+#undef UP
+  hipError_t he = hipStreamSynchronize(s);
+  if (he != hipSuccess) { chm_like_destroy(h); return fail(CHM_E_HIP, std::string("chm_like_create: ") + hipGetErrorString(he)); }
+  *out = h;
+  return CHM_OK;
+}
+
+static void like_free_ws(chm_like* h) {
+  LikeDev& L = h->L;
+  (void)hipFree(L.ws_z); (void)hipFree(L.ws_w); (void)hipFree(L.stats); (void)hipFree(L.pixmax); (void)hipFree(L.jac); (void)hipFree(L.prate); (void)hipFree(L.bkgA);
+  (void)hipFree(L.like_pix); (void)hipFree(L.p_gw_dump);
+  L.ws_z = L.ws_w = L.stats = L.pixmax = L.jac = L.prate = L.bkgA = L.like_pix = L.p_gw_dump = nullptr;
+  h->nb_ws = 0; h->ws_dump = false;
+}
+
+extern "C" int chm_like_destroy(chm_like* h) {
+  if (!h) return CHM_OK;
+  (void)hipSetDevice(h->ctx.device);
+  if (h->ctx.stream) (void)hipStreamSynchronize(h->ctx.stream);
+  like_free_ws(h);
+  for (void* p : h->owned) (void)hipFree(p);
+  ctx_destroy(h->ctx);
+  delete h;
+  return CHM_OK;
+}
+
+static int like_ensure_ws(chm_like* h, int nb, bool dump) {
+  if (nb <= h->nb_ws && (!dump || h->ws_dump)) return CHM_OK;
+  HIPCHK(hipStreamSynchronize(h->ctx.stream));
+  like_free_ws(h);
+  LikeDev& L = h->L;
+  size_t E = L.E, S = L.S, Z = L.Z, Pd = L.P > 0 ? L.P : 1, n = nb;
+  HIPCHK(hipMalloc(&L.ws_z, sizeof(double) * n * E * S));
+  HIPCHK(hipMalloc(&L.ws_w, sizeof(double) * n * E * S));
+  HIPCHK(hipMalloc(&L.stats, sizeof(double) * n * E * NSTAT));
+  HIPCHK(hipMalloc(&L.pixmax, sizeof(double) * n * E * Pd));
+  HIPCHK(hipMalloc(&L.jac, sizeof(double) * n * E * Z));
+  HIPCHK(hipMalloc(&L.prate, sizeof(double) * n * E * Z));
+  HIPCHK(hipMalloc(&L.bkgA, sizeof(double) * n * E * Z));
+  HIPCHK(hipMalloc(&L.like_pix, sizeof(double) * n * E * Pd));
+  if (dump) HIPCHK(hipMalloc(&L.p_gw_dump, sizeof(double) * n * E * Pd * Z));
+  h->nb_ws = nb; h->ws_dump = dump;
+  return CHM_OK;
+}
+
+extern "C" int chm_sel_create(const chm_sel_desc* d, chm_sel** out) {
+  if (!d || !out) return fail(CHM_E_ARG, "chm_sel_create: null argument");
+  *out = nullptr;
+  if (d->I <= 0 || !d->dL || !d->m1det || !d->m2det || !d->p_draw) return fail(CHM_E_ARG, "chm_sel_create: need I > 0 and dL, m1det, m2det, p_draw");
+  if (!(d->N_inj > 0)) return fail(CHM_E_ARG, "chm_sel_create: N_inj must be > 0");
+  long long i0 = d->inj_begin, i1 = d->inj_end;
+  if (i0 == 0 && i1 == 0) i1 = d->I;
+  if (i0 < 0 || i1 > d->I || i0 > i1) return fail(CHM_E_ARG, "chm_sel_create: bad injection range");
+  int ndev = chm_device_count();
+  if (d->device < 0 || d->device >= ndev) return fail(CHM_E_HIP, "chm_sel_create: no such HIP device (is a GPU visible?)");
+  chm_sel* h = new chm_sel();
+  int rc = ctx_init(h->ctx, d->device);
+  if (rc) { delete h; return rc; }
+  SelDev& S = h->S;
+  memset(&S, 0, sizeof(S));
+  size_t n = (size_t)(i1 - i0);
+  S.I = (long long)n; S.N_inj = d->N_inj; S.has_neff = std::isnan(d->N_eff) ? 0 : 1; S.N_eff = d->N_eff;
+  hipStream_t s = h->ctx.stream;
+#define UP(field, src) do { rc = upload(h->owned, (src) + i0, n, &S.field, s); if (rc) { chm_sel_destroy(h); return rc; } } while (0)
+  UP(dL, d->dL); UP(m1det, d->m1det); UP(m2det, d->m2det); UP(p_draw, d->p_draw);
+#undef UP
+  long long nblk = (S.I + 255) / 256;
+  S.nblocks = (int)(nblk < 1 ? 1 : (nblk > 2048 ? 2048 : nblk));
+  hipError_t he = hipStreamSynchronize(s);
+  if (he != hipSuccess) { chm_sel_destroy(h); return fail(CHM_E_HIP, std::string("chm_sel_create: ") + hipGetErrorString(he)); }
+  *out = h;
+  return CHM_OK;
+}
+
+extern "C" int chm_sel_destroy(chm_sel* h) {
+  if (!h) return CHM_OK;
+  (void)hipSetDevice(h->ctx.device);
+  if (h->ctx.stream) (void)hipStreamSynchronize(h->ctx.stream);
+  (void)hipFree(h->S.partial);
+  for (void* p : h->owned) (void)hipFree(p);
+  ctx_destroy(h->ctx);
+  delete h;
+  return CHM_OK;
+}
+
+static int sel_ensure_ws(chm_sel* h, int nb) {
+  if (nb <= h->nb_ws) return CHM_OK;
+  HIPCHK(hipStreamSynchronize(h->ctx.stream));
+  (void)hipFree(h->S.partial); h->S.partial = nullptr;
+  HIPCHK(hipMalloc(&h->S.partial, sizeof(double) * (size_t)nb * h->S.nblocks * 2));
+  h->nb_ws = nb;
+  return CHM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// evaluation
+// ------------------------------------------------------------------------------------------------------
+static size_t table_lds_bytes(int Tc, int Tm) { return sizeof(double) * ((size_t)3 * Tc + (size_t)2 * Tm); }
+
+extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_params* params, int32_t nb,
+                        int64_t E_total, chm_out* out) {
+  if ((!like && !sel) || !params || !out || nb <= 0) return fail(CHM_E_ARG, "chm_eval: need a handle, params, out and nb > 0");
+  if (like && sel && like->ctx.device != sel->ctx.device) return fail(CHM_E_ARG, "chm_eval: like and sel live on different devices");
+  Ctx& c = like ? like->ctx : sel->ctx;
+  if (comm && comm->device != c.device) return fail(CHM_E_ARG, "chm_eval: comm lives on a different device");
+  HIPCHK(hipSetDevice(c.device));
+  hipStream_t s = c.stream;
+  const bool want_dump = like && out->p_gw != nullptr;
+  int rc;
+  if (like) { rc = like_ensure_ws(like, nb, want_dump); if (rc) return rc; }
+  if (sel) { rc = sel_ensure_ws(sel, nb); if (rc) return rc; }
+  if (like && !want_dump && like->L.p_gw_dump) { /* keep buffer, but do not write it */ }
+
+  HIPCHK(hipEventRecord(c.ev[0], s));
+  rc = ctx_tables(c, params, nb); if (rc) return rc;
+  HIPCHK(hipEventRecord(c.ev[1], s));
+
+  const int Tc = c.TcMax, Tm = c.TmMax;
+  const size_t tab_bytes = table_lds_bytes(Tc, Tm);
+  const bool lds_tab = tab_bytes <= 96 * 1024;
+
+  if (like) {
+    LikeDev L = like->L;
+    if (!want_dump) L.p_gw_dump = nullptr;
+    dim3 g1(L.E, nb);
+    if (lds_tab) {
+      static bool attr_set = false;
+      if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_samples<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_set = true; }
+      hipLaunchKernelGGL(k_samples<true>, g1, dim3(1024), tab_bytes, s, L, (const DevParams*)c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    } else {
+      hipLaunchKernelGGL(k_samples<false>, g1, dim3(1024), 0, s, L, (const DevParams*)c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c.ev[2], s));
+    const int Pd = L.P > 0 ? L.P : 1;
+    if (L.mode == CHM_MODE_FULL) {
+      hipLaunchKernelGGL(k_full_kde, dim3(L.E * Pd, nb), dim3(256), 0, s, L, (const DevParams*)c.d_params);
+    } else {
+      size_t N = L.binning ? L.num_bins : L.S;
+      size_t lds = sizeof(double) * (2 * N + 2 * (size_t)L.G);
+      if (lds > 150 * 1024) return fail(CHM_E_ARG, "chm_eval: binning=False needs 2*S + 2*G doubles of LDS (<= 150 KiB)");
+      static size_t attr_max = 0;
+      if (lds > 48 * 1024 && lds > attr_max) { (void)hipFuncSetAttribute((const void*)k_kde_integrate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_max = lds; }
+      hipLaunchKernelGGL(k_kde_integrate, dim3(L.E * Pd, nb), dim3(64), lds, s, L, (const DevParams*)c.d_params);
+    }
+    HIPCHK(hipGetLastError());
+  } else {
+    HIPCHK(hipEventRecord(c.ev[2], s));
+  }
+  HIPCHK(hipEventRecord(c.ev[3], s));
+
+  if (sel) {
+    SelDev S = sel->S;
+    dim3 g(S.nblocks, nb);
+    if (lds_tab) {
+      static bool attr_set = false;
+      if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_selection<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_set = true; }
+      hipLaunchKernelGGL(k_selection<true>, g, dim3(256), tab_bytes, s, S, (const DevParams*)c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    } else {
+      hipLaunchKernelGGL(k_selection<false>, g, dim3(256), 0, s, S, (const DevParams*)c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    }
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipEventRecord(c.ev[4], s));
+
+  // shard partials
+  double* d_lle = nullptr; double* d_nle = nullptr;
+  const size_t El = like ? like->L.E : 0;
+  if (like && out->log_like_evs) HIPCHK(hipMalloc(&d_lle, sizeof(double) * nb * El));
+  if (like && out->numlike_evs) HIPCHK(hipMalloc(&d_nle, sizeof(double) * nb * El));
+  hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), 0, s, like ? like->L.E : 0, like ? (like->L.P > 0 ? like->L.P : 1) : 1,
+                     like ? like->L.like_pix : nullptr, sel ? sel->S.nblocks : 0, sel ? sel->S.partial : nullptr,
+                     c.d_partials, d_lle, d_nle);
+  HIPCHK(hipGetLastError());
+  if (out->partials) HIPCHK(hipMemcpyAsync(c.h_out + 3 * nb, c.d_partials, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, s));
+  double Etot = like ? (double)like->L.E : 0.;
+  if (comm && comm->nranks > 1) {
+    NCCLCHK(ncclAllReduce(c.d_partials, c.d_partials, (size_t)nb * 3, ncclDouble, ncclSum, comm->comm, s));
+    Etot = (double)E_total;
+  } else if (comm) {
+    Etot = (double)E_total;
+  }
+  hipLaunchKernelGGL(k_combine, dim3((nb + 63) / 64), dim3(64), 0, s, nb, (const DevParams*)c.d_params, c.d_partials, Etot,
+                     sel ? sel->S.N_inj : 1., sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, c.d_out3);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c.h_out, c.d_out3, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipEventRecord(c.ev[5], s));
+  if (d_lle) HIPCHK(hipMemcpyAsync(out->log_like_evs, d_lle, sizeof(double) * nb * El, hipMemcpyDeviceToHost, s));
+  if (d_nle) HIPCHK(hipMemcpyAsync(out->numlike_evs, d_nle, sizeof(double) * nb * El, hipMemcpyDeviceToHost, s));
+  if (want_dump) {
+    size_t Pd = like->L.P > 0 ? like->L.P : 1;
+    HIPCHK(hipMemcpyAsync(out->p_gw, like->L.p_gw_dump, sizeof(double) * nb * El * Pd * like->L.Z, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  if (d_lle) (void)hipFree(d_lle);
+  if (d_nle) (void)hipFree(d_nle);
+  for (int b = 0; b < nb; b++) {
+    if (out->log_hyper) out->log_hyper[b] = c.h_out[b * 3];
+    if (out->log_num) out->log_num[b] = c.h_out[b * 3 + 1];
+    if (out->N_exp) out->N_exp[b] = c.h_out[b * 3 + 2];
+    if (out->partials) for (int k = 0; k < 3; k++) out->partials[b * 3 + k] = c.h_out[3 * nb + b * 3 + k];
+  }
+  float ms = 0.f;
+  for (int i = 0; i < 8; i++) c.ms[i] = 0.;
+  (void)hipEventElapsedTime(&ms, c.ev[0], c.ev[5]); c.ms[0] = ms;
+  for (int i = 1; i <= 5; i++) { (void)hipEventElapsedTime(&ms, c.ev[i - 1], c.ev[i]); c.ms[i] = ms; }
+  return CHM_OK;
+}
+
+extern "C" int chm_last_timing(chm_like* like, chm_sel* sel, double ms[8]) {
+  if (!ms || (!like && !sel)) return fail(CHM_E_ARG, "chm_last_timing: null argument");
+  Ctx& c = like ? like->ctx : sel->ctx;
+  for (int i = 0; i < 8; i++) ms[i] = c.ms[i];
+  return CHM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// elementwise model functions and tables (setup path; not performance critical)
+// ------------------------------------------------------------------------------------------------------
+static int with_tables(const chm_params* p, int device, Ctx& c) {
+  if (!p) return fail(CHM_E_ARG, "null chm_params");
+  int ndev = chm_device_count();
+  if (device < 0 || device >= ndev) return fail(CHM_E_HIP, "no such HIP device (is a GPU visible?)");
+  int rc = ctx_init(c, device); if (rc) return rc;
+  rc = ctx_tables(c, p, 1);
+  return rc;
+}
+
+extern "C" int chm_model_eval(const chm_params* p, int32_t func, const double* a, const double* b, int64_t n,
+                              double* out, int32_t device) {
+  if (!a || !out || n < 0) return fail(CHM_E_ARG, "chm_model_eval: null argument");
+  if (func < 0 || func > CHM_F_SMOOTHING) return fail(CHM_E_ARG, "chm_model_eval: unknown function id");
+  if ((func == CHM_F_PM1M2 || func == CHM_F_SECONDARY) && !b) return fail(CHM_E_ARG, "chm_model_eval: function needs two inputs");
+  if (n == 0) return CHM_OK;
+  Ctx c;
+  int rc = with_tables(p, device, c);
+  if (rc) { ctx_destroy(c); return rc; }
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  auto cleanup = [&]() { (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout); ctx_destroy(c); };
+#define CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { cleanup(); return fail(_e == hipErrorOutOfMemory ? CHM_E_NOMEM : CHM_E_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } } while (0)
+  CK(hipMalloc(&da, sizeof(double) * n));
+  CK(hipMalloc(&dout, sizeof(double) * n));
+  CK(hipMemcpyAsync(da, a, sizeof(double) * n, hipMemcpyHostToDevice, c.stream));
+  if (b) { CK(hipMalloc(&db, sizeof(double) * n)); CK(hipMemcpyAsync(db, b, sizeof(double) * n, hipMemcpyHostToDevice, c.stream)); }
+  TablePtrs g = { c.zt, c.It, c.dLt, c.mg, c.cdf };
+  long long nblk = (n + 255) / 256; if (nblk > 4096) nblk = 4096;
+  hipLaunchKernelGGL(k_model_eval, dim3((unsigned)nblk), dim3(256), 0, c.stream, (const DevParams*)c.d_params, g, func, (const double*)da, (const double*)db, (long long)n, dout);
+  CK(hipGetLastError());
+  CK(hipMemcpyAsync(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+#undef CK
+  cleanup();
+  return CHM_OK;
+}
+
+extern "C" int chm_model_tables(const chm_params* p, double* zt, double* It, double* dLt, double* mgrid,
+                                double* cdf_m2, double* scalars, int32_t device) {
+  Ctx c;
+  int rc = with_tables(p, device, c);
+  if (rc) { ctx_destroy(c); return rc; }
+  auto cleanup = [&]() { ctx_destroy(c); };
+#define CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) { cleanup(); return fail(CHM_E_HIP, std::string(#x) + ": " + hipGetErrorString(_e)); } } while (0)
+  size_t Tc = p->z_grid_res, Tm = p->mass_grid_res;
+  if (zt) CK(hipMemcpyAsync(zt, c.zt, sizeof(double) * Tc, hipMemcpyDeviceToHost, c.stream));
+  if (It) CK(hipMemcpyAsync(It, c.It, sizeof(double) * Tc, hipMemcpyDeviceToHost, c.stream));
+  if (dLt) CK(hipMemcpyAsync(dLt, c.dLt, sizeof(double) * Tc, hipMemcpyDeviceToHost, c.stream));
+  if (mgrid) CK(hipMemcpyAsync(mgrid, c.mg, sizeof(double) * Tm, hipMemcpyDeviceToHost, c.stream));
+  if (cdf_m2) CK(hipMemcpyAsync(cdf_m2, c.cdf, sizeof(double) * Tm, hipMemcpyDeviceToHost, c.stream));
+  DevParams hp;
+  CK(hipMemcpyAsync(&hp, c.d_params, sizeof(DevParams), hipMemcpyDeviceToHost, c.stream));
+  CK(hipStreamSynchronize(c.stream));
+#undef CK
+  if (scalars) { scalars[0] = hp.norm_p_m1; scalars[1] = hp.fR; }
+  cleanup();
+  return CHM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// RCCL communicator (one process per GPU)
+// ------------------------------------------------------------------------------------------------------
+static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId larger than the ABI's 128 bytes");
+
+extern "C" int chm_comm_unique_id(char id[128]) {
+  if (!id) return fail(CHM_E_ARG, "chm_comm_unique_id: null argument");
+  ncclUniqueId u;
+  NCCLCHK(ncclGetUniqueId(&u));
+  memset(id, 0, 128);
+  memcpy(id, &u, sizeof(u));
+  return CHM_OK;
+}
+
+extern "C" int chm_comm_init_rank(const char id[128], int32_t nranks, int32_t rank, int32_t device, chm_comm** out) {
+  if (!id || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail(CHM_E_ARG, "chm_comm_init_rank: bad argument");
+  *out = nullptr;
+  int ndev = chm_device_count();
+  if (device < 0 || device >= ndev) return fail(CHM_E_HIP, "chm_comm_init_rank: no such HIP device");
+  HIPCHK(hipSetDevice(device));
+  chm_comm* c = new chm_comm();
+  c->nranks = nranks; c->rank = rank; c->device = device;
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  ncclResult_t r = ncclCommInitRank(&c->comm, nranks, u, rank);
+  if (r != ncclSuccess) { delete c; return fail(CHM_E_RCCL, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+  hipError_t he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (he != hipSuccess) { ncclCommDestroy(c->comm); delete c; return fail(CHM_E_HIP, "chm_comm_init_rank: stream create failed"); }
+  *out = c;
+  return CHM_OK;
+}
+
+extern "C" int chm_comm_destroy(chm_comm* c) {
+  if (!c) return CHM_OK;
+  (void)hipSetDevice(c->device);
+  if (c->d_buf) (void)hipFree(c->d_buf);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->comm) ncclCommDestroy(c->comm);
+  delete c;
+  return CHM_OK;
+}
+
+extern "C" int chm_comm_allreduce_sum(chm_comm* c, double* buf, int32_t n) {
+  if (!c || !buf || n <= 0) return fail(CHM_E_ARG, "chm_comm_allreduce_sum: bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  if (n > c->cap) { if (c->d_buf) hipFree(c->d_buf); c->d_buf = nullptr; HIPCHK(hipMalloc(&c->d_buf, sizeof(double) * n)); c->cap = n; }
+  HIPCHK(hipMemcpyAsync(c->d_buf, buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  NCCLCHK(ncclAllReduce(c->d_buf, c->d_buf, (size_t)n, ncclDouble, ncclSum, c->comm, c->stream));
+  HIPCHK(hipMemcpyAsync(buf, c->d_buf, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return CHM_OK;
+}

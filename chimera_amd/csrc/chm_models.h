@@ -1,0 +1,281 @@
+// chm_models.h -- device-side population models and jnp-semantics helpers (gfx950, fp64).
+//
+// Every function restates one function of the reference (file:line cited, paths relative to CHIMERA/),
+// with the reference's operation order; the translation unit is compiled with -ffp-contract=off so that
+// a*b+c is never fused behind the author's back (fused forms are written explicitly as fma() where used).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CHM_PI 3.141592653589793238462643383279502884
+
+struct DevParams {
+  int cosmo_model, mass_model, rate_model, Tc, Tm, scale_free, has_catalog, pad0;
+  double z_max;
+  double H0, Om0, Ok0, Or0, w0, wa, Xi0, n_mg;
+  double Ode0, dH;                       // cosmo.py:79-84
+  double m[8];                           // chm_params.mass
+  double r[4];                           // chm_params.rate
+  double R0, Tobs, zc0, zc1;
+  // constants derived once per draw by k_tables (same expressions the reference re-evaluates per element)
+  double plp_plnorm;                     // tpl_cdf(-alpha, m_low, m_high)           mass.py:301
+  double tg_norm;                        // truncated_gaussian norm                   mass.py:272-274
+  double tg_hi;                          // mu_g + 5 sigma_g                          mass.py:302
+  double g_c0;                           // -0.5 log(2 pi) - log(sigma)               mass.py:268
+  double bpl_mbreak, bpl_pl1, bpl_pl2;   // mass.py:291-293
+  double md_norm;                        // 1 + (1+zp)^(-gamma-kappa)                 rate.py:114
+  double tpl_rate_norm;                  // rate.py:105
+  double norm_p_m1;                      // mass.py:51
+  double fR;                             // completeness.py:54-58
+};
+
+struct TablePtrs {                       // per-draw tables (global memory)
+  const double* zt;  const double* It;  const double* dLt;   // (Tc)
+  const double* mg;  const double* cdf;                      // (Tm)
+};
+
+#define DEVFN __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------------------
+// jax.numpy semantics
+// ------------------------------------------------------------------------------------------------------
+
+// jnp.linspace(start, stop, num)[i]  (endpoint=True): start*(1-i/div) + stop*(i/div); last point == stop.
+DEVFN double jnp_linspace_at(double start, double stop, int num, int i) {
+  int div = num - 1;
+  if (i >= div) return stop;
+  double step = (double)i / (double)div;
+  return start * (1. - step) + stop * step;
+}
+
+// searchsorted(xp, x, side='right'): number of elements <= x (xp ascending).
+template <class Acc>
+DEVFN int searchsorted_right(Acc xp, int n, double x) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (xp[mid] <= x) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// jnp.interp(x, xp, fp, left, right); has_lr == false -> clamp to fp[0] / fp[n-1].
+template <class AccX, class AccF>
+DEVFN double jnp_interp(double x, AccX xp, AccF fp, int n, bool has_lr, double left, double right) {
+  int i = searchsorted_right(xp, n, x);
+  i = i < 1 ? 1 : (i > n - 1 ? n - 1 : i);
+  double x0 = xp[i - 1], x1 = xp[i];
+  double f0 = fp[i - 1], f1 = fp[i];
+  double df = f1 - f0, dx = x1 - x0, delta = x - x0;
+  const double epsilon = 4.930380657631324e-32;          // np.spacing(np.finfo(float64).eps)
+  bool dx0 = fabs(dx) <= epsilon;
+  double f = dx0 ? f0 : f0 + (delta / dx) * df;
+  double xfirst = xp[0], xlast = xp[n - 1];
+  if (x < xfirst) f = has_lr ? left : (double)fp[0];
+  if (x > xlast) f = has_lr ? right : (double)fp[n - 1];
+  return f;
+}
+
+// jnp.logaddexp(0, x) = max(0,x) + log1p(exp(-|x|))
+DEVFN double logaddexp0(double x) {
+  double amax = x > 0. ? x : 0.;
+  if (x != x) return x;
+  return amax + log1p(exp(-fabs(x)));
+}
+
+// ------------------------------------------------------------------------------------------------------
+// cosmology  (population/cosmo.py)
+// ------------------------------------------------------------------------------------------------------
+
+// cosmo.py:122-130
+DEVFN double E_at_z(const DevParams& p, double z) {
+  double zp1 = 1. + z;
+  double w_z = p.w0 + p.wa * z / (1. + z);
+  double z2 = zp1 * zp1;
+  double z3 = z2 * zp1;
+  double z4 = z2 * z2;
+  return sqrt(p.Om0 * z3 + p.Or0 * z4 + p.Ok0 * z2 + p.Ode0 * pow(zp1, 3. * (1. + w_z)));
+}
+
+// cosmo.py:225-228
+DEVFN double Xi_at_z(const DevParams& p, double z) {
+  return p.Xi0 + (1. - p.Xi0) / pow(1. + z, p.n_mg);
+}
+
+// cosmo.py:141-153 given dCr
+DEVFN double dCt_from_dCr(const DevParams& p, double dCr) {
+  if (p.Ok0 == 0.0) return dCr;
+  double sqrtOk0 = sqrt(fabs(p.Ok0 + 1.e-10));
+  if (p.Ok0 > 0.0) return (p.dH / sqrtOk0) * sinh(sqrtOk0 * dCr / p.dH);
+  return (p.dH / sqrtOk0) * sin(sqrtOk0 * dCr / p.dH);
+}
+
+// cosmo.py:132-153
+template <class A1, class A2>
+DEVFN double dCt_at_z(const DevParams& p, double z, A1 zt, A2 It) {
+  double dCr = p.dH * jnp_interp(z, zt, It, p.Tc, false, 0., 0.);
+  return dCt_from_dCr(p, dCr);
+}
+
+// cosmo.py:201-203, 230-235
+DEVFN double dL2dCt(const DevParams& p, double dist, double z) {
+  if (p.cosmo_model == 1) return (dist / Xi_at_z(p, z)) / (1. + z);
+  return dist / (1. + z);
+}
+
+// cosmo.py:205-210, 237-243 given dCt
+DEVFN double dL_from_dCt(const DevParams& p, double dCt, double z) {
+  double dL = dCt * (1. + z);
+  if (p.cosmo_model == 1) return dL * Xi_at_z(p, z);
+  return dL;
+}
+
+// cosmo.py:212-221, 245-257 given dCt
+DEVFN double ddLdz_from_dCt(const DevParams& p, double dCt, double z) {
+  double Ez = E_at_z(p, z);
+  double ddLflrw = dCt + (p.dH / Ez) * (1. + z);
+  if (p.cosmo_model == 1) {
+    double dLflrw = dCt * (1. + z);
+    double Xiz = Xi_at_z(p, z);
+    double dXiz = p.n_mg * (p.Xi0 - 1.) / pow(1. + z, p.n_mg + 1.);
+    return ddLflrw * Xiz + dLflrw * dXiz;
+  }
+  return ddLflrw;
+}
+
+// cosmo.py:188-197 given dCt
+DEVFN double dVcdz_from_dCt(const DevParams& p, double dCt, double z) {
+  return 4. * CHM_PI * p.dH * (dCt * dCt) / E_at_z(p, z);
+}
+
+// cosmo.py:166-186 given dCt
+DEVFN double Vc_from_dCt(const DevParams& p, double dCt) {
+  double dH = p.dH;
+  if (p.Ok0 == 0.0) return 4. * CHM_PI * (dCt * dCt * dCt) / 3.;
+  double regOk0 = p.Ok0 + 1e-10;
+  double sqrtOk0 = sqrt(fabs(regOk0));
+  double dH3 = dH * dH * dH;
+  double pre = 4. * CHM_PI * dH3 / (2. * regOk0);
+  double a = (dCt / dH) * sqrt(1. + regOk0 * (dCt * dCt) / (dH * dH));
+  if (p.Ok0 > 0.0) return pre * (a - asinh(sqrtOk0 * dCt / dH) / sqrtOk0);
+  return pre * (a - asin(sqrtOk0 * dCt / dH) / sqrtOk0);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// mass  (population/mass.py)
+// ------------------------------------------------------------------------------------------------------
+
+// mass.py:255-264
+DEVFN double smoothing(double m, double delta_m, double m_low) {
+  if (m < m_low) return 0.;
+  if (m > m_low + delta_m) return 1.;
+  const double eps = 1.e-99;
+  double x = delta_m / (m - m_low + eps) + delta_m / (m - m_low - delta_m + eps);
+  return exp(-logaddexp0(x));
+}
+
+// mass.py:240-245
+DEVFN double tpl_notnorm(double m, double alpha, double m_low, double m_high) {
+  return (m_low <= m && m <= m_high) ? pow(m, alpha) : 0.;
+}
+
+// mass.py:247-252
+DEVFN double tpl_cdf(double alpha, double m_low, double m) {
+  if (alpha == -1.) return log(m_low) - log(m);
+  return (pow(m, 1. + alpha) - pow(m_low, 1. + alpha)) / (1. + alpha);
+}
+
+// mass.py:285-305
+DEVFN double primary_notnorm(const DevParams& p, double m) {
+  double m_low = p.m[0], m_high = p.m[1];
+  if (p.mass_model == 0) {                       // tpl: alpha=m[2]
+    return tpl_notnorm(m, -p.m[2], m_low, m_high);
+  } else if (p.mass_model == 1) {                // bpl: alpha_1, alpha_2, beta, delta_m, break_fraction
+    double pdf = tpl_notnorm(m, -p.m[2], m_low, p.bpl_mbreak);
+    pdf = pdf + tpl_notnorm(m, -p.m[3], p.bpl_mbreak, m_high) * p.bpl_pl1 / p.bpl_pl2;
+    return pdf * smoothing(m, p.m[5], m_low);
+  } else {                                       // plp: lambda_peak, alpha, beta, delta_m, mu_g, sigma_g
+    double lam = p.m[2], mu = p.m[6], sg = p.m[7];
+    double P = tpl_notnorm(m, -p.m[3], m_low, m_high) / p.plp_plnorm;
+    double G = 0.;
+    if (m_low <= m && m <= p.tg_hi) {
+      double d = m - mu;
+      G = exp(p.g_c0 - (d * d) / (2. * (sg * sg))) / p.tg_norm;    // mass.py:267-279
+    }
+    double pdf = (1. - lam) * P + lam * G;
+    return pdf * smoothing(m, p.m[5], m_low);
+  }
+}
+
+DEVFN double mass_beta(const DevParams& p) { return p.mass_model == 0 ? p.m[3] : (p.mass_model == 1 ? p.m[4] : p.m[4]); }
+DEVFN double mass_delta_m(const DevParams& p) { return p.m[5]; }
+
+// mass.py:320-328
+DEVFN double secondary_notnorm(const DevParams& p, double m2, double m1) {
+  double pdf = tpl_notnorm(m2, mass_beta(p), p.m[0], m1);
+  if (p.mass_model == 0) return pdf;
+  return pdf * smoothing(m2, mass_delta_m(p), p.m[0]);
+}
+
+// mass.py:334-341
+template <class A1, class A2>
+DEVFN double p_m1m2(const DevParams& p, double m1, double m2, A1 mg, A2 cdf) {
+  double p_m1 = primary_notnorm(p, m1) / p.norm_p_m1;
+  double p_m2m1 = secondary_notnorm(p, m2, m1) / jnp_interp(m1, mg, cdf, p.Tm, false, 0., 0.);
+  if (p_m2m1 != p_m2m1) p_m2m1 = 0.;
+  return p_m1 * p_m2m1;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// rate  (population/rate.py:96-122)
+// ------------------------------------------------------------------------------------------------------
+DEVFN double merger_rate(const DevParams& p, double z) {
+  double g = p.r[0];
+  if (p.rate_model == 0) return pow(1. + z, g);
+  if (p.rate_model == 2) {
+    double pdf = pow(1. + z, g);
+    return z < p.r[3] ? pdf / p.tpl_rate_norm : 0.;
+  }
+  double k = p.r[1], zp = p.r[2];
+  double md = pow(1. + z, g) / (1. + pow((1. + z) / (1. + zp), g + k));
+  if (p.rate_model == 1) return p.md_norm * md;
+  return z < p.r[3] ? p.md_norm * md : 0.;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// wave / block reductions (wave = 64 lanes)
+// ------------------------------------------------------------------------------------------------------
+DEVFN double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// NaN-propagating min / max (jnp.min / jnp.max semantics)
+DEVFN double nanmin2(double a, double b) { return (a != a) ? a : ((b != b) ? b : (b < a ? b : a)); }
+DEVFN double nanmax2(double a, double b) { return (a != a) ? a : ((b != b) ? b : (b > a ? b : a)); }
+DEVFN double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = nanmin2(v, __shfl_xor(v, o, 64));
+  return v;
+}
+DEVFN double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = nanmax2(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide reductions for blockDim.x <= 1024; scratch: >= 16 doubles of LDS; result broadcast to all threads.
+enum { RED_SUM = 0, RED_MIN = 1, RED_MAX = 2 };
+template <int OP>
+DEVFN double block_reduce(double v, double* scratch) {
+  int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = OP == RED_SUM ? wave_sum(v) : (OP == RED_MIN ? wave_min(v) : wave_max(v));
+  __syncthreads();
+  if (lane == 0) scratch[wid] = v;
+  __syncthreads();
+  double r;
+  if (OP == RED_SUM) { r = 0.; for (int i = 0; i < nw; i++) r += scratch[i]; }
+  else if (OP == RED_MIN) { r = scratch[0]; for (int i = 1; i < nw; i++) r = nanmin2(r, scratch[i]); }
+  else { r = scratch[0]; for (int i = 1; i < nw; i++) r = nanmax2(r, scratch[i]); }
+  return r;
+}

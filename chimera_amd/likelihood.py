@@ -1,0 +1,234 @@
+"""Hyper-likelihood (reference: CHIMERA/likelihood.py:14-338) on MI355X.
+
+Same constructor, attributes and methods as the reference class.  The events, their z-grids and the catalogue term
+are copied to HBM once (``chm_like_create``); every call evaluates the whole path -- tables, det->src conversion and
+population weights, histogram + KDE, interpolation, integrand, trapezoid, pixel and event sums, selection function --
+in HIP kernels behind ``chm_eval`` (include/chimera_hip.h).  There is no CPU path.
+"""
+import ctypes as C
+from numbers import Number
+import numpy as np
+from . import _lib
+from .utils.config import logger
+from .parallel import chunk_bounds
+
+_BW = {None: 0, 'scott': 0, 'silverman': 1}
+
+
+def _pix_of_sample(pe_pix, pixels):
+  """Position of each sample's HEALPix index in its event's pixel list (-1: in none of the event's pixels);
+  the device-side form of ``pe_pix == pixels[i]`` (likelihood.py:179)."""
+  pe_pix, pixels = np.asarray(pe_pix), np.asarray(pixels)
+  E, P = pixels.shape
+  out = np.full(pe_pix.shape, -1, dtype=np.int32)
+  for e in range(E):
+    valid = pixels[e] != -100
+    ids = pixels[e][valid]
+    pos = np.flatnonzero(valid)
+    order = np.argsort(ids, kind='stable')
+    sid = ids[order]
+    if sid.size == 0:
+      continue
+    k = np.clip(np.searchsorted(sid, pe_pix[e]), 0, sid.size - 1)
+    hit = sid[k] == pe_pix[e]
+    out[e, hit] = pos[order][k[hit]]
+  return out
+
+
+class hyperlikelihood(object):
+  def __init__(self, theta_gw_det, z_grids, population, selection_function=None, kind_p_gw3d=None, kernel='epan',
+               bw_method=None, cut_grid=2.0, binning=True, num_bins=200, pe_neff=2.0, comm=None, device=None):
+    self.theta_gw_det = theta_gw_det
+    self.population = population
+    self.z_grids = np.ascontiguousarray(z_grids, dtype=np.float64)
+    self.selection_function = selection_function
+    self.kind_p_gw3d = kind_p_gw3d
+    self.kernel = kernel
+    self.bw_method = bw_method
+    self.cut_grid = cut_grid
+    self.binning = binning
+    self.num_bins = num_bins
+    self.pe_neff = pe_neff
+    self.comm = comm
+    self.device = (comm.device if comm is not None else _lib.default_device()) if device is None else device
+
+    self.pixelated = True if self.theta_gw_det.pixels_opt_nsides is not None else False     # likelihood.py:79
+    self.nevents = len(self.theta_gw_det.dL)
+    self.z_int_res = self.z_grids.shape[1]
+
+    if not (bw_method is None or bw_method in ('scott', 'silverman')
+            or (isinstance(bw_method, Number) and not isinstance(bw_method, bool))):
+      raise ValueError("bw_method should be 'scott', 'silverman', or a scalar")               # math.py:75
+    if kernel not in ('epan', 'gauss'):
+      raise ValueError("kernel must be 'epan' or 'gauss'")
+
+    if self.pixelated:
+      assert self.kind_p_gw3d in ['approximate', 'marginalized', 'full'], \
+        "`kind_p_gw3d` must be one of `approximate`, `marginalized`, or `full`"              # likelihood.py:85
+      self.max_npixels = self.population.gal_cat.max_npixels
+      self.neff_pixels = self.population.gal_cat.neff_pixels
+      self.p_gw3d = {'approximate': self.p_gw3dapprox, 'marginalized': self.p_gw3dmarg,
+                     'full': self.p_gw3dfull}[self.kind_p_gw3d]
+      if self.kind_p_gw3d == 'full':
+        logger.info("`king_p_gw3d` has been set to 'full'. Only available kernel is `gaussian`. "
+                    "The `binning` option is not available.")
+      self._mode = self.kind_p_gw3d
+    else:
+      self._mode = '1d'
+    if comm is not None and comm.nranks > 1:
+      self._e0, self._e1 = chunk_bounds(self.nevents, comm.nranks, comm.rank)
+    else:
+      self._e0, self._e1 = 0, self.nevents
+    self._handles = {}
+    logger.info(f'Created hyperlikelihood model. Using {self.nevents} GW events.')
+
+  # -- device handles ----------------------------------------------------------------------------------
+  def _handle(self, mode=None):
+    mode = self._mode if mode is None else mode
+    if mode in self._handles:
+      return self._handles[mode][0]
+    th = self.theta_gw_det
+    E, S = np.shape(th.dL)
+    keep = []
+
+    def f64(a, shape, name):
+      a = _lib.as_f64(a)
+      if a.shape != shape:
+        raise ValueError(f"hyperlikelihood: `{name}` has shape {a.shape}, expected {shape}")
+      keep.append(a)
+      return _lib.dptr(a)
+
+    d = _lib.chm_like_desc()
+    d.E, d.S, d.Z = E, S, self.z_int_res
+    d.ev_begin, d.ev_end = self._e0, self._e1
+    d.dL, d.m1det, d.m2det = f64(th.dL, (E, S), 'dL'), f64(th.m1det, (E, S), 'm1det'), f64(th.m2det, (E, S), 'm2det')
+    d.pe_prior = f64(th.pe_prior, (E, S), 'pe_prior')
+    d.z_grids = f64(self.z_grids, (E, self.z_int_res), 'z_grids')
+    if mode != '1d':
+      gc = self.population.gal_cat
+      P = int(self.max_npixels)
+      d.P = P
+      d.p_cat = f64(gc.p_cat, (E, P, self.z_int_res), 'gal_cat.p_cat')
+      d.P_compl = f64(np.asarray(gc.P_compl).reshape(E, self.z_int_res), (E, self.z_int_res), 'gal_cat.P_compl')
+      d.gw_loc2d_pdf = f64(th.gw_loc2d_pdf, (E, P), 'gw_loc2d_pdf')
+      neff = np.ascontiguousarray(self.neff_pixels, dtype=np.int32)
+      if neff.shape != (E,):
+        raise ValueError("hyperlikelihood: `neff_pixels` must have shape (Nevents,)")
+      keep.append(neff)
+      d.neff_pixels = _lib.iptr(neff)
+      if mode == 'marginalized':
+        pos = np.ascontiguousarray(_pix_of_sample(th.pixels_pe_opt_nside, th.pixels_opt_nsides))
+        keep.append(pos)
+        d.pix_of_sample = _lib.iptr(pos)
+      if mode == 'full':
+        d.ra, d.dec = f64(th.ra, (E, S), 'ra'), f64(th.dec, (E, S), 'dec')
+        d.ra_pix, d.dec_pix = f64(th.ra_pix, (E, P), 'ra_pix'), f64(th.dec_pix, (E, P), 'dec_pix')
+    else:
+      d.P = 0
+    d.mode = _lib.MODE[mode]
+    d.kernel = _lib.KERNEL[self.kernel]
+    if isinstance(self.bw_method, Number):
+      d.bw_method, d.bw_scalar = 2, float(self.bw_method)
+    else:
+      d.bw_method, d.bw_scalar = _BW[self.bw_method], 0.
+    d.binning = int(bool(self.binning))
+    d.num_bins = int(self.num_bins)
+    d.cut_grid = float('nan') if self.cut_grid is None else float(self.cut_grid)
+    d.pe_neff = float(self.pe_neff)
+    d.device = self.device
+    h = C.c_void_p()
+    _lib.check(_lib.lib().chm_like_create(C.byref(d), C.byref(h)))
+    self._handles[mode] = (h, None)
+    return h
+
+  def close(self):
+    for h, _ in self._handles.values():
+      _lib.lib().chm_like_destroy(h)
+    self._handles = {}
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  # -- one evaluation through the C ABI ----------------------------------------------------------------
+  def _eval(self, pops, want=(), mode=None, with_sel=True):
+    """Evaluate a list of population draws.  ``want`` subset of {'log_like_evs','numlike_evs','p_gw','partials'}."""
+    nb = len(pops)
+    params = (_lib.chm_params * nb)(*[p.to_params() for p in pops])
+    h = self._handle(mode)
+    El = self._e1 - self._e0
+    res = {'log_hyper': np.empty(nb), 'log_num': np.empty(nb), 'N_exp': np.empty(nb)}
+    out = _lib.chm_out()
+    out.log_hyper, out.log_num, out.N_exp = (_lib.dptr(res[k]) for k in ('log_hyper', 'log_num', 'N_exp'))
+    if 'log_like_evs' in want:
+      res['log_like_evs'] = np.empty((nb, El)); out.log_like_evs = _lib.dptr(res['log_like_evs'])
+    if 'numlike_evs' in want:
+      res['numlike_evs'] = np.empty((nb, El)); out.numlike_evs = _lib.dptr(res['numlike_evs'])
+    if 'p_gw' in want:
+      m = self._mode if mode is None else mode
+      shape = (nb, El, self.z_int_res) if m == '1d' else (nb, El, int(self.max_npixels), self.z_int_res)
+      res['p_gw'] = np.empty(shape); out.p_gw = _lib.dptr(res['p_gw'])
+    if 'partials' in want:
+      res['partials'] = np.empty((nb, 3)); out.partials = _lib.dptr(res['partials'])
+    sel = self.selection_function._handle() if (with_sel and self.selection_function is not None) else None
+    comm_h = self.comm.handle if (self.comm is not None and self.comm.nranks > 1) else None
+    _lib.check(_lib.lib().chm_eval(h, sel, comm_h, params, nb, self.nevents, C.byref(out)))
+    return res
+
+  def last_timing(self):
+    """HIP-event timings [ms] of the last evaluation: total, tables, samples, kde+integrand, selection, reduce."""
+    ms = np.zeros(8)
+    sel = self.selection_function._handle() if self.selection_function is not None else None
+    _lib.check(_lib.lib().chm_last_timing(self._handle(), sel, _lib.dptr(ms)))
+    return ms
+
+  # -- reference surface: GW kernels -------------------------------------------------------------------
+  def p_gw1d(self, pop_lambdas):
+    """likelihood.py:105-144 -> (Nevents, z_int_res)."""
+    return self._eval([pop_lambdas], want=('p_gw',), mode='1d', with_sel=False)['p_gw'][0]
+
+  def p_gw3dapprox(self, pop_lambdas):
+    """likelihood.py:150-154 -> (Nevents, max_npixels, z_int_res)."""
+    return self._eval([pop_lambdas], want=('p_gw',), mode='approximate', with_sel=False)['p_gw'][0]
+
+  def p_gw3dmarg(self, pop_lambdas):
+    """likelihood.py:160-205."""
+    return self._eval([pop_lambdas], want=('p_gw',), mode='marginalized', with_sel=False)['p_gw'][0]
+
+  def p_gw3dfull(self, pop_lambdas):
+    """likelihood.py:211-260."""
+    return self._eval([pop_lambdas], want=('p_gw',), mode='full', with_sel=False)['p_gw'][0]
+
+  # -- reference surface: numerator --------------------------------------------------------------------
+  def compute_numlike_evs(self, pop_lambdas):
+    """likelihood.py:266-292 -> (Nevents,) [this rank's events when sharded]."""
+    return self._eval([pop_lambdas], want=('numlike_evs',), with_sel=False)['numlike_evs'][0]
+
+  def compute_log_likenum(self, pop_lambdas):
+    """likelihood.py:294-301."""
+    return self._eval([pop_lambdas], with_sel=False)['log_num'][0]
+
+  # -- reference surface: hyper-likelihood -------------------------------------------------------------
+  def compute_log_hyperlike(self, **hyper_lambdas):
+    """likelihood.py:307-316."""
+    pop_lambdas = self.population.update(**hyper_lambdas)
+    return self._eval([pop_lambdas])['log_hyper'][0]
+
+  def __call__(self, **hyper_lambdas):
+    """likelihood.py:318-320."""
+    return self.compute_log_hyperlike(**hyper_lambdas)
+
+  def compute_all(self, **hyper_lambdas):
+    """likelihood.py:326-338 -> (log_like_evs, log_like_num, log N_exp, log_hyper)."""
+    pop_lambdas = self.population.update(**hyper_lambdas)
+    r = self._eval([pop_lambdas], want=('log_like_evs',))
+    with np.errstate(all='ignore'):
+      return r['log_like_evs'][0], r['log_num'][0], np.log(r['N_exp'][0]), r['log_hyper'][0]
+
+  # -- batched draws (the reference's 'params' scheme, CHIMERA/parallel.py:258-278) ----------------------
+  def batch(self, list_of_hyper_lambdas):
+    """log-hyperlikelihood of several draws in one launch sequence: array of len(list)."""
+    pops = [self.population.update(**lam) for lam in list_of_hyper_lambdas]
+    return self._eval(pops)['log_hyper']

@@ -1,0 +1,83 @@
+"""Mass models (reference: CHIMERA/population/mass.py): ``tpl``, ``bpl``, ``plp`` with the reference's parameters and
+defaults.  ``pl2p`` and ``pls`` are broken / unfinished in the reference (mass.py:307-314, 193-233) and are not provided.
+Normalisation tables (mass.py:45-52) and pdfs are evaluated on the GPU.
+"""
+import numpy as np
+from .. import _lib
+from ..data import theta_src
+from ._base import base_struct, make_params, model_eval, model_tables
+
+
+class base_mass_paired_struct(base_struct):
+  default = {'m_low': 5.1, 'm_high': 87., 'grid_res': 1000}
+  name = 'base_mass_paired_struct'
+
+  def _tab(self):
+    if self._tables is None:
+      self._tables = model_tables(make_params(mass=self))
+    return self._tables
+
+  @property
+  def m_grid(self):
+    return self._tab()['m_grid']
+
+  @property
+  def cdf_m2_conditioned(self):
+    return self._tab()['cdf_m2_conditioned']
+
+  @property
+  def norm_p_m1(self):
+    return self._tab()['norm_p_m1']
+
+
+class tpl(base_mass_paired_struct):
+  """mass.py:56-83."""
+  default = {**base_mass_paired_struct.default, 'alpha': 2.5, 'beta': 1.1}
+  name = 'truncated_power_law'
+
+  def _pack(self):
+    return dict(model=0, vec=[self.m_low, self.m_high, self.alpha, self.beta], grid_res=self.grid_res)
+
+
+class bpl(base_mass_paired_struct):
+  """mass.py:85-115."""
+  default = {**base_mass_paired_struct.default, 'alpha_1': 1.6, 'alpha_2': 5.6, 'beta': 1.1, 'delta_m': 4.8,
+             'break_fraction': 0.43}
+  name = 'broken_power_law'
+
+  def _pack(self):
+    return dict(model=1, vec=[self.m_low, self.m_high, self.alpha_1, self.alpha_2, self.beta, self.delta_m,
+                              self.break_fraction], grid_res=self.grid_res)
+
+
+class plp(base_mass_paired_struct):
+  """mass.py:117-149."""
+  default = {**base_mass_paired_struct.default, 'lambda_peak': 0.039, 'alpha': 3.4, 'beta': 1.1, 'delta_m': 4.8,
+             'mu_g': 34., 'sigma_g': 3.6}
+  name = 'power_law_plus_peak'
+
+  def _pack(self):
+    return dict(model=2, vec=[self.m_low, self.m_high, self.lambda_peak, self.alpha, self.beta, self.delta_m,
+                              self.mu_g, self.sigma_g], grid_res=self.grid_res)
+
+
+def primary_mass_pdf_notnorm(mass, m):
+  """mass.py:285-305."""
+  return model_eval(make_params(mass=mass), _lib.F_PRIMARY, m)
+
+
+def secondary_mass_conditioned_pdf_notnorm(mass, m2, m1):
+  """mass.py:320-328."""
+  return model_eval(make_params(mass=mass), _lib.F_SECONDARY, m2, m1)
+
+
+def smoothing(m, delta_m, m_low):
+  """mass.py:255-264."""
+  return model_eval(make_params(mass=plp(delta_m=delta_m, m_low=m_low)), _lib.F_SMOOTHING, m)
+
+
+def p_m1m2(mass, m1, m2=None):
+  """mass.py:334-345 (array and theta_src overloads)."""
+  if isinstance(m1, theta_src):
+    m1, m2 = m1.m1src, m1.m2src
+  return model_eval(make_params(mass=mass), _lib.F_PM1M2, m1, m2)

@@ -1,0 +1,71 @@
+"""Selection function (reference: CHIMERA/selection_function.py:10-53).
+
+``N_exp(pop)`` = Tobs * nansum(dN/dtheta / p_draw) / N_inj with the N_eff guard, evaluated by the HIP kernels
+``k_selection`` + ``k_reduce`` + ``k_combine`` (chimera_amd/csrc/chm_kernels.h) over the detected injections resident
+in HBM.  With ``comm=`` the injections are sharded across ranks (CHIMERA/parallel.py:68-73).
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+from .data import theta_inj_det
+from .parallel import chunk_bounds
+
+
+class selection_function(object):
+  def __init__(self, theta_inj_det, N_inj, N_eff=5., comm=None, device=None):
+    self.theta_inj_det = theta_inj_det
+    self.N_inj = N_inj
+    self.N_eff = N_eff
+    self.comm = comm
+    self.device = (comm.device if comm is not None else _lib.default_device()) if device is None else device
+    self._h = None
+
+  # -- device handle -----------------------------------------------------------------------------------
+  def _handle(self):
+    if self._h is not None:
+      return self._h
+    th = self.theta_inj_det
+    arrs = [_lib.as_f64(getattr(th, k)).ravel() for k in ('dL', 'm1det', 'm2det', 'p_draw')]
+    n = arrs[0].size
+    if any(a.size != n for a in arrs):
+      raise ValueError("theta_inj_det: dL, m1det, m2det, p_draw must have the same length")
+    d = _lib.chm_sel_desc()
+    d.I = n
+    if self.comm is not None and self.comm.nranks > 1:
+      d.inj_begin, d.inj_end = chunk_bounds(n, self.comm.nranks, self.comm.rank)
+    else:
+      d.inj_begin, d.inj_end = 0, n
+    d.dL, d.m1det, d.m2det, d.p_draw = (_lib.dptr(a) for a in arrs)
+    d.N_inj = float(self.N_inj)
+    d.N_eff = float('nan') if self.N_eff is None else float(self.N_eff)
+    d.device = self.device
+    h = C.c_void_p()
+    _lib.check(_lib.lib().chm_sel_create(C.byref(d), C.byref(h)))
+    self._h = h
+    return h
+
+  def close(self):
+    if self._h is not None:
+      _lib.lib().chm_sel_destroy(self._h)
+      self._h = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  # -- reference surface -------------------------------------------------------------------------------
+  def N_exp(self, pop_lambdas):
+    """selection_function.py:34-48."""
+    p = pop_lambdas.to_params()
+    nexp = np.empty(1)
+    out = _lib.chm_out()
+    out.N_exp = _lib.dptr(nexp)
+    comm_h = self.comm.handle if (self.comm is not None and self.comm.nranks > 1) else None
+    _lib.check(_lib.lib().chm_eval(None, self._handle(), comm_h, C.byref(p), 1, 0, C.byref(out)))
+    return nexp[0]
+
+  def __call__(self, pop_lambdas):
+    """selection_function.py:50-53."""
+    return self.N_exp(pop_lambdas)

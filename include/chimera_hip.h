@@ -1,0 +1,183 @@
+/*
+ * chimera_hip.h -- C ABI of libchimera_hip.so: the MI355X (gfx950) implementation of CHIMERA's
+ * hyper-likelihood hot path.
+ *
+ * The reference (CosmoStatGW/CHIMERA v2.0.0) is pure Python on JAX and has NO foreign-function boundary;
+ * its "operator API" for this path is the Python surface
+ *     hyperlikelihood.__call__/compute_log_hyperlike/compute_all      CHIMERA/likelihood.py:307-338
+ *     selection_function.N_exp                                         CHIMERA/selection_function.py:34-48
+ *     population.update                                                CHIMERA/population/pop_wrapper.py:56-64
+ * This header is the boundary a maintainer would bind with ctypes underneath that unchanged surface
+ * (see INTEGRATION.md).  Each entry point cites the reference code it replaces.
+ *
+ * Conventions: every array is C-contiguous; floating point is IEEE fp64 (the reference enables jax x64,
+ * CHIMERA/utils/config.py:5); padded per-pixel arrays carry the reference's sentinel -100
+ * (CHIMERA/catalog/catalog.py:174-176, CHIMERA/data.py:348-351).  Host buffers passed to *_create are
+ * copied to the device and may be freed on return; outputs are written to caller-allocated host buffers.
+ * Every function returns 0 on success or a negative CHM_E_* code, with a message in chm_last_error()
+ * (thread-local).  NaN / -inf likelihood values are results, not errors (likelihood.py:296-297).
+ * A handle is not thread-safe; calls are synchronous (internally asynchronous on one HIP stream).
+ */
+#ifndef CHIMERA_HIP_H
+#define CHIMERA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHM_OK        0
+#define CHM_E_ARG    -1   /* bad argument (Python wrapper raises ValueError)     */
+#define CHM_E_HIP    -2   /* HIP runtime error (RuntimeError)                    */
+#define CHM_E_NOMEM  -3   /* device allocation failed                            */
+#define CHM_E_RCCL   -4   /* RCCL error                                          */
+
+/* kind of GW kernel: likelihood.py:88-97 */
+enum { CHM_MODE_1D = 0, CHM_MODE_APPROX = 1, CHM_MODE_MARG = 2, CHM_MODE_FULL = 3 };
+/* kde1d kernel: CHIMERA/utils/math.py:77,83-89 */
+enum { CHM_KERNEL_EPAN = 0, CHM_KERNEL_GAUSS = 1 };
+/* bandwidth rule: math.py:65-75, 178-185 */
+enum { CHM_BW_SCOTT = 0, CHM_BW_SILVERMAN = 1, CHM_BW_SCALAR = 2 };
+/* model ids: cosmo.py:50-115, mass.py:56-149, rate.py:32-88 */
+enum { CHM_COSMO_FLRW = 0, CHM_COSMO_MG_FLRW = 1 };
+enum { CHM_MASS_TPL = 0, CHM_MASS_BPL = 1, CHM_MASS_PLP = 2 };
+enum { CHM_RATE_PL = 0, CHM_RATE_MD = 1, CHM_RATE_TPL = 2, CHM_RATE_TMD = 3 };
+
+/* slots of chm_params.cosmo[] */
+enum { CHM_C_H0 = 0, CHM_C_OM0, CHM_C_OK0, CHM_C_OR0, CHM_C_W0, CHM_C_WA, CHM_C_XI0, CHM_C_N, CHM_NCOSMO };
+/* slots of chm_params.mass[]: common m_low, m_high; then per model
+ *   tpl: alpha, beta            bpl: alpha_1, alpha_2, beta, delta_m, break_fraction
+ *   plp: lambda_peak, alpha, beta, delta_m, mu_g, sigma_g                                    */
+enum { CHM_M_MLOW = 0, CHM_M_MHIGH = 1, CHM_M_P0 = 2, CHM_NMASS = 8 };
+/* slots of chm_params.rate[]: gamma, kappa, zp, zmax */
+enum { CHM_R_GAMMA = 0, CHM_R_KAPPA, CHM_R_ZP, CHM_R_ZMAX, CHM_NRATE };
+
+/* One hyper-parameter draw = the state of population.update(**lambda) (pop_wrapper.py:56-64). */
+typedef struct chm_params {
+  int32_t cosmo_model, mass_model, rate_model;
+  int32_t z_grid_res;            /* T_c: cosmology table length (cosmo.py:77, default 1500)          */
+  int32_t mass_grid_res;         /* T_m: mass table length (mass.py:20, default 1000)               */
+  int32_t scale_free;            /* pop_wrapper.py:31                                               */
+  int32_t has_catalog;           /* 0: empty_catalog (catalog.py:19-43); 1: pixelated_catalog       */
+  int32_t _pad;
+  double  z_max;                 /* cosmo.py:18                                                     */
+  double  cosmo[CHM_NCOSMO];
+  double  mass[CHM_NMASS];
+  double  rate[CHM_NRATE];
+  double  R0, Tobs;              /* pop_wrapper.py:18-20                                            */
+  double  compl_z0, compl_z1;    /* dVdz_completeness.z_range (completeness.py:35)                  */
+} chm_params;
+
+/* GW events + per-event grids + catalogue term: everything hyperlikelihood.__init__ receives
+ * (likelihood.py:48-99) apart from the population model.                                            */
+typedef struct chm_like_desc {
+  int32_t E, S, Z, P;            /* events, samples/event, z-grid points, max_npixels (0 if not pixelated) */
+  int32_t ev_begin, ev_end;      /* shard: only events [ev_begin, ev_end) are uploaded (0,E = all)   */
+  const double*  dL;             /* (E,S) theta_pe_det.dL         data.py:30                          */
+  const double*  m1det;          /* (E,S)                         data.py:28                          */
+  const double*  m2det;          /* (E,S)                         data.py:29                          */
+  const double*  pe_prior;       /* (E,S)                         data.py:35,45-47                    */
+  const double*  ra;             /* (E,S) full mode only, else NULL   data.py:33                      */
+  const double*  dec;            /* (E,S) full mode only, else NULL   data.py:34                      */
+  const int32_t* pix_of_sample;  /* (E,S) index into the event's pixel list (position of
+                                    pixels_pe_opt_nside in pixels_opt_nsides), -1 = in no pixel;
+                                    NULL if not pixelated.   likelihood.py:174-179                    */
+  const double*  z_grids;        /* (E,Z)                         likelihood.py:67                    */
+  const double*  p_cat;          /* (E,P,Z) -100 padded, NULL if not pixelated  catalog.py:189        */
+  const double*  P_compl;        /* (E,Z)   NULL if not pixelated               catalog.py:195        */
+  const double*  gw_loc2d_pdf;   /* (E,P) -100 padded             data.py:42                          */
+  const double*  ra_pix;         /* (E,P) -100 padded (full mode) data.py:40                          */
+  const double*  dec_pix;        /* (E,P) -100 padded (full mode) data.py:41                          */
+  const int32_t* neff_pixels;    /* (E,)                          catalog.py:118                      */
+  int32_t mode;                  /* CHM_MODE_*                                                        */
+  int32_t kernel;                /* CHM_KERNEL_* (ignored by marginalized: always epan, likelihood.py:192) */
+  int32_t bw_method;             /* CHM_BW_*                                                          */
+  int32_t binning;               /* likelihood.py:58                                                  */
+  int32_t num_bins;              /* likelihood.py:59                                                  */
+  int32_t device;                /* HIP device ordinal                                                */
+  double  bw_scalar;             /* used when bw_method == CHM_BW_SCALAR                              */
+  double  cut_grid;              /* NaN = None (likelihood.py:115,185)                                */
+  double  pe_neff;               /* likelihood.py:61                                                  */
+} chm_like_desc;
+
+/* Detected injections: selection_function.__init__ (selection_function.py:24-32). */
+typedef struct chm_sel_desc {
+  int64_t I;                     /* detected injections in the arrays                                 */
+  int64_t inj_begin, inj_end;    /* shard [inj_begin, inj_end) (0,I = all)                            */
+  const double* dL;              /* (I,) theta_inj_det.dL      data.py:52                             */
+  const double* m1det;           /* (I,)                                                             */
+  const double* m2det;           /* (I,)                                                             */
+  const double* p_draw;          /* (I,)                       data.py:53                             */
+  double N_inj;                  /* total generated injections (all shards)                           */
+  double N_eff;                  /* NaN = None (selection_function.py:43)                             */
+  int32_t device;
+  int32_t _pad;
+} chm_sel_desc;
+
+/* Outputs of one evaluation; any pointer may be NULL (not wanted). nb = number of draws. */
+typedef struct chm_out {
+  double* log_hyper;     /* (nb,)       compute_log_hyperlike           likelihood.py:307-316         */
+  double* log_num;       /* (nb,)       compute_log_likenum             likelihood.py:294-301         */
+  double* N_exp;         /* (nb,)       selection_function.N_exp        selection_function.py:34-48   */
+  double* log_like_evs;  /* (nb,E_loc)  nan_to_num(log L_i)             likelihood.py:329-330         */
+  double* numlike_evs;   /* (nb,E_loc)  L_i = compute_numlike_evs       likelihood.py:266-292         */
+  double* p_gw;          /* (nb,E_loc,P,Z) p_gw3d, or (nb,E_loc,Z) p_gw1d in 1-D mode  likelihood.py:105-260 */
+  double* partials;      /* (nb,3)      this shard's [sum_i log L_i, nansum dN, sum dN^2]             */
+} chm_out;
+
+typedef struct chm_like chm_like;
+typedef struct chm_sel  chm_sel;
+typedef struct chm_comm chm_comm;
+
+const char* chm_version(void);
+int         chm_device_count(void);
+const char* chm_last_error(void);
+
+/* hyperlikelihood.__init__ (likelihood.py:48-99): upload one shard of events to desc->device. */
+int chm_like_create(const chm_like_desc* desc, chm_like** out);
+int chm_like_destroy(chm_like* h);
+
+/* selection_function.__init__ (selection_function.py:24-32). */
+int chm_sel_create(const chm_sel_desc* desc, chm_sel** out);
+int chm_sel_destroy(chm_sel* h);
+
+/* hyperlikelihood.compute_all / __call__ for nb draws (likelihood.py:307-338).  `like` or `sel` may be NULL:
+ * with sel == NULL only the numerator outputs are produced; with like == NULL only N_exp.
+ * With comm != NULL the shard partials are summed over ranks with one RCCL all-reduce of 3*nb doubles
+ * (what CHIMERA/parallel.py:366-376,406-407 intended with mpi4jax.allreduce) before the combination;
+ * E_total is the number of events over all shards (ignored when comm == NULL).                        */
+int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_params* params, int32_t nb,
+             int64_t E_total, chm_out* out);
+
+/* Elementwise model functions on the device (cosmo.py:122-264, mass.py:334-341, rate.py:96-122),
+ * used by the Python free functions and by compute_z_grids (pop_wrapper.py:133-208).                  */
+enum { CHM_F_E = 0, CHM_F_INT_INVE, CHM_F_DCR, CHM_F_DCT, CHM_F_DL, CHM_F_DDLDZ, CHM_F_DVCDZ, CHM_F_VC,
+       CHM_F_XI, CHM_F_Z_FROM_DGW, CHM_F_RATE, CHM_F_PM1M2, CHM_F_PRIMARY, CHM_F_SECONDARY, CHM_F_SMOOTHING };
+/* out[i] = f(a[i] [, b[i]]):  cosmology functions take a = z and optional b = original distances
+ * (cosmo.py:155-221; b may be NULL); Z_FROM_DGW takes a = dGW; RATE takes a = z; PM1M2 / SECONDARY take
+ * a = m1, b = m2 (SECONDARY: a = m2, b = m1); PRIMARY / SMOOTHING take a = m.                           */
+int chm_model_eval(const chm_params* p, int32_t func, const double* a, const double* b, int64_t n,
+                   double* out, int32_t device);
+/* Per-draw tables (cosmo.py:43-46, 263; mass.py:45-52). Any pointer may be NULL.
+ * zt, It, dLt: (z_grid_res,)   mgrid, cdf_m2: (mass_grid_res,)   scalars: [norm_p_m1, fR]             */
+int chm_model_tables(const chm_params* p, double* zt, double* It, double* dLt, double* mgrid,
+                     double* cdf_m2, double* scalars, int32_t device);
+
+/* Event/injection sharding across GPUs: one process per GPU, RCCL over xGMI.
+ * Replaces the MPI layer CHIMERA/parallel.py:94-99,68-73,366-376 (dead code in v2.0.0).               */
+int chm_comm_unique_id(char id[128]);                       /* rank 0; broadcast the bytes out-of-band */
+int chm_comm_init_rank(const char id[128], int32_t nranks, int32_t rank, int32_t device, chm_comm** out);
+int chm_comm_destroy(chm_comm* c);
+/* sum a small fp64 vector over ranks in place (host pointer; staged through the device). */
+int chm_comm_allreduce_sum(chm_comm* c, double* buf, int32_t n);
+
+/* Timing of the last chm_eval on a handle, from HIP events recorded on the handle's own stream:
+ * ms[0] = whole evaluation, ms[1] = tables, ms[2] = sample stage, ms[3] = KDE+integrand kernel,
+ * ms[4] = selection kernel, ms[5] = reduce/combine.  Used by bench.py for the roofline line.          */
+int chm_last_timing(chm_like* like, chm_sel* sel, double ms[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

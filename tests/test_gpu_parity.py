@@ -1,0 +1,156 @@
+"""GPU parity tests: the HIP path (through the C ABI / ctypes) against the NumPy oracle on the same seeded inputs.
+
+Stated fp64 tolerance: tables rtol 1e-13; per-event L_i rtol 1e-9; p_gw rtol 1e-9 (+ tiny atol at
+the edge of the Epanechnikov support); log-hyperlikelihood atol 1e-7*sqrt(E).
+"""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from oracle import chimera_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL_L = 1e-9
+
+
+@pytest.fixture(scope='module')
+def cfg_pix():
+  return H.small_config(E=6, S=256, P=4, Z=64, I=3000, seed=11, ragged=True)
+
+
+@pytest.fixture(scope='module')
+def cfg_1d():
+  return H.small_config(E=5, S=300, Z=80, I=3000, seed=12, pixelated=False)
+
+
+def test_tables_and_model_functions():
+  import chimera_amd as CH
+  for cname, kw in [('flrw', dict(H0=67., Om0=0.31, z_max=5.)), ('flrw', dict(H0=80., Om0=0.3, Ok0=0.05, w0=-0.9, wa=0.2)),
+                    ('flrw', dict(H0=60., Om0=0.3, Ok0=-0.04, Or0=1e-4)), ('mg_flrw', dict(H0=70., Xi0=1.8, n=1.9, z_max=5.))]:
+    co, cp = getattr(O, cname)(**kw), getattr(CH.cosmo, cname)(**kw)
+    np.testing.assert_allclose(cp.z_grid_interp, co.z_grid_interp, rtol=1e-13, atol=0)
+    np.testing.assert_allclose(cp.integral_invE_interp, co.integral_invE_interp, rtol=1e-13, atol=1e-300)
+    z = np.concatenate([[0., 1e-12, 1e-5], np.linspace(0.001, co.z_max * 1.05, 301)])
+    dL = O.dL_at_z(co, z)
+    for fn in ('E_at_z', 'int_invE_at_z', 'dCr_at_z', 'dCt_at_z', 'dL_at_z', 'ddLdz_at_z', 'dVcdz_at_z', 'Vc_at_z'):
+      np.testing.assert_allclose(getattr(CH.cosmo, fn)(cp, z), getattr(O, fn)(co, z), rtol=2e-13, atol=1e-300, err_msg=fn)
+    for fn in ('ddLdz_at_z', 'dVcdz_at_z', 'Vc_at_z'):
+      np.testing.assert_allclose(getattr(CH.cosmo, fn)(cp, z[3:], dL[3:]), getattr(O, fn)(co, z[3:], dL[3:]), rtol=2e-13, err_msg=fn)
+    d = np.concatenate([[0., 1e-9], np.linspace(0.01, 1.2 * dL.max(), 400)])
+    np.testing.assert_allclose(CH.cosmo.z_from_dGW(cp, d), O.z_from_dGW(co, d), rtol=2e-13, atol=1e-300)
+  m1 = np.linspace(3., 100., 389)
+  m2 = m1 * np.linspace(0.05, 1.1, 389)
+  for mname, kw in [('plp', {}), ('plp', dict(alpha=2.1, mu_g=30., delta_m=3.)), ('tpl', {}), ('bpl', {}), ('tpl', dict(alpha=1.0))]:
+    mo, mp = getattr(O, mname)(**kw), getattr(CH.mass, mname)(**kw)
+    np.testing.assert_allclose(mp.m_grid, mo.m_grid, rtol=1e-13)
+    np.testing.assert_allclose(mp.cdf_m2_conditioned, mo.cdf_m2_conditioned, rtol=1e-13, atol=1e-300)
+    np.testing.assert_allclose(mp.norm_p_m1, mo.norm_p_m1, rtol=1e-13)
+    np.testing.assert_allclose(CH.mass.p_m1m2(mp, m1, m2), O.p_m1m2(mo, m1, m2), rtol=1e-12, atol=1e-300, err_msg=mname)
+    np.testing.assert_allclose(CH.mass.primary_mass_pdf_notnorm(mp, m1), O.primary_mass_pdf_notnorm(mo, m1), rtol=1e-12, atol=1e-300)
+  z = np.linspace(0., 3., 200)
+  for rname in ('power_law', 'madau_dickinson', 'trunc_power_law', 'trunc_madau_dickinson'):
+    np.testing.assert_allclose(CH.rate.merger_rate(getattr(CH.rate, rname)(), z), O.merger_rate(getattr(O, rname)(), z), rtol=1e-13)
+  comp_o, comp_p = O.dVdz_completeness(), CH.completeness.dVdz_completeness()
+  np.testing.assert_allclose(comp_p.fR(CH.cosmo.flrw(H0=67.)), comp_o.fR(O.flrw(H0=67.)), rtol=1e-12)
+
+
+def _compare(like_p, like_o, lam, E, check_pgw=True):
+  ro = like_o.compute_all(**lam)
+  rp = like_p.compute_all(**lam)
+  H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
+  if np.isfinite(ro[3]):
+    np.testing.assert_allclose(rp[1], ro[1], rtol=0, atol=1e-7 * np.sqrt(E))
+    np.testing.assert_allclose(rp[2], ro[2], rtol=1e-10)
+    np.testing.assert_allclose(rp[3], ro[3], rtol=0, atol=1e-7 * np.sqrt(E))
+    np.testing.assert_allclose(like_p(**lam), ro[3], rtol=0, atol=1e-7 * np.sqrt(E))
+  if check_pgw:
+    pop_o, pop_p = like_o.population.update(**lam), like_p.population.update(**lam)
+    go = like_o.p_gw3d(pop_o) if like_o.pixelated else like_o.p_gw1d(pop_o)
+    gp = like_p.p_gw3d(pop_p) if like_p.pixelated else like_p.p_gw1d(pop_p)
+    fin = np.isfinite(go)
+    assert np.array_equal(fin, np.isfinite(gp))
+    np.testing.assert_allclose(gp[fin], go[fin], rtol=1e-9, atol=1e-9 * np.max(np.abs(go[fin])))
+    no, npp = like_o.compute_numlike_evs(pop_o), like_p.compute_numlike_evs(pop_p)
+    f2 = np.isfinite(no)
+    np.testing.assert_allclose(npp[f2], no[f2], rtol=RTOL_L, atol=1e-300)
+
+
+@pytest.mark.parametrize('kind', ['marginalized', 'approximate', 'full'])
+def test_pixelated_modes(cfg_pix, kind):
+  cfg, ev, inj = cfg_pix
+  like_o, _, _ = H.build_oracle(ev, inj, kind=kind)
+  like_p, _, _ = H.build_product(ev, inj, kind=kind)
+  for lam in (dict(H0=70.), dict(H0=55., alpha=3.0), dict(H0=95., gamma=2.0, mu_g=32.)):
+    _compare(like_p, like_o, lam, cfg['E'])
+
+
+@pytest.mark.parametrize('kernel', ['epan', 'gauss'])
+def test_1d_mode(cfg_1d, kernel):
+  cfg, ev, inj = cfg_1d
+  kw = dict(kernel=kernel)
+  like_o, _, _ = H.build_oracle(ev, inj, pixelated=False, like_kw=kw)
+  like_p, _, _ = H.build_product(ev, inj, pixelated=False, like_kw=kw)
+  for lam in (dict(H0=70.), dict(H0=110., lambda_peak=0.1)):
+    _compare(like_p, like_o, lam, cfg['E'])
+
+
+@pytest.mark.parametrize('like_kw', [dict(binning=False), dict(bw_method='silverman'), dict(bw_method=0.3),
+                                     dict(cut_grid=None), dict(num_bins=37, cut_grid=1.0), dict(kernel='gauss')])
+def test_kde_options(cfg_pix, like_kw):
+  cfg, ev, inj = cfg_pix
+  for kind in ('marginalized', 'approximate'):
+    like_o, _, _ = H.build_oracle(ev, inj, kind=kind, like_kw=like_kw)
+    like_p, _, _ = H.build_product(ev, inj, kind=kind, like_kw=like_kw)
+    _compare(like_p, like_o, dict(H0=72.), cfg['E'])
+
+
+@pytest.mark.parametrize('models', [dict(cosmo='mg_flrw', cosmo_kw=dict(Xi0=1.8, n=1.9)), dict(mass='tpl'), dict(mass='bpl'),
+                                    dict(rate='power_law'), dict(rate='trunc_madau_dickinson', rate_kw=dict(zmax=2.5)),
+                                    dict(cosmo_kw=dict(Ok0=0.03, w0=-0.95, wa=0.1))])
+def test_model_families(cfg_pix, models):
+  cfg, ev, inj = cfg_pix
+  like_o, _, _ = H.build_oracle(ev, inj, models=models)
+  like_p, _, _ = H.build_product(ev, inj, models=models)
+  _compare(like_p, like_o, dict(H0=68.), cfg['E'], check_pgw=False)
+
+
+def test_not_scale_free_and_neff_guards(cfg_pix):
+  cfg, ev, inj = cfg_pix
+  pk = dict(scale_free=False, R0=20., Tobs=2.)
+  like_o, _, _ = H.build_oracle(ev, inj, pop_kw=pk)
+  like_p, _, _ = H.build_product(ev, inj, pop_kw=pk)
+  _compare(like_p, like_o, dict(H0=70., R0=25.), cfg['E'], check_pgw=False)
+  # pe_neff guard: a huge threshold zeroes every event -> L_i = 0 -> -1.797e308 each -> sum = -inf  
+  like_o, _, _ = H.build_oracle(ev, inj, like_kw=dict(pe_neff=1e9))
+  like_p, _, _ = H.build_product(ev, inj, like_kw=dict(pe_neff=1e9))
+  ro, rp = like_o.compute_all(H0=70.), like_p.compute_all(H0=70.)
+  assert np.all(rp[0] == -np.finfo(np.float64).max) and np.all(ro[0] == rp[0])
+  assert rp[1] == -np.inf and ro[1] == -np.inf
+  # N_eff guard: N_exp = 0 when the injections are too few effective samples   (selection_function.py:43-47)
+  like_o, pop_o, sel_o = H.build_oracle(ev, inj, N_eff=1e12)
+  like_p, pop_p, sel_p = H.build_product(ev, inj, N_eff=1e12)
+  assert sel_o.N_exp(pop_o) == 0. and sel_p.N_exp(pop_p) == 0.
+  like_o, pop_o, sel_o = H.build_oracle(ev, inj, N_eff=None)
+  like_p, pop_p, sel_p = H.build_product(ev, inj, N_eff=None)
+  np.testing.assert_allclose(sel_p.N_exp(pop_p), sel_o.N_exp(pop_o), rtol=1e-11)
+
+
+def test_batch_matches_single(cfg_pix):
+  cfg, ev, inj = cfg_pix
+  like_p, _, _ = H.build_product(ev, inj)
+  lams = [dict(H0=h) for h in (50., 60., 70., 80., 90.)]
+  single = np.array([like_p(**l) for l in lams])
+  batched = like_p.batch(lams)
+  np.testing.assert_array_equal(batched, single)
+
+
+def test_compute_z_grids(cfg_pix):
+  import chimera_amd as CH
+  cfg, ev, inj = cfg_pix
+  th_o, th_p = O.theta_pe_det(dL=ev['dL']), CH.data.theta_pe_det(dL=ev['dL'])
+  for cname, kw, prior in [('flrw', dict(H0=70., Om0=0.25, z_max=5.), {'H0': [20, 200]}),
+                           ('mg_flrw', dict(H0=70., z_max=5.), {'H0': [40, 120], 'Xi0': [0.5, 3.], 'n': [0.5, 3.]})]:
+    zo = O.compute_z_grids(getattr(O, cname)(**kw), th_o, cosmo_prior=prior, z_int_res=50)
+    zp = CH.compute_z_grids(getattr(CH.cosmo, cname)(**kw), th_p, cosmo_prior=prior, z_int_res=50)
+    np.testing.assert_allclose(zp, zo, rtol=1e-12)
