@@ -33,10 +33,15 @@ def test_tables_and_model_functions():
     np.testing.assert_allclose(cp.integral_invE_interp, co.integral_invE_interp, rtol=1e-13, atol=1e-300)
     z = np.concatenate([[0., 1e-12, 1e-5], np.linspace(0.001, co.z_max * 1.05, 301)])
     dL = O.dL_at_z(co, z)
-    for fn in ('E_at_z', 'int_invE_at_z', 'dCr_at_z', 'dCt_at_z', 'dL_at_z', 'ddLdz_at_z', 'dVcdz_at_z', 'Vc_at_z'):
+    for fn in ('E_at_z', 'int_invE_at_z', 'dCr_at_z', 'dCt_at_z', 'dL_at_z', 'ddLdz_at_z', 'dVcdz_at_z'):
       np.testing.assert_allclose(getattr(CH.cosmo, fn)(cp, z), getattr(O, fn)(co, z), rtol=2e-13, atol=1e-300, err_msg=fn)
-    for fn in ('ddLdz_at_z', 'dVcdz_at_z', 'Vc_at_z'):
+    for fn in ('ddLdz_at_z', 'dVcdz_at_z'):
       np.testing.assert_allclose(getattr(CH.cosmo, fn)(cp, z[3:], dL[3:]), getattr(O, fn)(co, z[3:], dL[3:]), rtol=2e-13, err_msg=fn)
+    # Vc: the curved-space expression (cosmo.py:178-184) subtracts two nearly equal terms, so one ulp in asinh/asin is
+    # amplified by ~(dH/(sqrt|Ok0| dCt))^2: compare it in absolute terms there, to rtol in the flat case.
+    vtol = dict(rtol=2e-13, atol=1e-300) if co.Ok0 == 0 else dict(rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(CH.cosmo.Vc_at_z(cp, z), O.Vc_at_z(co, z), err_msg='Vc_at_z', **vtol)
+    np.testing.assert_allclose(CH.cosmo.Vc_at_z(cp, z[3:], dL[3:]), O.Vc_at_z(co, z[3:], dL[3:]), err_msg='Vc_at_z(d)', **vtol)
     d = np.concatenate([[0., 1e-9], np.linspace(0.01, 1.2 * dL.max(), 400)])
     np.testing.assert_allclose(CH.cosmo.z_from_dGW(cp, d), O.z_from_dGW(co, d), rtol=2e-13, atol=1e-300)
   m1 = np.linspace(3., 100., 389)
@@ -44,7 +49,8 @@ def test_tables_and_model_functions():
   for mname, kw in [('plp', {}), ('plp', dict(alpha=2.1, mu_g=30., delta_m=3.)), ('tpl', {}), ('bpl', {}), ('tpl', dict(alpha=1.0))]:
     mo, mp = getattr(O, mname)(**kw), getattr(CH.mass, mname)(**kw)
     np.testing.assert_allclose(mp.m_grid, mo.m_grid, rtol=1e-13)
-    np.testing.assert_allclose(mp.cdf_m2_conditioned, mo.cdf_m2_conditioned, rtol=1e-13, atol=1e-300)
+    # the first entries sit in the smoothing window, where exp(-delta_m/(m - m_low)...) amplifies one ulp of m_grid
+    np.testing.assert_allclose(mp.cdf_m2_conditioned, mo.cdf_m2_conditioned, rtol=1e-13, atol=1e-16 * mo.cdf_m2_conditioned[-1])
     np.testing.assert_allclose(mp.norm_p_m1, mo.norm_p_m1, rtol=1e-13)
     np.testing.assert_allclose(CH.mass.p_m1m2(mp, m1, m2), O.p_m1m2(mo, m1, m2), rtol=1e-12, atol=1e-300, err_msg=mname)
     np.testing.assert_allclose(CH.mass.primary_mass_pdf_notnorm(mp, m1), O.primary_mass_pdf_notnorm(mo, m1), rtol=1e-12, atol=1e-300)
@@ -68,6 +74,9 @@ def _compare(like_p, like_o, lam, E, check_pgw=True):
     pop_o, pop_p = like_o.population.update(**lam), like_p.population.update(**lam)
     go = like_o.p_gw3d(pop_o) if like_o.pixelated else like_o.p_gw1d(pop_o)
     gp = like_p.p_gw3d(pop_p) if like_p.pixelated else like_p.p_gw1d(pop_p)
+    if like_o.pixelated:        # padded pixels (p >= neff_pixels) are masked out of the integrand (likelihood.py:274-277):
+      valid = np.arange(go.shape[1])[None, :] < np.asarray(like_o.neff_pixels)[:, None]       # compare the real ones
+      go, gp = go[valid], gp[valid]
     fin = np.isfinite(go)
     assert np.array_equal(fin, np.isfinite(gp))
     np.testing.assert_allclose(gp[fin], go[fin], rtol=1e-9, atol=1e-9 * np.max(np.abs(go[fin])))
