@@ -39,10 +39,14 @@ struct Ctx {
   DevParams* d_params = nullptr;
   DevParams* h_params = nullptr;       // pinned
   double *zt = nullptr, *It = nullptr, *dLt = nullptr, *mg = nullptr, *cdf = nullptr, *tmp = nullptr;
+  double* d_evpart = nullptr;          // (nb, nblk_ev) block sums of log L_i
+  int evpart_cap = 0;
   double* d_partials = nullptr;        // (nb,3)
   double* d_out3 = nullptr;            // (nb,3)
   double* h_out = nullptr;             // pinned (nb,6)
-  hipEvent_t ev[8] = {};
+  hipStream_t stream2 = nullptr;        // forked after k_tables: k_zfactors, k_selection
+  hipEvent_t ev[8] = {};                // timing on `stream`
+  hipEvent_t evb[4] = {};               // fork/join + timing on `stream2`
   double ms[8] = {};
   bool init = false;
 };
@@ -51,7 +55,9 @@ static int ctx_init(Ctx& c, int device) {
   c.device = device;
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
   for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c.ev[i]));
+  for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c.evb[i]));
   c.init = true;
   return CHM_OK;
 }
@@ -59,7 +65,8 @@ static int ctx_init(Ctx& c, int device) {
 static void ctx_free_tables(Ctx& c) {
   (void)hipFree(c.d_params); (void)hipHostFree(c.h_params);
   (void)hipFree(c.zt); (void)hipFree(c.It); (void)hipFree(c.dLt); (void)hipFree(c.mg); (void)hipFree(c.cdf); (void)hipFree(c.tmp);
-  (void)hipFree(c.d_partials); (void)hipFree(c.d_out3); (void)hipHostFree(c.h_out);
+  (void)hipFree(c.d_partials); (void)hipFree(c.d_out3); (void)hipHostFree(c.h_out); (void)hipFree(c.d_evpart);
+  c.d_evpart = nullptr; c.evpart_cap = 0;
   c.d_params = nullptr; c.h_params = nullptr; c.zt = c.It = c.dLt = c.mg = c.cdf = c.tmp = nullptr;
   c.d_partials = c.d_out3 = nullptr; c.h_out = nullptr;
   c.nb_cap = c.TcMax = c.TmMax = 0;
@@ -70,6 +77,8 @@ static void ctx_destroy(Ctx& c) {
   (void)hipSetDevice(c.device);
   ctx_free_tables(c);
   for (int i = 0; i < 8; i++) if (c.ev[i]) (void)hipEventDestroy(c.ev[i]);
+  for (int i = 0; i < 4; i++) if (c.evb[i]) (void)hipEventDestroy(c.evb[i]);
+  if (c.stream2) (void)hipStreamDestroy(c.stream2);
   if (c.stream) (void)hipStreamDestroy(c.stream);
   c.init = false;
 }
@@ -169,6 +178,23 @@ static int upload(std::vector<void*>& owned, const T* host, size_t n, const T** 
   return CHM_OK;
 }
 
+// Stable sort of one event's samples by pixel index (samples in no pixel last); fills perm and seg (P+1 offsets).
+static void pixel_sort(const int32_t* pix, int S, int P, std::vector<int>& perm, int* seg) {
+  std::vector<int> cnt(P + 2, 0);
+  for (int s = 0; s < S; s++) { int q = pix[s]; cnt[(q >= 0 && q < P) ? q + 1 : P + 1]++; }
+  // cnt[q+1] = number in pixel q; cnt[P+1] = outside
+  std::vector<int> start(P + 1, 0);
+  for (int q = 0; q < P; q++) start[q + 1] = start[q] + cnt[q + 1];
+  for (int q = 0; q <= P; q++) seg[q] = start[q];
+  std::vector<int> cur(start);
+  int out_cur = start[P];
+  perm.resize(S);
+  for (int s = 0; s < S; s++) {
+    int q = pix[s];
+    if (q >= 0 && q < P) perm[cur[q]++] = s; else perm[out_cur++] = s;
+  }
+}
+
 extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
   if (!d || !out) return fail(CHM_E_ARG, "chm_like_create: null argument");
   *out = nullptr;
@@ -203,13 +229,43 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
   L.mode = d->mode; L.kernel = d->kernel; L.bw_method = d->bw_method; L.binning = d->binning ? 1 : 0; L.num_bins = d->num_bins;
   L.has_cut = std::isnan(d->cut_grid) ? 0 : 1;
   L.G = L.has_cut ? d->Z / 2 : d->Z;                         // likelihood.py:121,188
+  L.NC = (int)((S + SAMPLE_CHUNK - 1) / SAMPLE_CHUNK);
+  { const char* dbg = getenv("CHM_DEBUG_SKIP"); L.dbg = dbg ? atoi(dbg) : 0; }
   L.bw_scalar = d->bw_scalar; L.cut_grid = d->cut_grid; L.pe_neff = d->pe_neff;
   if (L.mode != CHM_MODE_FULL && L.G < 2) { chm_like_destroy(h); return fail(CHM_E_ARG, "chm_like_create: Z//2 must be >= 2 when cut_grid is set"); }
 #define UP(field, src, n) do { rc = upload(h->owned, (src) ? (src) + (size_t)e0 * (n) : (src), (size_t)E * (n), &L.field, s); if (rc) { chm_like_destroy(h); return rc; } } while (0)
-  UP(dL, d->dL, S); UP(m1det, d->m1det, S); UP(m2det, d->m2det, S); UP(pe_prior, d->pe_prior, S);
+  std::vector<double> tmp;                                   // must outlive the async copies below
+  std::vector<std::vector<double>> sorted;
+  std::vector<int> seg;
+  if (d->mode == CHM_MODE_MARG) {
+    // marginalized: store every event's samples sorted by pixel, so that each (event, pixel) wave reads one contiguous
+    // segment (the device-side form of `pe_pix == pixels[i]`, likelihood.py:179)
+    seg.resize(E * (P + 1));
+    const double* src[4] = { d->dL, d->m1det, d->m2det, d->pe_prior };
+    sorted.assign(4, std::vector<double>(E * S));
+    std::vector<int> perm;
+    for (size_t e = 0; e < E; e++) {
+      pixel_sort(d->pix_of_sample + (size_t)(e0 + e) * S, (int)S, (int)P, perm, &seg[e * (P + 1)]);
+      for (int a = 0; a < 4; a++) {
+        const double* in = src[a] + (size_t)(e0 + e) * S;
+        double* o = sorted[a].data() + e * S;
+        for (size_t k = 0; k < S; k++) o[k] = in[perm[k]];
+      }
+    }
+    const double** dst[4] = { &L.dL, &L.m1det, &L.m2det, &L.pe_prior };
+    for (int a = 0; a < 4; a++) { rc = upload(h->owned, (const double*)sorted[a].data(), E * S, dst[a], s); if (rc) { chm_like_destroy(h); return rc; } }
+    rc = upload(h->owned, (const int*)seg.data(), E * (P + 1), &L.seg_off, s); if (rc) { chm_like_destroy(h); return rc; }
+  } else {
+    UP(dL, d->dL, S); UP(m1det, d->m1det, S); UP(m2det, d->m2det, S); UP(pe_prior, d->pe_prior, S);
+  }
   if (d->mode == CHM_MODE_FULL) { UP(ra, d->ra, S); UP(dec, d->dec, S); }
-  if (pixelated && d->pix_of_sample) UP(pix, d->pix_of_sample, S);
   UP(z_grids, d->z_grids, Z);
+  // step fractions of jnp.linspace (i/div), shared by every event: bin edges (math.py:37) and effective grid (likelihood.py:188)
+  std::vector<double> fracB(L.num_bins > 0 ? L.num_bins + 1 : 1), fracG(L.G > 0 ? L.G : 1);
+  for (size_t i = 0; i < fracB.size(); i++) fracB[i] = (double)i / (double)(L.num_bins > 0 ? L.num_bins : 1);
+  for (size_t i = 0; i < fracG.size(); i++) fracG[i] = (double)i / (double)(L.G > 1 ? L.G - 1 : 1);
+  rc = upload(h->owned, (const double*)fracB.data(), fracB.size(), &L.fracB, s); if (rc) { chm_like_destroy(h); return rc; }
+  rc = upload(h->owned, (const double*)fracG.data(), fracG.size(), &L.fracG, s); if (rc) { chm_like_destroy(h); return rc; }
   if (pixelated) {
     UP(p_cat, d->p_cat, P * Z); UP(P_compl, d->P_compl, Z); UP(gw_pdf, d->gw_loc2d_pdf, P);
     if (d->ra_pix) UP(ra_pix, d->ra_pix, P);
@@ -225,9 +281,9 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
 
 static void like_free_ws(chm_like* h) {
   LikeDev& L = h->L;
-  (void)hipFree(L.ws_z); (void)hipFree(L.ws_w); (void)hipFree(L.stats); (void)hipFree(L.pixmax); (void)hipFree(L.jac); (void)hipFree(L.prate); (void)hipFree(L.bkgA);
-  (void)hipFree(L.like_pix); (void)hipFree(L.p_gw_dump);
-  L.ws_z = L.ws_w = L.stats = L.pixmax = L.jac = L.prate = L.bkgA = L.like_pix = L.p_gw_dump = nullptr;
+  (void)hipFree(L.ws_z); (void)hipFree(L.ws_w); (void)hipFree(L.part); (void)hipFree(L.jac); (void)hipFree(L.prate); (void)hipFree(L.bkgA);
+  (void)hipFree(L.pgw1d); (void)hipFree(L.like_pix); (void)hipFree(L.p_gw_dump); (void)hipFree(L.Aw); (void)hipFree(L.evstat); (void)hipFree(L.effg);
+  L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.pgw1d = L.like_pix = L.p_gw_dump = L.Aw = L.evstat = L.effg = nullptr;
   h->nb_ws = 0; h->ws_dump = false;
 }
 
@@ -235,6 +291,7 @@ extern "C" int chm_like_destroy(chm_like* h) {
   if (!h) return CHM_OK;
   (void)hipSetDevice(h->ctx.device);
   if (h->ctx.stream) (void)hipStreamSynchronize(h->ctx.stream);
+  if (h->ctx.stream2) (void)hipStreamSynchronize(h->ctx.stream2);
   like_free_ws(h);
   for (void* p : h->owned) (void)hipFree(p);
   ctx_destroy(h->ctx);
@@ -250,13 +307,15 @@ static int like_ensure_ws(chm_like* h, int nb, bool dump) {
   size_t E = L.E, S = L.S, Z = L.Z, Pd = L.P > 0 ? L.P : 1, n = nb;
   HIPCHK(hipMalloc(&L.ws_z, sizeof(double) * n * E * S));
   HIPCHK(hipMalloc(&L.ws_w, sizeof(double) * n * E * S));
-  HIPCHK(hipMalloc(&L.stats, sizeof(double) * n * E * NSTAT));
-  HIPCHK(hipMalloc(&L.pixmax, sizeof(double) * n * E * Pd));
+  HIPCHK(hipMalloc(&L.part, sizeof(double) * n * E * L.NC * NPART));
   HIPCHK(hipMalloc(&L.jac, sizeof(double) * n * E * Z));
   HIPCHK(hipMalloc(&L.prate, sizeof(double) * n * E * Z));
   HIPCHK(hipMalloc(&L.bkgA, sizeof(double) * n * E * Z));
+  if (L.mode == CHM_MODE_1D || L.mode == CHM_MODE_APPROX) HIPCHK(hipMalloc(&L.pgw1d, sizeof(double) * n * E * Z));
+  if (L.mode == CHM_MODE_MARG) { HIPCHK(hipMalloc(&L.Aw, sizeof(double) * n * E * Z)); HIPCHK(hipMalloc(&L.evstat, sizeof(double) * n * E * NEVSTAT));
+                                 HIPCHK(hipMalloc(&L.effg, sizeof(double) * n * E * L.G)); }
   HIPCHK(hipMalloc(&L.like_pix, sizeof(double) * n * E * Pd));
-  if (dump) HIPCHK(hipMalloc(&L.p_gw_dump, sizeof(double) * n * E * Pd * Z));
+  if (dump && L.mode != CHM_MODE_1D) HIPCHK(hipMalloc(&L.p_gw_dump, sizeof(double) * n * E * Pd * Z));
   h->nb_ws = nb; h->ws_dump = dump;
   return CHM_OK;
 }
@@ -294,6 +353,7 @@ extern "C" int chm_sel_destroy(chm_sel* h) {
   if (!h) return CHM_OK;
   (void)hipSetDevice(h->ctx.device);
   if (h->ctx.stream) (void)hipStreamSynchronize(h->ctx.stream);
+  if (h->ctx.stream2) (void)hipStreamSynchronize(h->ctx.stream2);
   (void)hipFree(h->S.partial);
   for (void* p : h->owned) (void)hipFree(p);
   ctx_destroy(h->ctx);
@@ -313,7 +373,10 @@ static int sel_ensure_ws(chm_sel* h, int nb) {
 // ------------------------------------------------------------------------------------------------------
 // evaluation
 // ------------------------------------------------------------------------------------------------------
-static size_t table_lds_bytes(int Tc, int Tm) { return sizeof(double) * ((size_t)3 * Tc + (size_t)2 * Tm); }
+template <class K>
+static void allow_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 
 extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_params* params, int32_t nb,
                         int64_t E_total, chm_out* out) {
@@ -322,94 +385,123 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
   Ctx& c = like ? like->ctx : sel->ctx;
   if (comm && comm->device != c.device) return fail(CHM_E_ARG, "chm_eval: comm lives on a different device");
   HIPCHK(hipSetDevice(c.device));
-  hipStream_t s = c.stream;
+  hipStream_t sA = c.stream, sB = c.stream2;
   const bool want_dump = like && out->p_gw != nullptr;
   int rc;
   if (like) { rc = like_ensure_ws(like, nb, want_dump); if (rc) return rc; }
   if (sel) { rc = sel_ensure_ws(sel, nb); if (rc) return rc; }
-  if (like && !want_dump && like->L.p_gw_dump) { /* keep buffer, but do not write it */ }
 
-  HIPCHK(hipEventRecord(c.ev[0], s));
+  HIPCHK(hipEventRecord(c.ev[0], sA));
   rc = ctx_tables(c, params, nb); if (rc) return rc;
-  HIPCHK(hipEventRecord(c.ev[1], s));
+  HIPCHK(hipEventRecord(c.ev[1], sA));
+  HIPCHK(hipStreamWaitEvent(sB, c.ev[1], 0));               // fork: stream B starts after the tables
 
   const int Tc = c.TcMax, Tm = c.TmMax;
-  const size_t tab_bytes = table_lds_bytes(Tc, Tm);
-  const bool lds_tab = tab_bytes <= 96 * 1024;
+  const DevParams* dp = c.d_params;
+  const size_t lds_samp = sizeof(double) * ((size_t)2 * Tc + (size_t)2 * Tm);      // zt, dLt, mg, cdf
+  const size_t lds_zfac = sizeof(double) * (size_t)2 * Tc;                          // zt, It
+  const bool tab_samp = lds_samp <= 64 * 1024, tab_zfac = lds_zfac <= 64 * 1024;
 
+  // ---- stream B: per-z factors, then the selection function
+  if (like) {
+    LikeDev L = like->L;
+    if (tab_zfac) { allow_lds(k_zfactors<true>, lds_zfac);
+      hipLaunchKernelGGL(k_zfactors<true>, dim3(L.E, nb), dim3(256), lds_zfac, sB, L, dp, c.zt, c.It, Tc);
+    } else hipLaunchKernelGGL(k_zfactors<false>, dim3(L.E, nb), dim3(256), 0, sB, L, dp, c.zt, c.It, Tc);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c.evb[0], sB));
+  }
+  if (sel) {
+    SelDev S = sel->S;
+    HIPCHK(hipEventRecord(c.evb[1], sB));
+    if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
+      hipLaunchKernelGGL(k_selection<true>, dim3(S.nblocks, nb), dim3(256), lds_samp, sB, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    } else hipLaunchKernelGGL(k_selection<false>, dim3(S.nblocks, nb), dim3(256), 0, sB, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c.evb[2], sB));
+  }
+
+  // ---- stream A: samples, GW kernel + integrand
+  int nblk_ev = 0;
   if (like) {
     LikeDev L = like->L;
     if (!want_dump) L.p_gw_dump = nullptr;
-    dim3 g1(L.E, nb);
-    if (lds_tab) {
-      static bool attr_set = false;
-      if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_samples<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_set = true; }
-      hipLaunchKernelGGL(k_samples<true>, g1, dim3(1024), tab_bytes, s, L, (const DevParams*)c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    } else {
-      hipLaunchKernelGGL(k_samples<false>, g1, dim3(1024), 0, s, L, (const DevParams*)c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    }
+    dim3 g1(L.E * L.NC, nb);
+    if (tab_samp) { allow_lds(k_samples<true>, lds_samp);
+      hipLaunchKernelGGL(k_samples<true>, g1, dim3(256), lds_samp, sA, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    } else hipLaunchKernelGGL(k_samples<false>, g1, dim3(256), 0, sA, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c.ev[2], s));
+    HIPCHK(hipEventRecord(c.ev[2], sA));
+    HIPCHK(hipStreamWaitEvent(sA, c.evb[0], 0));            // join: per-z factors
+    HIPCHK(hipEventRecord(c.ev[6], sA));
     const int Pd = L.P > 0 ? L.P : 1;
+    const size_t N = L.binning ? L.num_bins : L.S;
     if (L.mode == CHM_MODE_FULL) {
-      hipLaunchKernelGGL(k_full_kde, dim3(L.E * Pd, nb), dim3(256), 0, s, L, (const DevParams*)c.d_params);
+      hipLaunchKernelGGL(k_full_kde, dim3(L.E * Pd, nb), dim3(256), 0, sA, L, dp);
+    } else if (L.mode == CHM_MODE_MARG) {
+      size_t lds = sizeof(double) * (2 * N + (L.binning ? 3 * (N + 1) : 0) + 2 * (size_t)L.G);
+      if (lds > 150 * 1024) return fail(CHM_E_ARG, "chm_eval: KDE working set exceeds the LDS (binning=False needs 2*S + 2*G doubles <= 150 KiB)");
+      allow_lds(k_kde_marg, lds);
+      hipLaunchKernelGGL(k_event_prep, dim3(L.E, nb), dim3(64), 0, sA, L);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(c.ev[6], sA));
+      const bool fast = L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC");
+      if (fast) hipLaunchKernelGGL(k_kde_marg_fast, dim3(L.E * Pd, nb), dim3(64), sizeof(double) * (4 * N + 3), sA, L, dp);
+      else hipLaunchKernelGGL(k_kde_marg, dim3(L.E * Pd, nb), dim3(64), lds, sA, L, dp);
     } else {
-      size_t N = L.binning ? L.num_bins : L.S;
-      size_t lds = sizeof(double) * (2 * N + 2 * (size_t)L.G);
-      if (lds > 150 * 1024) return fail(CHM_E_ARG, "chm_eval: binning=False needs 2*S + 2*G doubles of LDS (<= 150 KiB)");
-      static size_t attr_max = 0;
-      if (lds > 48 * 1024 && lds > attr_max) { (void)hipFuncSetAttribute((const void*)k_kde_integrate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_max = lds; }
-      hipLaunchKernelGGL(k_kde_integrate, dim3(L.E * Pd, nb), dim3(64), lds, s, L, (const DevParams*)c.d_params);
+      size_t lds = sizeof(double) * (2 * N + (L.binning ? 3 * (N + 1) : 0) + 2 * (size_t)L.G);
+      if (lds > 150 * 1024) return fail(CHM_E_ARG, "chm_eval: KDE working set exceeds the LDS (binning=False needs 2*S + 2*G doubles <= 150 KiB)");
+      allow_lds(k_kde1d, lds);
+      hipLaunchKernelGGL(k_kde1d, dim3(L.E, nb), dim3(256), lds, sA, L, dp);
+      HIPCHK(hipGetLastError());
+      hipLaunchKernelGGL(k_integrate_1d, dim3(L.E * Pd, nb), dim3(64), 0, sA, L, dp);
     }
     HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c.ev[3], sA));
+    // per-event log-likelihoods and their block sums
+    nblk_ev = (L.E + 255) / 256;
+    if (nb * nblk_ev > c.evpart_cap) {
+      HIPCHK(hipStreamSynchronize(sA));
+      (void)hipFree(c.d_evpart); c.d_evpart = nullptr;
+      HIPCHK(hipMalloc(&c.d_evpart, sizeof(double) * nb * nblk_ev));
+      c.evpart_cap = nb * nblk_ev;
+    }
   } else {
-    HIPCHK(hipEventRecord(c.ev[2], s));
+    HIPCHK(hipEventRecord(c.ev[2], sA)); HIPCHK(hipEventRecord(c.ev[6], sA)); HIPCHK(hipEventRecord(c.ev[3], sA));
   }
-  HIPCHK(hipEventRecord(c.ev[3], s));
-
-  if (sel) {
-    SelDev S = sel->S;
-    dim3 g(S.nblocks, nb);
-    if (lds_tab) {
-      static bool attr_set = false;
-      if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_selection<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); attr_set = true; }
-      hipLaunchKernelGGL(k_selection<true>, g, dim3(256), tab_bytes, s, S, (const DevParams*)c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    } else {
-      hipLaunchKernelGGL(k_selection<false>, g, dim3(256), 0, s, S, (const DevParams*)c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    }
-    HIPCHK(hipGetLastError());
-  }
-  HIPCHK(hipEventRecord(c.ev[4], s));
-
-  // shard partials
   double* d_lle = nullptr; double* d_nle = nullptr;
   const size_t El = like ? like->L.E : 0;
   if (like && out->log_like_evs) HIPCHK(hipMalloc(&d_lle, sizeof(double) * nb * El));
   if (like && out->numlike_evs) HIPCHK(hipMalloc(&d_nle, sizeof(double) * nb * El));
-  hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), 0, s, like ? like->L.E : 0, like ? (like->L.P > 0 ? like->L.P : 1) : 1,
-                     like ? like->L.like_pix : nullptr, sel ? sel->S.nblocks : 0, sel ? sel->S.partial : nullptr,
-                     c.d_partials, d_lle, d_nle);
-  HIPCHK(hipGetLastError());
-  if (out->partials) HIPCHK(hipMemcpyAsync(c.h_out + 3 * nb, c.d_partials, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, s));
-  double Etot = like ? (double)like->L.E : 0.;
-  if (comm && comm->nranks > 1) {
-    NCCLCHK(ncclAllReduce(c.d_partials, c.d_partials, (size_t)nb * 3, ncclDouble, ncclSum, comm->comm, s));
-    Etot = (double)E_total;
-  } else if (comm) {
-    Etot = (double)E_total;
+  if (like) {
+    hipLaunchKernelGGL(k_reduce_events, dim3(nblk_ev, nb), dim3(256), 0, sA, like->L.E, like->L.P > 0 ? like->L.P : 1,
+                       (const double*)like->L.like_pix, c.d_evpart, d_lle, d_nle);
+    HIPCHK(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_combine, dim3((nb + 63) / 64), dim3(64), 0, s, nb, (const DevParams*)c.d_params, c.d_partials, Etot,
-                     sel ? sel->S.N_inj : 1., sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, c.d_out3);
+  if (sel) HIPCHK(hipStreamWaitEvent(sA, c.evb[2], 0));     // join: selection sums
+  const bool multi = comm && comm->nranks > 1;
+  double Etot = comm ? (double)E_total : (like ? (double)like->L.E : 0.);
+  hipLaunchKernelGGL(k_final, dim3(nb), dim3(256), 0, sA, nblk_ev, (const double*)c.d_evpart, sel ? sel->S.nblocks : 0,
+                     sel ? (const double*)sel->S.partial : nullptr, c.d_partials, dp, Etot, sel ? sel->S.N_inj : 1.,
+                     sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, multi ? 0 : 1, c.d_out3);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(c.h_out, c.d_out3, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipEventRecord(c.ev[5], s));
-  if (d_lle) HIPCHK(hipMemcpyAsync(out->log_like_evs, d_lle, sizeof(double) * nb * El, hipMemcpyDeviceToHost, s));
-  if (d_nle) HIPCHK(hipMemcpyAsync(out->numlike_evs, d_nle, sizeof(double) * nb * El, hipMemcpyDeviceToHost, s));
+  if (out->partials) HIPCHK(hipMemcpyAsync(c.h_out + 3 * nb, c.d_partials, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
+  if (multi) {
+    NCCLCHK(ncclAllReduce(c.d_partials, c.d_partials, (size_t)nb * 3, ncclDouble, ncclSum, comm->comm, sA));
+    hipLaunchKernelGGL(k_combine, dim3((nb + 63) / 64), dim3(64), 0, sA, nb, dp, (const double*)c.d_partials, Etot,
+                       sel ? sel->S.N_inj : 1., sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, c.d_out3);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipMemcpyAsync(c.h_out, c.d_out3, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
+  HIPCHK(hipEventRecord(c.ev[5], sA));
+  if (d_lle) HIPCHK(hipMemcpyAsync(out->log_like_evs, d_lle, sizeof(double) * nb * El, hipMemcpyDeviceToHost, sA));
+  if (d_nle) HIPCHK(hipMemcpyAsync(out->numlike_evs, d_nle, sizeof(double) * nb * El, hipMemcpyDeviceToHost, sA));
   if (want_dump) {
     size_t Pd = like->L.P > 0 ? like->L.P : 1;
-    HIPCHK(hipMemcpyAsync(out->p_gw, like->L.p_gw_dump, sizeof(double) * nb * El * Pd * like->L.Z, hipMemcpyDeviceToHost, s));
+    const double* src = like->L.mode == CHM_MODE_1D ? like->L.pgw1d : like->L.p_gw_dump;
+    HIPCHK(hipMemcpyAsync(out->p_gw, src, sizeof(double) * nb * El * Pd * like->L.Z, hipMemcpyDeviceToHost, sA));
   }
-  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipStreamSynchronize(sA));
   if (d_lle) (void)hipFree(d_lle);
   if (d_nle) (void)hipFree(d_nle);
   for (int b = 0; b < nb; b++) {
@@ -420,8 +512,13 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
   }
   float ms = 0.f;
   for (int i = 0; i < 8; i++) c.ms[i] = 0.;
-  (void)hipEventElapsedTime(&ms, c.ev[0], c.ev[5]); c.ms[0] = ms;
-  for (int i = 1; i <= 5; i++) { (void)hipEventElapsedTime(&ms, c.ev[i - 1], c.ev[i]); c.ms[i] = ms; }
+  if (hipEventElapsedTime(&ms, c.ev[0], c.ev[5]) == hipSuccess) c.ms[0] = ms;       // whole evaluation
+  if (hipEventElapsedTime(&ms, c.ev[0], c.ev[1]) == hipSuccess) c.ms[1] = ms;       // tables
+  if (hipEventElapsedTime(&ms, c.ev[1], c.ev[2]) == hipSuccess) c.ms[2] = ms;       // sample stage
+  if (hipEventElapsedTime(&ms, c.ev[6], c.ev[3]) == hipSuccess) c.ms[3] = ms;       // GW kernel + integrand
+  if (sel && hipEventElapsedTime(&ms, c.evb[1], c.evb[2]) == hipSuccess) c.ms[4] = ms;   // selection (stream B)
+  if (hipEventElapsedTime(&ms, c.ev[3], c.ev[5]) == hipSuccess) c.ms[5] = ms;       // reduce + combine (+ all-reduce)
+  if (like && hipEventElapsedTime(&ms, c.ev[1], c.evb[0]) == hipSuccess) c.ms[6] = ms;   // per-z factors (stream B)
   return CHM_OK;
 }
 

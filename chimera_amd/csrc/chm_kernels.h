@@ -1,38 +1,72 @@
 // chm_kernels.h -- HIP kernels of the hyper-likelihood path (gfx950 / CDNA4, wave64, fp64).
 //
-// Pipeline of one evaluation (all on one HIP stream; nb = draws in the batch, blockIdx.y = draw):
-//   k_tables        1 block / draw         per-draw tables + constants        cosmo.py:43-46, mass.py:45-52
-//   k_samples       1 block / event        det->src, weights, event stats,    pop_wrapper.py:67-80,
-//                                          per-z factors of the integrand      likelihood.py:111-121,272
-//   k_kde_integrate 1 wave  / (event,pix)  histogram, KDE, interp, integrand,  math.py:32-89,
-//                                          trapz                               likelihood.py:105-205,266-292
-//   k_full_kde      1 block / (event,pix)  3-D Gaussian KDE                    math.py:154-229, likelihood.py:211-260
-//   k_selection     grid-stride            dN/dtheta per injection + 2 sums    pop_wrapper.py:102-111
-//   k_reduce/k_combine                     log, nan_to_num, sums, N_exp guard  likelihood.py:294-338, selection_function.py:38-48
+// One evaluation (nb = draws in the batch, blockIdx.y = draw).  Stream A: k_tables -> k_samples -> GW-kernel -> reduce;
+// stream B (forked after k_tables): k_zfactors, k_selection.
+//   k_tables        1 block / draw            per-draw tables + constants            cosmo.py:43-46,263, mass.py:45-52
+//   k_samples       1 block / 1024 samples    det->src, weights, partial statistics  pop_wrapper.py:67-80, likelihood.py:111-118
+//   k_zfactors      1 block / event           per-z factors of the integrand          likelihood.py:270-272, pop_wrapper.py:82-90
+//   k_kde_marg      1 wave  / (event,pixel)   histogram, KDE, interp, integrand, trapz  math.py:32-89, likelihood.py:160-205,266-281
+//   k_kde1d         1 block / event           1-D GW kernel p_gw(z)                   likelihood.py:105-144
+//   k_integrate_1d  1 wave  / (event,pixel)   integrand + trapz for 1d / approximate  likelihood.py:150-154,266-292
+//   k_full_kde      1 block / (event,pixel)   3-D Gaussian KDE + integrand            math.py:154-229, likelihood.py:211-260
+//   k_selection     grid-stride               dN/dtheta per injection + 2 sums        pop_wrapper.py:102-111
+//   k_reduce_events / k_final / k_combine     log, nan_to_num, sums, N_exp guard      likelihood.py:294-338, selection_function.py:38-48
+//
+// HBM layout: sample arrays are (E,S) row-major fp64; in marginalized mode the samples of an event are stored SORTED
+// BY PIXEL at upload time (stable, samples outside every pixel last) with seg_off[e][0..P] giving each pixel's
+// contiguous segment, so a (event,pixel) wave reads exactly its own samples; p_cat is (E,P,Z) and is streamed once.
 #pragma once
 #include "chm_models.h"
 
-#define NSTAT 16
-// per-(draw,event) statistics written by k_samples
-enum { ST_ZMIN = 0, ST_ZMAX, ST_STD, ST_NORM, ST_NEFF, ST_SUMW, ST_LOGNORM, ST_L00, ST_L10, ST_L11, ST_L20, ST_L21, ST_L22,
-       ST_FACTOR3, ST_X0, ST_X1 };
+#define NPART 16
+// per-(draw,event,chunk) partial statistics written by k_samples; d = z - z_ref (z_ref = z of the event's first sample)
+enum { PT_SW = 0, PT_SW2, PT_SD1, PT_SD2, PT_ZMIN, PT_ZMAX, PT_WD0, PT_WD1, PT_WD2, PT_W00, PT_W01, PT_W02, PT_W11, PT_W12, PT_W22, PT_ZREF };
+#define SAMPLE_CHUNK 1024
 
 struct LikeDev {                  // device-resident shard of events (see chm_like_desc)
   int E, S, Z, P;
-  int mode, kernel, bw_method, binning, num_bins, G, has_cut, pad;
+  int mode, kernel, bw_method, binning, num_bins, G, has_cut, NC;
+  int dbg, pad1;                  // CHM_DEBUG_SKIP ablation bits (timing experiments only; results are wrong when set)
   double bw_scalar, cut_grid, pe_neff;
   const double *dL, *m1det, *m2det, *pe_prior, *ra, *dec;
-  const int* pix;
+  const int* seg_off;             // (E,P+1) marginalized: pixel segments of the pixel-sorted samples
   const double *z_grids, *p_cat, *P_compl, *gw_pdf, *ra_pix, *dec_pix;
   const int* neff_pixels;
+  const double *fracB, *fracG;    // i/num_bins (num_bins+1), i/(G-1) (G): the step fractions of jnp.linspace
   // workspaces (nb-major)
   double *ws_z, *ws_w;            // (nb,E,S)
-  double *stats;                  // (nb,E,NSTAT)
-  double *pixmax;                 // (nb,E,P)
+  double *part;                   // (nb,E,NC,NPART)
   double *jac, *prate, *bkgA;     // (nb,E,Z)
+  double *Aw;                     // (nb,E,Z)  prate/jac * trapezoid weight (marginalized)
+  double *evstat;                 // (nb,E,8)  per-event statistics (k_event_prep)
+  double *effg;                   // (nb,E,G)  per-event effective grid (k_event_prep)
+  double *pgw1d;                  // (nb,E,Z)   1d / approximate
   double *like_pix;               // (nb,E,max(P,1))
   double *p_gw_dump;              // optional (nb,E,P,Z) or NULL
 };
+
+struct EvStats { double zmin, zmax, sd, norm, n_eff, sumw; };
+
+// Combine the chunk partials of one event.  std via the shifted one-pass form: var = <d^2> - <d>^2 with
+// d = z - z_ref (jnp.std two-pass result to ~1e-15 relative; likelihood.py:118,186,222).
+DEVFN EvStats combine_stats(const double* part, int NC, int S) {
+  double sw = 0., sw2 = 0., sd1 = 0., sd2 = 0.;
+  double zmn = part[PT_ZMIN], zmx = part[PT_ZMAX];
+  for (int c = 0; c < NC; c++) {
+    const double* q = part + (size_t)c * NPART;
+    sw += q[PT_SW]; sw2 += q[PT_SW2]; sd1 += q[PT_SD1]; sd2 += q[PT_SD2];
+    zmn = nanmin2(zmn, q[PT_ZMIN]); zmx = nanmax2(zmx, q[PT_ZMAX]);
+  }
+  EvStats s;
+  double md = sd1 / (double)S;
+  double var = sd2 / (double)S - md * md;
+  s.zmin = zmn; s.zmax = zmx;
+  s.sd = sqrt(var > 0. ? var : (var != var ? var : 0.));
+  s.norm = sw / (double)S;                       // jnp.mean(weights)          likelihood.py:111
+  s.n_eff = (sw * sw) / sw2;                     // sum(w)^2 / sum(w^2)        likelihood.py:112
+  s.sumw = sw;
+  return s;
+}
 
 // ------------------------------------------------------------------------------------------------------
 // k_tables
@@ -149,273 +183,221 @@ DEVFN TabView stage_tables(const DevParams& P, const TablePtrs& g, bool use_lds,
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_samples: one block per (event, draw)
+// k_samples: one block (256 threads) per chunk of SAMPLE_CHUNK samples of one event
 // ------------------------------------------------------------------------------------------------------
 template <bool LDS_TAB>
-__global__ void __launch_bounds__(1024) k_samples(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
-                                                   const double* dLt_all, const double* mg_all, const double* cdf_all,
-                                                   int TcMax, int TmMax) {
+__global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
+                                                  const double* dLt_all, const double* mg_all, const double* cdf_all,
+                                                  int TcMax, int TmMax) {
   extern __shared__ double lds[];
   __shared__ double red[16];
-  __shared__ unsigned long long pmax_bits[1024];
-  const int e = blockIdx.x, b = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+  const int e = blockIdx.x / L.NC, c = blockIdx.x % L.NC, b = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
   const DevParams& P = params[b];
   TablePtrs g = { zt_all + (size_t)b * TcMax, It_all + (size_t)b * TcMax, dLt_all + (size_t)b * TcMax,
                   mg_all + (size_t)b * TmMax, cdf_all + (size_t)b * TmMax };
-  TabView T = stage_tables(P, g, LDS_TAB, lds, true);
-  const int S = L.S, Z = L.Z, Pn = L.P;
+  TabView T = stage_tables(P, g, LDS_TAB, lds, false);
+  const int S = L.S;
   const size_t so = ((size_t)b * L.E + e) * S;
   const size_t eo = (size_t)e * S;
   double* wz = L.ws_z + so;
   double* ww = L.ws_w + so;
-  for (int i = t; i < Pn && i < 1024; i += nt) pmax_bits[i] = 0ull;
-  __syncthreads();
+  const bool full = L.mode == 3;
+  // reference point of the shifted sums: the event's first sample
+  const double z_ref = jnp_interp(L.dL[eo], T.dLt, T.zt, P.Tc, false, 0., 0.);
+  const double ra_ref = full ? L.ra[eo] : 0., dec_ref = full ? L.dec[eo] : 0.;
 
-  // pass 1: z = z_from_dGW(dL) (cosmo.py:260-264); m_src = m_det/(1+z) (pop_wrapper.py:70);
-  //         w = p_m1m2 / pe_prior (pop_wrapper.py:79)
-  double sw = 0., sw2 = 0., sz = 0.;
+  // z = z_from_dGW(dL) (cosmo.py:260-264); m_src = m_det/(1+z) (pop_wrapper.py:70); w = p_m1m2/pe_prior (pop_wrapper.py:79)
+  double sw = 0., sw2 = 0., sd1 = 0., sd2 = 0.;
   double zmn = __builtin_inf(), zmx = -__builtin_inf();
-  for (int s = t; s < S; s += nt) {
+  double a0 = 0., a1 = 0., a2 = 0., c00 = 0., c01 = 0., c02 = 0., c11 = 0., c12 = 0., c22 = 0.;
+  const int s_end = min(S, (c + 1) * SAMPLE_CHUNK);
+  for (int s = c * SAMPLE_CHUNK + t; s < s_end; s += nt) {
     double dl = L.dL[eo + s];
     double z = jnp_interp(dl, T.dLt, T.zt, P.Tc, false, 0., 0.);
     double m1 = L.m1det[eo + s] / (1. + z);
     double m2 = L.m2det[eo + s] / (1. + z);
     double w = p_m1m2(P, m1, m2, T.mg, T.cdf) / L.pe_prior[eo + s];
     wz[s] = z; ww[s] = w;
-    sw += w; sw2 += w * w; sz += z;
+    double d = z - z_ref;
+    sw += w; sw2 += w * w; sd1 += d; sd2 += d * d;
     zmn = nanmin2(zmn, z); zmx = nanmax2(zmx, z);
-    if (L.pix) {
-      int px = L.pix[eo + s];
-      if (px >= 0 && px < Pn && px < 1024) atomicMax(&pmax_bits[px], (unsigned long long)__double_as_longlong(z));
+    if (full) {                                   // un-normalised weighted moments of (z, ra, dec) about the reference
+      double d1 = L.ra[eo + s] - ra_ref, d2 = L.dec[eo + s] - dec_ref;
+      a0 += w * d; a1 += w * d1; a2 += w * d2;
+      c00 += w * d * d; c01 += w * d * d1; c02 += w * d * d2; c11 += w * d1 * d1; c12 += w * d1 * d2; c22 += w * d2 * d2;
     }
   }
-  sw = block_reduce<RED_SUM>(sw, red);
-  sw2 = block_reduce<RED_SUM>(sw2, red);
-  sz = block_reduce<RED_SUM>(sz, red);
-  zmn = block_reduce<RED_MIN>(zmn, red);
-  zmx = block_reduce<RED_MAX>(zmx, red);
-  // pass 2: jnp.std = sqrt(mean(|z - mean|^2))   (likelihood.py:118,186,222)
-  double mean = sz / (double)S;
-  double sv = 0.;
-  for (int s = t; s < S; s += nt) { double d = wz[s] - mean; sv += d * d; }
-  sv = block_reduce<RED_SUM>(sv, red);
-  double sd = sqrt(sv / (double)S);
-  double* st = L.stats + ((size_t)b * L.E + e) * NSTAT;
-  if (t == 0) {
-    st[ST_ZMIN] = zmn; st[ST_ZMAX] = zmx; st[ST_STD] = sd;
-    st[ST_NORM] = sw / (double)S;                  // jnp.mean(weights)          likelihood.py:111
-    st[ST_NEFF] = (sw * sw) / sw2;                 // sum(w)^2 / sum(w^2)        likelihood.py:112
-    st[ST_SUMW] = sw;
+  double* q = L.part + (((size_t)b * L.E + e) * L.NC + c) * NPART;
+  sw = block_reduce<RED_SUM>(sw, red); sw2 = block_reduce<RED_SUM>(sw2, red);
+  sd1 = block_reduce<RED_SUM>(sd1, red); sd2 = block_reduce<RED_SUM>(sd2, red);
+  zmn = block_reduce<RED_MIN>(zmn, red); zmx = block_reduce<RED_MAX>(zmx, red);
+  if (t == 0) { q[PT_SW] = sw; q[PT_SW2] = sw2; q[PT_SD1] = sd1; q[PT_SD2] = sd2; q[PT_ZMIN] = zmn; q[PT_ZMAX] = zmx; q[PT_ZREF] = z_ref; }
+  if (full) {
+    a0 = block_reduce<RED_SUM>(a0, red); a1 = block_reduce<RED_SUM>(a1, red); a2 = block_reduce<RED_SUM>(a2, red);
+    c00 = block_reduce<RED_SUM>(c00, red); c01 = block_reduce<RED_SUM>(c01, red); c02 = block_reduce<RED_SUM>(c02, red);
+    c11 = block_reduce<RED_SUM>(c11, red); c12 = block_reduce<RED_SUM>(c12, red); c22 = block_reduce<RED_SUM>(c22, red);
+    if (t == 0) { q[PT_WD0] = a0; q[PT_WD1] = a1; q[PT_WD2] = a2; q[PT_W00] = c00; q[PT_W01] = c01; q[PT_W02] = c02;
+                  q[PT_W11] = c11; q[PT_W12] = c12; q[PT_W22] = c22; }
   }
-  // per-pixel upper histogram edge: max(where(mask, z, min z))                   likelihood.py:180, math.py:36
-  for (int i = t; i < Pn && i < 1024; i += nt) {
-    double pm = __longlong_as_double((long long)pmax_bits[i]);
-    L.pixmax[((size_t)b * L.E + e) * Pn + i] = (zmn != zmn) ? zmn : (pm > zmn ? pm : zmn);
-  }
+}
 
-  // per-z factors of the integrand on the event grid                             likelihood.py:270-272, pop_wrapper.py:82-90
+// ------------------------------------------------------------------------------------------------------
+// k_zfactors: per-z factors of the integrand on each event grid; one block per (event, draw)
+//   jac = ddL/dz (1+z)^2 (likelihood.py:272);  prate = merger_rate/(1+z) (pop_wrapper.py:85);
+//   bkgA = (1 - P_compl) p_bkg (catalog.py:202)  or  p_bkg for the empty catalogue (catalog.py:43)
+// ------------------------------------------------------------------------------------------------------
+template <bool LDS_TAB>
+__global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
+                                                   int TcMax) {
+  extern __shared__ double lds[];
+  const int e = blockIdx.x, b = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+  const DevParams& P = params[b];
+  const double* zt = zt_all + (size_t)b * TcMax;
+  const double* It = It_all + (size_t)b * TcMax;
+  if (LDS_TAB) {
+    double* a = lds; double* c = lds + P.Tc;
+    for (int i = t; i < P.Tc; i += nt) { a[i] = zt[i]; c[i] = It[i]; }
+    __syncthreads();
+    zt = a; It = c;
+  }
+  const int Z = L.Z;
   const size_t zo = ((size_t)b * L.E + e) * Z;
   for (int k = t; k < Z; k += nt) {
     double z = L.z_grids[(size_t)e * Z + k];
-    double dCt = dCt_at_z(P, z, T.zt, T.It);
+    double dCt = dCt_at_z(P, z, zt, It);
     double zp1 = 1. + z;
     L.jac[zo + k] = ddLdz_from_dCt(P, dCt, z) * (zp1 * zp1);
     L.prate[zo + k] = merger_rate(P, z) / (1. + z);
     double p_bkg = dVcdz_from_dCt(P, dCt, z);
-    L.bkgA[zo + k] = P.has_catalog ? (1. - L.P_compl[(size_t)e * Z + k]) * p_bkg : p_bkg;   // catalog.py:202 / :43
-  }
-
-  // full mode: weighted mean / covariance / whitening of (z, ra, dec)            math.py:173-197
-  if (L.mode == 3) {
-    double m0 = 0., m1 = 0., m2 = 0., sW2 = 0.;
-    for (int s = t; s < S; s += nt) {
-      double W = ww[s] / sw;
-      m0 += W * wz[s]; m1 += W * L.ra[eo + s]; m2 += W * L.dec[eo + s]; sW2 += W * W;
-    }
-    m0 = block_reduce<RED_SUM>(m0, red); m1 = block_reduce<RED_SUM>(m1, red);
-    m2 = block_reduce<RED_SUM>(m2, red); sW2 = block_reduce<RED_SUM>(sW2, red);
-    double c00 = 0., c01 = 0., c02 = 0., c11 = 0., c12 = 0., c22 = 0.;
-    for (int s = t; s < S; s += nt) {
-      double W = ww[s] / sw;
-      double r0 = wz[s] - m0, r1 = L.ra[eo + s] - m1, r2 = L.dec[eo + s] - m2;
-      c00 += r0 * W * r0; c01 += r0 * W * r1; c02 += r0 * W * r2;
-      c11 += r1 * W * r1; c12 += r1 * W * r2; c22 += r2 * W * r2;
-    }
-    c00 = block_reduce<RED_SUM>(c00, red); c01 = block_reduce<RED_SUM>(c01, red); c02 = block_reduce<RED_SUM>(c02, red);
-    c11 = block_reduce<RED_SUM>(c11, red); c12 = block_reduce<RED_SUM>(c12, red); c22 = block_reduce<RED_SUM>(c22, red);
-    if (t == 0) {
-      double den = 1. - sW2;
-      c00 /= den; c01 /= den; c02 /= den; c11 /= den; c12 /= den; c22 /= den;
-      double neff = 1. / sW2, factor;
-      if (L.bw_method == 0) factor = pow(neff, -1. / 7.);
-      else if (L.bw_method == 1) factor = pow(neff * 5. / 4.0, -1. / 7.);
-      else factor = L.bw_scalar;
-      // inverse of the symmetric 3x3 covariance (adjugate / determinant)
-      double a00 = c11 * c22 - c12 * c12, a01 = c02 * c12 - c01 * c22, a02 = c01 * c12 - c02 * c11;
-      double a11 = c00 * c22 - c02 * c02, a12 = c01 * c02 - c00 * c12, a22 = c00 * c11 - c01 * c01;
-      double det = c00 * a00 + c01 * a01 + c02 * a02;
-      double f2 = factor * factor;
-      double i00 = a00 / det / f2, i01 = a01 / det / f2, i02 = a02 / det / f2;
-      double i11 = a11 / det / f2, i12 = a12 / det / f2, i22 = a22 / det / f2;
-      // lower Cholesky factor of inv_cov
-      double l00 = sqrt(i00), l10 = i01 / l00, l20 = i02 / l00;
-      double l11 = sqrt(i11 - l10 * l10), l21 = (i12 - l20 * l10) / l11;
-      double l22 = sqrt(i22 - l20 * l20 - l21 * l21);
-      st[ST_L00] = l00; st[ST_L10] = l10; st[ST_L11] = l11; st[ST_L20] = l20; st[ST_L21] = l21; st[ST_L22] = l22;
-      st[ST_LOGNORM] = (log(l00) + log(l11) + log(l22)) - 0.5 * 3. * log(2. * CHM_PI);
-      st[ST_FACTOR3] = factor;
+    L.bkgA[zo + k] = P.has_catalog ? (1. - L.P_compl[(size_t)e * Z + k]) * p_bkg : p_bkg;
+    if (L.Aw) {
+      // trapezoid weight of grid point k: y_k enters the two adjacent intervals (jnp.trapezoid, likelihood.py:278)
+      const double* zg = L.z_grids + (size_t)e * Z;
+      double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
+      double tw = 0.5 * ((z - zl) + (zr - z));
+      L.Aw[zo + k] = (L.prate[zo + k] / L.jac[zo + k]) * tw;
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_kde_integrate: one wave per (event, pixel, draw)   [modes 1d / approximate / marginalized]
+// KDE building blocks shared by k_kde_marg (one wave) and k_kde1d (one block)
 // ------------------------------------------------------------------------------------------------------
-// Dynamic LDS: data[N] (bin centres or raw z), wgt[N] (bin counts -> normalised weights), eff[G], dens[G];
-// N = num_bins when binning else S.
-__global__ void __launch_bounds__(64) k_kde_integrate(LikeDev L, const DevParams* params) {
-  extern __shared__ double lds[];
-  const int lane = threadIdx.x;
-  const int Pd = L.P > 0 ? L.P : 1;
-  const int p = blockIdx.x % Pd, e = blockIdx.x / Pd, b = blockIdx.y;
-  const DevParams& P = params[b];
-  const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
-  const int N = L.binning ? B : S;
-  double* data = lds; double* wgt = data + N; double* eff = wgt + N; double* dens = eff + G;
-  const double* st = L.stats + ((size_t)b * L.E + e) * NSTAT;
-  const size_t so = ((size_t)b * L.E + e) * S;
-  const double* wz = L.ws_z + so;
-  const double* ww = L.ws_w + so;
-  const int* pix = L.pix ? L.pix + (size_t)e * S : nullptr;
-  const bool marg = L.mode == 2;
-  const bool pixelated = L.mode != 0;
-  double* out_like = L.like_pix + ((size_t)b * L.E + e) * Pd + p;
-  double* dump = L.p_gw_dump ? L.p_gw_dump + (((size_t)b * L.E + e) * Pd + p) * Z : nullptr;
+// bin index of binning1d (math.py:41): clip(floor((x - lo)/(hi - lo) * B), 0, B-1); a NaN index (hi == lo) -> 0,
+// the density is NaN downstream either way (bandwidth 0).
+DEVFN int bin_index(double z, double lo, double hi, int B) {
+  double f = floor((z - lo) / (hi - lo) * (double)B);
+  f = f < 0. ? 0. : (f > (double)(B - 1) ? (double)(B - 1) : f);
+  return (f != f) ? 0 : (int)f;
+}
 
-  const int npix = pixelated ? L.neff_pixels[e] : 1;
-  if (p >= npix) {                    // padded pixel: p_cat == -100 there, integrand masked to 0 (likelihood.py:274-277)
-    if (lane == 0) *out_like = 0.;
-    if (dump) for (int k = lane; k < Z; k += 64) dump[k] = 0.;
-    return;
+DEVFN double kde_bandwidth_factor(int bw_method, double bw_scalar, double neff, int d) {
+  // math.py:65-73 (d = 1), :178-183 (d = 3)
+  // x^y as exp(y log x): |y log x| eps ~ 1e-16 away from pow()
+  if (bw_method == 0) return exp(log(neff) * (-1. / (double)(d + 4)));
+  if (bw_method == 1) return exp(log(neff * (double)(d + 2) / 4.0) * (-1. / (double)(d + 4)));
+  return bw_scalar;
+}
+
+// lower/upper ends of the effective grid (likelihood.py:119-120 for p_gw1d, :186-187 for p_gw3dmarg)
+DEVFN void eff_bounds(bool marg, double zmin, double zmax, double sd, double cut, double& lb, double& ub) {
+  lb = zmin - cut * sd;
+  if (marg) lb = (lb != lb) ? lb : (lb > 1e-8 ? lb : 1e-8);     // jnp.maximum(., 1e-8)
+  else lb = lb > 0. ? lb : 1.e-8;                                // jnp.where(. > 0, ., 1e-8)
+  ub = zmax + cut * sd;
+}
+
+// Epanechnikov density at g from the prefix sums of the (sorted, uniform) binned dataset:
+//   sum_j W_j 3/4 (1 - u_j^2) [|u_j| <= 1] / h,  u_j = (g - c_j)/h
+// = 3/4 (S0 - (g'^2 S0 - 2 g' S1 + S2)/h^2) / h over the index range [ja, jb) of bins inside the support, with
+// S_k = P_k[jb] - P_k[ja], P_k = prefix sums of W c'^k, c' = c - c_ref, g' = g - c_ref.  The range is found from the
+// bin spacing and fixed up with the reference's own predicate |(g - c_j)/h| <= 1 (math.py:78,85).
+// Differs from the dense left-to-right sum by rounding only (~(R/h)^2 eps, R = span of the bins).
+DEVFN double epan_prefix_eval(double g, const double* cen, const double* P0, const double* P1, const double* P2, int N,
+                              double lo, double inv_dbin, double bw, double inv_bw, double c_ref) {
+  double fa = ceil((g - bw - lo) * inv_dbin - 0.5), fb = floor((g + bw - lo) * inv_dbin - 0.5) + 1.;
+  int ja = fa > 0. ? (fa < (double)N ? (int)fa : N) : 0;
+  int jb = fb > 0. ? (fb < (double)N ? (int)fb : N) : 0;
+  // fix-ups with the exact predicate (each loop runs 0 or 1 times for a sane guess)
+  while (ja > 0 && fabs((g - cen[ja - 1]) * inv_bw) <= 1.) ja--;
+  while (ja < N && cen[ja] < g && !(fabs((g - cen[ja]) * inv_bw) <= 1.)) ja++;
+  if (jb < ja) jb = ja;
+  while (jb < N && fabs((g - cen[jb]) * inv_bw) <= 1.) jb++;
+  while (jb > ja && !(fabs((g - cen[jb - 1]) * inv_bw) <= 1.)) jb--;
+  double S0 = P0[jb] - P0[ja], S1 = P1[jb] - P1[ja], S2 = P2[jb] - P2[ja];
+  double gp = g - c_ref;
+  double qq = fma(gp, fma(gp, S0, -2. * S1), S2);                // sum W (g' - c')^2
+  return 0.75 * (S0 - qq * (inv_bw * inv_bw)) * inv_bw;
+}
+
+// dense density at g (math.py:77-81), used for the Gaussian kernel, for binning=False and for degenerate bandwidths
+DEVFN double kde_dense_eval(double g, const double* data, const double* wgt, int N, bool epan, double bw, double inv_bw) {
+  double acc = 0.;
+  if (epan) {
+    for (int j = 0; j < N; j++) {
+      double u = (g - data[j]) * inv_bw;
+      double kv = fabs(u) <= 1. ? 0.75 * (1. - u * u) : 0.;
+      acc += wgt[j] * kv;
+    }
+  } else {
+    const double isq = 1. / sqrt(2. * CHM_PI);
+    for (int j = 0; j < N; j++) {
+      double u = (g - data[j]) * inv_bw;
+      acc += wgt[j] * (exp(-0.5 * (u * u)) * isq);
+    }
   }
-  const double zmin = st[ST_ZMIN], zmax = st[ST_ZMAX], sd = st[ST_STD], norm = st[ST_NORM], n_eff = st[ST_NEFF];
-  const bool ok = n_eff >= L.pe_neff;                       // lax.cond(n_eff >= pe_neff, ...)   likelihood.py:133,199
-  const double gwp = pixelated ? L.gw_pdf[(size_t)e * L.P + p] : 1.;
+  return acc / bw;
+}
 
-  if (ok) {
-    // ---- dataset for the KDE: binned (math.py:32-46) or raw samples
-    const double lo = zmin;
-    const double hi = marg ? L.pixmax[((size_t)b * L.E + e) * L.P + p] : zmax;
-    if (L.binning) {
-      for (int j = lane; j < B; j += 64) {
-        double e0 = jnp_linspace_at(lo, hi, B + 1, j), e1 = jnp_linspace_at(lo, hi, B + 1, j + 1);
-        data[j] = (e0 + e1) / 2.;
-        wgt[j] = 0.;
-      }
-      __syncthreads();
-      for (int s0 = 0; s0 < S; s0 += 64) {
-        int s = s0 + lane;
-        if (s < S && (!marg || pix[s] == p)) {
-          double z = wz[s], w = ww[s];
-          double f = floor((z - lo) / (hi - lo) * (double)B);
-          f = f < 0. ? 0. : (f > (double)(B - 1) ? (double)(B - 1) : f);
-          int idx = (f != f) ? 0 : (int)f;
-          atomicAdd(&wgt[idx], w);
-        }
-      }
-      __syncthreads();
-    } else {
-      for (int s = lane; s < S; s += 64) {
-        bool in = !marg || pix[s] == p;
-        data[s] = in ? wz[s] : zmin;                        // likelihood.py:180-181
-        wgt[s] = in ? ww[s] : 0.;
-      }
-      __syncthreads();
-    }
-    // ---- kde1d prologue (math.py:58-75): normalise weights, neff, std(dataset), bandwidth
-    double a = 0.;
-    for (int j = lane; j < N; j += 64) a += wgt[j];
-    const double tot = wave_sum(a);
-    a = 0.;
-    double c = 0.;
-    for (int j = lane; j < N; j += 64) { double W = wgt[j] / tot; wgt[j] = W; a += W * W; c += data[j]; }
-    const double neff_k = 1.0 / wave_sum(a);
-    const double meanc = wave_sum(c) / (double)N;
-    a = 0.;
-    for (int j = lane; j < N; j += 64) { double d = data[j] - meanc; a += d * d; }
-    const double stdc = sqrt(wave_sum(a) / (double)N);
-    double bw;
-    if (L.bw_method == 0) bw = pow(neff_k, -1. / 5.);
-    else if (L.bw_method == 1) bw = pow(neff_k * 3. / 4.0, -1. / 5.);
-    else bw = L.bw_scalar;
-    bw *= stdc;
-    // ---- effective grid (likelihood.py:115-123, 185-190)
-    if (L.has_cut) {
-      double lb = zmin - L.cut_grid * sd;
-      if (marg) lb = (lb != lb) ? lb : (lb > 1e-8 ? lb : 1e-8);      // jnp.maximum(., 1e-8)         :186
-      else lb = lb > 0. ? lb : 1.e-8;                                 // jnp.where(. > 0, ., 1e-8)    :119
-      double ub = zmax + L.cut_grid * sd;
-      for (int i = lane; i < G; i += 64) eff[i] = jnp_linspace_at(lb, ub, G, i);
-    } else {
-      for (int i = lane; i < G; i += 64) eff[i] = L.z_grids[(size_t)e * Z + i];
-    }
-    __syncthreads();
-    // ---- density on the effective grid (math.py:77-81).  u = (g - x) * (1/bw): one rounding away from the
-    //      reference's (g - x)/bw.  The Epanechnikov sum runs over the bins that can have |u| <= 1 only; the
-    //      skipped terms are exact zeros, so the sum is the one the dense product gives.
-    const bool epan = marg || L.kernel == 0;                 // p_gw3dmarg never passes kernel= (likelihood.py:192)
-    const double inv_bw = 1. / bw;
-    const double dbin = (hi - lo) / (double)B;
-    const bool window = epan && L.binning && dbin > 0. && bw > 0. && bw < 1e300;
-    for (int i = lane; i < G; i += 64) {
-      double g = eff[i];
-      int j0 = 0, j1 = N - 1;
-      if (window) {
-        double f0 = floor((g - bw - lo) / dbin - 0.5) - 1., f1 = ceil((g + bw - lo) / dbin - 0.5) + 1.;
-        j0 = f0 > 0. ? (f0 < (double)N ? (int)f0 : N) : 0;
-        j1 = f1 < (double)(N - 1) ? (f1 >= 0. ? (int)f1 : -1) : N - 1;
-      }
-      double acc = 0.;
-      if (epan) {
-        for (int j = j0; j <= j1; j++) {
-          double u = (g - data[j]) * inv_bw;
-          double kv = fabs(u) <= 1. ? 0.75 * (1. - u * u) : 0.;
-          acc += wgt[j] * kv;
-        }
-      } else {
-        const double isq = 1. / sqrt(2. * CHM_PI);
-        for (int j = j0; j <= j1; j++) {
-          double u = (g - data[j]) * inv_bw;
-          acc += wgt[j] * (exp(-0.5 * (u * u)) * isq);
-        }
-      }
-      double d = acc / bw;
-      dens[i] = marg ? d : d * norm;                         // 1-D: kde*norms before interp (likelihood.py:137)
-    }
-    __syncthreads();
-  }
+// jnp.linspace(start, stop, num)[i] with the step fraction i/(num-1) read from a table (same value as the division)
+DEVFN double linspace_tab(double start, double stop, int num, int i, const double* frac) {
+  if (i >= num - 1) return stop;
+  double step = frac[i];
+  return start * (1. - step) + stop * step;
+}
 
-  // ---- interp to the event grid, integrand, trapezoid (likelihood.py:137/193, 274-278 / 291)
-  const double* zg = L.z_grids + (size_t)e * Z;
-  const size_t zo = ((size_t)b * L.E + e) * Z;
-  const double* jac = L.jac + zo;
-  const double* prate = L.prate + zo;
-  const double* bkgA = L.bkgA + zo;
-  const double* pc = pixelated ? L.p_cat + ((size_t)e * L.P + p) * Z : nullptr;
-  const double fR = P.fR;
+// searchsorted(eff, z, side='right') clipped to [1, G-1] (jnp.interp) starting from a guess
+DEVFN int interp_index(const double* eff, int G, double z, int guess) {
+  int i = guess < 1 ? 1 : (guess > G - 1 ? G - 1 : guess);
+  while (i > 1 && eff[i - 1] > z) i--;
+  while (i < G - 1 && eff[i] <= z) i++;
+  return i;
+}
+
+// jnp.interp(z, eff, dens, left=0, right=0) with an index guess
+DEVFN double interp_lr0(const double* eff, const double* dens, int G, double z, int guess) {
+  int i = interp_index(eff, G, z, guess);
+  double x0 = eff[i - 1], x1 = eff[i], f0 = dens[i - 1], f1 = dens[i];
+  double dx = x1 - x0;
+  double f = (fabs(dx) <= 4.930380657631324e-32) ? f0 : f0 + ((z - x0) / dx) * (f1 - f0);
+  if (z < eff[0]) f = 0.;
+  if (z > eff[G - 1]) f = 0.;
+  return f;
+}
+
+DEVFN int eff_guess(double z, double lb, double ub, int G, bool has_cut, int k) {
+  if (!has_cut) return k + 1;
+  double tpos = (z - lb) / (ub - lb) * (double)(G - 1);
+  if (!(tpos >= 0.)) return 1;
+  if (tpos > (double)G) return G - 1;
+  return (int)tpos + 1;
+}
+
+// One wave: integrand + trapezoid over the event grid for one (event, pixel)   (likelihood.py:274-278 / 291)
+//   y_k = pgw_k * p_z / jac,  p_z = (fR p_cat + bkgA) prate  (pixelated)  |  bkgA prate  (no catalogue)
+template <class PGW>
+DEVFN double wave_integrate(PGW pgw_at, const double* zg, const double* jac, const double* prate, const double* bkgA,
+                            const double* pc, double fR, int Z, double* dump) {
+  const int lane = threadIdx.x & 63;
   double acc = 0.;
   for (int k0 = 0; k0 < Z - 1 || k0 == 0; k0 += 63) {
     int k = k0 + lane;
     double zk = 0., y = 0.;
     if (k < Z) {
       zk = zg[k];
-      double pgw = 0.;
-      if (ok) {
-        double f = jnp_interp(zk, eff, dens, G, true, 0., 0.);
-        pgw = marg ? f * norm * gwp : (pixelated ? f * gwp : f);
-      }
+      double pgw = pgw_at(k, zk);
       if (dump) dump[k] = pgw;
-      if (pixelated) {
+      if (pc) {
         double pcv = pc[k];
         if (pcv != -100.) {
           double p_gal = fR * pcv + bkgA[k];                 // catalog.py:202
@@ -430,44 +412,567 @@ __global__ void __launch_bounds__(64) k_kde_integrate(LikeDev L, const DevParams
     double y1 = __shfl_down(y, 1, 64), z1 = __shfl_down(zk, 1, 64);
     if (lane < 63 && k + 1 < Z) acc += (z1 - zk) * (y1 + y);
   }
-  acc = wave_sum(acc);
-  if (lane == 0) *out_like = 0.5 * acc;
+  return 0.5 * wave_sum(acc);
+}
+
+// inclusive->exclusive prefix sums of W, W c', W c'^2 over N bins by one wave; P*[0..N]
+DEVFN void wave_prefix3(const double* cen, const double* wgt, int N, double c_ref, double* P0, double* P1, double* P2) {
+  const int lane = threadIdx.x & 63;
+  const int per = (N + 63) / 64;
+  const int j0 = lane * per, j1 = min(j0 + per, N);
+  double s0 = 0., s1 = 0., s2 = 0.;
+  for (int j = j0; j < j1; j++) { double W = wgt[j], cc = cen[j] - c_ref; s0 += W; s1 += W * cc; s2 += W * cc * cc; }
+  // exclusive scan of the lane totals
+  double x0 = s0, x1 = s1, x2 = s2;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double y0 = __shfl_up(x0, o, 64), y1 = __shfl_up(x1, o, 64), y2 = __shfl_up(x2, o, 64);
+    if (lane >= o) { x0 += y0; x1 += y1; x2 += y2; }
+  }
+  double r0 = x0 - s0, r1 = x1 - s1, r2 = x2 - s2;
+  if (lane == 0) { P0[0] = 0.; P1[0] = 0.; P2[0] = 0.; }
+  for (int j = j0; j < j1; j++) {
+    double W = wgt[j], cc = cen[j] - c_ref;
+    r0 += W; r1 += W * cc; r2 += W * cc * cc;
+    P0[j + 1] = r0; P1[j + 1] = r1; P2[j + 1] = r2;
+  }
+}
+
+// k_event_prep: one wave per (event, draw): combine the chunk partials once for all the event's pixel blocks.
+// evstat (nb,E,8): zmin, zmax, std, norm, n_eff, sum w, lb, ub  (effective-grid ends, likelihood.py:186-187)
+#define NEVSTAT 8
+__global__ void __launch_bounds__(64) k_event_prep(LikeDev L) {
+  const int e = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const EvStats st = combine_stats(L.part + ((size_t)b * L.E + e) * L.NC * NPART, L.NC, L.S);
+  double* o = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
+  double lb = 0., ub = 0.;
+  if (L.has_cut) eff_bounds(L.mode == 2, st.zmin, st.zmax, st.sd, L.cut_grid, lb, ub);
+  else { lb = L.z_grids[(size_t)e * L.Z]; ub = L.z_grids[(size_t)e * L.Z + L.Z - 1]; }
+  if (lane == 0) { o[0] = st.zmin; o[1] = st.zmax; o[2] = st.sd; o[3] = st.norm; o[4] = st.n_eff; o[5] = st.sumw; o[6] = lb; o[7] = ub; }
+  double* eg = L.effg + ((size_t)b * L.E + e) * L.G;
+  if (L.has_cut) { for (int i = lane; i < L.G; i += 64) eg[i] = linspace_tab(lb, ub, L.G, i, L.fracG); }   // likelihood.py:188
+  else { for (int i = lane; i < L.G; i += 64) eg[i] = L.z_grids[(size_t)e * L.Z + i]; }                        // likelihood.py:190
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_full_kde: 3-D Gaussian KDE, one block (256 threads) per (event, pixel, draw)   likelihood.py:211-260
+// k_kde_marg: one wave per (event, pixel, draw): p_gw3dmarg (likelihood.py:160-205) fused with the integrand,
+// the trapezoid and the -100 masking (likelihood.py:274-278)
+// ------------------------------------------------------------------------------------------------------
+// The integrand is non-zero only where the pixel's KDE is: inside [lb, ub] of the effective grid.  The wave therefore
+// (1) finds the k-range of the event grid inside [lb, ub] from the event statistics and prefetches exactly that part of
+// its p_cat row (HBM) into registers before doing anything else, (2) builds the pixel's histogram / prefix sums / KDE
+// while those loads are in flight, (3) accumulates  sum_k p_gw[k] (fR p_cat[k] + bkgA[k]) A[k]  over that range, with
+// A[k] = prate[k]/jac[k] * tw[k], tw = trapezoid weights of the event grid -- the same sum as
+// trapz(p_gw3d * p_z / jac) up to rounding (terms outside the range are exact zeros for finite inputs).
+// Dynamic LDS: cen[N], wgt[N], [P0,P1,P2 (N+1) when binning], eff[G], dens[G];  N = num_bins or S.
+#define MARG_PF 8            // prefetch depth: 8 x (64 lanes x 2 doubles) = 1024 grid points per pass
+__global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* params) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int p = blockIdx.x % L.P, e = blockIdx.x / L.P, b = blockIdx.y;
+  const DevParams& P = params[b];
+  const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
+  const int N = L.binning ? B : S;
+  double* data = lds; double* wgt = data + N;
+  double* P0 = wgt + N; double* P1 = P0 + (L.binning ? N + 1 : 0); double* P2 = P1 + (L.binning ? N + 1 : 0);
+  double* eff = P2 + (L.binning ? N + 1 : 0); double* dens = eff + G;
+  const size_t so = ((size_t)b * L.E + e) * S;
+  const double* wz = L.ws_z + so;
+  const double* ww = L.ws_w + so;
+  double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
+  double* dump = L.p_gw_dump ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
+
+  if (p >= L.neff_pixels[e]) {        // padded pixel: p_cat == -100 there, integrand masked to 0 (likelihood.py:274-277)
+    if (lane == 0) *out_like = 0.;
+    if (dump) for (int k = lane; k < Z; k += 64) dump[k] = 0.;
+    return;
+  }
+  const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
+  const double zmin = es[0], norm = es[3], n_eff = es[4], lb = es[6], ub = es[7];
+  const bool ok = n_eff >= L.pe_neff;                       // lax.cond(n_eff >= pe_neff, ...)   likelihood.py:199
+  const double* zg = L.z_grids + (size_t)e * Z;
+  const double* pc = L.p_cat + ((size_t)e * L.P + p) * Z;
+
+  // (1) k-range of the event grid that can see a non-zero KDE: z_k in [lb, ub].  Guess from the end points (the grid is
+  //     a linspace, pop_wrapper.py:207), verify against the stored grid, fall back to the whole grid otherwise.
+  int k_lo = 0, k_hi = Z - 1;
+  if (ok) {
+    const double z0 = zg[0], zl = zg[Z - 1];
+    const double inv_dz = (double)(Z - 1) / (zl - z0);
+    double fl = floor((lb - z0) * inv_dz) - 1., fh = ceil((ub - z0) * inv_dz) + 1.;
+    int gl = fl > 0. ? (fl < (double)(Z - 1) ? (int)fl : Z - 1) : 0;
+    int gh = fh < (double)(Z - 1) ? (fh > 0. ? (int)fh : 0) : Z - 1;
+    if (fl == fl && fh == fh && gl <= gh && (gl == 0 || zg[gl] < lb) && (gh == Z - 1 || zg[gh] > ub)) { k_lo = gl; k_hi = gh; }
+  }
+  k_lo &= ~1;                                               // 16-byte aligned pairs
+  // prefetch the first pass of the p_cat segment: lane owns grid points k_lo + 128*i + 2*lane + {0,1}
+  double pf0[MARG_PF], pf1[MARG_PF];
+  if (ok && !(L.dbg & 8)) {
+#pragma unroll
+    for (int i = 0; i < MARG_PF; i++) {
+      int k = k_lo + 128 * i + 2 * lane;
+      pf0[i] = 0.; pf1[i] = 0.;
+      if (k + 1 <= k_hi && ((Z & 1) == 0)) { double2 v = *reinterpret_cast<const double2*>(pc + k); pf0[i] = v.x; pf1[i] = v.y; }
+      else { if (k <= k_hi) pf0[i] = pc[k]; if (k + 1 <= k_hi) pf1[i] = pc[k + 1]; }
+    }
+  }
+
+  if (ok && !(L.dbg & 16)) {
+    const int s0 = L.seg_off[(size_t)e * (L.P + 1) + p], s1 = L.seg_off[(size_t)e * (L.P + 1) + p + 1];
+    const double lo = zmin;
+    // hi = max(where(mask, z, min z))  (likelihood.py:180, math.py:36)
+    double hi = lo;
+    for (int s = s0 + lane; s < s1; s += 64) hi = nanmax2(hi, wz[s]);
+    hi = wave_max(hi);
+    if (lo != lo) hi = lo;
+    if (L.binning) {
+      for (int j = lane; j < B; j += 64) {                  // bin centres (math.py:37-39)
+        double e0 = linspace_tab(lo, hi, B + 1, j, L.fracB), e1 = linspace_tab(lo, hi, B + 1, j + 1, L.fracB);
+        data[j] = (e0 + e1) / 2.;
+        wgt[j] = 0.;
+      }
+      __syncthreads();
+      if (!(L.dbg & 1)) for (int s = s0 + lane; s < s1; s += 64) atomicAdd(&wgt[bin_index(wz[s], lo, hi, B)], ww[s]);
+      __syncthreads();
+    } else {
+      for (int s = lane; s < S; s += 64) {
+        bool in = s >= s0 && s < s1;
+        data[s] = in ? wz[s] : zmin;                        // likelihood.py:180-181
+        wgt[s] = in ? ww[s] : 0.;
+      }
+      __syncthreads();
+    }
+    // kde1d prologue (math.py:58-75): normalise weights, neff, std(dataset), bandwidth
+    double a = 0.;
+    for (int j = lane; j < N; j += 64) a += wgt[j];
+    const double tot = wave_sum(a);
+    a = 0.;
+    double c = 0.;
+    for (int j = lane; j < N; j += 64) { double W = wgt[j] / tot; wgt[j] = W; a += W * W; c += data[j]; }
+    const double neff_k = 1.0 / wave_sum(a);
+    const double meanc = wave_sum(c) / (double)N;
+    a = 0.;
+    for (int j = lane; j < N; j += 64) { double d = data[j] - meanc; a += d * d; }
+    const double stdc = sqrt(wave_sum(a) / (double)N);
+    const double bw = kde_bandwidth_factor(L.bw_method, L.bw_scalar, neff_k, 1) * stdc;
+    // effective grid (likelihood.py:185-190), built once per event by k_event_prep
+    { const double* eg = L.effg + ((size_t)b * L.E + e) * G; for (int i = lane; i < G; i += 64) eff[i] = eg[i]; }
+    __syncthreads();
+    // density on the effective grid: always Epanechnikov here (kde1d is called without kernel=, likelihood.py:192)
+    const double inv_bw = 1. / bw;
+    const double dbin = (hi - lo) / (double)B;
+    const bool fast = L.binning && dbin > 0. && bw > 0. && bw < 1e300 && tot == tot && (tot > 0. || tot < 0.);
+    if (fast) {
+      wave_prefix3(data, wgt, N, lo, P0, P1, P2);
+      __syncthreads();
+      if (!(L.dbg & 2)) for (int i = lane; i < G; i += 64) dens[i] = epan_prefix_eval(eff[i], data, P0, P1, P2, N, lo, 1. / dbin, bw, inv_bw, lo);
+    } else {
+      for (int i = lane; i < G; i += 64) dens[i] = kde_dense_eval(eff[i], data, wgt, N, true, bw, inv_bw);
+    }
+    __syncthreads();
+  }
+
+  // (3) integrand over [k_lo, k_hi]
+  const size_t zo = ((size_t)b * L.E + e) * Z;
+  const double* bkgA = L.bkgA + zo;
+  const double* Aw = L.Aw + zo;
+  const double gwp = L.gw_pdf[(size_t)e * L.P + p];
+  const double fR = P.fR;
+  const double inv_de = (double)(G - 1) / (ub - lb);
+  const bool has_cut = L.has_cut;
+  double acc = 0.;
+  if (dump) { for (int k = lane; k < Z; k += 64) if (!ok || k < k_lo || k > k_hi) dump[k] = 0.; }
+  if (ok && !(L.dbg & 4)) {
+    for (int kb = k_lo; kb <= k_hi; kb += 128 * MARG_PF) {
+#pragma unroll
+      for (int i = 0; i < MARG_PF; i++) {
+        const int k = kb + 128 * i + 2 * lane;
+        if (k <= k_hi) {
+          double pc0, pc1;
+          if (kb == k_lo) { pc0 = pf0[i]; pc1 = pf1[i]; }
+          else { pc0 = pc[k]; pc1 = (k + 1 <= k_hi) ? pc[k + 1] : 0.; }
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int kk = k + h;
+            if (kk <= k_hi) {
+              const double zk = zg[kk];
+              int guess = has_cut ? ((zk - lb) * inv_de >= 0. ? (int)fmin((zk - lb) * inv_de, (double)G) + 1 : 1) : kk + 1;
+              double f = interp_lr0(eff, dens, G, zk, guess);
+              double pgw = f * norm * gwp;                  // kde_interp * norm * gw_pdf[i]    likelihood.py:194
+              if (dump) dump[kk] = pgw;
+              const double pcv = h == 0 ? pc0 : pc1;
+              if (pcv != -100.) acc += pgw * (fR * pcv + bkgA[kk]) * Aw[kk];    // catalog.py:202, pop_wrapper.py:87, likelihood.py:275
+            }
+          }
+        }
+      }
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) *out_like = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_kde_marg_fast: the marginalized GW kernel for the standard configuration (binning=True, cut_grid set):
+// one wave per (event, pixel, draw).  Same quantity as k_kde_marg, organised for latency and occupancy:
+//   * LDS holds only the bin centres and the three prefix-sum arrays (6.4 KB at 200 bins -> 20+ waves per CU);
+//   * the KDE is evaluated on demand at the two effective-grid nodes that bracket each event-grid point (the values
+//     jnp.interp combines, likelihood.py:193) instead of on the whole effective grid first;
+//   * weights stay un-normalised in the prefix sums, 1/sum(w) is applied at the end; std of the bin centres is the
+//     closed form for a uniform grid, (hi-lo) sqrt((B^2-1)/12)/B (math.py:67 evaluates it numerically: same to ~1e-16).
+// Degenerate pixels (no in-pixel weight, zero-width histogram, zero bandwidth) give NaN, as the reference's 0/0 does.
+// ------------------------------------------------------------------------------------------------------
+#define FAST_PF 4
+struct EpanCtx { const double* cen; const double* P0; const double* P1; const double* P2; int N; double lo, inv_dbin, bw, inv_bw, scale; };
+
+DEVFN double epan_node(const EpanCtx& c, double g) {
+  double fa = ceil((g - c.bw - c.lo) * c.inv_dbin - 0.5), fb = floor((g + c.bw - c.lo) * c.inv_dbin - 0.5) + 1.;
+  const int N = c.N;
+  int ja = fa > 0. ? (fa < (double)N ? (int)fa : N) : 0;
+  int jb = fb > 0. ? (fb < (double)N ? (int)fb : N) : 0;
+  while (ja > 0 && fabs((g - c.cen[ja - 1]) * c.inv_bw) <= 1.) ja--;
+  while (ja < N && c.cen[ja] < g && !(fabs((g - c.cen[ja]) * c.inv_bw) <= 1.)) ja++;
+  if (jb < ja) jb = ja;
+  while (jb < N && fabs((g - c.cen[jb]) * c.inv_bw) <= 1.) jb++;
+  while (jb > ja && !(fabs((g - c.cen[jb - 1]) * c.inv_bw) <= 1.)) jb--;
+  double S0 = c.P0[jb] - c.P0[ja], S1 = c.P1[jb] - c.P1[ja], S2 = c.P2[jb] - c.P2[ja];
+  double gp = g - c.lo;
+  double qq = fma(gp, fma(gp, S0, -2. * S1), S2);
+  return (S0 - qq * (c.inv_bw * c.inv_bw)) * c.scale;
+}
+
+__global__ void __launch_bounds__(64) k_kde_marg_fast(LikeDev L, const DevParams* params) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x;
+  const int p = blockIdx.x % L.P, e = blockIdx.x / L.P, b = blockIdx.y;
+  const DevParams& P = params[b];
+  const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
+  double* cen = lds; double* P0 = cen + B; double* P1 = P0 + (B + 1); double* P2 = P1 + (B + 1);
+  double* cnt = P0;                                         // bin counts live in P0[0..B) until the prefix pass
+  double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
+  double* dump = L.p_gw_dump ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
+  if (p >= L.neff_pixels[e]) {
+    if (lane == 0) *out_like = 0.;
+    if (dump) for (int k = lane; k < Z; k += 64) dump[k] = 0.;
+    return;
+  }
+  const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
+  const double zmin = es[0], norm = es[3], n_eff = es[4], lb = es[6], ub = es[7];
+  const bool ok = n_eff >= L.pe_neff;                       // likelihood.py:199
+  if (!ok) {
+    if (lane == 0) *out_like = 0.;
+    if (dump) for (int k = lane; k < Z; k += 64) dump[k] = 0.;
+    return;
+  }
+  const double* zg = L.z_grids + (size_t)e * Z;
+  const double* pc = L.p_cat + ((size_t)e * L.P + p) * Z;
+  // k-range of the event grid inside [lb, ub] (see k_kde_marg)
+  int k_lo = 0, k_hi = Z - 1;
+  {
+    const double z0 = zg[0], zl = zg[Z - 1];
+    const double inv_dz = (double)(Z - 1) / (zl - z0);
+    double fl = floor((lb - z0) * inv_dz) - 1., fh = ceil((ub - z0) * inv_dz) + 1.;
+    int gl = fl > 0. ? (fl < (double)(Z - 1) ? (int)fl : Z - 1) : 0;
+    int gh = fh < (double)(Z - 1) ? (fh > 0. ? (int)fh : 0) : Z - 1;
+    if (fl == fl && fh == fh && gl <= gh && (gl == 0 || zg[gl] < lb) && (gh == Z - 1 || zg[gh] > ub)) { k_lo = gl; k_hi = gh; }
+  }
+  k_lo &= ~1;
+  const bool vec2 = (Z & 1) == 0;
+  double pf0[FAST_PF], pf1[FAST_PF];
+#pragma unroll
+  for (int i = 0; i < FAST_PF; i++) {
+    int k = k_lo + 128 * i + 2 * lane;
+    pf0[i] = 0.; pf1[i] = 0.;
+    if (vec2 && k + 1 <= k_hi) { double2 v = *reinterpret_cast<const double2*>(pc + k); pf0[i] = v.x; pf1[i] = v.y; }
+    else { if (k <= k_hi) pf0[i] = pc[k]; if (k + 1 <= k_hi) pf1[i] = pc[k + 1]; }
+  }
+
+  // histogram of this pixel's samples on [min z, max z in pixel] (math.py:32-46, likelihood.py:180-183)
+  const size_t so = ((size_t)b * L.E + e) * S;
+  const double* wz = L.ws_z + so;
+  const double* ww = L.ws_w + so;
+  const int s0 = L.seg_off[(size_t)e * (L.P + 1) + p], s1 = L.seg_off[(size_t)e * (L.P + 1) + p + 1];
+  const double lo = zmin;
+  double zr[2], wr[2];                                      // first two samples per lane stay in registers
+#pragma unroll
+  for (int i = 0; i < 2; i++) { int s = s0 + lane + 64 * i; zr[i] = s < s1 ? wz[s] : lo; wr[i] = s < s1 ? ww[s] : 0.; }
+  double hi = nanmax2(nanmax2(lo, zr[0]), zr[1]);
+  for (int s = s0 + lane + 128; s < s1; s += 64) hi = nanmax2(hi, wz[s]);
+  hi = wave_max(hi);
+  if (lo != lo) hi = lo;
+  for (int j = lane; j < B; j += 64) {                      // bin centres (math.py:37-39)
+    double e0 = linspace_tab(lo, hi, B + 1, j, L.fracB), e1 = linspace_tab(lo, hi, B + 1, j + 1, L.fracB);
+    cen[j] = (e0 + e1) / 2.;
+    cnt[j] = 0.;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; i++) { int s = s0 + lane + 64 * i; if (s < s1) atomicAdd(&cnt[bin_index(zr[i], lo, hi, B)], wr[i]); }
+  for (int s = s0 + lane + 128; s < s1; s += 64) atomicAdd(&cnt[bin_index(wz[s], lo, hi, B)], ww[s]);
+  __syncthreads();
+  // sum w, sum w^2 over the bins; prefix sums of (w, w c', w c'^2), c' = centre - lo
+  const int per = (B + 63) / 64;
+  const int j0 = lane * per, j1 = min(j0 + per, B);
+  double s0w = 0., s1w = 0., s2w = 0., sq = 0.;
+  for (int j = j0; j < j1; j++) { double w = cnt[j], cc = cen[j] - lo; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
+  double x0 = s0w, x1 = s1w, x2 = s2w;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    double y0 = __shfl_up(x0, o, 64), y1 = __shfl_up(x1, o, 64), y2 = __shfl_up(x2, o, 64);
+    if (lane >= o) { x0 += y0; x1 += y1; x2 += y2; }
+  }
+  const double tot = __shfl(x0, 63, 64);
+  const double sum2 = wave_sum(sq);
+  {
+    double r0 = x0 - s0w, r1 = x1 - s1w, r2 = x2 - s2w;
+    double wv[8];                                           // the lane's counts, read before P0 overwrites them
+    const bool small = per <= 8;
+    if (small) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) wv[i] = (j0 + i < j1) ? cnt[j0 + i] : 0.;
+    }
+    __syncthreads();
+    if (small) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) if (j0 + i < j1) {
+        double w = wv[i], cc = cen[j0 + i] - lo;
+        r0 += w; r1 += w * cc; r2 += w * cc * cc;
+        P0[j0 + i + 1] = r0; P1[j0 + i + 1] = r1; P2[j0 + i + 1] = r2;
+      }
+    } else {                                                // many bins per lane: walk backwards so that cnt[j] is read before P0[j+1] lands on cnt[j+1]
+      // recompute from the top: P0[j+1] for j descending needs the inclusive value; do a forward pass into P1/P2 first
+      double a0 = r0, a1 = r1, a2 = r2;
+      for (int j = j0; j < j1; j++) { double w = cnt[j], cc = cen[j] - lo; a1 += w * cc; a2 += w * cc * cc; P1[j + 1] = a1; P2[j + 1] = a2; }
+      a0 = r0; for (int j = j0; j < j1; j++) a0 += cnt[j];
+      for (int j = j1 - 1; j >= j0; j--) { double w = cnt[j]; P0[j + 1] = a0; a0 -= w; }
+    }
+    if (lane == 0) { P1[0] = 0.; P2[0] = 0.; }
+    __syncthreads();
+    if (lane == 0) P0[0] = 0.;
+    __syncthreads();
+  }
+  // bandwidth: neff = 1/sum(W^2), W = w/tot (math.py:62-64); std of the uniform centres; factor (math.py:65-73)
+  const double neff_k = (tot * tot) / sum2;
+  const double stdc = (hi - lo) * (sqrt(((double)B * (double)B - 1.) / 12.) / (double)B);
+  const double bw = kde_bandwidth_factor(L.bw_method, L.bw_scalar, neff_k, 1) * stdc;
+  const double dbin = (hi - lo) / (double)B;
+  const bool degenerate = !(dbin > 0.) || !(bw > 0.) || !(bw < 1e300) || !(tot > 0. || tot < 0.);
+  EpanCtx cx;
+  cx.cen = cen; cx.P0 = P0; cx.P1 = P1; cx.P2 = P2; cx.N = B; cx.lo = lo; cx.inv_dbin = 1. / dbin; cx.bw = bw; cx.inv_bw = 1. / bw;
+  cx.scale = 0.75 * cx.inv_bw / tot;
+
+  const size_t zo = ((size_t)b * L.E + e) * Z;
+  const double* bkgA = L.bkgA + zo;
+  const double* Aw = L.Aw + zo;
+  const double* eg = L.effg + ((size_t)b * L.E + e) * G;
+  const double gwp = L.gw_pdf[(size_t)e * L.P + p];
+  const double fR = P.fR;
+  const double inv_de = (double)(G - 1) / (ub - lb);
+  const double nan = __builtin_nan("");
+  double acc = 0.;
+  if (dump) { for (int k = lane; k < Z; k += 64) if (k < k_lo || k > k_hi) dump[k] = 0.; }
+  for (int kb = k_lo; kb <= k_hi; kb += 128 * FAST_PF) {
+#pragma unroll
+    for (int i = 0; i < FAST_PF; i++) {
+      const int k = kb + 128 * i + 2 * lane;
+      if (k <= k_hi) {
+        double pc0, pc1;
+        if (kb == k_lo) { pc0 = pf0[i]; pc1 = pf1[i]; }
+        else { pc0 = pc[k]; pc1 = (k + 1 <= k_hi) ? pc[k + 1] : 0.; }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int kk = k + h;
+          if (kk <= k_hi) {
+            const double zk = zg[kk];
+            double pgw = 0.;
+            if (zk >= lb && zk <= ub) {                     // jnp.interp(..., left=0, right=0)
+              double tp = (zk - lb) * inv_de;
+              int i1 = interp_index(eg, G, zk, (int)fmin(tp, (double)G) + 1);
+              double xa = eg[i1 - 1], xb = eg[i1];
+              double da = epan_node(cx, xa), db = epan_node(cx, xb);
+              double dx = xb - xa;
+              double f = (fabs(dx) <= 4.930380657631324e-32) ? da : da + ((zk - xa) / dx) * (db - da);
+              pgw = degenerate ? nan : f * norm * gwp;     // kde_interp * norm * gw_pdf[i]    likelihood.py:194
+            } else if (zk != zk) pgw = nan;
+            if (dump) dump[kk] = pgw;
+            const double pcv = h == 0 ? pc0 : pc1;
+            if (pcv != -100.) acc += pgw * (fR * pcv + bkgA[kk]) * Aw[kk];
+          }
+        }
+      }
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) *out_like = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_kde1d: p_gw1d (likelihood.py:105-144): one block (256 threads) per (event, draw) -> pgw1d (nb,E,Z)
+// ------------------------------------------------------------------------------------------------------
+// Dynamic LDS: data[N], wgt[N], hw[3*N] (per-wave private histograms / prefix arrays), eff[G], dens[G]
+__global__ void __launch_bounds__(256) k_kde1d(LikeDev L, const DevParams* params) {
+  extern __shared__ double lds[];
+  __shared__ double red[16];
+  const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wid = t >> 6;
+  const int e = blockIdx.x, b = blockIdx.y;
+  const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
+  const int N = L.binning ? B : S;
+  double* data = lds; double* wgt = data + N;
+  double* hw = wgt + N;                                     // binning: 3*(N+1) doubles
+  double* eff = hw + (L.binning ? 3 * (N + 1) : 0); double* dens = eff + G;
+  const size_t so = ((size_t)b * L.E + e) * S;
+  const double* wz = L.ws_z + so;
+  const double* ww = L.ws_w + so;
+  double* out = L.pgw1d + ((size_t)b * L.E + e) * Z;
+  const EvStats st = combine_stats(L.part + ((size_t)b * L.E + e) * L.NC * NPART, L.NC, S);
+  const bool ok = st.n_eff >= L.pe_neff;                    // likelihood.py:133
+  if (!ok) { for (int k = t; k < Z; k += nt) out[k] = 0.; return; }
+  const double lo = st.zmin, hi = st.zmax;
+  if (L.binning) {
+    // per-wave private histograms (deterministic: each wave owns every 4th chunk of 64 samples), then a fixed-order sum
+    for (int j = t; j < 3 * (N + 1); j += nt) hw[j] = 0.;
+    for (int j = t; j < B; j += nt) {
+      double e0 = jnp_linspace_at(lo, hi, B + 1, j), e1 = jnp_linspace_at(lo, hi, B + 1, j + 1);
+      data[j] = (e0 + e1) / 2.;
+      wgt[j] = 0.;
+    }
+    __syncthreads();
+    double* mine = wid == 0 ? wgt : hw + (size_t)(wid - 1) * N;
+    for (int s = t; s < S; s += nt) atomicAdd(&mine[bin_index(wz[s], lo, hi, B)], ww[s]);
+    __syncthreads();
+    for (int j = t; j < B; j += nt) wgt[j] = ((wgt[j] + hw[j]) + hw[N + j]) + hw[2 * N + j];
+    __syncthreads();
+  } else {
+    for (int s = t; s < S; s += nt) { data[s] = wz[s]; wgt[s] = ww[s]; }
+    __syncthreads();
+  }
+  double a = 0.;
+  for (int j = t; j < N; j += nt) a += wgt[j];
+  const double tot = block_reduce<RED_SUM>(a, red);
+  a = 0.;
+  double c = 0.;
+  for (int j = t; j < N; j += nt) { double W = wgt[j] / tot; wgt[j] = W; a += W * W; c += data[j]; }
+  const double neff_k = 1.0 / block_reduce<RED_SUM>(a, red);
+  const double meanc = block_reduce<RED_SUM>(c, red) / (double)N;
+  a = 0.;
+  for (int j = t; j < N; j += nt) { double d = data[j] - meanc; a += d * d; }
+  const double stdc = sqrt(block_reduce<RED_SUM>(a, red) / (double)N);
+  const double bw = kde_bandwidth_factor(L.bw_method, L.bw_scalar, neff_k, 1) * stdc;
+  double lb = 0., ub = 0.;
+  if (L.has_cut) {
+    eff_bounds(false, st.zmin, st.zmax, st.sd, L.cut_grid, lb, ub);
+    for (int i = t; i < G; i += nt) eff[i] = jnp_linspace_at(lb, ub, G, i);
+  } else {
+    for (int i = t; i < G; i += nt) eff[i] = L.z_grids[(size_t)e * Z + i];
+  }
+  __syncthreads();
+  const bool epan = L.kernel == 0;
+  const double inv_bw = 1. / bw;
+  const double dbin = (hi - lo) / (double)B;
+  const bool fast = epan && L.binning && dbin > 0. && bw > 0. && bw < 1e300 && tot == tot && (tot > 0. || tot < 0.);
+  if (fast) {
+    double* P0 = hw; double* P1 = hw + (N + 1); double* P2 = hw + 2 * (N + 1);
+    if (wid == 0) wave_prefix3(data, wgt, N, lo, P0, P1, P2);
+    __syncthreads();
+    for (int i = t; i < G; i += nt) dens[i] = epan_prefix_eval(eff[i], data, P0, P1, P2, N, lo, 1. / dbin, bw, inv_bw, lo) * st.norm;
+  } else {
+    for (int i = t; i < G; i += nt) dens[i] = kde_dense_eval(eff[i], data, wgt, N, epan, bw, inv_bw) * st.norm;
+  }
+  __syncthreads();
+  // kde*norm interpolated to the event grid, left = right = 0 (likelihood.py:137)
+  for (int k = t; k < Z; k += nt) {
+    double zk = L.z_grids[(size_t)e * Z + k];
+    out[k] = interp_lr0(eff, dens, G, zk, eff_guess(zk, lb, ub, G, L.has_cut, k));
+  }
+}
+
+// k_integrate_1d: one wave per (event, pixel, draw): p_gw3dapprox (likelihood.py:150-154) or the 1-D case,
+// integrand and trapezoid (likelihood.py:266-292)
+__global__ void __launch_bounds__(64) k_integrate_1d(LikeDev L, const DevParams* params) {
+  const int lane = threadIdx.x;
+  const int Pd = L.P > 0 ? L.P : 1;
+  const int p = blockIdx.x % Pd, e = blockIdx.x / Pd, b = blockIdx.y;
+  const DevParams& P = params[b];
+  const int Z = L.Z;
+  const bool pixelated = L.mode != 0;
+  double* out_like = L.like_pix + ((size_t)b * L.E + e) * Pd + p;
+  double* dump = (L.p_gw_dump && pixelated) ? L.p_gw_dump + (((size_t)b * L.E + e) * Pd + p) * Z : nullptr;
+  if (pixelated && p >= L.neff_pixels[e]) {
+    if (lane == 0) *out_like = 0.;
+    if (dump) for (int k = lane; k < Z; k += 64) dump[k] = 0.;
+    return;
+  }
+  const double gwp = pixelated ? L.gw_pdf[(size_t)e * L.P + p] : 1.;
+  const size_t zo = ((size_t)b * L.E + e) * Z;
+  const double* g1 = L.pgw1d + zo;
+  auto pgw_at = [&](int k, double zk) -> double { return pixelated ? g1[k] * gwp : g1[k]; };
+  double r = wave_integrate(pgw_at, L.z_grids + (size_t)e * Z, L.jac + zo, L.prate + zo, L.bkgA + zo,
+                            pixelated ? L.p_cat + ((size_t)e * L.P + p) * Z : nullptr, P.fR, Z, dump);
+  if (lane == 0) *out_like = r;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_full_kde: 3-D Gaussian KDE, one block (256 threads) per (event, pixel, draw)   likelihood.py:211-260, math.py:154-229
 // ------------------------------------------------------------------------------------------------------
 #define FULL_TILE 1024
 __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* params) {
   __shared__ double xs0[FULL_TILE], xs1[FULL_TILE], xs2[FULL_TILE], xw[FULL_TILE];
   __shared__ double red[16];
+  __shared__ double wh[12];
   const int t = threadIdx.x, nt = blockDim.x;
   const int p = blockIdx.x % L.P, e = blockIdx.x / L.P, b = blockIdx.y;
   const DevParams& P = params[b];
   const int S = L.S, Z = L.Z;
-  const double* st = L.stats + ((size_t)b * L.E + e) * NSTAT;
   const size_t so = ((size_t)b * L.E + e) * S;
   const size_t eo = (size_t)e * S;
   const double* wz = L.ws_z + so;
   const double* ww = L.ws_w + so;
   double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
   double* dump = L.p_gw_dump ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
-  const int npix = L.neff_pixels[e];
-  if (p >= npix) {                                        // result[ev, :npix] only (likelihood.py:253)
+  if (p >= L.neff_pixels[e]) {                            // result[ev, :npix] only (likelihood.py:253)
     if (t == 0) *out_like = 0.;
     if (dump) for (int k = t; k < Z; k += nt) dump[k] = 0.;
     return;
   }
-  const double zmin = st[ST_ZMIN], zmax = st[ST_ZMAX], sd = st[ST_STD], norm = st[ST_NORM], n_eff = st[ST_NEFF], sumw = st[ST_SUMW];
-  const bool ok = !(n_eff < L.pe_neff);                   // `if n_effs[ev] < pe_neff: continue`   likelihood.py:234
-  const double l00 = st[ST_L00], l10 = st[ST_L10], l11 = st[ST_L11], l20 = st[ST_L20], l21 = st[ST_L21], l22 = st[ST_L22];
-  const double log_norm = st[ST_LOGNORM];
-  const double zhi = zmax + L.cut_grid * sd, zlo = zmin - L.cut_grid * sd;      // likelihood.py:225
+  const double* part = L.part + ((size_t)b * L.E + e) * L.NC * NPART;
+  const EvStats st = combine_stats(part, L.NC, S);
+  const bool ok = !(st.n_eff < L.pe_neff);                // `if n_effs[ev] < pe_neff: continue`   likelihood.py:234
+  if (t == 0) {
+    // weighted mean / covariance of (z, ra, dec) (math.py:173-190) from the shifted un-normalised moments, then
+    // inv_cov / factor^2 and its lower Cholesky factor (math.py:191-195)
+    double sw = 0., sw2 = 0., a[3] = {0., 0., 0.}, m[6] = {0., 0., 0., 0., 0., 0.};
+    for (int c = 0; c < L.NC; c++) {
+      const double* q = part + (size_t)c * NPART;
+      sw += q[PT_SW]; sw2 += q[PT_SW2];
+      a[0] += q[PT_WD0]; a[1] += q[PT_WD1]; a[2] += q[PT_WD2];
+      m[0] += q[PT_W00]; m[1] += q[PT_W01]; m[2] += q[PT_W02]; m[3] += q[PT_W11]; m[4] += q[PT_W12]; m[5] += q[PT_W22];
+    }
+    double sW2 = sw2 / (sw * sw);                         // sum(W^2), W = w / sum(w)
+    double m0 = a[0] / sw, m1 = a[1] / sw, m2 = a[2] / sw;
+    double den = 1. - sW2;
+    double c00 = (m[0] / sw - m0 * m0) / den, c01 = (m[1] / sw - m0 * m1) / den, c02 = (m[2] / sw - m0 * m2) / den;
+    double c11 = (m[3] / sw - m1 * m1) / den, c12 = (m[4] / sw - m1 * m2) / den, c22 = (m[5] / sw - m2 * m2) / den;
+    double neff = 1. / sW2;
+    double factor = kde_bandwidth_factor(L.bw_method, L.bw_scalar, neff, 3);
+    double a00 = c11 * c22 - c12 * c12, a01 = c02 * c12 - c01 * c22, a02 = c01 * c12 - c02 * c11;
+    double a11 = c00 * c22 - c02 * c02, a12 = c01 * c02 - c00 * c12, a22 = c00 * c11 - c01 * c01;
+    double det = c00 * a00 + c01 * a01 + c02 * a02;
+    double f2 = factor * factor;
+    double i00 = a00 / det / f2, i01 = a01 / det / f2, i02 = a02 / det / f2;
+    double i11 = a11 / det / f2, i12 = a12 / det / f2, i22 = a22 / det / f2;
+    double l00 = sqrt(i00), l10 = i01 / l00, l20 = i02 / l00;
+    double l11 = sqrt(i11 - l10 * l10), l21 = (i12 - l20 * l10) / l11;
+    double l22 = sqrt(i22 - l20 * l20 - l21 * l21);
+    wh[0] = l00; wh[1] = l10; wh[2] = l11; wh[3] = l20; wh[4] = l21; wh[5] = l22;
+    wh[6] = (log(l00) + log(l11) + log(l22)) - 0.5 * 3. * log(2. * CHM_PI);      // log_norm  math.py:215
+  }
+  __syncthreads();
+  const double l00 = wh[0], l10 = wh[1], l11 = wh[2], l20 = wh[3], l21 = wh[4], l22 = wh[5], log_norm = wh[6];
+  const double zhi = st.zmax + L.cut_grid * st.sd, zlo = st.zmin - L.cut_grid * st.sd;      // likelihood.py:225
   const double* zg = L.z_grids + (size_t)e * Z;
   const double rp = L.ra_pix[(size_t)e * L.P + p], dp = L.dec_pix[(size_t)e * L.P + p];
-  // whitened query: q = (z, ra_p, dec_p) . L   (math.py:196): q0 = z*l00 + ra*l10 + dec*l20; q1 = ra*l11 + dec*l21; q2 = dec*l22
+  // whitened query (math.py:196): q = (z, ra_p, dec_p) . L
   const double q1 = rp * l11 + dp * l21, q2 = dp * l22;
-  const int KPT = (Z + nt - 1) / nt;                      // grid points per thread (<= 8 supported per pass)
   const size_t zo = ((size_t)b * L.E + e) * Z;
   double accl = 0.;
   for (int kb = 0; kb < Z; kb += nt * 4) {
@@ -488,7 +993,7 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
           xs0[s] = x0 * l00 + x1 * l10 + x2 * l20;
           xs1[s] = x1 * l11 + x2 * l21;
           xs2[s] = x2 * l22;
-          xw[s] = ww[s0 + s] / sumw;
+          xw[s] = ww[s0 + s] / st.sumw;
         }
         __syncthreads();
         int ns = min(FULL_TILE, S - s0);
@@ -504,12 +1009,11 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
         }
       }
     }
-    // integrand + trapezoid for these grid points: y_k needs y_{k+1}; store y in the dump-free way via LDS ring
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       int k = kb + r * nt + t;
       if (k < Z) {
-        double pgw = inm[r] ? val[r] * norm : 0.;
+        double pgw = inm[r] ? val[r] * st.norm : 0.;
         if (dump) dump[k] = pgw;
         double pcv = L.p_cat[((size_t)e * L.P + p) * Z + k];
         double y = 0.;
@@ -518,14 +1022,12 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
           double p_z = p_gal * L.prate[zo + k];
           y = (p_z != -100.) ? pgw * p_z / L.jac[zo + k] : 0.;
         }
-        // trapezoid weights: y_k * (z_{k+1} - z_{k-1}) / 2 at interior points -- written as the sum of the two
-        // adjacent half-intervals so that no neighbour exchange is needed
+        // trapezoid: y_k enters the two adjacent intervals
         double zl = k > 0 ? zg[k - 1] : zg[k], zr = k < Z - 1 ? zg[k + 1] : zg[k];
         accl += y * ((zg[k] - zl) + (zr - zg[k]));
       }
     }
   }
-  (void)KPT;
   accl = block_reduce<RED_SUM>(accl, red);
   if (t == 0) *out_like = 0.5 * accl;
 }
@@ -577,54 +1079,39 @@ __global__ void __launch_bounds__(256) k_selection(SelDev Sd, const DevParams* p
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_reduce: shard partials [sum_i nan_to_num(log L_i), nansum dN, sum dN^2] per draw; optional per-event outputs
+// reductions
 // ------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_reduce(int E, int Pd, const double* like_pix, int nblocks_sel, const double* sel_partial,
-                                                 double* partials /* (nb,3) */, double* log_like_evs, double* numlike_evs) {
+// k_reduce_events: one thread per event: L_i = sum_p like_pix (likelihood.py:280), log, nan_to_num (:296-297); block sums
+__global__ void __launch_bounds__(256) k_reduce_events(int E, int Pd, const double* like_pix, double* ev_partial /* (nb, nblk) */,
+                                                        double* log_like_evs, double* numlike_evs) {
   __shared__ double red[16];
-  const int b = blockIdx.x, t = threadIdx.x;
-  double acc = 0.;
-  bool any_neginf = false;
-  for (int e = t; e < E; e += blockDim.x) {
+  const int b = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
+  double ll = 0.;
+  if (e < E) {
     const double* lp = like_pix + ((size_t)b * E + e) * Pd;
     double Li = 0.;
-    for (int p = 0; p < Pd; p++) Li += lp[p];                        // jnp.sum over pixels          likelihood.py:280
-    double ll = log(Li);                                             // likelihood.py:296,329
+    for (int p = 0; p < Pd; p++) Li += lp[p];
+    ll = log(Li);
     // jnp.nan_to_num(x, nan=-inf): NaN -> -inf, -inf -> -DBL_MAX, +inf -> DBL_MAX   
     if (ll != ll) ll = -__builtin_inf();
     else if (ll == -__builtin_inf()) ll = -1.7976931348623157e308;
     else if (ll == __builtin_inf()) ll = 1.7976931348623157e308;
     if (numlike_evs) numlike_evs[(size_t)b * E + e] = Li;
     if (log_like_evs) log_like_evs[(size_t)b * E + e] = ll;
-    if (ll == -__builtin_inf()) any_neginf = true; else acc += ll;
   }
-  acc = block_reduce<RED_SUM>(acc, red);
-  double inf_flag = block_reduce<RED_SUM>(any_neginf ? 1. : 0., red);
-  if (inf_flag > 0.) acc = -__builtin_inf();
-  double s1 = 0., s2 = 0.;
-  for (int i = t; i < nblocks_sel; i += blockDim.x) {
-    s1 += sel_partial[((size_t)b * nblocks_sel + i) * 2];
-    s2 += sel_partial[((size_t)b * nblocks_sel + i) * 2 + 1];
-  }
-  s1 = block_reduce<RED_SUM>(s1, red);
-  s2 = block_reduce<RED_SUM>(s2, red);
-  if (t == 0) { partials[b * 3] = acc; partials[b * 3 + 1] = s1; partials[b * 3 + 2] = s2; }
+  double s = block_reduce<RED_SUM>(ll, red);
+  if (threadIdx.x == 0) ev_partial[(size_t)b * gridDim.x + blockIdx.x] = s;
 }
 
-// k_combine: N_exp with the N_eff guard (selection_function.py:38-47) and the final combination
-// (likelihood.py:298-300, 313-316, 331-337).  out: (nb,3) = [log_hyper, log_num, N_exp]
-__global__ void k_combine(int nb, const DevParams* params, const double* partials, double E_total, double N_inj, double N_eff,
-                          int has_neff, int has_like, int has_sel, double* out) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nb) return;
-  const DevParams& P = params[b];
-  double log_num = partials[b * 3];
+// N_exp with the N_eff guard (selection_function.py:38-47) and the final combination (likelihood.py:298-300, 313-316)
+DEVFN void combine_one(const DevParams& P, double log_num, double s1, double s2, double E_total, double N_inj, double N_eff,
+                       int has_neff, int has_like, int has_sel, double* out) {
   double Nexp = __builtin_nan("");
   if (has_sel) {
-    double xi = partials[b * 3 + 1] / N_inj;
+    double xi = s1 / N_inj;
     Nexp = P.Tobs * xi;
     if (has_neff) {
-      double variance2 = partials[b * 3 + 2] / (N_inj * N_inj) - (xi * xi) / N_inj;
+      double variance2 = s2 / (N_inj * N_inj) - (xi * xi) / N_inj;
       double neff = (xi * xi) / variance2;
       if (neff < N_eff) Nexp = 0.0;
     }
@@ -634,7 +1121,37 @@ __global__ void k_combine(int nb, const DevParams* params, const double* partial
     if (!P.scale_free) log_num += E_total * log(P.R0 * P.Tobs);
     if (has_sel) log_hyper = P.scale_free ? log_num - E_total * log(Nexp) : log_num - Nexp;
   } else log_num = __builtin_nan("");
-  out[b * 3] = log_hyper; out[b * 3 + 1] = log_num; out[b * 3 + 2] = Nexp;
+  out[0] = log_hyper; out[1] = log_num; out[2] = Nexp;
+}
+
+// k_final: one block per draw: shard partials [sum_i log L_i, nansum dN, sum dN^2] in fixed order; when do_combine, also
+// the final combination (single GPU); otherwise k_combine runs after the all-reduce.
+__global__ void __launch_bounds__(256) k_final(int nblk_ev, const double* ev_partial, int nblk_sel, const double* sel_partial,
+                                                double* partials /* (nb,3) */, const DevParams* params, double E_total, double N_inj,
+                                                double N_eff, int has_neff, int has_like, int has_sel, int do_combine, double* out3) {
+  __shared__ double red[16];
+  const int b = blockIdx.x, t = threadIdx.x;
+  double acc = 0., s1 = 0., s2 = 0.;
+  for (int i = t; i < nblk_ev; i += blockDim.x) acc += ev_partial[(size_t)b * nblk_ev + i];
+  for (int i = t; i < nblk_sel; i += blockDim.x) {
+    s1 += sel_partial[((size_t)b * nblk_sel + i) * 2];
+    s2 += sel_partial[((size_t)b * nblk_sel + i) * 2 + 1];
+  }
+  acc = block_reduce<RED_SUM>(acc, red);
+  s1 = block_reduce<RED_SUM>(s1, red);
+  s2 = block_reduce<RED_SUM>(s2, red);
+  if (t == 0) {
+    partials[b * 3] = acc; partials[b * 3 + 1] = s1; partials[b * 3 + 2] = s2;
+    if (do_combine) combine_one(params[b], acc, s1, s2, E_total, N_inj, N_eff, has_neff, has_like, has_sel, out3 + b * 3);
+  }
+}
+
+__global__ void k_combine(int nb, const DevParams* params, const double* partials, double E_total, double N_inj, double N_eff,
+                          int has_neff, int has_like, int has_sel, double* out3) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  combine_one(params[b], partials[b * 3], partials[b * 3 + 1], partials[b * 3 + 2], E_total, N_inj, N_eff, has_neff, has_like,
+              has_sel, out3 + b * 3);
 }
 
 // ------------------------------------------------------------------------------------------------------
