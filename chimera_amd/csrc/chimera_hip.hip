@@ -249,14 +249,18 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
       for (int a = 0; a < 4; a++) {
         const double* in = src[a] + (size_t)(e0 + e) * S;
         double* o = sorted[a].data() + e * S;
-        for (size_t k = 0; k < S; k++) o[k] = in[perm[k]];
+        if (a == 3) { for (size_t k = 0; k < S; k++) o[k] = 1. / in[perm[k]]; }     // the device keeps 1/pe_prior
+        else { for (size_t k = 0; k < S; k++) o[k] = in[perm[k]]; }
       }
     }
     const double** dst[4] = { &L.dL, &L.m1det, &L.m2det, &L.pe_prior };
     for (int a = 0; a < 4; a++) { rc = upload(h->owned, (const double*)sorted[a].data(), E * S, dst[a], s); if (rc) { chm_like_destroy(h); return rc; } }
     rc = upload(h->owned, (const int*)seg.data(), E * (P + 1), &L.seg_off, s); if (rc) { chm_like_destroy(h); return rc; }
   } else {
-    UP(dL, d->dL, S); UP(m1det, d->m1det, S); UP(m2det, d->m2det, S); UP(pe_prior, d->pe_prior, S);
+    UP(dL, d->dL, S); UP(m1det, d->m1det, S); UP(m2det, d->m2det, S);
+    tmp.resize(E * S);
+    for (size_t k = 0; k < E * S; k++) tmp[k] = 1. / d->pe_prior[(size_t)e0 * S + k];          // the device keeps 1/pe_prior
+    rc = upload(h->owned, (const double*)tmp.data(), E * S, &L.pe_prior, s); if (rc) { chm_like_destroy(h); return rc; }
   }
   if (d->mode == CHM_MODE_FULL) { UP(ra, d->ra, S); UP(dec, d->dec, S); }
   UP(z_grids, d->z_grids, Z);
@@ -339,8 +343,11 @@ extern "C" int chm_sel_create(const chm_sel_desc* d, chm_sel** out) {
   S.I = (long long)n; S.N_inj = d->N_inj; S.has_neff = std::isnan(d->N_eff) ? 0 : 1; S.N_eff = d->N_eff;
   hipStream_t s = h->ctx.stream;
 #define UP(field, src) do { rc = upload(h->owned, (src) + i0, n, &S.field, s); if (rc) { chm_sel_destroy(h); return rc; } } while (0)
-  UP(dL, d->dL); UP(m1det, d->m1det); UP(m2det, d->m2det); UP(p_draw, d->p_draw);
+  UP(dL, d->dL); UP(m1det, d->m1det); UP(m2det, d->m2det);
 #undef UP
+  std::vector<double> ipd(n);
+  for (size_t k = 0; k < n; k++) ipd[k] = 1. / d->p_draw[i0 + k];                                 // the device keeps 1/p_draw
+  rc = upload(h->owned, (const double*)ipd.data(), n, &S.p_draw, s); if (rc) { chm_sel_destroy(h); return rc; }
   long long nblk = (S.I + 255) / 256;
   S.nblocks = (int)(nblk < 1 ? 1 : (nblk > 2048 ? 2048 : nblk));
   hipError_t he = hipStreamSynchronize(s);
@@ -385,7 +392,8 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
   Ctx& c = like ? like->ctx : sel->ctx;
   if (comm && comm->device != c.device) return fail(CHM_E_ARG, "chm_eval: comm lives on a different device");
   HIPCHK(hipSetDevice(c.device));
-  hipStream_t sA = c.stream, sB = c.stream2;
+  static const bool serial = getenv("CHM_SERIAL") != nullptr;     // diagnostics: everything on one stream
+  hipStream_t sA = c.stream, sB = serial ? c.stream : c.stream2;
   const bool want_dump = like && out->p_gw != nullptr;
   int rc;
   if (like) { rc = like_ensure_ws(like, nb, want_dump); if (rc) return rc; }
@@ -426,10 +434,18 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
   if (like) {
     LikeDev L = like->L;
     if (!want_dump) L.p_gw_dump = nullptr;
-    dim3 g1(L.E * L.NC, nb);
-    if (tab_samp) { allow_lds(k_samples<true>, lds_samp);
-      hipLaunchKernelGGL(k_samples<true>, g1, dim3(256), lds_samp, sA, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    } else hipLaunchKernelGGL(k_samples<false>, g1, dim3(256), 0, sA, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    const int nchunk = L.E * L.NC;
+    dim3 g1(nchunk < 1024 ? nchunk : 1024, nb);
+    const bool fullm = L.mode == CHM_MODE_FULL;
+    if (tab_samp) {
+      if (fullm) { allow_lds(k_samples<true, true>, lds_samp);
+        hipLaunchKernelGGL((k_samples<true, true>), g1, dim3(256), lds_samp, sA, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+      } else { allow_lds(k_samples<true, false>, lds_samp);
+        hipLaunchKernelGGL((k_samples<true, false>), g1, dim3(256), lds_samp, sA, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm); }
+    } else {
+      if (fullm) hipLaunchKernelGGL((k_samples<false, true>), g1, dim3(256), 0, sA, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+      else hipLaunchKernelGGL((k_samples<false, false>), g1, dim3(256), 0, sA, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c.ev[2], sA));
     HIPCHK(hipStreamWaitEvent(sA, c.evb[0], 0));            // join: per-z factors

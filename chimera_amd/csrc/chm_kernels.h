@@ -114,6 +114,7 @@ __global__ void __launch_bounds__(256) k_tables(DevParams* params, double* zt_al
       double min_point = (m_low - mu) / (sg * sqrt(2.));
       P.tg_norm = 0.5 * erf(max_point) - 0.5 * erf(min_point);
       P.g_c0 = -0.5 * log(2. * CHM_PI) - log(sg);
+      P.inv_plnorm = 1. / P.plp_plnorm; P.inv_tg_norm = 1. / P.tg_norm; P.inv_2s2 = 1. / (2. * (sg * sg));
     } else if (P.mass_model == 1) {
       double mb = m_low + P.m[6] * (m_high - m_low);
       P.bpl_mbreak = mb;
@@ -122,6 +123,9 @@ __global__ void __launch_bounds__(256) k_tables(DevParams* params, double* zt_al
     }
     double g = P.r[0], k = P.r[1], zp = P.r[2], zmax = P.r[3];
     P.md_norm = 1. + pow(1. + zp, -g - k);
+    P.l1pzp = log(1. + zp);
+    P.lmg0 = log(m_low);
+    P.inv_dlmg = (double)(P.Tm - 1) / (log(m_high) - log(m_low));
     P.tpl_rate_norm = (pow(1. + zmax, g + 1.) - 1.) / (g + 1.);
   }
   __syncthreads();
@@ -162,7 +166,7 @@ __global__ void __launch_bounds__(256) k_tables(DevParams* params, double* zt_al
     acc += (mg[k + 1] - mg[k]) * (y1 + y0);
   }
   acc = block_reduce<RED_SUM>(acc, sh);
-  if (t == 0) P.norm_p_m1 = 0.5 * acc;
+  if (t == 0) { P.norm_p_m1 = 0.5 * acc; P.inv_norm_p_m1 = 1. / (0.5 * acc); }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -183,61 +187,112 @@ DEVFN TabView stage_tables(const DevParams& P, const TablePtrs& g, bool use_lds,
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_samples: one block (256 threads) per chunk of SAMPLE_CHUNK samples of one event
+// k_samples: blocks of 256 threads stage the per-draw tables in LDS once and then walk over chunks of SAMPLE_CHUNK
+// samples (chunk = blockIdx.x, += gridDim.x); one set of partial statistics per (event, chunk)
 // ------------------------------------------------------------------------------------------------------
-template <bool LDS_TAB>
+// all-in-one block reduction of NV values: sums for v[0..NS), then one min (v[NS]) and one max (v[NS+1])
+template <int NS>
+DEVFN void block_reduce_stats(double* v, double* scratch /* 4 x (NS+2) */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int i = 0; i < NS; i++) v[i] = wave_sum(v[i]);
+  v[NS] = wave_min(v[NS]); v[NS + 1] = wave_max(v[NS + 1]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NS + 2; i++) scratch[wid * (NS + 2) + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NS; i++) { double r = 0.; for (int w = 0; w < nw; w++) r += scratch[w * (NS + 2) + i]; v[i] = r; }
+  double mn = scratch[NS], mx = scratch[NS + 1];
+  for (int w = 1; w < nw; w++) { mn = nanmin2(mn, scratch[w * (NS + 2) + NS]); mx = nanmax2(mx, scratch[w * (NS + 2) + NS + 1]); }
+  v[NS] = mn; v[NS + 1] = mx;
+}
+
+template <bool LDS_TAB, bool FULL>
 __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
                                                   const double* dLt_all, const double* mg_all, const double* cdf_all,
                                                   int TcMax, int TmMax) {
   extern __shared__ double lds[];
-  __shared__ double red[16];
-  const int e = blockIdx.x / L.NC, c = blockIdx.x % L.NC, b = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+  __shared__ double red[4 * 16];
+  const int b = blockIdx.y, t = threadIdx.x;
   const DevParams& P = params[b];
   TablePtrs g = { zt_all + (size_t)b * TcMax, It_all + (size_t)b * TcMax, dLt_all + (size_t)b * TcMax,
                   mg_all + (size_t)b * TmMax, cdf_all + (size_t)b * TmMax };
   TabView T = stage_tables(P, g, LDS_TAB, lds, false);
   const int S = L.S;
-  const size_t so = ((size_t)b * L.E + e) * S;
-  const size_t eo = (size_t)e * S;
-  double* wz = L.ws_z + so;
-  double* ww = L.ws_w + so;
-  const bool full = L.mode == 3;
-  // reference point of the shifted sums: the event's first sample
-  const double z_ref = jnp_interp(L.dL[eo], T.dLt, T.zt, P.Tc, false, 0., 0.);
-  const double ra_ref = full ? L.ra[eo] : 0., dec_ref = full ? L.dec[eo] : 0.;
-
-  // z = z_from_dGW(dL) (cosmo.py:260-264); m_src = m_det/(1+z) (pop_wrapper.py:70); w = p_m1m2/pe_prior (pop_wrapper.py:79)
-  double sw = 0., sw2 = 0., sd1 = 0., sd2 = 0.;
-  double zmn = __builtin_inf(), zmx = -__builtin_inf();
-  double a0 = 0., a1 = 0., a2 = 0., c00 = 0., c01 = 0., c02 = 0., c11 = 0., c12 = 0., c22 = 0.;
-  const int s_end = min(S, (c + 1) * SAMPLE_CHUNK);
-  for (int s = c * SAMPLE_CHUNK + t; s < s_end; s += nt) {
-    double dl = L.dL[eo + s];
-    double z = jnp_interp(dl, T.dLt, T.zt, P.Tc, false, 0., 0.);
-    double m1 = L.m1det[eo + s] / (1. + z);
-    double m2 = L.m2det[eo + s] / (1. + z);
-    double w = p_m1m2(P, m1, m2, T.mg, T.cdf) / L.pe_prior[eo + s];
-    wz[s] = z; ww[s] = w;
-    double d = z - z_ref;
-    sw += w; sw2 += w * w; sd1 += d; sd2 += d * d;
-    zmn = nanmin2(zmn, z); zmx = nanmax2(zmx, z);
-    if (full) {                                   // un-normalised weighted moments of (z, ra, dec) about the reference
-      double d1 = L.ra[eo + s] - ra_ref, d2 = L.dec[eo + s] - dec_ref;
-      a0 += w * d; a1 += w * d1; a2 += w * d2;
-      c00 += w * d * d; c01 += w * d * d1; c02 += w * d * d2; c11 += w * d1 * d1; c12 += w * d1 * d2; c22 += w * d2 * d2;
+  const int nchunk = L.E * L.NC;
+  const bool vec2 = ((S & 1) == 0);
+  for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+    const int e = ch / L.NC, c = ch % L.NC;
+    const size_t so = ((size_t)b * L.E + e) * S;
+    const size_t eo = (size_t)e * S;
+    double* wz = L.ws_z + so;
+    double* ww = L.ws_w + so;
+    // reference point of the shifted sums: the event's first sample
+    const double z_ref = jnp_interp(L.dL[eo], T.dLt, T.zt, P.Tc, false, 0., 0.);
+    const double ra_ref = FULL ? L.ra[eo] : 0., dec_ref = FULL ? L.dec[eo] : 0.;
+    double v[6] = { 0., 0., 0., 0., __builtin_inf(), -__builtin_inf() };     // sw, sw2, sd1, sd2, zmin, zmax
+    double m[9] = { 0., 0., 0., 0., 0., 0., 0., 0., 0. };
+    const int s_end = min(S, (c + 1) * SAMPLE_CHUNK);
+    // 256 threads x 2 consecutive samples (16 B per lane per array) per pass
+#pragma unroll 1
+    for (int s = c * SAMPLE_CHUNK + 2 * t; s < s_end; s += 512) {
+      double dl[2], md1[2], md2[2], ipr[2];
+      if (vec2) {                                 // s even, S even -> s + 1 < s_end and 16-byte aligned
+        double2 a = *reinterpret_cast<const double2*>(L.dL + eo + s), bb = *reinterpret_cast<const double2*>(L.m1det + eo + s);
+        double2 cc = *reinterpret_cast<const double2*>(L.m2det + eo + s), dd = *reinterpret_cast<const double2*>(L.pe_prior + eo + s);
+        dl[0] = a.x; dl[1] = a.y; md1[0] = bb.x; md1[1] = bb.y; md2[0] = cc.x; md2[1] = cc.y; ipr[0] = dd.x; ipr[1] = dd.y;
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const bool in = s + h < s_end;
+          dl[h] = in ? L.dL[eo + s + h] : 1.; md1[h] = in ? L.m1det[eo + s + h] : 1.;
+          md2[h] = in ? L.m2det[eo + s + h] : 1.; ipr[h] = in ? L.pe_prior[eo + s + h] : 1.;
+        }
+      }
+      double zz[2], wv[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        // z = z_from_dGW(dL) (cosmo.py:260-264); m_src = m_det/(1+z) (pop_wrapper.py:70);
+        // w = p_m1m2 / pe_prior (pop_wrapper.py:79; the device array holds 1/pe_prior)
+        double z = (L.dbg & 64) ? dl[h] * 0.2 : jnp_interp(dl[h], T.dLt, T.zt, P.Tc, false, 0., 0.);
+        double r = 1. / (1. + z);
+        double m1 = md1[h] * r, m2 = md2[h] * r;
+        double w = ((L.dbg & 32) ? m1 * m2 : p_m1m2(P, m1, m2, T.mg, T.cdf)) * ipr[h];
+        zz[h] = z; wv[h] = w;
+        if (s + h < s_end) {
+          double d = z - z_ref;
+          v[0] += w; v[1] += w * w; v[2] += d; v[3] += d * d;
+          v[4] = nanmin2(v[4], z); v[5] = nanmax2(v[5], z);
+          if (FULL) {                             // un-normalised weighted moments of (z, ra, dec) about the reference
+            double d1 = L.ra[eo + s + h] - ra_ref, d2 = L.dec[eo + s + h] - dec_ref;
+            m[0] += w * d; m[1] += w * d1; m[2] += w * d2;
+            m[3] += w * d * d; m[4] += w * d * d1; m[5] += w * d * d2; m[6] += w * d1 * d1; m[7] += w * d1 * d2; m[8] += w * d2 * d2;
+          }
+        }
+      }
+      if (vec2) {
+        *reinterpret_cast<double2*>(wz + s) = make_double2(zz[0], zz[1]);
+        *reinterpret_cast<double2*>(ww + s) = make_double2(wv[0], wv[1]);
+      } else {
+        if (s < s_end) { wz[s] = zz[0]; ww[s] = wv[0]; }
+        if (s + 1 < s_end) { wz[s + 1] = zz[1]; ww[s + 1] = wv[1]; }
+      }
     }
-  }
-  double* q = L.part + (((size_t)b * L.E + e) * L.NC + c) * NPART;
-  sw = block_reduce<RED_SUM>(sw, red); sw2 = block_reduce<RED_SUM>(sw2, red);
-  sd1 = block_reduce<RED_SUM>(sd1, red); sd2 = block_reduce<RED_SUM>(sd2, red);
-  zmn = block_reduce<RED_MIN>(zmn, red); zmx = block_reduce<RED_MAX>(zmx, red);
-  if (t == 0) { q[PT_SW] = sw; q[PT_SW2] = sw2; q[PT_SD1] = sd1; q[PT_SD2] = sd2; q[PT_ZMIN] = zmn; q[PT_ZMAX] = zmx; q[PT_ZREF] = z_ref; }
-  if (full) {
-    a0 = block_reduce<RED_SUM>(a0, red); a1 = block_reduce<RED_SUM>(a1, red); a2 = block_reduce<RED_SUM>(a2, red);
-    c00 = block_reduce<RED_SUM>(c00, red); c01 = block_reduce<RED_SUM>(c01, red); c02 = block_reduce<RED_SUM>(c02, red);
-    c11 = block_reduce<RED_SUM>(c11, red); c12 = block_reduce<RED_SUM>(c12, red); c22 = block_reduce<RED_SUM>(c22, red);
-    if (t == 0) { q[PT_WD0] = a0; q[PT_WD1] = a1; q[PT_WD2] = a2; q[PT_W00] = c00; q[PT_W01] = c01; q[PT_W02] = c02;
-                  q[PT_W11] = c11; q[PT_W12] = c12; q[PT_W22] = c22; }
+    double* q = L.part + (((size_t)b * L.E + e) * L.NC + c) * NPART;
+    block_reduce_stats<4>(v, red);
+    if (t == 0) { q[PT_SW] = v[0]; q[PT_SW2] = v[1]; q[PT_SD1] = v[2]; q[PT_SD2] = v[3]; q[PT_ZMIN] = v[4]; q[PT_ZMAX] = v[5]; q[PT_ZREF] = z_ref; }
+    if (FULL) {
+      double mm[11];
+#pragma unroll
+      for (int i = 0; i < 9; i++) mm[i] = m[i];
+      mm[9] = 0.; mm[10] = 0.;
+      block_reduce_stats<9>(mm, red);
+      if (t == 0) { q[PT_WD0] = mm[0]; q[PT_WD1] = mm[1]; q[PT_WD2] = mm[2]; q[PT_W00] = mm[3]; q[PT_W01] = mm[4]; q[PT_W02] = mm[5];
+                    q[PT_W11] = mm[6]; q[PT_W12] = mm[7]; q[PT_W22] = mm[8]; }
+    }
   }
 }
 
@@ -266,9 +321,11 @@ __global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* pa
     double z = L.z_grids[(size_t)e * Z + k];
     double dCt = dCt_at_z(P, z, zt, It);
     double zp1 = 1. + z;
-    L.jac[zo + k] = ddLdz_from_dCt(P, dCt, z) * (zp1 * zp1);
-    L.prate[zo + k] = merger_rate(P, z) / (1. + z);
-    double p_bkg = dVcdz_from_dCt(P, dCt, z);
+    double lzp1 = log(zp1);
+    double Ez = E_at_z_l(P, z, lzp1);
+    L.jac[zo + k] = ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1) * (zp1 * zp1);
+    L.prate[zo + k] = merger_rate_l(P, z, lzp1) / (1. + z);
+    double p_bkg = dVcdz_from_dCt_E(P, dCt, Ez);
     L.bkgA[zo + k] = P.has_catalog ? (1. - L.P_compl[(size_t)e * Z + k]) * p_bkg : p_bkg;
     if (L.Aw) {
       // trapezoid weight of grid point k: y_k enters the two adjacent intervals (jnp.trapezoid, likelihood.py:278)
@@ -625,16 +682,15 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
 #define FAST_PF 4
 struct EpanCtx { const double* cen; const double* P0; const double* P1; const double* P2; int N; double lo, inv_dbin, bw, inv_bw, scale; };
 
+// Index range [ja, jb) of the bins with |g - c_j| <= h straight from the uniform spacing c_j = lo + (j + 1/2) dbin.  A bin
+// whose |u| is within rounding of 1 may land on either side; its kernel value 3/4 (1 - u^2) is then < 1e-12, far below the
+// stated tolerance (k_kde_marg keeps the exact predicate of math.py:85).
 DEVFN double epan_node(const EpanCtx& c, double g) {
   double fa = ceil((g - c.bw - c.lo) * c.inv_dbin - 0.5), fb = floor((g + c.bw - c.lo) * c.inv_dbin - 0.5) + 1.;
-  const int N = c.N;
-  int ja = fa > 0. ? (fa < (double)N ? (int)fa : N) : 0;
-  int jb = fb > 0. ? (fb < (double)N ? (int)fb : N) : 0;
-  while (ja > 0 && fabs((g - c.cen[ja - 1]) * c.inv_bw) <= 1.) ja--;
-  while (ja < N && c.cen[ja] < g && !(fabs((g - c.cen[ja]) * c.inv_bw) <= 1.)) ja++;
-  if (jb < ja) jb = ja;
-  while (jb < N && fabs((g - c.cen[jb]) * c.inv_bw) <= 1.) jb++;
-  while (jb > ja && !(fabs((g - c.cen[jb - 1]) * c.inv_bw) <= 1.)) jb--;
+  const double dN = (double)c.N;
+  fa = fa > 0. ? (fa < dN ? fa : dN) : 0.;
+  fb = fb > fa ? (fb < dN ? fb : dN) : fa;
+  const int ja = (int)fa, jb = (int)fb;
   double S0 = c.P0[jb] - c.P0[ja], S1 = c.P1[jb] - c.P1[ja], S2 = c.P2[jb] - c.P2[ja];
   double gp = g - c.lo;
   double qq = fma(gp, fma(gp, S0, -2. * S1), S2);
@@ -768,6 +824,7 @@ __global__ void __launch_bounds__(64) k_kde_marg_fast(LikeDev L, const DevParams
   const double gwp = L.gw_pdf[(size_t)e * L.P + p];
   const double fR = P.fR;
   const double inv_de = (double)(G - 1) / (ub - lb);
+  const double inv_de_x = inv_de;
   const double nan = __builtin_nan("");
   double acc = 0.;
   if (dump) { for (int k = lane; k < Z; k += 64) if (k < k_lo || k > k_hi) dump[k] = 0.; }
@@ -786,12 +843,14 @@ __global__ void __launch_bounds__(64) k_kde_marg_fast(LikeDev L, const DevParams
             const double zk = zg[kk];
             double pgw = 0.;
             if (zk >= lb && zk <= ub) {                     // jnp.interp(..., left=0, right=0)
-              double tp = (zk - lb) * inv_de;
-              int i1 = interp_index(eg, G, zk, (int)fmin(tp, (double)G) + 1);
+              // bracket on the uniform effective grid: i1 - 1 = floor((z - lb)/de); a z within rounding of a node may pick
+              // either neighbouring segment -- the interpolant is continuous there
+              double tp = floor((zk - lb) * inv_de);
+              tp = tp < (double)(G - 2) ? tp : (double)(G - 2);
+              const int i1 = (int)tp + 1;
               double xa = eg[i1 - 1], xb = eg[i1];
               double da = epan_node(cx, xa), db = epan_node(cx, xb);
-              double dx = xb - xa;
-              double f = (fabs(dx) <= 4.930380657631324e-32) ? da : da + ((zk - xa) / dx) * (db - da);
+              double f = da + ((zk - xa) * inv_de_x) * (db - da);       // (z - x0)/dx with dx = (ub - lb)/(G - 1)
               pgw = degenerate ? nan : f * norm * gwp;     // kde_interp * norm * gw_pdf[i]    likelihood.py:194
             } else if (zk != zk) pgw = nan;
             if (dump) dump[kk] = pgw;
@@ -1058,15 +1117,18 @@ __global__ void __launch_bounds__(256) k_selection(SelDev Sd, const DevParams* p
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < Sd.I; i += (long long)gridDim.x * blockDim.x) {
     double dl = Sd.dL[i];
     double z = jnp_interp(dl, T.dLt, T.zt, P.Tc, false, 0., 0.);
-    double m1 = Sd.m1det[i] / (1. + z), m2 = Sd.m2det[i] / (1. + z);
-    double dCt = dL2dCt(P, dl, z);                                   // original distances: cosmo.py:191-192,215-216
-    double p_z = dVcdz_from_dCt(P, dCt, z);                          // gal_cat.p_bkg              pop_wrapper.py:106
-    p_z = p_z * (merger_rate(P, z) / (1. + z));                      //                            pop_wrapper.py:107
-    double dN = P.R0 * p_m1m2(P, m1, m2, T.mg, T.cdf) * p_z;         //                            pop_wrapper.py:108
     double zp1 = 1. + z;
-    double jacobian = fabs(ddLdz_from_dCt(P, dCt, z)) * (zp1 * zp1); //                            pop_wrapper.py:109
+    double rz = 1. / zp1;
+    double m1 = Sd.m1det[i] * rz, m2 = Sd.m2det[i] * rz;
+    double lzp1 = log(zp1);
+    double Ez = E_at_z_l(P, z, lzp1);
+    double dCt = dL2dCt_l(P, dl, z, lzp1);                           // original distances: cosmo.py:191-192,215-216
+    double p_z = dVcdz_from_dCt_E(P, dCt, Ez);                       // gal_cat.p_bkg              pop_wrapper.py:106
+    p_z = p_z * (merger_rate_l(P, z, lzp1) / (1. + z));              //                            pop_wrapper.py:107
+    double dN = P.R0 * p_m1m2(P, m1, m2, T.mg, T.cdf) * p_z;         //                            pop_wrapper.py:108
+    double jacobian = fabs(ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1)) * (zp1 * zp1);   //              pop_wrapper.py:109
     dN = dN / jacobian;
-    dN = dN / Sd.p_draw[i];                                          // selection_function.py:38
+    dN = dN * Sd.p_draw[i];                                          // selection_function.py:38 (array holds 1/p_draw)
     if (dN == dN) s1 += dN;                                          // nansum                     selection_function.py:39
     s2 += dN * dN;                                                   // plain sum     selection_function.py:44
   }

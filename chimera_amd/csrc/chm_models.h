@@ -25,7 +25,10 @@ struct DevParams {
   double bpl_mbreak, bpl_pl1, bpl_pl2;   // mass.py:291-293
   double md_norm;                        // 1 + (1+zp)^(-gamma-kappa)                 rate.py:114
   double tpl_rate_norm;                  // rate.py:105
-  double norm_p_m1;                      // mass.py:51
+  double l1pzp;                          // log(1 + zp)
+  double lmg0, inv_dlmg;                 // log(m_low), (Tm-1)/(log(m_high) - log(m_low)): position of log(m) on the mass grid
+  double inv_plnorm, inv_tg_norm, inv_2s2;   // reciprocals of plp_plnorm, tg_norm, 2 sigma_g^2
+  double norm_p_m1, inv_norm_p_m1;       // mass.py:51
   double fR;                             // completeness.py:54-58
 };
 
@@ -35,6 +38,12 @@ struct TablePtrs {                       // per-draw tables (global memory)
 };
 
 #define DEVFN __device__ __forceinline__
+
+// x^y for x > 0 as exp(y log x).  The reference's jnp.power is correctly rounded to ~1 ulp; this form is within
+// (|y ln x| + 2) ulp of it -- <= 2e-15 relative for every use below (|y ln x| <= 16) -- and costs a third of ocml's pow().
+// Callers that already hold log(x) pass it in and share it between several powers.
+DEVFN double pow_l(double lx, double y) { return exp(y * lx); }
+DEVFN double pow_el(double x, double y) { return exp(y * log(x)); }
 
 // ------------------------------------------------------------------------------------------------------
 // jax.numpy semantics
@@ -87,20 +96,27 @@ DEVFN double logaddexp0(double x) {
 // cosmology  (population/cosmo.py)
 // ------------------------------------------------------------------------------------------------------
 
-// cosmo.py:122-130
-DEVFN double E_at_z(const DevParams& p, double z) {
+// cosmo.py:122-130; lzp1 = log(1+z)
+DEVFN double E_at_z_l(const DevParams& p, double z, double lzp1) {
   double zp1 = 1. + z;
   double w_z = p.w0 + p.wa * z / (1. + z);
   double z2 = zp1 * zp1;
   double z3 = z2 * zp1;
   double z4 = z2 * z2;
-  return sqrt(p.Om0 * z3 + p.Or0 * z4 + p.Ok0 * z2 + p.Ode0 * pow(zp1, 3. * (1. + w_z)));
+  double ex = 3. * (1. + w_z);
+  double de = ex == 0. ? 1. : pow_l(lzp1, ex);               // (1+z)^(3(1+w(z))); exponent 0 for a cosmological constant
+  return sqrt(p.Om0 * z3 + p.Or0 * z4 + p.Ok0 * z2 + p.Ode0 * de);
+}
+DEVFN bool de_needs_log(const DevParams& p) { return !(p.wa == 0. && p.w0 == -1.); }
+DEVFN double E_at_z(const DevParams& p, double z) {
+  return E_at_z_l(p, z, de_needs_log(p) ? log(1. + z) : 0.);
 }
 
 // cosmo.py:225-228
-DEVFN double Xi_at_z(const DevParams& p, double z) {
-  return p.Xi0 + (1. - p.Xi0) / pow(1. + z, p.n_mg);
+DEVFN double Xi_at_z_l(const DevParams& p, double lzp1) {
+  return p.Xi0 + (1. - p.Xi0) / pow_l(lzp1, p.n_mg);
 }
+DEVFN double Xi_at_z(const DevParams& p, double z) { return Xi_at_z_l(p, log(1. + z)); }
 
 // cosmo.py:141-153 given dCr
 DEVFN double dCt_from_dCr(const DevParams& p, double dCr) {
@@ -118,9 +134,12 @@ DEVFN double dCt_at_z(const DevParams& p, double z, A1 zt, A2 It) {
 }
 
 // cosmo.py:201-203, 230-235
-DEVFN double dL2dCt(const DevParams& p, double dist, double z) {
-  if (p.cosmo_model == 1) return (dist / Xi_at_z(p, z)) / (1. + z);
+DEVFN double dL2dCt_l(const DevParams& p, double dist, double z, double lzp1) {
+  if (p.cosmo_model == 1) return (dist / Xi_at_z_l(p, lzp1)) / (1. + z);
   return dist / (1. + z);
+}
+DEVFN double dL2dCt(const DevParams& p, double dist, double z) {
+  return dL2dCt_l(p, dist, z, p.cosmo_model == 1 ? log(1. + z) : 0.);
 }
 
 // cosmo.py:205-210, 237-243 given dCt
@@ -130,22 +149,28 @@ DEVFN double dL_from_dCt(const DevParams& p, double dCt, double z) {
   return dL;
 }
 
-// cosmo.py:212-221, 245-257 given dCt
-DEVFN double ddLdz_from_dCt(const DevParams& p, double dCt, double z) {
-  double Ez = E_at_z(p, z);
+// cosmo.py:212-221, 245-257 given dCt, E(z) and log(1+z)
+DEVFN double ddLdz_from_dCt_E(const DevParams& p, double dCt, double z, double Ez, double lzp1) {
   double ddLflrw = dCt + (p.dH / Ez) * (1. + z);
   if (p.cosmo_model == 1) {
     double dLflrw = dCt * (1. + z);
-    double Xiz = Xi_at_z(p, z);
-    double dXiz = p.n_mg * (p.Xi0 - 1.) / pow(1. + z, p.n_mg + 1.);
+    double Xiz = Xi_at_z_l(p, lzp1);
+    double dXiz = p.n_mg * (p.Xi0 - 1.) / pow_l(lzp1, p.n_mg + 1.);
     return ddLflrw * Xiz + dLflrw * dXiz;
   }
   return ddLflrw;
 }
+DEVFN double ddLdz_from_dCt(const DevParams& p, double dCt, double z) {
+  double l = (p.cosmo_model == 1 || de_needs_log(p)) ? log(1. + z) : 0.;
+  return ddLdz_from_dCt_E(p, dCt, z, E_at_z_l(p, z, l), l);
+}
 
-// cosmo.py:188-197 given dCt
+// cosmo.py:188-197 given dCt and E(z)
+DEVFN double dVcdz_from_dCt_E(const DevParams& p, double dCt, double Ez) {
+  return 4. * CHM_PI * p.dH * (dCt * dCt) / Ez;
+}
 DEVFN double dVcdz_from_dCt(const DevParams& p, double dCt, double z) {
-  return 4. * CHM_PI * p.dH * (dCt * dCt) / E_at_z(p, z);
+  return dVcdz_from_dCt_E(p, dCt, E_at_z(p, z));
 }
 
 // cosmo.py:166-186 given dCt
@@ -170,13 +195,20 @@ DEVFN double smoothing(double m, double delta_m, double m_low) {
   if (m < m_low) return 0.;
   if (m > m_low + delta_m) return 1.;
   const double eps = 1.e-99;
-  double x = delta_m / (m - m_low + eps) + delta_m / (m - m_low - delta_m + eps);
-  return exp(-logaddexp0(x));
+  double a = m - m_low + eps, b = m - m_low - delta_m + eps;
+  double x = delta_m * ((a + b) / (a * b));                  // = delta_m/a + delta_m/b with one division
+  // exp(-logaddexp(0, x)) = 1/(1 + e^x), evaluated without overflow; equal to the reference's form to ~2 ulp
+  if (x != x) return x;
+  if (x > 0.) { double t = exp(-x); return t / (1. + t); }
+  return 1. / (1. + exp(x));
 }
 
-// mass.py:240-245
+// mass.py:240-245; lm = log(m)
+DEVFN double tpl_notnorm_l(double m, double lm, double alpha, double m_low, double m_high) {
+  return (m_low <= m && m <= m_high) ? pow_l(lm, alpha) : 0.;
+}
 DEVFN double tpl_notnorm(double m, double alpha, double m_low, double m_high) {
-  return (m_low <= m && m <= m_high) ? pow(m, alpha) : 0.;
+  return (m_low <= m && m <= m_high) ? pow_el(m, alpha) : 0.;
 }
 
 // mass.py:247-252
@@ -185,43 +217,65 @@ DEVFN double tpl_cdf(double alpha, double m_low, double m) {
   return (pow(m, 1. + alpha) - pow(m_low, 1. + alpha)) / (1. + alpha);
 }
 
-// mass.py:285-305
-DEVFN double primary_notnorm(const DevParams& p, double m) {
+// mass.py:285-305; lm = log(m)
+DEVFN double primary_notnorm_l(const DevParams& p, double m, double lm) {
   double m_low = p.m[0], m_high = p.m[1];
   if (p.mass_model == 0) {                       // tpl: alpha=m[2]
-    return tpl_notnorm(m, -p.m[2], m_low, m_high);
+    return tpl_notnorm_l(m, lm, -p.m[2], m_low, m_high);
   } else if (p.mass_model == 1) {                // bpl: alpha_1, alpha_2, beta, delta_m, break_fraction
-    double pdf = tpl_notnorm(m, -p.m[2], m_low, p.bpl_mbreak);
-    pdf = pdf + tpl_notnorm(m, -p.m[3], p.bpl_mbreak, m_high) * p.bpl_pl1 / p.bpl_pl2;
+    double pdf = tpl_notnorm_l(m, lm, -p.m[2], m_low, p.bpl_mbreak);
+    pdf = pdf + tpl_notnorm_l(m, lm, -p.m[3], p.bpl_mbreak, m_high) * p.bpl_pl1 / p.bpl_pl2;
     return pdf * smoothing(m, p.m[5], m_low);
   } else {                                       // plp: lambda_peak, alpha, beta, delta_m, mu_g, sigma_g
     double lam = p.m[2], mu = p.m[6], sg = p.m[7];
-    double P = tpl_notnorm(m, -p.m[3], m_low, m_high) / p.plp_plnorm;
+    double P = tpl_notnorm_l(m, lm, -p.m[3], m_low, m_high) * p.inv_plnorm;
     double G = 0.;
     if (m_low <= m && m <= p.tg_hi) {
       double d = m - mu;
-      G = exp(p.g_c0 - (d * d) / (2. * (sg * sg))) / p.tg_norm;    // mass.py:267-279
+      G = exp(p.g_c0 - (d * d) * p.inv_2s2) * p.inv_tg_norm;       // mass.py:267-279 (divisions by constants as reciprocals)
     }
     double pdf = (1. - lam) * P + lam * G;
     return pdf * smoothing(m, p.m[5], m_low);
   }
 }
 
+DEVFN double primary_notnorm(const DevParams& p, double m) { return primary_notnorm_l(p, m, log(m)); }
+
 DEVFN double mass_beta(const DevParams& p) { return p.mass_model == 0 ? p.m[3] : (p.mass_model == 1 ? p.m[4] : p.m[4]); }
 DEVFN double mass_delta_m(const DevParams& p) { return p.m[5]; }
 
-// mass.py:320-328
-DEVFN double secondary_notnorm(const DevParams& p, double m2, double m1) {
-  double pdf = tpl_notnorm(m2, mass_beta(p), p.m[0], m1);
+// mass.py:320-328; lm2 = log(m2)
+DEVFN double secondary_notnorm_l(const DevParams& p, double m2, double lm2, double m1) {
+  double pdf = tpl_notnorm_l(m2, lm2, mass_beta(p), p.m[0], m1);
   if (p.mass_model == 0) return pdf;
   return pdf * smoothing(m2, mass_delta_m(p), p.m[0]);
+}
+DEVFN double secondary_notnorm(const DevParams& p, double m2, double m1) { return secondary_notnorm_l(p, m2, log(m2), m1); }
+
+// jnp.interp(m1, m_grid, cdf) (mass.py:339) with the bracket found from log(m1): m_grid is a logspace (mass.py:46), so
+// the index is floor((log10 m1 - l0)/(l1 - l0) (Tm-1)) up to rounding; the fix-up loops restore searchsorted exactly.
+template <class A1, class A2>
+DEVFN double interp_mgrid(const DevParams& p, double m1, double lm1, A1 mg, A2 cdf) {
+  const int n = p.Tm;
+  double t = (lm1 - p.lmg0) * p.inv_dlmg;                  // position in units of grid steps
+  int i = (t >= 0.) ? (t < (double)n ? (int)t + 1 : n - 1) : 1;
+  i = i < 1 ? 1 : (i > n - 1 ? n - 1 : i);
+  while (i > 1 && mg[i - 1] > m1) i--;
+  while (i < n - 1 && mg[i] <= m1) i++;
+  double x0 = mg[i - 1], x1 = mg[i], f0 = cdf[i - 1], f1 = cdf[i];
+  double dx = x1 - x0;
+  double f = (fabs(dx) <= 4.930380657631324e-32) ? f0 : f0 + ((m1 - x0) / dx) * (f1 - f0);
+  if (m1 < (double)mg[0]) f = cdf[0];
+  if (m1 > (double)mg[n - 1]) f = cdf[n - 1];
+  return f;
 }
 
 // mass.py:334-341
 template <class A1, class A2>
 DEVFN double p_m1m2(const DevParams& p, double m1, double m2, A1 mg, A2 cdf) {
-  double p_m1 = primary_notnorm(p, m1) / p.norm_p_m1;
-  double p_m2m1 = secondary_notnorm(p, m2, m1) / jnp_interp(m1, mg, cdf, p.Tm, false, 0., 0.);
+  double lm1 = log(m1), lm2 = log(m2);
+  double p_m1 = primary_notnorm_l(p, m1, lm1) * p.inv_norm_p_m1;
+  double p_m2m1 = secondary_notnorm_l(p, m2, lm2, m1) / interp_mgrid(p, m1, lm1, mg, cdf);
   if (p_m2m1 != p_m2m1) p_m2m1 = 0.;
   return p_m1 * p_m2m1;
 }
@@ -229,18 +283,20 @@ DEVFN double p_m1m2(const DevParams& p, double m1, double m2, A1 mg, A2 cdf) {
 // ------------------------------------------------------------------------------------------------------
 // rate  (population/rate.py:96-122)
 // ------------------------------------------------------------------------------------------------------
-DEVFN double merger_rate(const DevParams& p, double z) {
+DEVFN double merger_rate_l(const DevParams& p, double z, double lzp1) {
   double g = p.r[0];
-  if (p.rate_model == 0) return pow(1. + z, g);
+  if (p.rate_model == 0) return pow_l(lzp1, g);
   if (p.rate_model == 2) {
-    double pdf = pow(1. + z, g);
+    double pdf = pow_l(lzp1, g);
     return z < p.r[3] ? pdf / p.tpl_rate_norm : 0.;
   }
-  double k = p.r[1], zp = p.r[2];
-  double md = pow(1. + z, g) / (1. + pow((1. + z) / (1. + zp), g + k));
+  double k = p.r[1];
+  // ((1+z)/(1+zp))^(g+k) with log((1+z)/(1+zp)) = log(1+z) - log(1+zp)
+  double md = pow_l(lzp1, g) / (1. + pow_l(lzp1 - p.l1pzp, g + k));
   if (p.rate_model == 1) return p.md_norm * md;
   return z < p.r[3] ? p.md_norm * md : 0.;
 }
+DEVFN double merger_rate(const DevParams& p, double z) { return merger_rate_l(p, z, log(1. + z)); }
 
 // ------------------------------------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)
