@@ -155,7 +155,7 @@ def main():
                    "path_bytes_per_eval": path_bytes,
                    "path_frac": path_bytes * nb / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[0] > 0 else None,
                    "stage_ms": {"eval": kt[0], "tables": kt[1], "samples": kt[2], "kde_integrate": kt[3],
-                                "selection": kt[4], "reduce": kt[5], "zfactors": kt[6]}},
+                                "selection": kt[4], "reduce": kt[5], "events_wall": kt[6], "event_groups": kt[7]}},
       "setup_s": {"synthetic": t_gen},
       "last_log_hyper": float(np.asarray(vals[-1]).ravel()[-1]),
     }

@@ -44,7 +44,9 @@ struct Ctx {
   double* d_partials = nullptr;        // (nb,3)
   double* d_out3 = nullptr;            // (nb,3)
   double* h_out = nullptr;             // pinned (nb,6)
-  hipStream_t stream2 = nullptr;        // forked after k_tables: k_zfactors, k_selection
+  hipStream_t stream2 = nullptr;        // second lane of the event-group pipeline
+  hipStream_t stream3 = nullptr;        // selection function
+  hipEvent_t evg[64] = {};              // per event-group timing: [4g+0..1] sample stage, [4g+2..3] GW kernel
   hipEvent_t ev[8] = {};                // timing on `stream`
   hipEvent_t evb[4] = {};               // fork/join + timing on `stream2`
   double ms[8] = {};
@@ -56,6 +58,8 @@ static int ctx_init(Ctx& c, int device) {
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c.stream3, hipStreamNonBlocking));
+  for (int i = 0; i < 64; i++) HIPCHK(hipEventCreate(&c.evg[i]));
   for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c.ev[i]));
   for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c.evb[i]));
   c.init = true;
@@ -78,6 +82,8 @@ static void ctx_destroy(Ctx& c) {
   ctx_free_tables(c);
   for (int i = 0; i < 8; i++) if (c.ev[i]) (void)hipEventDestroy(c.ev[i]);
   for (int i = 0; i < 4; i++) if (c.evb[i]) (void)hipEventDestroy(c.evb[i]);
+  for (int i = 0; i < 64; i++) if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
+  if (c.stream3) (void)hipStreamDestroy(c.stream3);
   if (c.stream2) (void)hipStreamDestroy(c.stream2);
   if (c.stream) (void)hipStreamDestroy(c.stream);
   c.init = false;
@@ -96,7 +102,7 @@ static int ctx_ensure(Ctx& c, int nb, int Tc, int Tm) {
   HIPCHK(hipMalloc(&c.dLt, sizeof(double) * nbn * Tcn));
   HIPCHK(hipMalloc(&c.mg, sizeof(double) * nbn * Tmn));
   HIPCHK(hipMalloc(&c.cdf, sizeof(double) * nbn * Tmn));
-  HIPCHK(hipMalloc(&c.tmp, sizeof(double) * nbn * T));
+  HIPCHK(hipMalloc(&c.tmp, sizeof(double) * nbn * ((size_t)Tcn + Tmn)));
   HIPCHK(hipMalloc(&c.d_partials, sizeof(double) * nbn * 3));
   HIPCHK(hipMalloc(&c.d_out3, sizeof(double) * nbn * 3));
   HIPCHK(hipHostMalloc(&c.h_out, sizeof(double) * nbn * 6));
@@ -138,7 +144,7 @@ static int ctx_tables(Ctx& c, const chm_params* params, int nb) {
   int rc = ctx_ensure(c, nb, Tc, Tm); if (rc) return rc;
   for (int b = 0; b < nb; b++) fill_dev_params(&params[b], &c.h_params[b]);
   HIPCHK(hipMemcpyAsync(c.d_params, c.h_params, sizeof(DevParams) * nb, hipMemcpyHostToDevice, c.stream));
-  hipLaunchKernelGGL(k_tables, dim3(nb), dim3(256), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax);
+  hipLaunchKernelGGL(k_tables, dim3(nb, 2), dim3(1024), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax);
   HIPCHK(hipGetLastError());
   return CHM_OK;
 }
@@ -296,6 +302,7 @@ extern "C" int chm_like_destroy(chm_like* h) {
   (void)hipSetDevice(h->ctx.device);
   if (h->ctx.stream) (void)hipStreamSynchronize(h->ctx.stream);
   if (h->ctx.stream2) (void)hipStreamSynchronize(h->ctx.stream2);
+  if (h->ctx.stream3) (void)hipStreamSynchronize(h->ctx.stream3);
   like_free_ws(h);
   for (void* p : h->owned) (void)hipFree(p);
   ctx_destroy(h->ctx);
@@ -361,6 +368,7 @@ extern "C" int chm_sel_destroy(chm_sel* h) {
   (void)hipSetDevice(h->ctx.device);
   if (h->ctx.stream) (void)hipStreamSynchronize(h->ctx.stream);
   if (h->ctx.stream2) (void)hipStreamSynchronize(h->ctx.stream2);
+  if (h->ctx.stream3) (void)hipStreamSynchronize(h->ctx.stream3);
   (void)hipFree(h->S.partial);
   for (void* p : h->owned) (void)hipFree(p);
   ctx_destroy(h->ctx);
@@ -393,7 +401,7 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
   if (comm && comm->device != c.device) return fail(CHM_E_ARG, "chm_eval: comm lives on a different device");
   HIPCHK(hipSetDevice(c.device));
   static const bool serial = getenv("CHM_SERIAL") != nullptr;     // diagnostics: everything on one stream
-  hipStream_t sA = c.stream, sB = serial ? c.stream : c.stream2;
+  hipStream_t sA = c.stream, sB = serial ? c.stream : c.stream2, sC = serial ? c.stream : c.stream3;
   const bool want_dump = like && out->p_gw != nullptr;
   int rc;
   if (like) { rc = like_ensure_ws(like, nb, want_dump); if (rc) return rc; }
@@ -402,7 +410,8 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
   HIPCHK(hipEventRecord(c.ev[0], sA));
   rc = ctx_tables(c, params, nb); if (rc) return rc;
   HIPCHK(hipEventRecord(c.ev[1], sA));
-  HIPCHK(hipStreamWaitEvent(sB, c.ev[1], 0));               // fork: stream B starts after the tables
+  HIPCHK(hipStreamWaitEvent(sB, c.ev[1], 0));               // fork: the other lanes start after the tables
+  HIPCHK(hipStreamWaitEvent(sC, c.ev[1], 0));
 
   const int Tc = c.TcMax, Tm = c.TmMax;
   const DevParams* dp = c.d_params;
@@ -410,72 +419,85 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
   const size_t lds_zfac = sizeof(double) * (size_t)2 * Tc;                          // zt, It
   const bool tab_samp = lds_samp <= 64 * 1024, tab_zfac = lds_zfac <= 64 * 1024;
 
-  // ---- stream B: per-z factors, then the selection function
-  if (like) {
-    LikeDev L = like->L;
-    if (tab_zfac) { allow_lds(k_zfactors<true>, lds_zfac);
-      hipLaunchKernelGGL(k_zfactors<true>, dim3(L.E, nb), dim3(256), lds_zfac, sB, L, dp, c.zt, c.It, Tc);
-    } else hipLaunchKernelGGL(k_zfactors<false>, dim3(L.E, nb), dim3(256), 0, sB, L, dp, c.zt, c.It, Tc);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c.evb[0], sB));
-  }
+  // ---- selection function on its own stream
   if (sel) {
     SelDev S = sel->S;
-    HIPCHK(hipEventRecord(c.evb[1], sB));
+    HIPCHK(hipEventRecord(c.evb[1], sC));
     if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
-      hipLaunchKernelGGL(k_selection<true>, dim3(S.nblocks, nb), dim3(256), lds_samp, sB, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    } else hipLaunchKernelGGL(k_selection<false>, dim3(S.nblocks, nb), dim3(256), 0, sB, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+      hipLaunchKernelGGL(k_selection<true>, dim3(S.nblocks, nb), dim3(256), lds_samp, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    } else hipLaunchKernelGGL(k_selection<false>, dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c.evb[2], sB));
+    HIPCHK(hipEventRecord(c.evb[2], sC));
   }
 
-  // ---- stream A: samples, GW kernel + integrand
-  int nblk_ev = 0;
+  // ---- events: groups of events alternate between two streams, so that the (VALU-bound) sample stage of one group
+  //      overlaps the (latency-bound) GW-kernel stage of the previous one
+  int nblk_ev = 0, ngroups = 0;
   if (like) {
-    LikeDev L = like->L;
-    if (!want_dump) L.p_gw_dump = nullptr;
-    const int nchunk = L.E * L.NC;
-    dim3 g1(nchunk < 1024 ? nchunk : 1024, nb);
-    const bool fullm = L.mode == CHM_MODE_FULL;
-    if (tab_samp) {
-      if (fullm) { allow_lds(k_samples<true, true>, lds_samp);
-        hipLaunchKernelGGL((k_samples<true, true>), g1, dim3(256), lds_samp, sA, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-      } else { allow_lds(k_samples<true, false>, lds_samp);
-        hipLaunchKernelGGL((k_samples<true, false>), g1, dim3(256), lds_samp, sA, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm); }
-    } else {
-      if (fullm) hipLaunchKernelGGL((k_samples<false, true>), g1, dim3(256), 0, sA, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-      else hipLaunchKernelGGL((k_samples<false, false>), g1, dim3(256), 0, sA, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    }
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c.ev[2], sA));
-    HIPCHK(hipStreamWaitEvent(sA, c.evb[0], 0));            // join: per-z factors
-    HIPCHK(hipEventRecord(c.ev[6], sA));
-    const int Pd = L.P > 0 ? L.P : 1;
-    const size_t N = L.binning ? L.num_bins : L.S;
-    if (L.mode == CHM_MODE_FULL) {
-      hipLaunchKernelGGL(k_full_kde, dim3(L.E * Pd, nb), dim3(256), 0, sA, L, dp);
-    } else if (L.mode == CHM_MODE_MARG) {
-      size_t lds = sizeof(double) * (2 * N + (L.binning ? 3 * (N + 1) : 0) + 2 * (size_t)L.G);
-      if (lds > 150 * 1024) return fail(CHM_E_ARG, "chm_eval: KDE working set exceeds the LDS (binning=False needs 2*S + 2*G doubles <= 150 KiB)");
-      allow_lds(k_kde_marg, lds);
-      hipLaunchKernelGGL(k_event_prep, dim3(L.E, nb), dim3(64), 0, sA, L);
+    const LikeDev& L0 = like->L;
+    const int Pd = L0.P > 0 ? L0.P : 1;
+    const size_t N = L0.binning ? L0.num_bins : L0.S;
+    const size_t lds_kde = sizeof(double) * (2 * N + (L0.binning ? 3 * (N + 1) : 0) + 2 * (size_t)L0.G);
+    if (L0.mode != CHM_MODE_FULL && lds_kde > 150 * 1024)
+      return fail(CHM_E_ARG, "chm_eval: KDE working set exceeds the LDS (binning=False needs 2*S + 2*G doubles <= 150 KiB)");
+    static const int env_groups = getenv("CHM_GROUPS") ? atoi(getenv("CHM_GROUPS")) : 0;
+    ngroups = env_groups > 0 ? env_groups : (L0.E * nb >= 512 ? 2 : 1);
+    if (ngroups > 16) ngroups = 16;
+    if (ngroups > L0.E) ngroups = L0.E;
+    if (serial) ngroups = 1;
+    for (int g = 0; g < ngroups; g++) {
+      hipStream_t sg = (g & 1) ? sB : sA;
+      LikeDev L = like->L;
+      if (!want_dump) L.p_gw_dump = nullptr;
+      const int eb = (int)((long long)L0.E * g / ngroups), ee = (int)((long long)L0.E * (g + 1) / ngroups);
+      L.e_off = eb; L.E_cnt = ee - eb;
+      // per-z factors of the group's events
+      if (tab_zfac) { allow_lds(k_zfactors<true>, lds_zfac);
+        hipLaunchKernelGGL(k_zfactors<true>, dim3(L.E_cnt, nb), dim3(256), lds_zfac, sg, L, dp, c.zt, c.It, Tc);
+      } else hipLaunchKernelGGL(k_zfactors<false>, dim3(L.E_cnt, nb), dim3(256), 0, sg, L, dp, c.zt, c.It, Tc);
       HIPCHK(hipGetLastError());
-      HIPCHK(hipEventRecord(c.ev[6], sA));
-      const bool fast = L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC");
-      if (fast) hipLaunchKernelGGL(k_kde_marg_fast, dim3(L.E * Pd, nb), dim3(64), sizeof(double) * (4 * N + 3), sA, L, dp);
-      else hipLaunchKernelGGL(k_kde_marg, dim3(L.E * Pd, nb), dim3(64), lds, sA, L, dp);
-    } else {
-      size_t lds = sizeof(double) * (2 * N + (L.binning ? 3 * (N + 1) : 0) + 2 * (size_t)L.G);
-      if (lds > 150 * 1024) return fail(CHM_E_ARG, "chm_eval: KDE working set exceeds the LDS (binning=False needs 2*S + 2*G doubles <= 150 KiB)");
-      allow_lds(k_kde1d, lds);
-      hipLaunchKernelGGL(k_kde1d, dim3(L.E, nb), dim3(256), lds, sA, L, dp);
+      // sample stage
+      HIPCHK(hipEventRecord(c.evg[4 * g], sg));
+      const int nchunk = L.E_cnt * L.NC;
+      dim3 g1(nchunk < 1024 ? nchunk : 1024, nb);
+      const bool fullm = L.mode == CHM_MODE_FULL;
+      if (tab_samp) {
+        if (fullm) { allow_lds(k_samples<true, true>, lds_samp);
+          hipLaunchKernelGGL((k_samples<true, true>), g1, dim3(256), lds_samp, sg, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+        } else { allow_lds(k_samples<true, false>, lds_samp);
+          hipLaunchKernelGGL((k_samples<true, false>), g1, dim3(256), lds_samp, sg, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm); }
+      } else {
+        if (fullm) hipLaunchKernelGGL((k_samples<false, true>), g1, dim3(256), 0, sg, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+        else hipLaunchKernelGGL((k_samples<false, false>), g1, dim3(256), 0, sg, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+      }
       HIPCHK(hipGetLastError());
-      hipLaunchKernelGGL(k_integrate_1d, dim3(L.E * Pd, nb), dim3(64), 0, sA, L, dp);
+      HIPCHK(hipEventRecord(c.evg[4 * g + 1], sg));
+      // GW kernel + integrand
+      if (L.mode == CHM_MODE_FULL) {
+        HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
+        hipLaunchKernelGGL(k_full_kde, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp);
+      } else if (L.mode == CHM_MODE_MARG) {
+        hipLaunchKernelGGL(k_event_prep, dim3(L.E_cnt, nb), dim3(64), 0, sg, L);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
+        const bool fast = L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC");
+        if (fast) hipLaunchKernelGGL(k_kde_marg_fast, dim3(L.E_cnt * ((Pd + MARG_WPB - 1) / MARG_WPB), nb), dim3(64 * MARG_WPB),
+                                     sizeof(double) * (4 * N + 3) * MARG_WPB, sg, L, dp);
+        else { allow_lds(k_kde_marg, lds_kde); hipLaunchKernelGGL(k_kde_marg, dim3(L.E_cnt * Pd, nb), dim3(64), lds_kde, sg, L, dp); }
+      } else {
+        HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
+        allow_lds(k_kde1d, lds_kde);
+        hipLaunchKernelGGL(k_kde1d, dim3(L.E_cnt, nb), dim3(256), lds_kde, sg, L, dp);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(k_integrate_1d, dim3(L.E_cnt * Pd, nb), dim3(64), 0, sg, L, dp);
+      }
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipEventRecord(c.evg[4 * g + 3], sg));
     }
-    HIPCHK(hipGetLastError());
+    if (ngroups > 1) { HIPCHK(hipEventRecord(c.evb[0], sB)); HIPCHK(hipStreamWaitEvent(sA, c.evb[0], 0)); }   // join the two lanes
     HIPCHK(hipEventRecord(c.ev[3], sA));
     // per-event log-likelihoods and their block sums
-    nblk_ev = (L.E + 255) / 256;
+    nblk_ev = (L0.E + 255) / 256;
     if (nb * nblk_ev > c.evpart_cap) {
       HIPCHK(hipStreamSynchronize(sA));
       (void)hipFree(c.d_evpart); c.d_evpart = nullptr;
@@ -483,7 +505,7 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
       c.evpart_cap = nb * nblk_ev;
     }
   } else {
-    HIPCHK(hipEventRecord(c.ev[2], sA)); HIPCHK(hipEventRecord(c.ev[6], sA)); HIPCHK(hipEventRecord(c.ev[3], sA));
+    HIPCHK(hipEventRecord(c.ev[3], sA));
   }
   double* d_lle = nullptr; double* d_nle = nullptr;
   const size_t El = like ? like->L.E : 0;
@@ -530,11 +552,14 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
   for (int i = 0; i < 8; i++) c.ms[i] = 0.;
   if (hipEventElapsedTime(&ms, c.ev[0], c.ev[5]) == hipSuccess) c.ms[0] = ms;       // whole evaluation
   if (hipEventElapsedTime(&ms, c.ev[0], c.ev[1]) == hipSuccess) c.ms[1] = ms;       // tables
-  if (hipEventElapsedTime(&ms, c.ev[1], c.ev[2]) == hipSuccess) c.ms[2] = ms;       // sample stage
-  if (hipEventElapsedTime(&ms, c.ev[6], c.ev[3]) == hipSuccess) c.ms[3] = ms;       // GW kernel + integrand
-  if (sel && hipEventElapsedTime(&ms, c.evb[1], c.evb[2]) == hipSuccess) c.ms[4] = ms;   // selection (stream B)
+  for (int g = 0; g < ngroups; g++) {                                                // summed over the event groups
+    if (hipEventElapsedTime(&ms, c.evg[4 * g], c.evg[4 * g + 1]) == hipSuccess) c.ms[2] += ms;       // sample stage
+    if (hipEventElapsedTime(&ms, c.evg[4 * g + 2], c.evg[4 * g + 3]) == hipSuccess) c.ms[3] += ms;   // GW kernel + integrand
+  }
+  if (sel && hipEventElapsedTime(&ms, c.evb[1], c.evb[2]) == hipSuccess) c.ms[4] = ms;   // selection (own stream)
   if (hipEventElapsedTime(&ms, c.ev[3], c.ev[5]) == hipSuccess) c.ms[5] = ms;       // reduce + combine (+ all-reduce)
-  if (like && hipEventElapsedTime(&ms, c.ev[1], c.evb[0]) == hipSuccess) c.ms[6] = ms;   // per-z factors (stream B)
+  if (like && hipEventElapsedTime(&ms, c.ev[1], c.ev[3]) == hipSuccess) c.ms[6] = ms;    // all event groups, wall
+  c.ms[7] = (double)ngroups;
   return CHM_OK;
 }
 

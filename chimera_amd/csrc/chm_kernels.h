@@ -26,6 +26,7 @@ enum { PT_SW = 0, PT_SW2, PT_SD1, PT_SD2, PT_ZMIN, PT_ZMAX, PT_WD0, PT_WD1, PT_W
 struct LikeDev {                  // device-resident shard of events (see chm_like_desc)
   int E, S, Z, P;
   int mode, kernel, bw_method, binning, num_bins, G, has_cut, NC;
+  int e_off, E_cnt;               // event group handled by this launch: events [e_off, e_off + E_cnt)
   int dbg, pad1;                  // CHM_DEBUG_SKIP ablation bits (timing experiments only; results are wrong when set)
   double bw_scalar, cut_grid, pe_neff;
   const double *dL, *m1det, *m2det, *pe_prior, *ra, *dec;
@@ -69,104 +70,142 @@ DEVFN EvStats combine_stats(const double* part, int NC, int S) {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_tables
+// k_tables: per-draw tables; grid (nb, 2): blockIdx.y = 0 cosmology (cosmo.py:43-46, 263; completeness.py:54-58),
+//           blockIdx.y = 1 mass normalisations (mass.py:45-52).  1024 threads per block.
 // ------------------------------------------------------------------------------------------------------
-// cumtrapz(y, x) (math.py:22-26) of n points held in global memory, by one block: thread t owns a contiguous
-// chunk; chunk totals are combined by an exclusive scan in LDS.  out[0] = 0.
-DEVFN void block_cumtrapz(const double* y, const double* x, double* out, int n, double* sh /* blockDim+1 */) {
-  int nt = blockDim.x, t = threadIdx.x;
-  int nterm = n - 1;
-  int per = (nterm + nt - 1) / nt;
-  int k0 = t * per, k1 = min(k0 + per, nterm);
+// exclusive prefix sum of one value per thread over the block (blockDim.x <= 1024); sh: >= 17 doubles
+DEVFN double block_excl_scan(double v, double* sh) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  double x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { double y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+  __syncthreads();
+  if (lane == 63) sh[wid] = x;
+  __syncthreads();
+  double off = 0.;
+  for (int w = 0; w < wid && w < nw; w++) off += sh[w];
+  return off + (x - v);
+}
+
+// cumtrapz(y, x) (math.py:22-26) of n points in global memory by one block: thread t owns a contiguous chunk of
+// terms 0.5 (y_k + y_{k+1}) (x_{k+1} - x_k); out[0] = 0.
+DEVFN void block_cumtrapz(const double* y, const double* x, double* out, int n, double* sh) {
+  const int nt = blockDim.x, t = threadIdx.x;
+  const int nterm = n - 1;
+  const int per = (nterm + nt - 1) / nt;
+  const int k0 = min(t * per, nterm), k1 = min(k0 + per, nterm);
   double acc = 0.;
   for (int k = k0; k < k1; k++) acc += 0.5 * (y[k] + y[k + 1]) * (x[k + 1] - x[k]);
-  sh[t] = acc;
-  __syncthreads();
-  if (t == 0) { double run = 0.; for (int i = 0; i < nt; i++) { double v = sh[i]; sh[i] = run; run += v; } }
-  __syncthreads();
-  acc = sh[t];
+  acc = block_excl_scan(acc, sh);
   if (t == 0) out[0] = 0.;
   for (int k = k0; k < k1; k++) { acc += 0.5 * (y[k] + y[k + 1]) * (x[k + 1] - x[k]); out[k + 1] = acc; }
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) k_tables(DevParams* params, double* zt_all, double* It_all, double* dLt_all,
-                                                 double* mg_all, double* cdf_all, double* tmp_all, int TcMax, int TmMax) {
-  __shared__ double sh[260];
-  int b = blockIdx.x, t = threadIdx.x;
+// jnp.interp(x, xp, fp) (clamped) by the whole block: the thread that owns the bracketing interval publishes it
+DEVFN double block_interp(double x, const double* xp, const double* fp, int n, double* sh) {
+  const int nt = blockDim.x, t = threadIdx.x;
+  __syncthreads();
+  if (t == 0) sh[0] = -1.;
+  __syncthreads();
+  for (int i = t + 1; i < n; i += nt) {               // interval (i-1, i): xp[i-1] <= x < xp[i]  (searchsorted right)
+    if (xp[i - 1] <= x && (x < xp[i] || i == n - 1)) sh[0] = (double)i;
+  }
+  __syncthreads();
+  int i = (int)sh[0];
+  if (i < 1) i = 1;                                   // x < xp[0] (or NaN): jnp.interp clamps to the first interval
+  double f0 = fp[i - 1], f1 = fp[i], x0 = xp[i - 1], x1 = xp[i];
+  double dx = x1 - x0;
+  double f = (fabs(dx) <= 4.930380657631324e-32) ? f0 : f0 + ((x - x0) / dx) * (f1 - f0);
+  if (x < xp[0]) f = fp[0];
+  if (x > xp[n - 1]) f = fp[n - 1];
+  return f;
+}
+
+__global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_all, double* It_all, double* dLt_all,
+                                                  double* mg_all, double* cdf_all, double* tmp_all, int TcMax, int TmMax) {
+  __shared__ double sh[32];
+  const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
   DevParams& P = params[b];
-  int Tc = P.Tc, Tm = P.Tm;
+  const int Tc = P.Tc, Tm = P.Tm;
   double* zt = zt_all + (size_t)b * TcMax;
   double* It = It_all + (size_t)b * TcMax;
   double* dLt = dLt_all + (size_t)b * TcMax;
   double* mg = mg_all + (size_t)b * TmMax;
   double* cdf = cdf_all + (size_t)b * TmMax;
-  int Tmax = TcMax > TmMax ? TcMax : TmMax;
-  double* tmp = tmp_all + (size_t)b * Tmax;
+  double* tmp = tmp_all + (size_t)b * (TcMax + TmMax) + (blockIdx.y == 0 ? 0 : TcMax);
 
-  if (t == 0) {                                   // per-draw constants
-    double m_low = P.m[0], m_high = P.m[1];
-    if (P.mass_model == 2) {
-      double mu = P.m[6], sg = P.m[7];
-      P.plp_plnorm = tpl_cdf(-P.m[3], m_low, m_high);
-      P.tg_hi = mu + 5. * sg;
-      double max_point = (P.tg_hi - mu) / (sg * sqrt(2.));
-      double min_point = (m_low - mu) / (sg * sqrt(2.));
-      P.tg_norm = 0.5 * erf(max_point) - 0.5 * erf(min_point);
-      P.g_c0 = -0.5 * log(2. * CHM_PI) - log(sg);
-      P.inv_plnorm = 1. / P.plp_plnorm; P.inv_tg_norm = 1. / P.tg_norm; P.inv_2s2 = 1. / (2. * (sg * sg));
-    } else if (P.mass_model == 1) {
-      double mb = m_low + P.m[6] * (m_high - m_low);
-      P.bpl_mbreak = mb;
-      P.bpl_pl1 = tpl_notnorm(mb, -P.m[2], m_low, mb);
-      P.bpl_pl2 = tpl_notnorm(mb, -P.m[3], mb, m_high);
+  if (blockIdx.y == 0) {
+    if (t == 0) {                                   // rate constants
+      double g = P.r[0], k = P.r[1], zp = P.r[2], zmax = P.r[3];
+      P.md_norm = 1. + pow(1. + zp, -g - k);                              // rate.py:114
+      P.tpl_rate_norm = (pow(1. + zmax, g + 1.) - 1.) / (g + 1.);         // rate.py:105
+      P.l1pzp = log(1. + zp);
     }
-    double g = P.r[0], k = P.r[1], zp = P.r[2], zmax = P.r[3];
-    P.md_norm = 1. + pow(1. + zp, -g - k);
-    P.l1pzp = log(1. + zp);
-    P.lmg0 = log(m_low);
-    P.inv_dlmg = (double)(P.Tm - 1) / (log(m_high) - log(m_low));
-    P.tpl_rate_norm = (pow(1. + zmax, g + 1.) - 1.) / (g + 1.);
+    // zt = [0] U logspace(-10, log10 z_max, Tc-1); It = cumtrapz(1/E, zt)     cosmo.py:43-46
+    const double lzmax = log10(P.z_max);
+    for (int i = t; i < Tc; i += nt) {
+      double z = i == 0 ? 0. : pow(10., jnp_linspace_at(-10., lzmax, Tc - 1, i - 1));
+      zt[i] = z;
+      tmp[i] = 1. / E_at_z(P, z);
+    }
+    __syncthreads();
+    block_cumtrapz(tmp, zt, It, Tc, sh);
+    // dL table of z_from_dGW: dL_at_z(cosmo, z_grid_interp) (cosmo.py:263).  jnp.interp evaluated AT its own nodes returns
+    // It[i] exactly for i < Tc-1 (delta = 0) and It[Tc-2] + (dx/dx) dI at the last node.
+    for (int i = t; i < Tc; i += nt) {
+      double z = zt[i];
+      double ii = It[i];
+      if (i == Tc - 1) { double dx = zt[i] - zt[i - 1]; ii = It[i - 1] + (dx / dx) * (It[i] - It[i - 1]); }
+      dLt[i] = dL_from_dCt(P, dCt_from_dCr(P, P.dH * ii), z);
+    }
+    // fR = Vc(z1) - Vc(z0)                                                       completeness.py:54-58
+    double i0 = block_interp(P.zc0, zt, It, Tc, sh);
+    double i1 = block_interp(P.zc1, zt, It, Tc, sh);
+    if (t == 0) {
+      double v0 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * i0));
+      double v1 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * i1));
+      P.fR = v1 - v0;
+    }
+  } else {
+    if (t == 0) {                                   // mass-model constants
+      double m_low = P.m[0], m_high = P.m[1];
+      if (P.mass_model == 2) {
+        double mu = P.m[6], sg = P.m[7];
+        P.plp_plnorm = tpl_cdf(-P.m[3], m_low, m_high);                   // mass.py:301
+        P.tg_hi = mu + 5. * sg;                                           // mass.py:302
+        double max_point = (P.tg_hi - mu) / (sg * sqrt(2.));
+        double min_point = (m_low - mu) / (sg * sqrt(2.));
+        P.tg_norm = 0.5 * erf(max_point) - 0.5 * erf(min_point);          // mass.py:272-274
+        P.g_c0 = -0.5 * log(2. * CHM_PI) - log(sg);                       // mass.py:268
+        P.inv_plnorm = 1. / P.plp_plnorm; P.inv_tg_norm = 1. / P.tg_norm; P.inv_2s2 = 1. / (2. * (sg * sg));
+      } else if (P.mass_model == 1) {
+        double mb = m_low + P.m[6] * (m_high - m_low);                    // mass.py:291-293
+        P.bpl_mbreak = mb;
+        P.bpl_pl1 = tpl_notnorm(mb, -P.m[2], m_low, mb);
+        P.bpl_pl2 = tpl_notnorm(mb, -P.m[3], mb, m_high);
+      }
+      P.lmg0 = log(m_low);
+      P.inv_dlmg = (double)(P.Tm - 1) / (log(m_high) - log(m_low));
+    }
+    __syncthreads();
+    // m_grid = logspace(log10 m_low, log10 m_high, Tm); cdf = cumtrapz(secondary(m_grid; m_high))   mass.py:45-49
+    const double l0 = log10(P.m[0]), l1 = log10(P.m[1]);
+    for (int i = t; i < Tm; i += nt) {
+      double m = pow(10., jnp_linspace_at(l0, l1, Tm, i));
+      mg[i] = m;
+      tmp[i] = secondary_notnorm(P, m, P.m[1]);
+    }
+    __syncthreads();
+    block_cumtrapz(tmp, mg, cdf, Tm, sh);
+    // norm_p_m1 = trapz(primary(m_grid), m_grid) = 0.5 * sum(dx * (y1 + y0))             mass.py:50-52
+    for (int i = t; i < Tm; i += nt) tmp[i] = primary_notnorm(P, mg[i]);
+    __syncthreads();
+    double acc = 0.;
+    for (int k = t; k < Tm - 1; k += nt) acc += (mg[k + 1] - mg[k]) * (tmp[k + 1] + tmp[k]);
+    acc = block_reduce<RED_SUM>(acc, sh);
+    if (t == 0) { P.norm_p_m1 = 0.5 * acc; P.inv_norm_p_m1 = 1. / (0.5 * acc); }
   }
-  __syncthreads();
-
-  // cosmology: zt = [0] U logspace(-10, log10 z_max, Tc-1); It = cumtrapz(1/E, zt)     cosmo.py:43-46
-  double lzmax = log10(P.z_max);
-  for (int i = t; i < Tc; i += blockDim.x) {
-    double z = i == 0 ? 0. : pow(10., jnp_linspace_at(-10., lzmax, Tc - 1, i - 1));
-    zt[i] = z;
-    tmp[i] = 1. / E_at_z(P, z);
-  }
-  __syncthreads();
-  block_cumtrapz(tmp, zt, It, Tc, sh);
-  // dL table of z_from_dGW: dL_at_z(cosmo, z_grid_interp)                               cosmo.py:263
-  for (int i = t; i < Tc; i += blockDim.x) {
-    double z = zt[i];
-    dLt[i] = dL_from_dCt(P, dCt_at_z(P, z, zt, It), z);
-  }
-  // fR = Vc(z1) - Vc(z0)                                                                completeness.py:54-58
-  if (t == 0) {
-    double v0 = Vc_from_dCt(P, dCt_at_z(P, P.zc0, zt, It));
-    double v1 = Vc_from_dCt(P, dCt_at_z(P, P.zc1, zt, It));
-    P.fR = v1 - v0;
-  }
-  // mass: m_grid = logspace(log10 m_low, log10 m_high, Tm); cdf = cumtrapz(secondary(m_grid; m_high))   mass.py:45-49
-  double l0 = log10(P.m[0]), l1 = log10(P.m[1]);
-  for (int i = t; i < Tm; i += blockDim.x) {
-    double m = pow(10., jnp_linspace_at(l0, l1, Tm, i));
-    mg[i] = m;
-    tmp[i] = secondary_notnorm(P, m, P.m[1]);
-  }
-  __syncthreads();
-  block_cumtrapz(tmp, mg, cdf, Tm, sh);
-  // norm_p_m1 = trapz(primary(m_grid), m_grid) = 0.5 * sum(dx * (y1 + y0))             mass.py:50-52
-  double acc = 0.;
-  for (int k = t; k < Tm - 1; k += blockDim.x) {
-    double y0 = primary_notnorm(P, mg[k]), y1 = primary_notnorm(P, mg[k + 1]);
-    acc += (mg[k + 1] - mg[k]) * (y1 + y0);
-  }
-  acc = block_reduce<RED_SUM>(acc, sh);
-  if (t == 0) { P.norm_p_m1 = 0.5 * acc; P.inv_norm_p_m1 = 1. / (0.5 * acc); }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -222,10 +261,10 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
                   mg_all + (size_t)b * TmMax, cdf_all + (size_t)b * TmMax };
   TabView T = stage_tables(P, g, LDS_TAB, lds, false);
   const int S = L.S;
-  const int nchunk = L.E * L.NC;
+  const int nchunk = L.E_cnt * L.NC;
   const bool vec2 = ((S & 1) == 0);
   for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
-    const int e = ch / L.NC, c = ch % L.NC;
+    const int e = L.e_off + ch / L.NC, c = ch % L.NC;
     const size_t so = ((size_t)b * L.E + e) * S;
     const size_t eo = (size_t)e * S;
     double* wz = L.ws_z + so;
@@ -305,7 +344,7 @@ template <bool LDS_TAB>
 __global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
                                                    int TcMax) {
   extern __shared__ double lds[];
-  const int e = blockIdx.x, b = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+  const int e = L.e_off + blockIdx.x, b = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
   const DevParams& P = params[b];
   const double* zt = zt_all + (size_t)b * TcMax;
   const double* It = It_all + (size_t)b * TcMax;
@@ -499,7 +538,7 @@ DEVFN void wave_prefix3(const double* cen, const double* wgt, int N, double c_re
 // evstat (nb,E,8): zmin, zmax, std, norm, n_eff, sum w, lb, ub  (effective-grid ends, likelihood.py:186-187)
 #define NEVSTAT 8
 __global__ void __launch_bounds__(64) k_event_prep(LikeDev L) {
-  const int e = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int e = L.e_off + blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const EvStats st = combine_stats(L.part + ((size_t)b * L.E + e) * L.NC * NPART, L.NC, L.S);
   double* o = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
   double lb = 0., ub = 0.;
@@ -526,7 +565,7 @@ __global__ void __launch_bounds__(64) k_event_prep(LikeDev L) {
 __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* params) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x;
-  const int p = blockIdx.x % L.P, e = blockIdx.x / L.P, b = blockIdx.y;
+  const int p = blockIdx.x % L.P, e = L.e_off + blockIdx.x / L.P, b = blockIdx.y;
   const DevParams& P = params[b];
   const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
   const int N = L.binning ? B : S;
@@ -680,6 +719,14 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
 // Degenerate pixels (no in-pixel weight, zero-width histogram, zero bandwidth) give NaN, as the reference's 0/0 does.
 // ------------------------------------------------------------------------------------------------------
 #define FAST_PF 4
+#define MARG_WPB 1
+// ordering point for LDS traffic inside ONE wave (its lanes exchange data through the wave's private LDS slice): LDS
+// instructions of a wave execute in issue order, so only the compiler has to be kept from moving accesses across it
+DEVFN void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 struct EpanCtx { const double* cen; const double* P0; const double* P1; const double* P2; int N; double lo, inv_dbin, bw, inv_bw, scale; };
 
 // Index range [ja, jb) of the bins with |g - c_j| <= h straight from the uniform spacing c_j = lo + (j + 1/2) dbin.  A bin
@@ -697,10 +744,13 @@ DEVFN double epan_node(const EpanCtx& c, double g) {
   return (S0 - qq * (c.inv_bw * c.inv_bw)) * c.scale;
 }
 
-__global__ void __launch_bounds__(64) k_kde_marg_fast(LikeDev L, const DevParams* params) {
-  extern __shared__ double lds[];
-  const int lane = threadIdx.x;
-  const int p = blockIdx.x % L.P, e = blockIdx.x / L.P, b = blockIdx.y;
+__global__ void __launch_bounds__(64 * MARG_WPB, 6) k_kde_marg_fast(LikeDev L, const DevParams* params) {
+  extern __shared__ double lds_all[];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int PG = (L.P + MARG_WPB - 1) / MARG_WPB;            // pixel groups per event: one wave per pixel, MARG_WPB waves per block
+  const int p = (blockIdx.x % PG) * MARG_WPB + wid, e = L.e_off + blockIdx.x / PG, b = blockIdx.y;
+  if (p >= L.P) return;
+  double* lds = lds_all + (size_t)wid * (4 * L.num_bins + 3);   // each wave works in its own LDS slice: no block barriers
   const DevParams& P = params[b];
   const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
   double* cen = lds; double* P0 = cen + B; double* P1 = P0 + (B + 1); double* P2 = P1 + (B + 1);
@@ -761,11 +811,11 @@ __global__ void __launch_bounds__(64) k_kde_marg_fast(LikeDev L, const DevParams
     cen[j] = (e0 + e1) / 2.;
     cnt[j] = 0.;
   }
-  __syncthreads();
+  wave_sync();
 #pragma unroll
   for (int i = 0; i < 2; i++) { int s = s0 + lane + 64 * i; if (s < s1) atomicAdd(&cnt[bin_index(zr[i], lo, hi, B)], wr[i]); }
   for (int s = s0 + lane + 128; s < s1; s += 64) atomicAdd(&cnt[bin_index(wz[s], lo, hi, B)], ww[s]);
-  __syncthreads();
+  wave_sync();
   // sum w, sum w^2 over the bins; prefix sums of (w, w c', w c'^2), c' = centre - lo
   const int per = (B + 63) / 64;
   const int j0 = lane * per, j1 = min(j0 + per, B);
@@ -787,7 +837,7 @@ __global__ void __launch_bounds__(64) k_kde_marg_fast(LikeDev L, const DevParams
 #pragma unroll
       for (int i = 0; i < 8; i++) wv[i] = (j0 + i < j1) ? cnt[j0 + i] : 0.;
     }
-    __syncthreads();
+    wave_sync();
     if (small) {
 #pragma unroll
       for (int i = 0; i < 8; i++) if (j0 + i < j1) {
@@ -803,9 +853,9 @@ __global__ void __launch_bounds__(64) k_kde_marg_fast(LikeDev L, const DevParams
       for (int j = j1 - 1; j >= j0; j--) { double w = cnt[j]; P0[j + 1] = a0; a0 -= w; }
     }
     if (lane == 0) { P1[0] = 0.; P2[0] = 0.; }
-    __syncthreads();
+    wave_sync();
     if (lane == 0) P0[0] = 0.;
-    __syncthreads();
+    wave_sync();
   }
   // bandwidth: neff = 1/sum(W^2), W = w/tot (math.py:62-64); std of the uniform centres; factor (math.py:65-73)
   const double neff_k = (tot * tot) / sum2;
@@ -824,40 +874,40 @@ __global__ void __launch_bounds__(64) k_kde_marg_fast(LikeDev L, const DevParams
   const double gwp = L.gw_pdf[(size_t)e * L.P + p];
   const double fR = P.fR;
   const double inv_de = (double)(G - 1) / (ub - lb);
-  const double inv_de_x = inv_de;
   const double nan = __builtin_nan("");
   double acc = 0.;
   if (dump) { for (int k = lane; k < Z; k += 64) if (k < k_lo || k > k_hi) dump[k] = 0.; }
-  for (int kb = k_lo; kb <= k_hi; kb += 128 * FAST_PF) {
+#pragma unroll 1
+  for (int it = 0; k_lo + 128 * it <= k_hi; it++) {         // one pass = 64 lanes x 2 consecutive grid points
+    const int k = k_lo + 128 * it + 2 * lane;
+    double pc0, pc1;
+    if (it < FAST_PF) {                                     // prefetched at kernel start (uniform select)
+      pc0 = pf0[0]; pc1 = pf1[0];
 #pragma unroll
-    for (int i = 0; i < FAST_PF; i++) {
-      const int k = kb + 128 * i + 2 * lane;
-      if (k <= k_hi) {
-        double pc0, pc1;
-        if (kb == k_lo) { pc0 = pf0[i]; pc1 = pf1[i]; }
-        else { pc0 = pc[k]; pc1 = (k + 1 <= k_hi) ? pc[k + 1] : 0.; }
+      for (int i = 1; i < FAST_PF; i++) if (it == i) { pc0 = pf0[i]; pc1 = pf1[i]; }
+    } else {
+      pc0 = k <= k_hi ? pc[k] : 0.; pc1 = k + 1 <= k_hi ? pc[k + 1] : 0.;
+    }
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int kk = k + h;
-          if (kk <= k_hi) {
-            const double zk = zg[kk];
-            double pgw = 0.;
-            if (zk >= lb && zk <= ub) {                     // jnp.interp(..., left=0, right=0)
-              // bracket on the uniform effective grid: i1 - 1 = floor((z - lb)/de); a z within rounding of a node may pick
-              // either neighbouring segment -- the interpolant is continuous there
-              double tp = floor((zk - lb) * inv_de);
-              tp = tp < (double)(G - 2) ? tp : (double)(G - 2);
-              const int i1 = (int)tp + 1;
-              double xa = eg[i1 - 1], xb = eg[i1];
-              double da = epan_node(cx, xa), db = epan_node(cx, xb);
-              double f = da + ((zk - xa) * inv_de_x) * (db - da);       // (z - x0)/dx with dx = (ub - lb)/(G - 1)
-              pgw = degenerate ? nan : f * norm * gwp;     // kde_interp * norm * gw_pdf[i]    likelihood.py:194
-            } else if (zk != zk) pgw = nan;
-            if (dump) dump[kk] = pgw;
-            const double pcv = h == 0 ? pc0 : pc1;
-            if (pcv != -100.) acc += pgw * (fR * pcv + bkgA[kk]) * Aw[kk];
-          }
-        }
+    for (int h = 0; h < 2; h++) {
+      const int kk = k + h;
+      if (kk <= k_hi) {
+        const double zk = zg[kk];
+        double pgw = 0.;
+        if (zk >= lb && zk <= ub) {                         // jnp.interp(..., left=0, right=0)
+          // bracket on the uniform effective grid: i1 - 1 = floor((z - lb)/de); a z within rounding of a node may pick
+          // either neighbouring segment -- the interpolant is continuous there
+          double tp = floor((zk - lb) * inv_de);
+          tp = tp < (double)(G - 2) ? tp : (double)(G - 2);
+          const int i1 = (int)tp + 1;
+          double xa = eg[i1 - 1], xb = eg[i1];
+          double da = epan_node(cx, xa), db = epan_node(cx, xb);
+          double f = da + ((zk - xa) * inv_de) * (db - da);             // (z - x0)/dx with dx = (ub - lb)/(G - 1)
+          pgw = degenerate ? nan : f * norm * gwp;          // kde_interp * norm * gw_pdf[i]    likelihood.py:194
+        } else if (zk != zk) pgw = nan;
+        if (dump) dump[kk] = pgw;
+        const double pcv = h == 0 ? pc0 : pc1;
+        if (pcv != -100.) acc += pgw * (fR * pcv + bkgA[kk]) * Aw[kk];
       }
     }
   }
@@ -873,7 +923,7 @@ __global__ void __launch_bounds__(256) k_kde1d(LikeDev L, const DevParams* param
   extern __shared__ double lds[];
   __shared__ double red[16];
   const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wid = t >> 6;
-  const int e = blockIdx.x, b = blockIdx.y;
+  const int e = L.e_off + blockIdx.x, b = blockIdx.y;
   const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
   const int N = L.binning ? B : S;
   double* data = lds; double* wgt = data + N;
@@ -950,7 +1000,7 @@ __global__ void __launch_bounds__(256) k_kde1d(LikeDev L, const DevParams* param
 __global__ void __launch_bounds__(64) k_integrate_1d(LikeDev L, const DevParams* params) {
   const int lane = threadIdx.x;
   const int Pd = L.P > 0 ? L.P : 1;
-  const int p = blockIdx.x % Pd, e = blockIdx.x / Pd, b = blockIdx.y;
+  const int p = blockIdx.x % Pd, e = L.e_off + blockIdx.x / Pd, b = blockIdx.y;
   const DevParams& P = params[b];
   const int Z = L.Z;
   const bool pixelated = L.mode != 0;
@@ -979,7 +1029,7 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
   __shared__ double red[16];
   __shared__ double wh[12];
   const int t = threadIdx.x, nt = blockDim.x;
-  const int p = blockIdx.x % L.P, e = blockIdx.x / L.P, b = blockIdx.y;
+  const int p = blockIdx.x % L.P, e = L.e_off + blockIdx.x / L.P, b = blockIdx.y;
   const DevParams& P = params[b];
   const int S = L.S, Z = L.Z;
   const size_t so = ((size_t)b * L.E + e) * S;
