@@ -173,7 +173,7 @@ class hyperlikelihood(object):
     if 'partials' in want:
       res['partials'] = np.empty((nb, 3)); out.partials = _lib.dptr(res['partials'])
     sel = self.selection_function._handle() if (with_sel and self.selection_function is not None) else None
-    comm_h = self.comm.handle if (self.comm is not None and self.comm.nranks > 1) else None
+    comm_h = getattr(self.comm, 'handle', None) if self.comm is not None else None       # RCCL all-reduce inside chm_eval
     _lib.check(_lib.lib().chm_eval(h, sel, comm_h, params, nb, self.nevents, C.byref(out)))
     return res
 

@@ -62,7 +62,7 @@ class selection_function(object):
     nexp = np.empty(1)
     out = _lib.chm_out()
     out.N_exp = _lib.dptr(nexp)
-    comm_h = self.comm.handle if (self.comm is not None and self.comm.nranks > 1) else None
+    comm_h = getattr(self.comm, 'handle', None) if self.comm is not None else None
     _lib.check(_lib.lib().chm_eval(None, self._handle(), comm_h, C.byref(p), 1, 0, C.byref(out)))
     return nexp[0]
 

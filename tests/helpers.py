@@ -69,3 +69,48 @@ def assert_loglike_close(got, ref, rtol, atol=0.):
   a, b = neginf_class(got), neginf_class(ref)
   assert np.array_equal(a, b), f"-inf-class mismatch: got {got}, ref {ref}"
   np.testing.assert_allclose(got[~a], ref[~b], rtol=rtol, atol=atol)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# golden fixtures (tests/golden/*.npz, written by tests/golden/make_golden.py)
+# ----------------------------------------------------------------------------------------------------------
+import os
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load_golden(name):
+  with np.load(os.path.join(GOLDEN_DIR, name + '.npz')) as d:
+    ev = {k[3:]: d[k] for k in d.files if k.startswith('ev_')}
+    inj = {k[4:]: d[k] for k in d.files if k.startswith('inj_')}
+    inj['N_inj'] = float(d['N_inj'])
+    exp = {k: d[k] for k in ('log_like_evs', 'log_num', 'log_Nexp', 'log_hyper', 'p_gw')}
+  return ev, inj, exp
+
+
+# ----------------------------------------------------------------------------------------------------------
+# host mirror of the device-side combination (k_combine), used by the CPU sharding tests
+# ----------------------------------------------------------------------------------------------------------
+def shard_partials_oracle(like_o, lam, e0, e1, i0, i1):
+  """[sum_i nan_to_num(log L_i), nansum dN, sum dN^2] of events [e0,e1) and injections [i0,i1) (oracle)."""
+  pop = like_o.population.update(**lam)
+  with np.errstate(all='ignore'):
+    ll = O.nan_to_num_neginf(np.log(like_o.compute_numlike_evs(pop)))[e0:e1]
+    dN = like_o.selection_function.dN(pop)[i0:i1]
+    return np.array([np.sum(ll), np.nansum(dN), np.sum(dN**2)])
+
+
+def combine_partials(partials, E_total, pop, N_inj, N_eff):
+  """selection_function.py:38-47 + likelihood.py:298-300,313-316 on the all-reduced partial sums."""
+  log_num, s1, s2 = partials
+  with np.errstate(all='ignore'):
+    xi = s1 / N_inj
+    Nexp = pop.Tobs * xi
+    if N_eff is not None:
+      var = s2 / N_inj**2 - xi**2 / N_inj
+      if xi**2 / var < N_eff:
+        Nexp = 0.
+    if not pop.scale_free:
+      log_num = log_num + E_total * np.log(pop.R0 * pop.Tobs)
+      return log_num - Nexp
+    return log_num - E_total * np.log(Nexp)

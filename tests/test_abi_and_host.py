@@ -1,0 +1,203 @@
+"""CPU tests of the C-ABI boundary and of the host-side mirror of the reference interface (no GPU needed):
+the library loads and exports every symbol include/chimera_hip.h declares, the ctypes structures match the C layout,
+argument errors come back as the reference-side exception types, and without a GPU every compute entry fails loudly."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'chimera_hip.h')
+
+
+@pytest.fixture(scope='module')
+def lib():
+  import __graft_entry__ as g
+  g.build()
+  from chimera_amd import _lib
+  return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+  src = open(HEADER).read()
+  src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+  declared = set(re.findall(r'\b(chm_[a-z0-9_]+)\s*\(', src))
+  assert declared == set(lib.SYMBOLS), (declared ^ set(lib.SYMBOLS))
+  L = lib.lib()
+  for name in sorted(declared):
+    assert getattr(L, name) is not None
+  assert L.chm_version().decode().startswith('chimera_hip')
+  assert L.chm_device_count() >= 0
+
+
+def test_ctypes_structs_match_c_layout(lib, tmp_path):
+  structs = {'chm_params': lib.chm_params, 'chm_like_desc': lib.chm_like_desc, 'chm_sel_desc': lib.chm_sel_desc, 'chm_out': lib.chm_out}
+  prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
+  for sname, cls in structs.items():
+    prog.append(f'  printf("{sname} size %zu\\n", sizeof({sname}));')
+    for fname, _ in cls._fields_:
+      prog.append(f'  printf("{sname} {fname} %zu\\n", offsetof({sname}, {fname}));')
+  prog += ['  return 0; }']
+  cfile = tmp_path / 'layout.c'
+  cfile.write_text('\n'.join(prog))
+  exe = tmp_path / 'layout'
+  subprocess.check_call(['gcc', '-std=c99', '-o', str(exe), str(cfile)])
+  out = subprocess.check_output([str(exe)]).decode().split('\n')
+  for line in out:
+    if not line:
+      continue
+    sname, fname, val = line.split()
+    cls = structs[sname]
+    if fname == 'size':
+      assert C.sizeof(cls) == int(val), sname
+    else:
+      assert getattr(cls, fname).offset == int(val), (sname, fname)
+
+
+def test_argument_errors_and_missing_gpu(lib):
+  import chimera_amd as CH
+  L = lib.lib()
+  h = C.c_void_p()
+  d = lib.chm_like_desc()
+  assert L.chm_like_create(C.byref(d), C.byref(h)) == lib.CHM_E_ARG            # E = 0
+  assert b'E > 0' in L.chm_last_error()
+  with pytest.raises(ValueError):
+    lib.check(lib.CHM_E_ARG)
+  with pytest.raises(RuntimeError):
+    lib.check(lib.CHM_E_HIP)
+  if L.chm_device_count() == 0:
+    # no CPU fallback: model functions, tables and likelihoods refuse to run
+    with pytest.raises(RuntimeError):
+      CH.cosmo.dL_at_z(CH.cosmo.flrw(), np.array([0.1]))
+    with pytest.raises(RuntimeError):
+      CH.cosmo.flrw().z_grid_interp
+    from tests import helpers as H
+    cfg, ev, inj = H.small_config(E=2, S=32, P=2, Z=16, I=64, seed=1)
+    like, pop, sel = H.build_product(ev, inj)
+    with pytest.raises(RuntimeError):
+      like(H0=70.)
+    with pytest.raises(RuntimeError):
+      sel.N_exp(pop)
+
+
+def test_missing_library_fails_loudly(lib, monkeypatch):
+  monkeypatch.setattr(lib, '_lib', None)
+  monkeypatch.setattr(lib, 'LIB_PATH', '/nonexistent/libchimera_hip.so')
+  with pytest.raises(RuntimeError, match='no CPU fallback'):
+    lib.lib()
+
+
+def test_product_does_not_import_the_oracle():
+  """The oracle is test infrastructure: nothing under chimera_amd/ may import or execute it."""
+  bad = []
+  for dirpath, _, files in os.walk(os.path.join(ROOT, 'chimera_amd')):
+    for f in files:
+      if f.endswith('.py'):
+        txt = open(os.path.join(dirpath, f)).read()
+        if re.search(r'^\s*(from|import)\s+oracle\b', txt, flags=re.M) or 'chimera_oracle' in txt:
+          bad.append(os.path.join(dirpath, f))
+  assert not bad, bad
+  code = "import sys; import chimera_amd; sys.exit(1 if any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules) else 0)"
+  assert subprocess.call([sys.executable, '-c', code], cwd=ROOT) == 0
+
+
+# ----------------------------------------------------------------------------------------------------------
+# host-side mirror of the reference interface
+# ----------------------------------------------------------------------------------------------------------
+def test_model_containers_follow_the_reference_surface():
+  import chimera_amd as CH
+  from chimera_amd.cosmo import flrw, mg_flrw
+  from chimera_amd.mass import plp, tpl, bpl
+  from chimera_amd.rate import madau_dickinson, power_law, trunc_power_law, trunc_madau_dickinson
+  c = flrw(H0=67.)
+  assert c.keys == ['z_max', 'z_grid_res', 'H0', 'Om0', 'Ok0', 'Or0', 'w0', 'wa'] and c.z_grid_res == 1500 and c.z_max == 10.
+  assert c.Ode0 == 0.75 and c.dH == pytest.approx(299.792458 / 67.)
+  assert c.update(foo=1) is c and c.update(H0=80., gamma=1.).H0 == 80.
+  assert mg_flrw().as_dict['Xi0'] == 1. and mg_flrw().name == 'mg_flrw'
+  assert plp().as_dict == {'m_low': 5.1, 'm_high': 87., 'grid_res': 1000, 'lambda_peak': 0.039, 'alpha': 3.4, 'beta': 1.1,
+                           'delta_m': 4.8, 'mu_g': 34., 'sigma_g': 3.6}
+  assert tpl().alpha == 2.5 and bpl().break_fraction == 0.43 and madau_dickinson().zp == 2. and power_law().gamma == 1.7
+  assert trunc_power_law().zmax == 1.3 and trunc_madau_dickinson().kappa == 3.0
+  pop = CH.population(c, plp(), madau_dickinson(), R0=3.)
+  p2 = pop.update(H0=75., alpha=3., gamma=2., R0=5., nonsense=1.)
+  assert (p2.cosmo.H0, p2.mass.alpha, p2.rate.gamma, p2.R0, p2.scale_free) == (75., 3., 2., 5., True)
+  assert pop.cosmo.H0 == 67. and isinstance(pop.gal_cat, CH.catalog.empty_catalog)
+  par = p2.to_params()
+  assert par.cosmo_model == 0 and par.mass_model == 2 and par.rate_model == 1 and par.has_catalog == 0
+  assert par.cosmo[0] == 75. and par.mass[3] == 3. and par.rate[0] == 2. and par.R0 == 5. and par.z_grid_res == 1500
+  assert sys.modules['chimera_amd.cosmo'] is CH.cosmo and sys.modules['chimera_amd.completeness'] is CH.completeness
+
+
+def test_data_containers_and_pixel_index():
+  import chimera_amd as CH
+  from chimera_amd.likelihood import _pix_of_sample
+  th = CH.data.theta_pe_det(dL=np.ones((2, 3)))
+  assert th.pe_prior.shape == (2, 3) and np.all(th.pe_prior == 1.) and th.pixels_opt_nsides is None     # data.py:45-47
+  th2 = th.update(pe_prior=th.dL**2 * 4.)
+  assert th2 is not th and np.all(th2.pe_prior == 4.) and np.all(th.pe_prior == 1.)
+  with pytest.raises(TypeError):
+    CH.data.theta_inj_det(foo=1)
+  pixels = np.array([[40, 12, 33, -100], [7, -100, -100, -100]])
+  pe = np.array([[12, 40, 99, 33, 12], [7, 7, 8, -100, 7]])
+  np.testing.assert_array_equal(_pix_of_sample(pe, pixels), [[1, 0, -1, 2, 1], [0, 0, -1, -1, 0]])
+
+
+def test_hyperlikelihood_constructor_checks():
+  import chimera_amd as CH
+  from tests import helpers as H
+  cfg, ev, inj = H.small_config(E=2, S=32, P=2, Z=16, I=64, seed=1)
+  with pytest.raises(AssertionError):
+    H.build_product(ev, inj, kind='bogus')                                     # likelihood.py:85
+  with pytest.raises(ValueError):
+    H.build_product(ev, inj, like_kw=dict(bw_method='nonsense'))               # math.py:75
+  like, pop, sel = H.build_product(ev, inj)
+  assert like.pixelated and like.nevents == 2 and like.z_int_res == 16 and like.max_npixels == 2
+  np.testing.assert_array_equal(like.neff_pixels, ev['neff_pixels'])
+  like1, _, _ = H.build_product(ev, inj, pixelated=False)
+  assert not like1.pixelated and like1._mode == '1d'
+
+
+def test_catalog_and_completeness_plugins(tmp_path):
+  from chimera_amd.catalog import dVdz_completeness, pixelated_catalog, empty_catalog
+  comp = dVdz_completeness(z_range=[0.1, 1.0])
+  zg = np.array([[0.05, 0.1, 0.5, 1.0, 1.2]])
+  np.testing.assert_array_equal(comp.P_compl(zg), [[0., 0., 1., 0., 0.]])        # strict inequalities, completeness.py:46
+  with pytest.raises(ValueError):
+    dVdz_completeness(kind='step_smooth')
+  p_cat = np.full((1, 2, 5), -100.); p_cat[0, 0] = 1.
+  gc = pixelated_catalog(comp, p_cat=p_cat, z_grids=zg, neff_pixels=[1])
+  assert gc.max_npixels == 2 and gc.P_compl.shape == (1, 1, 5) and gc.z_range == (0.1, 1.0)
+  f = str(tmp_path / 'gc.npz'); gc.save(f)
+  gc2 = pixelated_catalog(comp, gal_cat_file=f)
+  np.testing.assert_array_equal(gc2.p_cat, p_cat); assert gc2.max_npixels == 2
+  with pytest.raises(NotImplementedError):
+    pixelated_catalog(comp)
+  assert empty_catalog().max_npixels is None
+
+
+def test_chunk_bounds_partition():
+  from chimera_amd.parallel import chunk_bounds
+  for n, r in ((1000, 8), (69, 8), (7, 8), (10, 3)):
+    b = [chunk_bounds(n, r, k) for k in range(r)]
+    assert b[0][0] == 0 and b[-1][1] == n and all(b[k][1] == b[k + 1][0] for k in range(r - 1))
+    sizes = [hi - lo for lo, hi in b]
+    assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)       # first n % R ranks get one extra
+
+
+def test_synthetic_inputs_are_seeded_and_well_formed():
+  from chimera_amd import synth
+  cfg, ev, inj = synth.make_config('C2', E=5, S=64, P=4, Z=24, I=300, ragged=True)
+  cfg2, ev2, inj2 = synth.make_config('C2', E=5, S=64, P=4, Z=24, I=300, ragged=True)
+  for k in ev:
+    np.testing.assert_array_equal(ev[k], ev2[k])
+  assert ev['p_cat'].shape == (5, 4, 24) and ev['z_grids'].shape == (5, 24) and inj['dL'].shape == (300,)
+  for e in range(5):
+    n = ev['neff_pixels'][e]
+    assert np.all(ev['p_cat'][e, n:] == -100.) and np.all(ev['p_cat'][e, :n] >= 0.) and np.all(np.isfinite(ev['p_cat'][e, :n]))
+    assert np.all(ev['pixels_opt_nsides'][e, n:] == -100) and np.all(ev['gw_loc2d_pdf'][e, n:] == -100.)
+    assert np.all(np.diff(ev['z_grids'][e]) > 0)
+  assert np.all(ev['m2det'] <= ev['m1det']) and np.all(ev['dL'] > 0) and np.all(inj['p_draw'] > 0) and inj['N_inj'] > 300

@@ -163,3 +163,104 @@ def test_compute_z_grids(cfg_pix):
     zo = O.compute_z_grids(getattr(O, cname)(**kw), th_o, cosmo_prior=prior, z_int_res=50)
     zp = CH.compute_z_grids(getattr(CH.cosmo, cname)(**kw), th_p, cosmo_prior=prior, z_int_res=50)
     np.testing.assert_allclose(zp, zo, rtol=1e-12)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# sharding (device partials) and RCCL plumbing on one GPU
+# ----------------------------------------------------------------------------------------------------------
+class _FakeRank(object):
+  """Shard selector without a communicator: chm_eval then returns this shard's partial sums un-reduced."""
+  handle = None
+
+  def __init__(self, nranks, rank):
+    self.nranks, self.rank, self.device = nranks, rank, 0
+
+
+@pytest.mark.parametrize('kind', ['marginalized', 'full'])
+def test_sharded_partials_add_up(cfg_pix, kind):
+  cfg, ev, inj = cfg_pix
+  like, pop, sel = H.build_product(ev, inj, kind=kind)
+  lam = dict(H0=66.)
+  whole = like._eval([like.population.update(**lam)], want=('partials', 'log_like_evs'))
+  parts, evs = [], []
+  for r in range(3):
+    lk, _, _ = H.build_product(ev, inj, kind=kind, comm=_FakeRank(3, r))
+    res = lk._eval([lk.population.update(**lam)], want=('partials', 'log_like_evs'))
+    parts.append(res['partials'][0]); evs.append(res['log_like_evs'][0])
+  np.testing.assert_array_equal(np.concatenate(evs), whole['log_like_evs'][0])     # same events, same device arithmetic
+  np.testing.assert_allclose(np.sum(parts, axis=0), whole['partials'][0], rtol=1e-13)
+  like_o, pop_o, sel_o = H.build_oracle(ev, inj, kind=kind)
+  got = H.combine_partials(np.sum(parts, axis=0), cfg['E'], pop_o.update(**lam), inj['N_inj'], 5.)
+  np.testing.assert_allclose(got, like_o(**lam), rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
+
+
+def test_rccl_single_rank_communicator(cfg_pix):
+  from chimera_amd.parallel import Comm
+  cfg, ev, inj = cfg_pix
+  comm = Comm(1, 0, device=0)
+  x = np.array([1.5, -2.25, 1e300])
+  np.testing.assert_array_equal(comm.allreduce_sum(x), x)
+  like, _, _ = H.build_product(ev, inj, comm=comm)
+  ref, _, _ = H.build_product(ev, inj)
+  assert like(H0=70.) == ref(H0=70.)
+  comm.close()
+
+
+# ----------------------------------------------------------------------------------------------------------
+# size-independent properties at a BASELINE-sized shape (300 events x 32 pixels x 1000 z-bins x 4096 samples)
+# ----------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def cfg_big():
+  from chimera_amd import synth
+  return synth.make_config('C3', E=300, I=100_000)
+
+
+def test_full_size_properties(cfg_big):
+  cfg, ev, inj = cfg_big
+  E = cfg['E']
+  like, pop, sel = H.build_product(ev, inj)
+  lam = dict(H0=70.)
+  base = like.compute_all(**lam)
+  assert np.all(np.isfinite(base[0])) and np.isfinite(base[3])
+  # (1) event permutation invariance: the per-event values move with the events, the sum is unchanged
+  perm = np.random.default_rng(0).permutation(E)
+  evp = {k: (v[perm] if hasattr(v, 'shape') and v.shape[:1] == (E,) else v) for k, v in ev.items()}
+  likep, _, _ = H.build_product(evp, inj)
+  rp = likep.compute_all(**lam)
+  np.testing.assert_array_equal(rp[0], base[0][perm])
+  np.testing.assert_allclose(rp[3], base[3], rtol=0, atol=1e-9 * E)
+  # (2) batch of draws == one draw at a time; repeated evaluation is reproducible bit for bit
+  lams = [dict(H0=h) for h in (62., 70., 78.)]
+  np.testing.assert_array_equal(like.batch(lams), np.array([like(**l) for l in lams]))
+  assert like(**lam) == base[3]
+  # (3) linearity in the sky-localisation density: doubling gw_loc2d_pdf doubles every L_i   (likelihood.py:194)
+  ev2 = dict(ev); ev2['gw_loc2d_pdf'] = np.where(ev['gw_loc2d_pdf'] != -100., 2. * ev['gw_loc2d_pdf'], -100.)
+  like2, _, _ = H.build_product(ev2, inj)
+  np.testing.assert_allclose(like2.compute_all(**lam)[0], base[0] + np.log(2.), rtol=0, atol=1e-12)
+  # (4) the selection term: N_exp scales linearly with 1/N_inj and with R0
+  n1 = sel.N_exp(pop)
+  sel2 = type(sel)(sel.theta_inj_det, N_inj=2 * inj['N_inj'], N_eff=None)
+  np.testing.assert_allclose(sel2.N_exp(pop), n1 / 2, rtol=1e-14)
+  np.testing.assert_allclose(sel.N_exp(pop.update(R0=3.)), 3 * n1, rtol=1e-14)
+  # (5) shards add up
+  parts = []
+  for r in range(4):
+    lk, _, _ = H.build_product(ev, inj, comm=_FakeRank(4, r))
+    parts.append(lk._eval([lk.population.update(**lam)], want=('partials',))['partials'][0])
+  whole = like._eval([like.population.update(**lam)], want=('partials',))['partials'][0]
+  np.testing.assert_allclose(np.sum(parts, axis=0), whole, rtol=1e-12)
+  # (6) approximate vs marginalized agree to a few per cent in log-likelihood per event on well-sampled events
+  likea, _, _ = H.build_product(ev, inj, kind='approximate')
+  ra = likea.compute_all(**lam)
+  assert np.median(np.abs(ra[0] - base[0])) < 0.2
+
+
+def test_full_size_against_oracle_sample(cfg_big):
+  """The first 6 events of the big configuration, checked one by one against the oracle."""
+  cfg, ev, inj = cfg_big
+  n = 6
+  sub = {k: (v[:n] if hasattr(v, 'shape') and v.shape[:1] == (cfg['E'],) else v) for k, v in ev.items()}
+  like_p, _, _ = H.build_product(ev, inj)
+  like_o, _, _ = H.build_oracle(sub, inj)
+  for lam in (dict(H0=70.), dict(H0=84., alpha=3.0)):
+    H.assert_loglike_close(like_p.compute_all(**lam)[0][:n], like_o.compute_all(**lam)[0], rtol=1e-9, atol=1e-9)

@@ -1,0 +1,258 @@
+"""CPU pins of the oracle (oracle/chimera_oracle.py).
+
+The reference has no tests or golden vectors for this path and cannot be imported here, so the oracle is pinned by
+independent checks: SciPy implementations of the same estimators, numerical quadrature, analytic
+identities, and targeted tests of each reference quirk.
+"""
+import numpy as np
+import pytest
+from scipy import integrate, stats
+
+from oracle import chimera_oracle as O
+from tests import helpers as H
+
+
+# ---------------------------------------------------------------------------------------------------------
+# jax.numpy semantics restated in the oracle
+# ---------------------------------------------------------------------------------------------------------
+def test_jnp_helpers_against_numpy():
+  rng = np.random.default_rng(0)
+  a, b = 0.3, 2.7
+  ls = O.jnp_linspace(a, b, 17)
+  assert ls[0] == a and ls[-1] == b
+  np.testing.assert_allclose(ls, np.linspace(a, b, 17), rtol=4e-16)
+  lo, hi = rng.random(5), 1 + rng.random(5)
+  np.testing.assert_allclose(O.jnp_linspace(lo, hi, 9), np.linspace(lo, hi, 9, axis=1), rtol=4e-16)
+  xp = np.sort(rng.random(50)); fp = rng.random(50)
+  x = np.concatenate([[-1., 2., xp[0], xp[-1], xp[7]], rng.random(200)])
+  np.testing.assert_allclose(O.jnp_interp(x, xp, fp), np.interp(x, xp, fp), rtol=1e-14, atol=1e-16)
+  np.testing.assert_allclose(O.jnp_interp(x, xp, fp, left=0., right=0.), np.interp(x, xp, fp, left=0., right=0.), rtol=1e-14, atol=1e-16)
+  y = rng.random((3, 40)); xx = np.sort(rng.random((3, 40)), axis=1)
+  np.testing.assert_allclose(O.trapz(y, xx), np.trapezoid(y, xx, axis=-1), rtol=1e-14)
+  np.testing.assert_allclose(O.cumtrapz(y[0], xx[0]), integrate.cumulative_trapezoid(y[0], xx[0], initial=0), rtol=1e-13)
+  v = O.nan_to_num_neginf(np.array([1., np.nan, -np.inf, np.inf]))
+  assert v[0] == 1. and v[1] == -np.inf and v[2] == -np.finfo(np.float64).max and v[3] == np.finfo(np.float64).max
+
+
+# ---------------------------------------------------------------------------------------------------------
+# KDEs
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('bw', [None, 'silverman', 0.37])
+def test_gkde_nd_equals_scipy_gaussian_kde(bw):
+  """The reference states its N-d KDE is 'the same as jax.scipy.stats.gaussian_kde' (math.py:96)."""
+  rng = np.random.default_rng(1)
+  data = rng.standard_normal((3, 400)) * np.array([[0.2], [0.05], [0.03]]) + np.array([[0.5], [2.0], [-0.3]])
+  w = rng.random(400)
+  pts = data[:, :50] + 0.01 * rng.standard_normal((3, 50))
+  ref = stats.gaussian_kde(data, bw_method='scott' if bw is None else bw, weights=w)(pts)
+  np.testing.assert_allclose(O.gkde_nd(data, pts, weights=w, bw_method=bw), ref, rtol=1e-11)
+
+
+def test_kde1d_shape_normalisation_and_support():
+  # a single sample reproduces the kernel itself (bandwidth = neff^-1/5 * std, math.py:64-67: use 2 equal samples for std > 0)
+  grid = np.linspace(-3, 3, 2001)
+  data = np.array([-0.5, 0.5]); w = np.array([1., 1.])
+  h = 2.**(-0.2) * 0.5
+  for kern, fn in (('epan', lambda u: np.where(np.abs(u) <= 1, 0.75 * (1 - u**2), 0.)),
+                   ('gauss', lambda u: np.exp(-0.5 * u**2) / np.sqrt(2 * np.pi))):
+    d = O.kde1d(data, grid, w, kernel=kern)
+    expect = 0.5 * (fn((grid + 0.5) / h) + fn((grid - 0.5) / h)) / h
+    np.testing.assert_allclose(d, expect, rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(np.trapezoid(d, grid), 1., rtol=2e-4)
+  d = O.kde1d(data, grid, w, kernel='epan')
+  assert np.all(d[np.abs(grid) > 0.5 + h + 1e-12] == 0.)
+  # bandwidth rules (math.py:65-73)
+  rng = np.random.default_rng(2)
+  x = rng.standard_normal(300); ww = rng.random(300)
+  W = ww / ww.sum(); neff = 1 / np.sum(W**2)
+  g = np.array([0.1])
+  for bw, fac in ((None, neff**-0.2), ('scott', neff**-0.2), ('silverman', (neff * 3 / 4.)**-0.2), (0.5, 0.5)):
+    hh = fac * np.std(x)
+    np.testing.assert_allclose(O.kde1d(x, g, ww, 'gauss', bw), np.sum(W * np.exp(-0.5 * ((g - x) / hh)**2)) / np.sqrt(2 * np.pi) / hh, rtol=1e-13)
+  with pytest.raises(ValueError):
+    O.kde1d(x, g, ww, 'gauss', 'nonsense')
+
+
+def test_binning1d_conserves_weight_and_edges():
+  rng = np.random.default_rng(3)
+  x = rng.random(1000) * 2 + 1; w = rng.random(1000)
+  c, n = O.binning1d(x, w, 50)
+  np.testing.assert_allclose(n.sum(), w.sum(), rtol=1e-13)
+  assert c.shape == (50,) and np.all(np.diff(c) > 0)
+  np.testing.assert_allclose(c[0] - x.min(), (x.max() - x.min()) / 100, rtol=1e-12)
+  # the maximum lands in the last bin (clip), the minimum in the first   (math.py:41)
+  c, n = O.binning1d(np.array([1., 2., 3.]), np.array([1., 10., 100.]), 4)
+  np.testing.assert_array_equal(n, [1., 0., 10., 100.])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# cosmology
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kw', [dict(H0=70., Om0=0.25), dict(H0=67., Om0=0.31, w0=-0.9, wa=0.1), dict(H0=75., Om0=0.3, Ok0=0.05)])
+def test_distances_against_quadrature(kw):
+  c = O.flrw(z_max=5., **kw)
+  z = np.array([0.01, 0.1, 0.5, 1.0, 2.5, 4.5])
+  Ez = lambda zz: float(O.E_at_z(c, zz))
+  dCr = np.array([c.dH * integrate.quad(lambda t: 1. / Ez(t), 0, zi, epsabs=0, epsrel=1e-12)[0] for zi in z])
+  np.testing.assert_allclose(O.dCr_at_z(c, z), dCr, rtol=2e-5)        # accuracy of the 1500-point trapezoid table
+  if c.Ok0 == 0:
+    np.testing.assert_allclose(O.dL_at_z(c, z), dCr * (1 + z), rtol=2e-5)
+    np.testing.assert_allclose(O.Vc_at_z(c, z), 4 * np.pi * dCr**3 / 3, rtol=6e-5)
+  else:
+    s = np.sqrt(c.Ok0)
+    np.testing.assert_allclose(O.dCt_at_z(c, z), c.dH / s * np.sinh(s * dCr / c.dH), rtol=3e-5)
+  # round trip and Jacobians
+  dL = O.dL_at_z(c, z)
+  np.testing.assert_allclose(O.z_from_dGW(c, dL), z, rtol=5e-5)     # dL(z) and z(dL) are piecewise linear in different variables
+  eps = 1e-4
+  fd = (O.dL_at_z(c, z + eps) - O.dL_at_z(c, z - eps)) / (2 * eps)
+  if c.Ok0 == 0:
+    np.testing.assert_allclose(O.ddLdz_at_z(c, z), fd, rtol=5e-3)       # finite difference of the piecewise-linear table vs analytic derivative
+  assert c.dH == pytest.approx(299.792458 / kw['H0'])
+
+
+def test_table_layout_and_mg_limits():
+  c = O.flrw()
+  assert c.z_grid_interp.shape == (1500,) and c.z_grid_interp[0] == 0. and c.z_grid_interp[1] == pytest.approx(1e-10)
+  assert c.z_grid_interp[-1] == pytest.approx(10.) and c.integral_invE_interp[0] == 0.
+  z = np.linspace(0.01, 4., 50)
+  base = O.flrw(H0=70., z_max=5.)
+  for mg in (O.mg_flrw(H0=70., z_max=5., Xi0=1., n=2.), O.mg_flrw(H0=70., z_max=5., Xi0=1.7, n=0.)):
+    np.testing.assert_allclose(O.dL_at_z(mg, z), O.dL_at_z(base, z), rtol=1e-14)
+    np.testing.assert_allclose(O.ddLdz_at_z(mg, z), O.ddLdz_at_z(base, z), rtol=1e-14)
+  mg = O.mg_flrw(H0=70., z_max=5., Xi0=1.8, n=1.9)
+  np.testing.assert_allclose(O.dL_at_z(mg, z) / O.dL_at_z(base, z), 1.8 + (1 - 1.8) / (1 + z)**1.9, rtol=1e-14)
+  dL = O.dL_at_z(mg, z)
+  np.testing.assert_allclose(O.dVcdz_at_z(mg, z, dL), O.dVcdz_at_z(mg, z), rtol=1e-12)    # original distances == table distances
+  # update(): unknown keys ignored, same object when nothing changes (cosmo.py:33-40)
+  assert base.update(foo=1) is base and base.update(H0=80.).H0 == 80. and base.update(H0=80.).Om0 == base.Om0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# mass / rate
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('model', ['plp', 'tpl', 'bpl'])
+def test_mass_pdf_normalisation_and_support(model):
+  m = getattr(O, model)()
+  # p(m1) integrates to 1 and, for every m1, p(m2 | m1) integrates to 1 over [m_low, m1]      (mass.py:45-52, 334-341)
+  m1 = np.linspace(m.m_low, m.m_high, 20001)
+  assert np.trapezoid(O.primary_mass_pdf_notnorm(m, m1) / m.norm_p_m1, m1) == pytest.approx(1., abs=2e-4)
+  for m1v in (8., 20., 35., 60., 86.):
+    m2 = np.linspace(m.m_low, m1v, 20001)
+    pj = O.p_m1m2(m, np.full_like(m2, m1v), m2)
+    p1 = O.primary_mass_pdf_notnorm(m, np.array([m1v]))[0] / m.norm_p_m1
+    assert np.trapezoid(pj, m2) / p1 == pytest.approx(1., abs=2e-4)
+  M1, M2 = np.meshgrid(np.linspace(6., 87., 200), np.linspace(5.2, 87., 190), indexing='ij')
+  p = O.p_m1m2(m, M1, M2)
+  assert np.all(p[M2 > M1] == 0.) and np.all(p >= 0.) and np.all(np.isfinite(p))
+  assert O.p_m1m2(m, np.array([m.m_low - 1., m.m_high + 1.]), np.array([6., 6.])).tolist() == [0., 0.]
+  assert O.p_m1m2(m, np.array([30.]), np.array([m.m_low - 0.1]))[0] == 0.
+  assert m.m_grid.shape == (1000,) and m.cdf_m2_conditioned[0] == 0.
+
+
+def test_smoothing_and_gaussians():
+  s = O.smoothing(np.array([5.0, 5.1, 7.5, 9.9, 9.91, 20.]), 4.8, 5.1)
+  assert s[0] == 0. and s[1] == 0. and 0. < s[2] < 1. and s[4] == 1. and s[5] == 1.
+  x = np.linspace(20., 52., 4001)
+  tg = O.truncated_gaussian(x, 34., 3.6, 25., 34. + 18.)
+  assert np.trapezoid(tg, x) == pytest.approx(1., abs=1e-3) and np.all(tg[x < 25.] == 0.)
+
+
+def test_rates():
+  z = np.array([0., 0.5, 2., 3.])
+  assert O.merger_rate(O.madau_dickinson(), z)[0] == pytest.approx(1., rel=1e-14)
+  np.testing.assert_allclose(O.merger_rate(O.power_law(gamma=2.), z), (1 + z)**2.)
+  r = O.merger_rate(O.trunc_madau_dickinson(zmax=1.3), z)
+  assert r[2] == 0. and r[3] == 0. and r[1] == O.merger_rate(O.madau_dickinson(), z)[1]
+  zz = np.linspace(0, 1.3, 20001)
+  assert np.trapezoid(O.merger_rate(O.trunc_power_law(), zz), zz) == pytest.approx(1., abs=2e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# likelihood semantics
+# ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def small():
+  return H.small_config(E=5, S=200, P=4, Z=48, I=1500, seed=21, ragged=True)
+
+
+def test_q1_marginalized_ignores_kernel(small):
+  cfg, ev, inj = small
+  a, _, _ = H.build_oracle(ev, inj, kind='marginalized', like_kw=dict(kernel='epan'))
+  b, _, _ = H.build_oracle(ev, inj, kind='marginalized', like_kw=dict(kernel='gauss'))
+  np.testing.assert_array_equal(a.compute_all(H0=70.)[0], b.compute_all(H0=70.)[0])
+  c, _, _ = H.build_oracle(ev, inj, kind='approximate', like_kw=dict(kernel='epan'))
+  d, _, _ = H.build_oracle(ev, inj, kind='approximate', like_kw=dict(kernel='gauss'))
+  assert not np.array_equal(c.compute_all(H0=70.)[0], d.compute_all(H0=70.)[0])
+
+
+def test_q3_q9_guards_and_padding(small):
+  cfg, ev, inj = small
+  like, pop, _ = H.build_oracle(ev, inj, like_kw=dict(pe_neff=1e9))
+  r = like.compute_all(H0=70.)
+  assert np.all(r[0] == -np.finfo(np.float64).max) and r[1] == -np.inf        # L_i = 0 -> -1.797e308 each -> -inf sum
+  like, pop, _ = H.build_oracle(ev, inj)
+  p3 = like.p_gw3d(pop)
+  L = like.compute_numlike_evs(pop)
+  for e in range(cfg['E']):
+    n = int(ev['neff_pixels'][e])
+    assert np.all(ev['p_cat'][e, n:] == -100.)
+    # padded pixels do not contribute whatever p_gw3d holds there (NaN in marginalized mode)
+    p_z = O.p_cbc(pop, like.z_grids)[e, :n]
+    jac = (O.ddLdz_at_z(pop.cosmo, like.z_grids) * (1 + like.z_grids)**2)[e]
+    manual = np.sum(O.trapz(p3[e, :n] * p_z / jac[None, :], like.z_grids[e][None, :], axis=-1))
+    assert L[e] == pytest.approx(manual, rel=1e-13)
+
+
+def test_q7_marginalised_histogram_range(small):
+  """Out-of-pixel samples sit at min(z) with weight 0; the histogram spans [min z (all), max z (in pixel)]."""
+  cfg, ev, inj = small
+  like, pop, _ = H.build_oracle(ev, inj)
+  th, w = O.get_theta_src_and_weights(pop, like.theta_gw_det)
+  e, i = 0, 0
+  mask = ev['pixels_pe_opt_nside'][e] == ev['pixels_opt_nsides'][e, i]
+  z = th.z[e]
+  c, n = O.binning1d(np.where(mask, z, z.min()), np.where(mask, w[e], 0.), 200)
+  assert c[0] - z.min() == pytest.approx((z[mask].max() - z.min()) / 400, rel=1e-9)
+  assert n.sum() == pytest.approx(w[e][mask].sum(), rel=1e-13)
+
+
+def test_q8_lower_cut_variants():
+  # likelihood.py:119 vs :186 differ only for 0 < min - c*sigma < 1e-8
+  x = 5e-9
+  assert (x if x > 0. else 1e-8) == 5e-9 and np.maximum(x, 1e-8) == 1e-8
+
+
+def test_q10_selection_nansum_vs_sum(small):
+  cfg, ev, inj = small
+  inj2 = dict(inj); inj2['p_draw'] = inj['p_draw'].copy(); inj2['p_draw'][3] = np.nan
+  _, pop, sel = H.build_oracle(ev, inj2, N_eff=5.)
+  dN = sel.dN(pop)
+  assert np.isnan(dN[3])
+  # xi is a nansum (finite), the variance is a plain sum (NaN) -> neff NaN -> the guard does not trigger
+  assert np.isfinite(sel.N_exp(pop)) and sel.N_exp(pop) == pytest.approx(pop.Tobs * np.nansum(dN) / inj['N_inj'])
+  _, pop, sel = H.build_oracle(ev, inj, N_eff=1e12)
+  assert sel.N_exp(pop) == 0.
+  _, pop, sel = H.build_oracle(ev, inj, N_eff=None)
+  assert sel.N_exp(pop) > 0.
+
+
+def test_scale_free_and_rate_normalised_combinations(small):
+  cfg, ev, inj = small
+  like, _, _ = H.build_oracle(ev, inj)
+  r = like.compute_all(H0=70.)
+  assert r[3] == pytest.approx(r[1] - cfg['E'] * r[2], rel=1e-13)               # likelihood.py:337
+  like, _, _ = H.build_oracle(ev, inj, pop_kw=dict(scale_free=False, R0=20., Tobs=2.))
+  r2 = like.compute_all(H0=70.)
+  assert r2[1] == pytest.approx(r[1] + cfg['E'] * np.log(40.), rel=1e-12)         # likelihood.py:333-334
+  assert r2[3] == pytest.approx(r2[1] - np.exp(r2[2]), rel=1e-12)
+
+
+def test_h0_scan_recovers_the_injected_value():
+  """Mock events drawn at H0 = 70 with the same toy detection as the injections: the posterior peaks near 70
+  (the reference's notebook finds 70.9 for truth 70, examples/test1dgalaxies.ipynb:361-394)."""
+  cfg, ev, inj = H.small_config(E=80, S=256, P=4, Z=120, I=30000, seed=5, ragged=False)
+  like, _, _ = H.build_oracle(ev, inj, kind='approximate')
+  H0 = np.linspace(40., 110., 15)
+  lp = np.array([like(H0=h) for h in H0])
+  assert abs(H0[np.nanargmax(lp)] - 70.) <= 10.

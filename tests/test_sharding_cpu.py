@@ -1,0 +1,61 @@
+"""N > 1 path on CPU: two gloo ranks shard events and injections with the product's own partition rule
+(chimera_amd.parallel.chunk_bounds), each rank forms the three partial sums the HIP path forms per shard
+([sum_i log L_i, nansum dN, sum dN^2], here with the oracle as the per-shard evaluator), one SUM all-reduce, and the
+shared combination -- the result must equal the single-process evaluation.  (On the GPU the same three doubles are
+all-reduced by RCCL inside chm_eval; tests/test_gpu_parity.py::test_sharded_partials checks the device partials.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+  return p
+
+
+def _worker(rank, world, port, outdir):
+  sys.path.insert(0, ROOT)
+  import torch
+  import torch.distributed as dist
+  from chimera_amd.parallel import chunk_bounds
+  from tests import helpers as H
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  cfg, ev, inj = H.small_config(E=7, S=96, P=3, Z=32, I=501, seed=31, ragged=True)
+  results = []
+  for kind, pop_kw in (('marginalized', {}), ('approximate', dict(scale_free=False, R0=15., Tobs=2.))):
+    like, pop0, sel = H.build_oracle(ev, inj, kind=kind, pop_kw=pop_kw)
+    for lam in (dict(H0=70.), dict(H0=61., alpha=3.0)):
+      e0, e1 = chunk_bounds(cfg['E'], world, rank)
+      i0, i1 = chunk_bounds(cfg['I'], world, rank)
+      part = torch.from_numpy(H.shard_partials_oracle(like, lam, e0, e1, i0, i1))
+      dist.all_reduce(part, op=dist.ReduceOp.SUM)
+      pop = like.population.update(**lam)
+      sharded = H.combine_partials(part.numpy(), cfg['E'], pop, inj['N_inj'], sel.N_eff)
+      results.append((sharded, like(**lam)))
+  np.save(os.path.join(outdir, f'rank{rank}.npy'), np.array(results))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_sharding_matches_single_process(tmp_path):
+  import torch.multiprocessing as mp
+  world = 2
+  mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+  r0, r1 = np.load(tmp_path / 'rank0.npy'), np.load(tmp_path / 'rank1.npy')
+  np.testing.assert_array_equal(r0, r1)                                   # every rank forms the same answer
+  np.testing.assert_allclose(r0[:, 0], r0[:, 1], rtol=1e-13)              # sharded == single process
+  assert np.all(np.isfinite(r0))
+
+
+def test_partials_with_zero_likelihood_events_overflow_like_the_reference():
+  """Two events with L_i = 0 contribute -1.797e308 each; their sum is -inf on one rank or across ranks."""
+  big = -np.finfo(np.float64).max
+  assert big + big == -np.inf and (big + 1.0) + (big - 2.0) == -np.inf
