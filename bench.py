@@ -49,6 +49,7 @@ def main():
   ap.add_argument('--mode', default='marginalized')
   ap.add_argument('--nbatch', type=int, default=1, help='hyper-parameter draws per call')
   ap.add_argument('--events', type=int, default=None, help='shrink the number of events (debug)')
+  ap.add_argument('--inj', type=int, default=None, help='shrink the number of injections (debug)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--cpu-events', type=int, default=24)
   args = ap.parse_args()
@@ -72,7 +73,7 @@ def main():
   from chimera_amd.parallel import Comm
 
   t0 = time.time()
-  cfg, ev, inj = synth.make_config(args.config, E=args.events)
+  cfg, ev, inj = synth.make_config(args.config, E=args.events, I=args.inj)
   E, S, P, Z, I = cfg['E'], cfg['S'], cfg['P'], cfg['Z'], cfg['I']
   pixelated = cfg['pixelated']
   t_gen = time.time() - t0

@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -50,6 +51,7 @@ struct Ctx {
   hipEvent_t ev[8] = {};                // timing on `stream`
   hipEvent_t evb[4] = {};               // fork/join + timing on `stream2`
   double ms[8] = {};
+  int t_ngroups = 0; bool t_like = false, t_sel = false, t_valid = false;
   bool init = false;
 };
 
@@ -144,7 +146,13 @@ static int ctx_tables(Ctx& c, const chm_params* params, int nb) {
   int rc = ctx_ensure(c, nb, Tc, Tm); if (rc) return rc;
   for (int b = 0; b < nb; b++) fill_dev_params(&params[b], &c.h_params[b]);
   HIPCHK(hipMemcpyAsync(c.d_params, c.h_params, sizeof(DevParams) * nb, hipMemcpyHostToDevice, c.stream));
-  hipLaunchKernelGGL(k_tables, dim3(nb, 2), dim3(1024), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax);
+  const size_t tl = sizeof(double) * 3 * (size_t)(Tc > Tm ? Tc : Tm);
+  if (tl <= 120 * 1024) {
+    if (tl > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_tables<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
+    hipLaunchKernelGGL(k_tables<true>, dim3(nb, 2), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax);
+  } else {
+    hipLaunchKernelGGL(k_tables<false>, dim3(nb, 2), dim3(1024), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax);
+  }
   HIPCHK(hipGetLastError());
   return CHM_OK;
 }
@@ -441,7 +449,7 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
     if (L0.mode != CHM_MODE_FULL && lds_kde > 150 * 1024)
       return fail(CHM_E_ARG, "chm_eval: KDE working set exceeds the LDS (binning=False needs 2*S + 2*G doubles <= 150 KiB)");
     static const int env_groups = getenv("CHM_GROUPS") ? atoi(getenv("CHM_GROUPS")) : 0;
-    ngroups = env_groups > 0 ? env_groups : (L0.E * nb >= 512 ? 2 : 1);
+    ngroups = env_groups > 0 ? env_groups : 1;      // >1: event groups alternate between two streams (measured: no net gain at C3)
     if (ngroups > 16) ngroups = 16;
     if (ngroups > L0.E) ngroups = L0.E;
     if (serial) ngroups = 1;
@@ -511,17 +519,25 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
   const size_t El = like ? like->L.E : 0;
   if (like && out->log_like_evs) HIPCHK(hipMalloc(&d_lle, sizeof(double) * nb * El));
   if (like && out->numlike_evs) HIPCHK(hipMalloc(&d_nle, sizeof(double) * nb * El));
-  if (like) {
+  const bool multi = comm && comm->nranks > 1;
+  double Etot = comm ? (double)E_total : (like ? (double)like->L.E : 0.);
+  const bool one_kernel = !like || like->L.E <= 4096;
+  if (like && !one_kernel) {
     hipLaunchKernelGGL(k_reduce_events, dim3(nblk_ev, nb), dim3(256), 0, sA, like->L.E, like->L.P > 0 ? like->L.P : 1,
                        (const double*)like->L.like_pix, c.d_evpart, d_lle, d_nle);
     HIPCHK(hipGetLastError());
   }
   if (sel) HIPCHK(hipStreamWaitEvent(sA, c.evb[2], 0));     // join: selection sums
-  const bool multi = comm && comm->nranks > 1;
-  double Etot = comm ? (double)E_total : (like ? (double)like->L.E : 0.);
-  hipLaunchKernelGGL(k_final, dim3(nb), dim3(256), 0, sA, nblk_ev, (const double*)c.d_evpart, sel ? sel->S.nblocks : 0,
-                     sel ? (const double*)sel->S.partial : nullptr, c.d_partials, dp, Etot, sel ? sel->S.N_inj : 1.,
-                     sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, multi ? 0 : 1, c.d_out3);
+  if (one_kernel) {
+    hipLaunchKernelGGL(k_reduce_final, dim3(nb), dim3(1024), 0, sA, like ? like->L.E : 0, like ? (like->L.P > 0 ? like->L.P : 1) : 1,
+                       like ? (const double*)like->L.like_pix : nullptr, sel ? sel->S.nblocks : 0,
+                       sel ? (const double*)sel->S.partial : nullptr, c.d_partials, dp, Etot, sel ? sel->S.N_inj : 1.,
+                       sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, multi ? 0 : 1, c.d_out3, d_lle, d_nle);
+  } else {
+    hipLaunchKernelGGL(k_final, dim3(nb), dim3(256), 0, sA, nblk_ev, (const double*)c.d_evpart, sel ? sel->S.nblocks : 0,
+                       sel ? (const double*)sel->S.partial : nullptr, c.d_partials, dp, Etot, sel ? sel->S.N_inj : 1.,
+                       sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, multi ? 0 : 1, c.d_out3);
+  }
   HIPCHK(hipGetLastError());
   if (out->partials) HIPCHK(hipMemcpyAsync(c.h_out + 3 * nb, c.d_partials, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
   if (multi) {
@@ -548,25 +564,28 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
     if (out->N_exp) out->N_exp[b] = c.h_out[b * 3 + 2];
     if (out->partials) for (int k = 0; k < 3; k++) out->partials[b * 3 + k] = c.h_out[3 * nb + b * 3 + k];
   }
-  float ms = 0.f;
-  for (int i = 0; i < 8; i++) c.ms[i] = 0.;
-  if (hipEventElapsedTime(&ms, c.ev[0], c.ev[5]) == hipSuccess) c.ms[0] = ms;       // whole evaluation
-  if (hipEventElapsedTime(&ms, c.ev[0], c.ev[1]) == hipSuccess) c.ms[1] = ms;       // tables
-  for (int g = 0; g < ngroups; g++) {                                                // summed over the event groups
-    if (hipEventElapsedTime(&ms, c.evg[4 * g], c.evg[4 * g + 1]) == hipSuccess) c.ms[2] += ms;       // sample stage
-    if (hipEventElapsedTime(&ms, c.evg[4 * g + 2], c.evg[4 * g + 3]) == hipSuccess) c.ms[3] += ms;   // GW kernel + integrand
-  }
-  if (sel && hipEventElapsedTime(&ms, c.evb[1], c.evb[2]) == hipSuccess) c.ms[4] = ms;   // selection (own stream)
-  if (hipEventElapsedTime(&ms, c.ev[3], c.ev[5]) == hipSuccess) c.ms[5] = ms;       // reduce + combine (+ all-reduce)
-  if (like && hipEventElapsedTime(&ms, c.ev[1], c.ev[3]) == hipSuccess) c.ms[6] = ms;    // all event groups, wall
-  c.ms[7] = (double)ngroups;
+  c.t_ngroups = ngroups; c.t_like = like != nullptr; c.t_sel = sel != nullptr; c.t_valid = true;
   return CHM_OK;
 }
 
-extern "C" int chm_last_timing(chm_like* like, chm_sel* sel, double ms[8]) {
-  if (!ms || (!like && !sel)) return fail(CHM_E_ARG, "chm_last_timing: null argument");
+extern "C" int chm_last_timing(chm_like* like, chm_sel* sel, double msout[8]) {
+  if (!msout || (!like && !sel)) return fail(CHM_E_ARG, "chm_last_timing: null argument");
   Ctx& c = like ? like->ctx : sel->ctx;
-  for (int i = 0; i < 8; i++) ms[i] = c.ms[i];
+  float ms = 0.f;
+  for (int i = 0; i < 8; i++) c.ms[i] = 0.;
+  if (c.t_valid) {                                                                      // elapsed times are formed on demand
+    if (hipEventElapsedTime(&ms, c.ev[0], c.ev[5]) == hipSuccess) c.ms[0] = ms;       // whole evaluation
+    if (hipEventElapsedTime(&ms, c.ev[0], c.ev[1]) == hipSuccess) c.ms[1] = ms;       // tables
+    for (int g = 0; g < c.t_ngroups; g++) {                                            // summed over the event groups
+      if (hipEventElapsedTime(&ms, c.evg[4 * g], c.evg[4 * g + 1]) == hipSuccess) c.ms[2] += ms;       // sample stage
+      if (hipEventElapsedTime(&ms, c.evg[4 * g + 2], c.evg[4 * g + 3]) == hipSuccess) c.ms[3] += ms;   // GW kernel + integrand
+    }
+    if (c.t_sel && hipEventElapsedTime(&ms, c.evb[1], c.evb[2]) == hipSuccess) c.ms[4] = ms;   // selection (own stream)
+    if (hipEventElapsedTime(&ms, c.ev[3], c.ev[5]) == hipSuccess) c.ms[5] = ms;       // reduce + combine (+ all-reduce)
+    if (c.t_like && hipEventElapsedTime(&ms, c.ev[1], c.ev[3]) == hipSuccess) c.ms[6] = ms;    // all event groups, wall
+    c.ms[7] = (double)c.t_ngroups;
+  }
+  for (int i = 0; i < 8; i++) msout[i] = c.ms[i];
   return CHM_OK;
 }
 

@@ -122,25 +122,40 @@ DEVFN double block_interp(double x, const double* xp, const double* fp, int n, d
   return f;
 }
 
-__global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_all, double* It_all, double* dLt_all,
-                                                  double* mg_all, double* cdf_all, double* tmp_all, int TcMax, int TmMax) {
+// LDS_ARR: the working arrays (grid, integrand, running integral) live in LDS (3 T doubles) and are written to global
+// memory once at the end; otherwise (very long tables) the global arrays are used throughout.
+// Data exchanged between the threads of the block goes through LDS (the draw's parameter block `Ps`, the working arrays when
+// LDS_ARR) or, for very long tables, through global memory behind an agent-scope fence (gsync).
+DEVFN void gsync() { __threadfence(); __syncthreads(); }
+
+template <bool LDS_ARR>
+__global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_all, double* It_all,
+                                                  double* dLt_all, double* mg_all, double* cdf_all, double* tmp_all, int TcMax, int TmMax) {
+  extern __shared__ double larr[];
   __shared__ double sh[32];
+  __shared__ DevParams Ps;                          // block-local copy of the draw: constants derived here are shared through LDS
   const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
-  DevParams& P = params[b];
+  DevParams& Pg = params[b];
+  if (t < (int)(sizeof(DevParams) / sizeof(double))) reinterpret_cast<double*>(&Ps)[t] = reinterpret_cast<const double*>(&Pg)[t];
+  __syncthreads();
+  const DevParams& P = Ps;
   const int Tc = P.Tc, Tm = P.Tm;
-  double* zt = zt_all + (size_t)b * TcMax;
-  double* It = It_all + (size_t)b * TcMax;
+  double* g_zt = zt_all + (size_t)b * TcMax;
+  double* g_It = It_all + (size_t)b * TcMax;
   double* dLt = dLt_all + (size_t)b * TcMax;
-  double* mg = mg_all + (size_t)b * TmMax;
-  double* cdf = cdf_all + (size_t)b * TmMax;
-  double* tmp = tmp_all + (size_t)b * (TcMax + TmMax) + (blockIdx.y == 0 ? 0 : TcMax);
+  double* g_mg = mg_all + (size_t)b * TmMax;
+  double* g_cdf = cdf_all + (size_t)b * TmMax;
+  double* g_tmp = tmp_all + (size_t)b * (TcMax + TmMax) + (blockIdx.y == 0 ? 0 : TcMax);
 
   if (blockIdx.y == 0) {
-    if (t == 0) {                                   // rate constants
+    double* zt = LDS_ARR ? larr : g_zt;
+    double* tmp = LDS_ARR ? larr + Tc : g_tmp;
+    double* It = LDS_ARR ? larr + 2 * Tc : g_It;
+    if (t == 0) {                                   // rate constants (used by later kernels only)
       double g = P.r[0], k = P.r[1], zp = P.r[2], zmax = P.r[3];
-      P.md_norm = 1. + pow(1. + zp, -g - k);                              // rate.py:114
-      P.tpl_rate_norm = (pow(1. + zmax, g + 1.) - 1.) / (g + 1.);         // rate.py:105
-      P.l1pzp = log(1. + zp);
+      Pg.md_norm = 1. + pow(1. + zp, -g - k);                             // rate.py:114
+      Pg.tpl_rate_norm = (pow(1. + zmax, g + 1.) - 1.) / (g + 1.);        // rate.py:105
+      Pg.l1pzp = log(1. + zp);
     }
     // zt = [0] U logspace(-10, log10 z_max, Tc-1); It = cumtrapz(1/E, zt)     cosmo.py:43-46
     const double lzmax = log10(P.z_max);
@@ -149,8 +164,9 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
       zt[i] = z;
       tmp[i] = 1. / E_at_z(P, z);
     }
-    __syncthreads();
+    if (LDS_ARR) __syncthreads(); else gsync();
     block_cumtrapz(tmp, zt, It, Tc, sh);
+    if (!LDS_ARR) gsync();
     // dL table of z_from_dGW: dL_at_z(cosmo, z_grid_interp) (cosmo.py:263).  jnp.interp evaluated AT its own nodes returns
     // It[i] exactly for i < Tc-1 (delta = 0) and It[Tc-2] + (dx/dx) dI at the last node.
     for (int i = t; i < Tc; i += nt) {
@@ -158,6 +174,7 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
       double ii = It[i];
       if (i == Tc - 1) { double dx = zt[i] - zt[i - 1]; ii = It[i - 1] + (dx / dx) * (It[i] - It[i - 1]); }
       dLt[i] = dL_from_dCt(P, dCt_from_dCr(P, P.dH * ii), z);
+      if (LDS_ARR) { g_zt[i] = z; g_It[i] = It[i]; }
     }
     // fR = Vc(z1) - Vc(z0)                                                       completeness.py:54-58
     double i0 = block_interp(P.zc0, zt, It, Tc, sh);
@@ -165,28 +182,34 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
     if (t == 0) {
       double v0 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * i0));
       double v1 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * i1));
-      P.fR = v1 - v0;
+      Pg.fR = v1 - v0;
     }
   } else {
-    if (t == 0) {                                   // mass-model constants
+    double* mg = LDS_ARR ? larr : g_mg;
+    double* tmp = LDS_ARR ? larr + Tm : g_tmp;
+    double* cdf = LDS_ARR ? larr + 2 * Tm : g_cdf;
+    if (t == 0) {                                   // mass-model constants: into the LDS copy (used below) and to global memory
       double m_low = P.m[0], m_high = P.m[1];
       if (P.mass_model == 2) {
         double mu = P.m[6], sg = P.m[7];
-        P.plp_plnorm = tpl_cdf(-P.m[3], m_low, m_high);                   // mass.py:301
-        P.tg_hi = mu + 5. * sg;                                           // mass.py:302
-        double max_point = (P.tg_hi - mu) / (sg * sqrt(2.));
+        Ps.plp_plnorm = tpl_cdf(-P.m[3], m_low, m_high);                  // mass.py:301
+        Ps.tg_hi = mu + 5. * sg;                                          // mass.py:302
+        double max_point = (Ps.tg_hi - mu) / (sg * sqrt(2.));
         double min_point = (m_low - mu) / (sg * sqrt(2.));
-        P.tg_norm = 0.5 * erf(max_point) - 0.5 * erf(min_point);          // mass.py:272-274
-        P.g_c0 = -0.5 * log(2. * CHM_PI) - log(sg);                       // mass.py:268
-        P.inv_plnorm = 1. / P.plp_plnorm; P.inv_tg_norm = 1. / P.tg_norm; P.inv_2s2 = 1. / (2. * (sg * sg));
+        Ps.tg_norm = 0.5 * erf(max_point) - 0.5 * erf(min_point);         // mass.py:272-274
+        Ps.g_c0 = -0.5 * log(2. * CHM_PI) - log(sg);                      // mass.py:268
+        Ps.inv_plnorm = 1. / Ps.plp_plnorm; Ps.inv_tg_norm = 1. / Ps.tg_norm; Ps.inv_2s2 = 1. / (2. * (sg * sg));
+        Pg.plp_plnorm = Ps.plp_plnorm; Pg.tg_hi = Ps.tg_hi; Pg.tg_norm = Ps.tg_norm; Pg.g_c0 = Ps.g_c0;
+        Pg.inv_plnorm = Ps.inv_plnorm; Pg.inv_tg_norm = Ps.inv_tg_norm; Pg.inv_2s2 = Ps.inv_2s2;
       } else if (P.mass_model == 1) {
         double mb = m_low + P.m[6] * (m_high - m_low);                    // mass.py:291-293
-        P.bpl_mbreak = mb;
-        P.bpl_pl1 = tpl_notnorm(mb, -P.m[2], m_low, mb);
-        P.bpl_pl2 = tpl_notnorm(mb, -P.m[3], mb, m_high);
+        Ps.bpl_mbreak = mb;
+        Ps.bpl_pl1 = tpl_notnorm(mb, -P.m[2], m_low, mb);
+        Ps.bpl_pl2 = tpl_notnorm(mb, -P.m[3], mb, m_high);
+        Pg.bpl_mbreak = Ps.bpl_mbreak; Pg.bpl_pl1 = Ps.bpl_pl1; Pg.bpl_pl2 = Ps.bpl_pl2;
       }
-      P.lmg0 = log(m_low);
-      P.inv_dlmg = (double)(P.Tm - 1) / (log(m_high) - log(m_low));
+      Pg.lmg0 = log(m_low);
+      Pg.inv_dlmg = (double)(P.Tm - 1) / (log(m_high) - log(m_low));
     }
     __syncthreads();
     // m_grid = logspace(log10 m_low, log10 m_high, Tm); cdf = cumtrapz(secondary(m_grid; m_high))   mass.py:45-49
@@ -196,15 +219,19 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
       mg[i] = m;
       tmp[i] = secondary_notnorm(P, m, P.m[1]);
     }
-    __syncthreads();
+    if (LDS_ARR) __syncthreads(); else gsync();
     block_cumtrapz(tmp, mg, cdf, Tm, sh);
+    if (!LDS_ARR) gsync();
     // norm_p_m1 = trapz(primary(m_grid), m_grid) = 0.5 * sum(dx * (y1 + y0))             mass.py:50-52
-    for (int i = t; i < Tm; i += nt) tmp[i] = primary_notnorm(P, mg[i]);
-    __syncthreads();
+    for (int i = t; i < Tm; i += nt) {
+      tmp[i] = primary_notnorm(P, mg[i]);
+      if (LDS_ARR) { g_mg[i] = mg[i]; g_cdf[i] = cdf[i]; }
+    }
+    if (LDS_ARR) __syncthreads(); else gsync();
     double acc = 0.;
     for (int k = t; k < Tm - 1; k += nt) acc += (mg[k + 1] - mg[k]) * (tmp[k + 1] + tmp[k]);
     acc = block_reduce<RED_SUM>(acc, sh);
-    if (t == 0) { P.norm_p_m1 = 0.5 * acc; P.inv_norm_p_m1 = 1. / (0.5 * acc); }
+    if (t == 0) { Pg.norm_p_m1 = 0.5 * acc; Pg.inv_norm_p_m1 = 1. / (0.5 * acc); }
   }
 }
 
@@ -744,7 +771,7 @@ DEVFN double epan_node(const EpanCtx& c, double g) {
   return (S0 - qq * (c.inv_bw * c.inv_bw)) * c.scale;
 }
 
-__global__ void __launch_bounds__(64 * MARG_WPB, 6) k_kde_marg_fast(LikeDev L, const DevParams* params) {
+__global__ void __launch_bounds__(64 * MARG_WPB, 5) k_kde_marg_fast(LikeDev L, const DevParams* params) {
   extern __shared__ double lds_all[];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int PG = (L.P + MARG_WPB - 1) / MARG_WPB;            // pixel groups per event: one wave per pixel, MARG_WPB waves per block
@@ -1245,6 +1272,40 @@ __global__ void __launch_bounds__(256) k_final(int nblk_ev, const double* ev_par
   const int b = blockIdx.x, t = threadIdx.x;
   double acc = 0., s1 = 0., s2 = 0.;
   for (int i = t; i < nblk_ev; i += blockDim.x) acc += ev_partial[(size_t)b * nblk_ev + i];
+  for (int i = t; i < nblk_sel; i += blockDim.x) {
+    s1 += sel_partial[((size_t)b * nblk_sel + i) * 2];
+    s2 += sel_partial[((size_t)b * nblk_sel + i) * 2 + 1];
+  }
+  acc = block_reduce<RED_SUM>(acc, red);
+  s1 = block_reduce<RED_SUM>(s1, red);
+  s2 = block_reduce<RED_SUM>(s2, red);
+  if (t == 0) {
+    partials[b * 3] = acc; partials[b * 3 + 1] = s1; partials[b * 3 + 2] = s2;
+    if (do_combine) combine_one(params[b], acc, s1, s2, E_total, N_inj, N_eff, has_neff, has_like, has_sel, out3 + b * 3);
+  }
+}
+
+// k_reduce_final: k_reduce_events + k_final in one launch (one block of 1024 threads per draw) for shards of up to a few
+// thousand events: per-event pixel sums, log, nan_to_num, the three partial sums and (single GPU) the combination.
+__global__ void __launch_bounds__(1024) k_reduce_final(int E, int Pd, const double* like_pix, int nblk_sel, const double* sel_partial,
+                                                        double* partials, const DevParams* params, double E_total, double N_inj,
+                                                        double N_eff, int has_neff, int has_like, int has_sel, int do_combine,
+                                                        double* out3, double* log_like_evs, double* numlike_evs) {
+  __shared__ double red[16];
+  const int b = blockIdx.x, t = threadIdx.x;
+  double acc = 0., s1 = 0., s2 = 0.;
+  for (int e = t; e < E; e += blockDim.x) {
+    const double* lp = like_pix + ((size_t)b * E + e) * Pd;
+    double Li = 0.;
+    for (int p = 0; p < Pd; p++) Li += lp[p];                      // jnp.sum over pixels          likelihood.py:280
+    double ll = log(Li);                                             // likelihood.py:296,329
+    if (ll != ll) ll = -__builtin_inf();                             // nan_to_num(nan=-inf)        
+    else if (ll == -__builtin_inf()) ll = -1.7976931348623157e308;
+    else if (ll == __builtin_inf()) ll = 1.7976931348623157e308;
+    if (numlike_evs) numlike_evs[(size_t)b * E + e] = Li;
+    if (log_like_evs) log_like_evs[(size_t)b * E + e] = ll;
+    acc += ll;
+  }
   for (int i = t; i < nblk_sel; i += blockDim.x) {
     s1 += sel_partial[((size_t)b * nblk_sel + i) * 2];
     s2 += sel_partial[((size_t)b * nblk_sel + i) * 2 + 1];

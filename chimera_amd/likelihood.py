@@ -156,7 +156,10 @@ class hyperlikelihood(object):
   def _eval(self, pops, want=(), mode=None, with_sel=True):
     """Evaluate a list of population draws.  ``want`` subset of {'log_like_evs','numlike_evs','p_gw','partials'}."""
     nb = len(pops)
-    params = (_lib.chm_params * nb)(*[p.to_params() for p in pops])
+    if isinstance(pops, C.Array):
+      params = pops
+    else:
+      params = (_lib.chm_params * nb)(*[p.to_params() for p in pops])
     h = self._handle(mode)
     El = self._e1 - self._e0
     res = {'log_hyper': np.empty(nb), 'log_num': np.empty(nb), 'N_exp': np.empty(nb)}
@@ -213,8 +216,7 @@ class hyperlikelihood(object):
   # -- reference surface: hyper-likelihood -------------------------------------------------------------
   def compute_log_hyperlike(self, **hyper_lambdas):
     """likelihood.py:307-316."""
-    pop_lambdas = self.population.update(**hyper_lambdas)
-    return self._eval([pop_lambdas])['log_hyper'][0]
+    return self._eval(self._params_array([hyper_lambdas]))['log_hyper'][0]
 
   def __call__(self, **hyper_lambdas):
     """likelihood.py:318-320."""
@@ -228,7 +230,28 @@ class hyperlikelihood(object):
       return r['log_like_evs'][0], r['log_num'][0], np.log(r['N_exp'][0]), r['log_hyper'][0]
 
   # -- batched draws (the reference's 'params' scheme, CHIMERA/parallel.py:258-278) ----------------------
+  def _params_array(self, list_of_hyper_lambdas):
+    """One chm_params per draw = population.update(**lambda).to_params(), formed by patching a copy of the base struct
+    (same values: unknown keys are ignored, every model picks the keys it owns -- pop_wrapper.py:56-64)."""
+    if getattr(self, '_slots', None) is None:
+      from .population._base import param_slots
+      pop = self.population
+      self._slots = param_slots(pop.cosmo, pop.mass, pop.rate)
+      self._base_params = pop.to_params()
+    nb = len(list_of_hyper_lambdas)
+    arr = (_lib.chm_params * nb)()
+    sz = C.sizeof(_lib.chm_params)
+    for b, lam in enumerate(list_of_hyper_lambdas):
+      C.memmove(C.byref(arr, b * sz), C.byref(self._base_params), sz)
+      p = arr[b]
+      for k, v in lam.items():
+        for field, idx, is_int in self._slots.get(k, ()):
+          if idx is None:
+            setattr(p, field, int(v) if is_int else float(v))
+          else:
+            getattr(p, field)[idx] = float(v)
+    return arr
+
   def batch(self, list_of_hyper_lambdas):
     """log-hyperlikelihood of several draws in one launch sequence: array of len(list)."""
-    pops = [self.population.update(**lam) for lam in list_of_hyper_lambdas]
-    return self._eval(pops)['log_hyper']
+    return self._eval(self._params_array(list_of_hyper_lambdas))['log_hyper']

@@ -58,6 +58,37 @@ def make_params(cosmo=None, mass=None, rate=None, R0=1., Tobs=1., scale_free=Tru
   return p
 
 
+def param_slots(cosmo, mass, rate):
+  """hyper-parameter name -> [(chm_params field, index or None, is_int)] for the models of a population: lets
+  ``hyperlikelihood.batch`` patch a copy of the base ``chm_params`` instead of rebuilding the model objects per draw."""
+  slots = {}
+
+  def add(key, field, idx=None, is_int=False):
+    slots.setdefault(key, []).append((field, idx, is_int))
+  cnames = ['H0', 'Om0', 'Ok0', 'Or0', 'w0', 'wa', 'Xi0', 'n']
+  for k in cosmo.keys:
+    if k in cnames:
+      add(k, 'cosmo', cnames.index(k))
+    elif k == 'z_max':
+      add(k, 'z_max')
+    elif k == 'z_grid_res':
+      add(k, 'z_grid_res', None, True)
+  mnames = {0: ['m_low', 'm_high', 'alpha', 'beta'],
+            1: ['m_low', 'm_high', 'alpha_1', 'alpha_2', 'beta', 'delta_m', 'break_fraction'],
+            2: ['m_low', 'm_high', 'lambda_peak', 'alpha', 'beta', 'delta_m', 'mu_g', 'sigma_g']}[mass._pack()['model']]
+  for k in mass.keys:
+    if k in mnames:
+      add(k, 'mass', mnames.index(k))
+    elif k == 'grid_res':
+      add(k, 'mass_grid_res', None, True)
+  rnames = {0: ['gamma'], 1: ['gamma', 'kappa', 'zp'], 2: ['gamma', None, None, 'zmax'], 3: ['gamma', 'kappa', 'zp', 'zmax']}[rate._pack()['model']]
+  for k in rate.keys:
+    if k in rnames:
+      add(k, 'rate', rnames.index(k))
+  add('R0', 'R0')
+  return slots
+
+
 def model_eval(params, func, a, b=None, device=None):
   """out = f(a[, b]) elementwise on the device (chm_model_eval); keeps the input shape."""
   L = _lib.lib()
