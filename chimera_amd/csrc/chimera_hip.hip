@@ -490,7 +490,7 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
         HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         const bool fast = L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC");
         if (fast) hipLaunchKernelGGL(k_kde_marg_fast, dim3(L.E_cnt * ((Pd + MARG_WPB - 1) / MARG_WPB), nb), dim3(64 * MARG_WPB),
-                                     sizeof(double) * (4 * N + 3) * MARG_WPB, sg, L, dp);
+                                     sizeof(double) * (3 * N + 3) * MARG_WPB, sg, L, dp);
         else { allow_lds(k_kde_marg, lds_kde); hipLaunchKernelGGL(k_kde_marg, dim3(L.E_cnt * Pd, nb), dim3(64), lds_kde, sg, L, dp); }
       } else {
         HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));

@@ -319,15 +319,16 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
         }
       }
       double zz[2], wv[2];
+      // z = z_from_dGW(dL) (cosmo.py:260-264) for the two samples together
+      jnp_interp_x2(dl[0], dl[1], T.dLt, T.zt, P.Tc, zz[0], zz[1]);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        // z = z_from_dGW(dL) (cosmo.py:260-264); m_src = m_det/(1+z) (pop_wrapper.py:70);
-        // w = p_m1m2 / pe_prior (pop_wrapper.py:79; the device array holds 1/pe_prior)
-        double z = (L.dbg & 64) ? dl[h] * 0.2 : jnp_interp(dl[h], T.dLt, T.zt, P.Tc, false, 0., 0.);
+        // m_src = m_det/(1+z) (pop_wrapper.py:70); w = p_m1m2 / pe_prior (pop_wrapper.py:79; the device array holds 1/pe_prior)
+        double z = zz[h];
         double r = 1. / (1. + z);
         double m1 = md1[h] * r, m2 = md2[h] * r;
         double w = ((L.dbg & 32) ? m1 * m2 : p_m1m2(P, m1, m2, T.mg, T.cdf)) * ipr[h];
-        zz[h] = z; wv[h] = w;
+        wv[h] = w;
         if (s + h < s_end) {
           double d = z - z_ref;
           v[0] += w; v[1] += w * w; v[2] += d; v[3] += d * d;
@@ -563,7 +564,7 @@ DEVFN void wave_prefix3(const double* cen, const double* wgt, int N, double c_re
 
 // k_event_prep: one wave per (event, draw): combine the chunk partials once for all the event's pixel blocks.
 // evstat (nb,E,8): zmin, zmax, std, norm, n_eff, sum w, lb, ub  (effective-grid ends, likelihood.py:186-187)
-#define NEVSTAT 8
+#define NEVSTAT 10
 __global__ void __launch_bounds__(64) k_event_prep(LikeDev L) {
   const int e = L.e_off + blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const EvStats st = combine_stats(L.part + ((size_t)b * L.E + e) * L.NC * NPART, L.NC, L.S);
@@ -571,7 +572,21 @@ __global__ void __launch_bounds__(64) k_event_prep(LikeDev L) {
   double lb = 0., ub = 0.;
   if (L.has_cut) eff_bounds(L.mode == 2, st.zmin, st.zmax, st.sd, L.cut_grid, lb, ub);
   else { lb = L.z_grids[(size_t)e * L.Z]; ub = L.z_grids[(size_t)e * L.Z + L.Z - 1]; }
-  if (lane == 0) { o[0] = st.zmin; o[1] = st.zmax; o[2] = st.sd; o[3] = st.norm; o[4] = st.n_eff; o[5] = st.sumw; o[6] = lb; o[7] = ub; }
+  // k-range of the event grid that can see a non-zero KDE: z_k in [lb, ub].  Guess from the end points (the grid is a
+  // linspace, pop_wrapper.py:207), verify against the stored grid, fall back to the whole grid otherwise.
+  const int Z = L.Z;
+  const double* zg = L.z_grids + (size_t)e * Z;
+  int k_lo = 0, k_hi = Z - 1;
+  {
+    const double z0 = zg[0], zl = zg[Z - 1];
+    const double inv_dz = (double)(Z - 1) / (zl - z0);
+    double fl = floor((lb - z0) * inv_dz) - 1., fh = ceil((ub - z0) * inv_dz) + 1.;
+    int gl = fl > 0. ? (fl < (double)(Z - 1) ? (int)fl : Z - 1) : 0;
+    int gh = fh < (double)(Z - 1) ? (fh > 0. ? (int)fh : 0) : Z - 1;
+    if (fl == fl && fh == fh && gl <= gh && (gl == 0 || zg[gl] < lb) && (gh == Z - 1 || zg[gh] > ub)) { k_lo = gl; k_hi = gh; }
+  }
+  if (lane == 0) { o[0] = st.zmin; o[1] = st.zmax; o[2] = st.sd; o[3] = st.norm; o[4] = st.n_eff; o[5] = st.sumw; o[6] = lb; o[7] = ub;
+                   o[8] = (double)k_lo; o[9] = (double)k_hi; }
   double* eg = L.effg + ((size_t)b * L.E + e) * L.G;
   if (L.has_cut) { for (int i = lane; i < L.G; i += 64) eg[i] = linspace_tab(lb, ub, L.G, i, L.fracG); }   // likelihood.py:188
   else { for (int i = lane; i < L.G; i += 64) eg[i] = L.z_grids[(size_t)e * L.Z + i]; }                        // likelihood.py:190
@@ -754,7 +769,7 @@ DEVFN void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-struct EpanCtx { const double* cen; const double* P0; const double* P1; const double* P2; int N; double lo, inv_dbin, bw, inv_bw, scale; };
+struct EpanCtx { const double* P0; const double* P1; const double* P2; int N; double lo, inv_dbin, bw, inv_bw, scale; };
 
 // Index range [ja, jb) of the bins with |g - c_j| <= h straight from the uniform spacing c_j = lo + (j + 1/2) dbin.  A bin
 // whose |u| is within rounding of 1 may land on either side; its kernel value 3/4 (1 - u^2) is then < 1e-12, far below the
@@ -777,10 +792,10 @@ __global__ void __launch_bounds__(64 * MARG_WPB, 5) k_kde_marg_fast(LikeDev L, c
   const int PG = (L.P + MARG_WPB - 1) / MARG_WPB;            // pixel groups per event: one wave per pixel, MARG_WPB waves per block
   const int p = (blockIdx.x % PG) * MARG_WPB + wid, e = L.e_off + blockIdx.x / PG, b = blockIdx.y;
   if (p >= L.P) return;
-  double* lds = lds_all + (size_t)wid * (4 * L.num_bins + 3);   // each wave works in its own LDS slice: no block barriers
+  double* lds = lds_all + (size_t)wid * (3 * L.num_bins + 3);   // each wave works in its own LDS slice: no block barriers
   const DevParams& P = params[b];
   const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
-  double* cen = lds; double* P0 = cen + B; double* P1 = P0 + (B + 1); double* P2 = P1 + (B + 1);
+  double* P0 = lds; double* P1 = P0 + (B + 1); double* P2 = P1 + (B + 1);
   double* cnt = P0;                                         // bin counts live in P0[0..B) until the prefix pass
   double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
   double* dump = L.p_gw_dump ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
@@ -799,16 +814,8 @@ __global__ void __launch_bounds__(64 * MARG_WPB, 5) k_kde_marg_fast(LikeDev L, c
   }
   const double* zg = L.z_grids + (size_t)e * Z;
   const double* pc = L.p_cat + ((size_t)e * L.P + p) * Z;
-  // k-range of the event grid inside [lb, ub] (see k_kde_marg)
-  int k_lo = 0, k_hi = Z - 1;
-  {
-    const double z0 = zg[0], zl = zg[Z - 1];
-    const double inv_dz = (double)(Z - 1) / (zl - z0);
-    double fl = floor((lb - z0) * inv_dz) - 1., fh = ceil((ub - z0) * inv_dz) + 1.;
-    int gl = fl > 0. ? (fl < (double)(Z - 1) ? (int)fl : Z - 1) : 0;
-    int gh = fh < (double)(Z - 1) ? (fh > 0. ? (int)fh : 0) : Z - 1;
-    if (fl == fl && fh == fh && gl <= gh && (gl == 0 || zg[gl] < lb) && (gh == Z - 1 || zg[gh] > ub)) { k_lo = gl; k_hi = gh; }
-  }
+  // k-range of the event grid inside [lb, ub], found once per event by k_event_prep
+  int k_lo = (int)es[8], k_hi = (int)es[9];
   k_lo &= ~1;
   const bool vec2 = (Z & 1) == 0;
   double pf0[FAST_PF], pf1[FAST_PF];
@@ -821,6 +828,7 @@ __global__ void __launch_bounds__(64 * MARG_WPB, 5) k_kde_marg_fast(LikeDev L, c
   }
 
   // histogram of this pixel's samples on [min z, max z in pixel] (math.py:32-46, likelihood.py:180-183)
+  if (L.dbg & 16) { double a = 0.; for (int i = 0; i < FAST_PF; i++) a += pf0[i] + pf1[i]; a = wave_sum(a); if (lane == 0) *out_like = a; return; }
   const size_t so = ((size_t)b * L.E + e) * S;
   const double* wz = L.ws_z + so;
   const double* ww = L.ws_w + so;
@@ -833,21 +841,20 @@ __global__ void __launch_bounds__(64 * MARG_WPB, 5) k_kde_marg_fast(LikeDev L, c
   for (int s = s0 + lane + 128; s < s1; s += 64) hi = nanmax2(hi, wz[s]);
   hi = wave_max(hi);
   if (lo != lo) hi = lo;
-  for (int j = lane; j < B; j += 64) {                      // bin centres (math.py:37-39)
-    double e0 = linspace_tab(lo, hi, B + 1, j, L.fracB), e1 = linspace_tab(lo, hi, B + 1, j + 1, L.fracB);
-    cen[j] = (e0 + e1) / 2.;
-    cnt[j] = 0.;
-  }
+  for (int j = lane; j < B; j += 64) cnt[j] = 0.;
+  // bin centres relative to the lower edge: c'_j = c_j - lo = (j + 1/2) dbin for the uniform edges of math.py:37-39
+  // (the linspace form differs from this by rounding of order eps*lo, i.e. 1e-13 of a bin width)
+  const double dbin = (hi - lo) / (double)B;
   wave_sync();
 #pragma unroll
-  for (int i = 0; i < 2; i++) { int s = s0 + lane + 64 * i; if (s < s1) atomicAdd(&cnt[bin_index(zr[i], lo, hi, B)], wr[i]); }
+  for (int i = 0; i < 2; i++) { int s = s0 + lane + 64 * i; if (s < s1 && !(L.dbg & 1)) atomicAdd(&cnt[bin_index(zr[i], lo, hi, B)], wr[i]); }
   for (int s = s0 + lane + 128; s < s1; s += 64) atomicAdd(&cnt[bin_index(wz[s], lo, hi, B)], ww[s]);
   wave_sync();
   // sum w, sum w^2 over the bins; prefix sums of (w, w c', w c'^2), c' = centre - lo
   const int per = (B + 63) / 64;
   const int j0 = lane * per, j1 = min(j0 + per, B);
   double s0w = 0., s1w = 0., s2w = 0., sq = 0.;
-  for (int j = j0; j < j1; j++) { double w = cnt[j], cc = cen[j] - lo; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
+  for (int j = j0; j < j1; j++) { double w = cnt[j], cc = ((double)j + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
   double x0 = s0w, x1 = s1w, x2 = s2w;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -868,14 +875,14 @@ __global__ void __launch_bounds__(64 * MARG_WPB, 5) k_kde_marg_fast(LikeDev L, c
     if (small) {
 #pragma unroll
       for (int i = 0; i < 8; i++) if (j0 + i < j1) {
-        double w = wv[i], cc = cen[j0 + i] - lo;
+        double w = wv[i], cc = ((double)(j0 + i) + 0.5) * dbin;
         r0 += w; r1 += w * cc; r2 += w * cc * cc;
         P0[j0 + i + 1] = r0; P1[j0 + i + 1] = r1; P2[j0 + i + 1] = r2;
       }
     } else {                                                // many bins per lane: walk backwards so that cnt[j] is read before P0[j+1] lands on cnt[j+1]
       // recompute from the top: P0[j+1] for j descending needs the inclusive value; do a forward pass into P1/P2 first
       double a0 = r0, a1 = r1, a2 = r2;
-      for (int j = j0; j < j1; j++) { double w = cnt[j], cc = cen[j] - lo; a1 += w * cc; a2 += w * cc * cc; P1[j + 1] = a1; P2[j + 1] = a2; }
+      for (int j = j0; j < j1; j++) { double w = cnt[j], cc = ((double)j + 0.5) * dbin; a1 += w * cc; a2 += w * cc * cc; P1[j + 1] = a1; P2[j + 1] = a2; }
       a0 = r0; for (int j = j0; j < j1; j++) a0 += cnt[j];
       for (int j = j1 - 1; j >= j0; j--) { double w = cnt[j]; P0[j + 1] = a0; a0 -= w; }
     }
@@ -888,10 +895,9 @@ __global__ void __launch_bounds__(64 * MARG_WPB, 5) k_kde_marg_fast(LikeDev L, c
   const double neff_k = (tot * tot) / sum2;
   const double stdc = (hi - lo) * (sqrt(((double)B * (double)B - 1.) / 12.) / (double)B);
   const double bw = kde_bandwidth_factor(L.bw_method, L.bw_scalar, neff_k, 1) * stdc;
-  const double dbin = (hi - lo) / (double)B;
   const bool degenerate = !(dbin > 0.) || !(bw > 0.) || !(bw < 1e300) || !(tot > 0. || tot < 0.);
   EpanCtx cx;
-  cx.cen = cen; cx.P0 = P0; cx.P1 = P1; cx.P2 = P2; cx.N = B; cx.lo = lo; cx.inv_dbin = 1. / dbin; cx.bw = bw; cx.inv_bw = 1. / bw;
+  cx.P0 = P0; cx.P1 = P1; cx.P2 = P2; cx.N = B; cx.lo = lo; cx.inv_dbin = 1. / dbin; cx.bw = bw; cx.inv_bw = 1. / bw;
   cx.scale = 0.75 * cx.inv_bw / tot;
 
   const size_t zo = ((size_t)b * L.E + e) * Z;
@@ -905,7 +911,7 @@ __global__ void __launch_bounds__(64 * MARG_WPB, 5) k_kde_marg_fast(LikeDev L, c
   double acc = 0.;
   if (dump) { for (int k = lane; k < Z; k += 64) if (k < k_lo || k > k_hi) dump[k] = 0.; }
 #pragma unroll 1
-  for (int it = 0; k_lo + 128 * it <= k_hi; it++) {         // one pass = 64 lanes x 2 consecutive grid points
+  for (int it = 0; k_lo + 128 * it <= k_hi && !(L.dbg & 4); it++) {         // one pass = 64 lanes x 2 consecutive grid points
     const int k = k_lo + 128 * it + 2 * lane;
     double pc0, pc1;
     if (it < FAST_PF) {                                     // prefetched at kernel start (uniform select)

@@ -85,6 +85,33 @@ DEVFN double jnp_interp(double x, AccX xp, AccF fp, int n, bool has_lr, double l
   return f;
 }
 
+// Two independent jnp.interp evaluations on the same table with the binary searches run in lock step (fixed trip count,
+// no data-dependent branches), so that the LDS latencies of the two searches overlap.  Same result as jnp_interp().
+template <class AccX, class AccF>
+DEVFN void jnp_interp_x2(double xa, double xb, AccX xp, AccF fp, int n, double& fa, double& fb) {
+  int pa = 0, pb = 0;                                    // number of elements <= x  (searchsorted side='right')
+  int step = 1;
+  while (step * 2 <= n) step *= 2;
+  for (; step > 0; step >>= 1) {
+    int ta = pa + step, tb = pb + step;
+    double va = xp[(ta <= n ? ta : n) - 1], vb = xp[(tb <= n ? tb : n) - 1];
+    if (ta <= n && va <= xa) pa = ta;
+    if (tb <= n && vb <= xb) pb = tb;
+  }
+  int ia = pa < 1 ? 1 : (pa > n - 1 ? n - 1 : pa), ib = pb < 1 ? 1 : (pb > n - 1 ? n - 1 : pb);
+  double x0a = xp[ia - 1], x1a = xp[ia], f0a = fp[ia - 1], f1a = fp[ia];
+  double x0b = xp[ib - 1], x1b = xp[ib], f0b = fp[ib - 1], f1b = fp[ib];
+  const double epsilon = 4.930380657631324e-32;
+  double dxa = x1a - x0a, dxb = x1b - x0b;
+  fa = (fabs(dxa) <= epsilon) ? f0a : f0a + ((xa - x0a) / dxa) * (f1a - f0a);
+  fb = (fabs(dxb) <= epsilon) ? f0b : f0b + ((xb - x0b) / dxb) * (f1b - f0b);
+  double xfirst = xp[0], xlast = xp[n - 1];
+  if (xa < xfirst) fa = fp[0];
+  if (xa > xlast) fa = fp[n - 1];
+  if (xb < xfirst) fb = fp[0];
+  if (xb > xlast) fb = fp[n - 1];
+}
+
 // jnp.logaddexp(0, x) = max(0,x) + log1p(exp(-|x|))
 DEVFN double logaddexp0(double x) {
   double amax = x > 0. ? x : 0.;
