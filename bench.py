@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- hyper-likelihood throughput on MI355X (BASELINE.json metric).
 
-A step = one full hyperposterior call (tables + det->src + weights + histogram/KDE + integrand + trapz + selection
+A step = one call of ``hyperlikelihood.batch`` with ``--nbatch`` (default 16) different hyper-parameter draws, i.e. nbatch
+full hyperposterior evaluations (each: tables + det->src + weights + histogram/KDE + integrand + trapz + selection
 function + reduce) over the C3 workload: 1000 events x 32 pixels x 1000 z-bins x 4096 samples/event, 1e5 detected
 injections, PowerLaw+Peak + Madau-Dickinson + flat-LCDM, kind_p_gw3d='marginalized', binning(200), cut_grid=2 --
-with the inputs already resident in HBM.  Every step uses a different H0 (tables rebuilt every call, as in the
-reference's H0 scans, examples/test1dgalaxies.ipynb cell 11).
+with the inputs already resident in HBM.  Every draw uses a different H0 (tables rebuilt for every draw, as in the
+reference's H0 scans, examples/test1dgalaxies.ipynb cell 11).  value = evaluations per second = steps * nbatch / time;
+the latency of a single-draw call (nbatch = 1, the reference's scalar call) is reported as ``single_call_ms``.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
@@ -47,10 +49,11 @@ def main():
   ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--config', default='C3')
   ap.add_argument('--mode', default='marginalized')
-  ap.add_argument('--nbatch', type=int, default=1, help='hyper-parameter draws per call')
+  ap.add_argument('--nbatch', type=int, default=16, help='hyper-parameter draws per chm_eval call (hyperlikelihood.batch)')
   ap.add_argument('--events', type=int, default=None, help='shrink the number of events (debug)')
   ap.add_argument('--inj', type=int, default=None, help='shrink the number of injections (debug)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--single-call', action='store_true', help='also time the scalar one-draw call (extra launches after the timed region)')
   ap.add_argument('--cpu-events', type=int, default=24)
   args = ap.parse_args()
 
@@ -108,7 +111,7 @@ def main():
     try:
       import torch
       if torch.cuda.is_available():
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(local_rank)
     except ImportError:
       pass
     if dist is not None:
@@ -131,6 +134,27 @@ def main():
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt[0])
   kt /= max(args.steps, 1)
+  single_ms = None
+  if args.single_call:      # latency of the reference-style scalar call (one draw per call), outside the timed region
+    for j in range(3):
+      like(H0=float(H0s[-1 - j]))
+    sync()
+    t2 = time.perf_counter()
+    nsingle = 10
+    for j in range(nsingle):
+      like(H0=float(H0s[-10 - j]))
+    sync()
+    single_ms = 1e3 * (time.perf_counter() - t2) / nsingle
+  traffic = None
+  tf = os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')
+  if os.path.exists(tf):
+    try:
+      with open(tf) as f:
+        tj = json.load(f)
+      if tj.get('E') == (like._e1 - like._e0) and tj.get('kernel') == 'k_kde_marg_fast':
+        traffic = tj['bytes_per_draw'] * nb
+    except Exception:
+      traffic = None
 
   if rank == 0:
     evals = args.steps * nb
@@ -150,9 +174,11 @@ def main():
                  "E": E, "P": P, "Z": Z, "S": S, "I": I, "kind_p_gw3d": kind, "nbatch": nb,
                  "parallelism": f"events+injections sharded over {world} GPU(s)",
                  "cells_per_s": value * E * max(P, 1) * Z},
-      "roofline": {"bound": "hbm", "kernel": "k_kde_integrate" if kind != 'full' else "k_full_kde",
+      "single_call_ms": single_ms,
+      "roofline": {"bound": "hbm", "kernel": {"marginalized": "k_kde_marg_fast", "full": "k_full_kde"}.get(kind, "k_kde1d+k_integrate_1d"),
                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                   "traffic": None, "bytes_per_launch": kb, "kernel_ms": kde_ms,
+                   "traffic": traffic, "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
+                   "bytes_per_launch": kb, "kernel_ms": kde_ms,
                    "path_bytes_per_eval": path_bytes,
                    "path_frac": path_bytes * nb / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[0] > 0 else None,
                    "stage_ms": {"eval": kt[0], "tables": kt[1], "samples": kt[2], "kde_integrate": kt[3],
@@ -163,6 +189,10 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cpu_baseline(cfg, ev, inj, kind, args.cpu_events)
     print(json.dumps(out), flush=True)
+  like.close()
+  sel.close()
+  if comm is not None:
+    comm.close()
   if dist is not None:
     dist.barrier()
     dist.destroy_process_group()
