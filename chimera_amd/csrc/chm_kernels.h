@@ -1056,9 +1056,18 @@ __global__ void __launch_bounds__(64) k_integrate_1d(LikeDev L, const DevParams*
 // ------------------------------------------------------------------------------------------------------
 // k_full_kde: 3-D Gaussian KDE, one block (256 threads) per (event, pixel, draw)   likelihood.py:211-260, math.py:154-229
 // ------------------------------------------------------------------------------------------------------
+// val(q_k) = sum_j W_j exp(log_norm - 1/2 |x_j - q_k|^2) in whitened coordinates.  The queries of one pixel differ only in z,
+// and whitening with the lower Cholesky factor maps z to the FIRST whitened coordinate only:
+//   |x_j - q_k|^2 = (a_j - t_k)^2 + b_j,   a_j = (x_j L)_0,  t_k = z_k l00 + ra_p l10 + dec_p l20,  b_j = k-independent,
+// so  val_k = sum_j c_j g_jk,  c_j = W_j exp(log_norm - b_j/2)  (one exp per sample and pixel),  g_jk = exp(-(a_j - t_k)^2/2).
+// On a uniform stretch of the event grid (t_k = t_0 + k D) the Gaussian obeys g_{k+1} = g_k r_k, r_{k+1} = r_k rho,
+// r_k = exp((a - t_k) D - D^2/2), rho = exp(-D^2): a thread marches FULL_LK = 16 grid points per sample with two exps and
+// then 2 multiplies + 1 fma per pair (relative error <= ~16^2/2 eps ~ 3e-14, restarted from exact exps every chunk).
+// A chunk whose grid is not uniform to 1e-11 falls back to one exp per pair.
 #define FULL_TILE 1024
+#define FULL_LK 16
 __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* params) {
-  __shared__ double xs0[FULL_TILE], xs1[FULL_TILE], xs2[FULL_TILE], xw[FULL_TILE];
+  __shared__ double sa[FULL_TILE], sc[FULL_TILE];
   __shared__ double red[16];
   __shared__ double wh[12];
   const int t = threadIdx.x, nt = blockDim.x;
@@ -1110,63 +1119,101 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
   }
   __syncthreads();
   const double l00 = wh[0], l10 = wh[1], l11 = wh[2], l20 = wh[3], l21 = wh[4], l22 = wh[5], log_norm = wh[6];
-  const double zhi = st.zmax + L.cut_grid * st.sd, zlo = st.zmin - L.cut_grid * st.sd;      // likelihood.py:225
+  const double zhi = st.zmax + L.cut_grid * st.sd, zlo = st.zmin - L.cut_grid * st.sd;      // z mask, likelihood.py:225
   const double* zg = L.z_grids + (size_t)e * Z;
   const double rp = L.ra_pix[(size_t)e * L.P + p], dp = L.dec_pix[(size_t)e * L.P + p];
   // whitened query (math.py:196): q = (z, ra_p, dec_p) . L
-  const double q1 = rp * l11 + dp * l21, q2 = dp * l22;
+  const double q1 = rp * l11 + dp * l21, q2 = dp * l22, t_base = rp * l10 + dp * l20;
   const size_t zo = ((size_t)b * L.E + e) * Z;
+  const double* pc = L.p_cat + ((size_t)e * L.P + p) * Z;
+
+  // chunks of FULL_LK grid points; NS threads (a power of two, adjacent lanes) share a chunk and split the samples
+  const int nch = (Z + FULL_LK - 1) / FULL_LK;
+  int NS = 1;
+  while (NS < 16 && nch * NS * 2 <= nt) NS *= 2;
+  const int cpp = nt / NS;                                // chunks per pass
   double accl = 0.;
-  for (int kb = 0; kb < Z; kb += nt * 4) {
-    double q0[4], val[4]; bool inm[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      int k = kb + r * nt + t;
-      double z = k < Z ? zg[k] : 0.;
-      inm[r] = ok && k < Z && (z <= zhi) && (z >= zlo);
-      q0[r] = z * l00 + rp * l10 + dp * l20;
-      val[r] = 0.;
+  if (dump && !ok) for (int k = t; k < Z; k += nt) dump[k] = 0.;
+  for (int cb = 0; cb < nch && ok; cb += cpp) {
+    const int c = cb + t / NS, sl = t % NS;
+    const bool has = c < nch;
+    const int k0 = has ? c * FULL_LK : 0;
+    const int nk = has ? min(FULL_LK, Z - k0) : 0;
+    // the chunk's grid in the first whitened coordinate; uniform?
+    double t0 = 0., D = 0.;
+    bool uni = false, any = false;
+    if (has) {
+      double z0 = zg[k0], z1 = zg[k0 + nk - 1];
+      double dz = nk > 1 ? (z1 - z0) / (double)(nk - 1) : 0.;
+      uni = nk > 1;
+      for (int i = 0; i < nk; i++) {
+        double z = zg[k0 + i];
+        if (fabs(z - (z0 + (double)i * dz)) > 1e-11 * fabs(dz)) uni = false;
+        if (z <= zhi && z >= zlo) any = true;
+      }
+      t0 = z0 * l00 + t_base; D = dz * l00;
     }
-    if (ok) {
-      for (int s0 = 0; s0 < S; s0 += FULL_TILE) {
-        __syncthreads();
-        for (int s = t; s < FULL_TILE && s0 + s < S; s += nt) {
-          double x0 = wz[s0 + s], x1 = L.ra[eo + s0 + s], x2 = L.dec[eo + s0 + s];
-          xs0[s] = x0 * l00 + x1 * l10 + x2 * l20;
-          xs1[s] = x1 * l11 + x2 * l21;
-          xs2[s] = x2 * l22;
-          xw[s] = ww[s0 + s] / st.sumw;
-        }
-        __syncthreads();
-        int ns = min(FULL_TILE, S - s0);
-        for (int s = 0; s < ns; s++) {
-          double d1 = xs1[s] - q1, d2 = xs2[s] - q2;
-          double base = d1 * d1 + d2 * d2;
-          double w = xw[s], a0 = xs0[s];
+    const double rho = exp(-(D * D)), hD2 = 0.5 * D * D;
+    double acc[FULL_LK];
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            double d0 = a0 - q0[r];
-            val[r] += w * exp(log_norm - 0.5 * (d0 * d0 + base));
+    for (int i = 0; i < FULL_LK; i++) acc[i] = 0.;
+    for (int s0 = 0; s0 < S; s0 += FULL_TILE) {
+      __syncthreads();
+      const int ns = min(FULL_TILE, S - s0);
+      for (int s = t; s < ns; s += nt) {                  // stage a_j and c_j = W_j exp(log_norm - b_j/2) of this tile
+        double x0 = wz[s0 + s], x1 = L.ra[eo + s0 + s], x2 = L.dec[eo + s0 + s];
+        double d1 = (x1 * l11 + x2 * l21) - q1, d2 = x2 * l22 - q2;
+        sa[s] = x0 * l00 + x1 * l10 + x2 * l20;
+        sc[s] = (ww[s0 + s] / st.sumw) * exp(log_norm - 0.5 * (d1 * d1 + d2 * d2));
+      }
+      __syncthreads();
+      if (has && any) {
+        if (uni) {
+          for (int s = sl; s < ns; s += NS) {
+            double d = sa[s] - t0;
+            double g = sc[s] * exp(-0.5 * (d * d));
+            double r = exp(d * D - hD2);
+#pragma unroll
+            for (int i = 0; i < FULL_LK; i++) { acc[i] += g; g *= r; r *= rho; }
+          }
+        } else {
+          for (int s = sl; s < ns; s += NS) {
+            double a0 = sa[s], cj = sc[s];
+#pragma unroll
+            for (int i = 0; i < FULL_LK; i++) {
+              double ti = (i < nk ? zg[k0 + i] : zg[k0]) * l00 + t_base;
+              double d = a0 - ti;
+              acc[i] += cj * exp(-0.5 * (d * d));
+            }
           }
         }
       }
     }
+    // sum over the NS sample slices (adjacent lanes)
+    for (int o = 1; o < NS; o <<= 1) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      int k = kb + r * nt + t;
-      if (k < Z) {
-        double pgw = inm[r] ? val[r] * st.norm : 0.;
-        if (dump) dump[k] = pgw;
-        double pcv = L.p_cat[((size_t)e * L.P + p) * Z + k];
-        double y = 0.;
-        if (pcv != -100.) {
-          double p_gal = P.fR * pcv + L.bkgA[zo + k];
-          double p_z = p_gal * L.prate[zo + k];
-          y = (p_z != -100.) ? pgw * p_z / L.jac[zo + k] : 0.;
+      for (int i = 0; i < FULL_LK; i++) acc[i] += __shfl_xor(acc[i], o, 64);
+    }
+    if (has && sl == 0) {
+#pragma unroll
+      for (int i = 0; i < FULL_LK; i++) {
+        if (i < nk) {
+          const int k = k0 + i;
+          const double z = zg[k];
+          const bool inm = (z <= zhi) && (z >= zlo);
+          double pgw = inm ? acc[i] * st.norm : 0.;       // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
+          if (dump) dump[k] = pgw;
+          double pcv = pc[k];
+          double y = 0.;
+          if (pcv != -100.) {
+            double p_gal = P.fR * pcv + L.bkgA[zo + k];
+            double p_z = p_gal * L.prate[zo + k];
+            y = (p_z != -100.) ? pgw * p_z / L.jac[zo + k] : 0.;
+          }
+          // trapezoid: y_k enters the two adjacent intervals
+          double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
+          accl += y * ((z - zl) + (zr - z));
         }
-        // trapezoid: y_k enters the two adjacent intervals
-        double zl = k > 0 ? zg[k - 1] : zg[k], zr = k < Z - 1 ? zg[k + 1] : zg[k];
-        accl += y * ((zg[k] - zl) + (zr - zg[k]));
       }
     }
   }
