@@ -49,6 +49,11 @@ class chm_sel_desc(C.Structure):
               ('N_inj', C.c_double), ('N_eff', C.c_double), ('device', C.c_int32), ('_pad', C.c_int32)]
 
 
+class chm_pcat_desc(C.Structure):
+  _fields_ = [('E', C.c_int32), ('P', C.c_int32), ('Z', C.c_int32), ('device', C.c_int32),
+              ('z_grids', c_dp), ('offsets', C.POINTER(C.c_int64)), ('gal_z', c_dp), ('gal_sig', c_dp), ('gal_w', c_dp)]
+
+
 class chm_out(C.Structure):
   _fields_ = [('log_hyper', c_dp), ('log_num', c_dp), ('N_exp', c_dp), ('log_like_evs', c_dp),
               ('numlike_evs', c_dp), ('p_gw', c_dp), ('partials', c_dp)]
@@ -57,7 +62,7 @@ class chm_out(C.Structure):
 SYMBOLS = ['chm_version', 'chm_device_count', 'chm_last_error', 'chm_like_create', 'chm_like_destroy',
            'chm_sel_create', 'chm_sel_destroy', 'chm_eval', 'chm_model_eval', 'chm_model_tables',
            'chm_comm_unique_id', 'chm_comm_init_rank', 'chm_comm_destroy', 'chm_comm_allreduce_sum',
-           'chm_last_timing']
+           'chm_last_timing', 'chm_pcat_compute']
 
 _lib = None
 
@@ -87,6 +92,7 @@ def lib():
   L.chm_comm_destroy.argtypes = [vp]
   L.chm_comm_allreduce_sum.argtypes = [vp, c_dp, C.c_int32]
   L.chm_last_timing.argtypes = [vp, vp, c_dp]
+  L.chm_pcat_compute.argtypes = [C.POINTER(chm_params), C.POINTER(chm_pcat_desc), c_dp]
   for name in SYMBOLS:
     if name not in ('chm_version', 'chm_last_error'):
       getattr(L, name).restype = C.c_int

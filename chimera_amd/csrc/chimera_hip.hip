@@ -651,6 +651,51 @@ extern "C" int chm_model_tables(const chm_params* p, double* zt, double* It, dou
 }
 
 // ------------------------------------------------------------------------------------------------------
+// catalogue term (setup path)
+// ------------------------------------------------------------------------------------------------------
+extern "C" int chm_pcat_compute(const chm_params* cosmo, const chm_pcat_desc* d, double* p_cat) {
+  if (!cosmo || !d || !p_cat) return fail(CHM_E_ARG, "chm_pcat_compute: null argument");
+  if (d->E <= 0 || d->P <= 0 || d->Z < 2 || !d->z_grids || !d->offsets) return fail(CHM_E_ARG, "chm_pcat_compute: need E, P > 0, Z >= 2, z_grids, offsets");
+  const size_t npix = (size_t)d->E * d->P;
+  const long long nnz = d->offsets[npix];
+  if (d->offsets[0] != 0 || nnz < 0) return fail(CHM_E_ARG, "chm_pcat_compute: offsets must start at 0 and be non-decreasing");
+  for (size_t i = 0; i < npix; i++) if (d->offsets[i + 1] < d->offsets[i]) return fail(CHM_E_ARG, "chm_pcat_compute: offsets must be non-decreasing");
+  if (nnz > 0 && (!d->gal_z || !d->gal_sig || !d->gal_w)) return fail(CHM_E_ARG, "chm_pcat_compute: missing galaxy arrays");
+  const size_t lds = sizeof(double) * 3 * (size_t)d->Z;
+  if (lds > 150 * 1024) return fail(CHM_E_ARG, "chm_pcat_compute: Z too large for the LDS working set (3 Z doubles <= 150 KiB)");
+  Ctx c;
+  int rc = with_tables(cosmo, d->device, c);
+  if (rc) { ctx_destroy(c); return rc; }
+  std::vector<void*> owned;
+  auto cleanup = [&]() { for (void* q : owned) (void)hipFree(q); ctx_destroy(c); };
+  PcatDev D; memset(&D, 0, sizeof(D));
+  D.E = d->E; D.P = d->P; D.Z = d->Z;
+  const long long* offs = nullptr;
+#define CKR(x) do { int _r = (x); if (_r) { cleanup(); return _r; } } while (0)
+  CKR(upload(owned, d->z_grids, (size_t)d->E * d->Z, &D.z_grids, c.stream));
+  CKR(upload(owned, (const long long*)d->offsets, npix + 1, &offs, c.stream));
+  D.offsets = offs;
+  if (nnz > 0) {
+    CKR(upload(owned, d->gal_z, (size_t)nnz, &D.gal_z, c.stream));
+    CKR(upload(owned, d->gal_sig, (size_t)nnz, &D.gal_sig, c.stream));
+    CKR(upload(owned, d->gal_w, (size_t)nnz, &D.gal_w, c.stream));
+  }
+#undef CKR
+  hipError_t he = hipMalloc(&D.p_cat, sizeof(double) * npix * d->Z);
+  if (he != hipSuccess) { cleanup(); return fail(CHM_E_NOMEM, std::string("chm_pcat_compute: ") + hipGetErrorString(he)); }
+  owned.push_back(D.p_cat);
+  TablePtrs g = { c.zt, c.It, c.dLt, c.mg, c.cdf };
+  allow_lds(k_pcat, lds);
+  hipLaunchKernelGGL(k_pcat, dim3((unsigned)npix), dim3(256), lds, c.stream, D, (const DevParams*)c.d_params, g);
+  he = hipGetLastError();
+  if (he == hipSuccess) he = hipMemcpyAsync(p_cat, D.p_cat, sizeof(double) * npix * d->Z, hipMemcpyDeviceToHost, c.stream);
+  if (he == hipSuccess) he = hipStreamSynchronize(c.stream);
+  cleanup();
+  if (he != hipSuccess) return fail(CHM_E_HIP, std::string("chm_pcat_compute: ") + hipGetErrorString(he));
+  return CHM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // RCCL communicator (one process per GPU)
 // ------------------------------------------------------------------------------------------------------
 static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId larger than the ABI's 128 bytes");

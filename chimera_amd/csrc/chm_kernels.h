@@ -1381,6 +1381,61 @@ __global__ void k_combine(int nb, const DevParams* params, const double* partial
 }
 
 // ------------------------------------------------------------------------------------------------------
+// k_pcat: pixelated_catalog.precompute_p_cat (catalog.py:152-195, 212-221); one block per (event, pixel)
+// ------------------------------------------------------------------------------------------------------
+struct PcatDev {
+  int E, P, Z, pad;
+  const double* z_grids;
+  const long long* offsets;
+  const double *gal_z, *gal_sig, *gal_w;
+  double* p_cat;
+};
+
+__global__ void __launch_bounds__(256) k_pcat(PcatDev D, const DevParams* params, TablePtrs g) {
+  extern __shared__ double lds[];                   // dv[Z], zz[Z], acc[Z]
+  __shared__ double red[16];
+  const DevParams& P = params[0];
+  const int Z = D.Z, t = threadIdx.x, nt = blockDim.x;
+  const int e = blockIdx.x / D.P;
+  double* dv = lds; double* zz = dv + Z; double* acc = zz + Z;
+  const double* zg = D.z_grids + (size_t)e * Z;
+  for (int k = t; k < Z; k += nt) {
+    double z = zg[k];
+    zz[k] = z;
+    dv[k] = dVcdz_from_dCt(P, dCt_at_z(P, z, g.zt, g.It), z);      // dVcdz_at_z(cosmo, zgrid)   catalog.py:219
+    acc[k] = 0.;
+  }
+  __syncthreads();
+  const long long g0 = D.offsets[blockIdx.x], g1 = D.offsets[blockIdx.x + 1];
+  double sw = 0.;
+  for (long long gi = g0; gi < g1; gi++) {
+    const double mu = D.gal_z[gi], sg = D.gal_sig[gi], w = D.gal_w[gi];
+    const double pref = 1. / sqrt(2. * CHM_PI * (sg * sg));          // np.power(2 pi sigma^2, -0.5)   catalog.py:210
+    // norm = trapz(gauss * dVdz, zgrid) = 0.5 sum dx (y1 + y0)                                         catalog.py:220
+    double part = 0.;
+    for (int k = t; k < Z - 1; k += nt) {
+      double u0 = (zz[k] - mu) / sg, u1 = (zz[k + 1] - mu) / sg;
+      double y0 = pref * exp(-0.5 * (u0 * u0)) * dv[k], y1 = pref * exp(-0.5 * (u1 * u1)) * dv[k + 1];
+      part += (zz[k + 1] - zz[k]) * (y1 + y0);
+    }
+    const double norm = 0.5 * block_reduce<RED_SUM>(part, red);
+    for (int k = t; k < Z; k += nt) {
+      double u = (zz[k] - mu) / sg;
+      double y = pref * exp(-0.5 * (u * u)) * dv[k];
+      acc[k] += w * y / norm;                                          // np.sum(weights * gauss / norm, axis=1)   :221
+    }
+    sw += w;
+  }
+  __syncthreads();
+  double* out = D.p_cat + (size_t)blockIdx.x * Z;
+  for (int k = t; k < Z; k += nt) {
+    double v = g1 > g0 ? acc[k] / sw : 0.;                             // len(mu) == 0 -> zeros           :213-214
+    if (!(fabs(v) <= 1.7976931348623157e308)) v = 0.;                  // p_cat[~isfinite(p_cat)] = 0     catalog.py:172
+    out[k] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // k_model_eval: elementwise model functions for the Python free functions (cosmo.py / mass.py / rate.py)
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_model_eval(const DevParams* params, TablePtrs g, int func, const double* a, const double* bb,

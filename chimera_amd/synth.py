@@ -160,7 +160,8 @@ def make_events(E, S, P=None, seed=SEED, z_range=(0.001, 1.25), ragged=False, fr
     r2 = (gx**2 + gy**2) / sig_sky[e]**2
     pdf2d[e, :n] = np.exp(-0.5 * r2) / (2 * np.pi * sig_sky[e]**2 / np.cos(dec0[e]))
   out.update(pixels_pe_opt_nside=pe_pix, pixels_opt_nsides=pixels, ra_pix=ra_pix, dec_pix=dec_pix,
-             gw_loc2d_pdf=pdf2d, neff_pixels=neff.astype(np.int32), host_pix=host_pix)
+             gw_loc2d_pdf=pdf2d, neff_pixels=neff.astype(np.int32), host_pix=host_pix,
+             opt_nsides=np.where(np.arange(E) % 2 == 0, 64, 128))
   return out
 
 
@@ -212,6 +213,37 @@ def make_p_cat(z_grids, neff_pixels, P, seed=SEED + 1, ngal_mean=30, z_err=0.001
       p_cat[e, j] = g[:, m].sum(1) / max(m.sum(), 1) if m.any() else 0.
     N_gal[e] = len(zgal)
   return p_cat, N_gal
+
+
+def make_galaxy_sample(ev, z_grids, seed=SEED + 3, ngal_mean=30, z_lim=(0.073, 1.3), frac_foreign=0.2):
+  """A galaxy sample in the layout `pixelated_catalog` consumes (CHIMERA/catalog/catalog.py:105-136): redshifts `z` and,
+  for every nside in ``ev['opt_nsides']``, the HEALPix-like index of each galaxy (`pix<nside>`; -1 where the galaxy lies
+  in no event pixel at that nside).  Galaxies follow dV/dz; a fraction lies outside every event pixel."""
+  rng = np.random.default_rng(seed)
+  fid = _Fid()
+  E, P = ev['pixels_opt_nsides'].shape
+  zz = np.linspace(z_lim[0], z_lim[1], 4000)
+  pdfz = fid.dVdz(zz)
+  nsides = np.unique(ev['opt_nsides'])
+  zs, pix = [], {int(ns): [] for ns in nsides}
+  for e in range(E):
+    n = int(ev['neff_pixels'][e])
+    ng = rng.poisson(ngal_mean, n)
+    z = _sample_pdf(rng, zz, pdfz, int(ng.sum()))
+    ids = np.repeat(ev['pixels_opt_nsides'][e, :n], ng)
+    zs.append(z)
+    for ns in nsides:
+      pix[int(ns)].append(ids if ev['opt_nsides'][e] == ns else np.full(ids.shape, -1, dtype=np.int64))
+  nf = int(frac_foreign * sum(len(z) for z in zs))
+  zs.append(_sample_pdf(rng, zz, pdfz, nf))
+  for ns in nsides:
+    pix[int(ns)].append(np.full(nf, -1, dtype=np.int64))
+  gal = {'z': np.concatenate(zs)}
+  perm = rng.permutation(len(gal['z']))
+  gal['z'] = gal['z'][perm]
+  for ns in nsides:
+    gal[f'pix{int(ns)}'] = np.concatenate(pix[int(ns)])[perm]
+  return gal
 
 
 def make_injections(I, seed=SEED + 2, oversample=40):

@@ -164,6 +164,21 @@ int chm_model_eval(const chm_params* p, int32_t func, const double* a, const dou
 int chm_model_tables(const chm_params* p, double* zt, double* It, double* dLt, double* mgrid,
                      double* cdf_m2, double* scalars, int32_t device);
 
+/* pixelated_catalog.precompute_p_cat (catalog.py:152-195, _sum_gaussians_ucv :212-221): per (event, pixel) the sum over the
+ * pixel's galaxies of N(z | z_gal, sigma_gal) dVc/dz(z), each normalised by its trapezoid integral over the event grid,
+ * weighted and divided by the summed weights; non-finite entries -> 0.  The galaxies of pixel (e,p) are entries
+ * [offsets[e*P+p], offsets[e*P+p+1]) of gal_z / gal_sig / gal_w (host selection by HEALPix index and z range:
+ * catalog.py:143-150).  Writes p_cat rows for every (e,p) -- rows of padded pixels are left to the caller (-100).        */
+typedef struct chm_pcat_desc {
+  int32_t E, P, Z, device;
+  const double*  z_grids;        /* (E,Z)                                                                */
+  const int64_t* offsets;        /* (E*P+1) CSR offsets into the galaxy entry arrays                     */
+  const double*  gal_z;          /* (nnz,) galaxy redshifts                   catalog.py:159             */
+  const double*  gal_sig;        /* (nnz,) z_err * (1 + z_gal)                catalog.py:115,160         */
+  const double*  gal_w;          /* (nnz,) host weights                       catalog.py:114,162         */
+} chm_pcat_desc;
+int chm_pcat_compute(const chm_params* cosmo, const chm_pcat_desc* desc, double* p_cat /* (E,P,Z) */);
+
 /* Event/injection sharding across GPUs: one process per GPU, RCCL over xGMI.
  * Replaces the MPI layer CHIMERA/parallel.py:94-99,68-73,366-376 (dead code in v2.0.0).               */
 int chm_comm_unique_id(char id[128]);                       /* rank 0; broadcast the bytes out-of-band */

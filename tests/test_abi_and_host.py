@@ -174,9 +174,47 @@ def test_catalog_and_completeness_plugins(tmp_path):
   f = str(tmp_path / 'gc.npz'); gc.save(f)
   gc2 = pixelated_catalog(comp, gal_cat_file=f)
   np.testing.assert_array_equal(gc2.p_cat, p_cat); assert gc2.max_npixels == 2
-  with pytest.raises(NotImplementedError):
+  with pytest.raises(ValueError):
     pixelated_catalog(comp)
   assert empty_catalog().max_npixels is None
+
+
+def test_fast_parameter_patching_equals_update():
+  """hyperlikelihood.batch patches a copy of the base chm_params; it must equal population.update(**lam).to_params()
+  byte for byte, for every model family and including unknown / structural keys."""
+  from tests import helpers as H
+  cfg, ev, inj = H.small_config(E=2, S=32, P=2, Z=16, I=64, seed=1)
+  lam = dict(H0=61., Om0=0.3, alpha=2.2, beta=0.7, gamma=1.1, zmax=2.2, kappa=2., mu_g=30., Xi0=1.4, n=2.2, R0=4., foo=3.,
+             z_max=6., z_grid_res=1700, grid_res=900, m_low=4., delta_m=3., alpha_1=1.1, break_fraction=0.3, zp=1.7,
+             lambda_peak=0.1, w0=-0.9)
+  for models in [{}, dict(cosmo='mg_flrw', mass='bpl', rate='trunc_madau_dickinson'), dict(mass='tpl', rate='trunc_power_law'),
+                 dict(rate='power_law')]:
+    like, pop, sel = H.build_product(ev, inj, models=models)
+    a = like._params_array([lam, {}])
+    assert bytes(a[0]) == bytes(like.population.update(**lam).to_params())
+    assert bytes(a[1]) == bytes(like.population.to_params())
+
+
+def test_event_pixel_galaxy_selection():
+  """Host side of precompute_p_cat: galaxies of each (event, pixel) by HEALPix index and grid range (catalog.py:143-150)."""
+  import chimera_amd as CH
+  from chimera_amd import synth
+  from chimera_amd.catalog import pixelated_catalog, dVdz_completeness
+  cfg, ev, inj = synth.make_config('C2', E=4, S=64, P=3, Z=24, I=100, ragged=True)
+  gal = synth.make_galaxy_sample(ev, ev['z_grids'], ngal_mean=8)
+  th = CH.data.theta_pe_det(dL=ev['dL'], pixels_opt_nsides=ev['pixels_opt_nsides'], ra_pix=ev['ra_pix'], opt_nsides=ev['opt_nsides'])
+  gc = pixelated_catalog.__new__(pixelated_catalog)
+  gc.nevents, gc.max_npixels, gc.data_gw_pixelated = 4, 3, th
+  gc.data_gal = dict(gal)
+  off, idx = gc._csr_of_event_pixels(ev['z_grids'])
+  assert off.shape == (13,) and off[0] == 0 and off[-1] == idx.size
+  for e in range(4):
+    ns = ev['opt_nsides'][e]
+    for p in range(3):
+      sel = idx[off[e * 3 + p]:off[e * 3 + p + 1]]
+      pid = ev['pixels_opt_nsides'][e, p]
+      expect = np.flatnonzero((gal[f'pix{ns}'] == pid) & (gal['z'] > ev['z_grids'][e, 0]) & (gal['z'] < ev['z_grids'][e, -1])) if pid != -100 else np.zeros(0, int)
+      np.testing.assert_array_equal(sel, expect)
 
 
 def test_chunk_bounds_partition():

@@ -264,3 +264,30 @@ def test_full_size_against_oracle_sample(cfg_big):
   like_o, _, _ = H.build_oracle(sub, inj)
   for lam in (dict(H0=70.), dict(H0=84., alpha=3.0)):
     H.assert_loglike_close(like_p.compute_all(**lam)[0][:n], like_o.compute_all(**lam)[0], rtol=1e-9, atol=1e-9)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# catalogue term computed on the GPU (pixelated_catalog.precompute_p_cat, catalog.py:152-231)
+# ----------------------------------------------------------------------------------------------------------
+def test_precompute_p_cat_matches_oracle():
+  import chimera_amd as CH
+  from chimera_amd import synth
+  from chimera_amd.catalog import pixelated_catalog, dVdz_completeness
+  cfg, ev, inj = synth.make_config('C2', E=6, S=64, P=4, Z=96, I=100, ragged=True)
+  gal = synth.make_galaxy_sample(ev, ev['z_grids'], ngal_mean=12)
+  w = np.random.default_rng(5).uniform(0.5, 2., gal['z'].size)
+  th = CH.data.theta_pe_det(dL=ev['dL'], pixels_opt_nsides=ev['pixels_opt_nsides'], ra_pix=ev['ra_pix'], opt_nsides=ev['opt_nsides'])
+  for z_err in (0.01, 0.001):            # the second is under-resolved by the grid: non-finite rows -> 0 (catalog.py:172)
+    gc = pixelated_catalog(dVdz_completeness(), cosmo=CH.cosmo.flrw(H0=70., Om0=0.25, z_max=5.), z_grids=ev['z_grids'],
+                           data_gal=gal, data_gw_pixelated=th, z_err=z_err, weights=w)
+    co = O.flrw(H0=70., Om0=0.25, z_max=5.)
+    for e in range(cfg['E']):
+      ns = ev['opt_nsides'][e]
+      good = ev['pixels_opt_nsides'][e][ev['pixels_opt_nsides'][e] != -100]
+      isin = np.isin(gal[f'pix{ns}'], good)
+      pc, ngal = O.compute_p_cat_event(ev['z_grids'][e], gal['z'][isin], z_err * (1 + gal['z'][isin]), w[isin], gal[f'pix{ns}'][isin],
+                                       good, cfg['P'], co)
+      np.testing.assert_allclose(gc.p_cat[e], pc, rtol=1e-10, atol=1e-300, err_msg=f'event {e} z_err {z_err}')
+      assert gc.N_gal[e] == ngal
+    assert gc.P_compl.shape == (cfg['E'], 1, 96) and gc.max_npixels == cfg['P']
+    np.testing.assert_array_equal(gc.neff_pixels, ev['neff_pixels'])
