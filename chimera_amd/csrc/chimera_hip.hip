@@ -459,11 +459,13 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
       if (!want_dump) L.p_gw_dump = nullptr;
       const int eb = (int)((long long)L0.E * g / ngroups), ee = (int)((long long)L0.E * (g + 1) / ngroups);
       L.e_off = eb; L.E_cnt = ee - eb;
-      // per-z factors of the group's events
+      // per-z factors of the group's events: on the other lane, concurrently with the sample stage
+      hipStream_t sz = serial ? sg : ((g & 1) ? sA : sB);
       if (tab_zfac) { allow_lds(k_zfactors<true>, lds_zfac);
-        hipLaunchKernelGGL(k_zfactors<true>, dim3(L.E_cnt, nb), dim3(256), lds_zfac, sg, L, dp, c.zt, c.It, Tc);
-      } else hipLaunchKernelGGL(k_zfactors<false>, dim3(L.E_cnt, nb), dim3(256), 0, sg, L, dp, c.zt, c.It, Tc);
+        hipLaunchKernelGGL(k_zfactors<true>, dim3(L.E_cnt, nb), dim3(256), lds_zfac, sz, L, dp, c.zt, c.It, Tc);
+      } else hipLaunchKernelGGL(k_zfactors<false>, dim3(L.E_cnt, nb), dim3(256), 0, sz, L, dp, c.zt, c.It, Tc);
       HIPCHK(hipGetLastError());
+      if (sz != sg) HIPCHK(hipEventRecord(c.evg[32 + g], sz));
       // sample stage
       HIPCHK(hipEventRecord(c.evg[4 * g], sg));
       const int nchunk = L.E_cnt * L.NC;
@@ -480,7 +482,8 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
       }
       HIPCHK(hipGetLastError());
       HIPCHK(hipEventRecord(c.evg[4 * g + 1], sg));
-      // GW kernel + integrand
+      // GW kernel + integrand (needs the per-z factors)
+      if (sz != sg) HIPCHK(hipStreamWaitEvent(sg, c.evg[32 + g], 0));
       if (L.mode == CHM_MODE_FULL) {
         HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         hipLaunchKernelGGL(k_full_kde, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp);
@@ -489,7 +492,10 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         const bool fast = L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC");
-        if (fast) hipLaunchKernelGGL(k_kde_marg_fast, dim3(L.E_cnt * ((Pd + MARG_WPB - 1) / MARG_WPB), nb), dim3(64 * MARG_WPB),
+        static const int sub = getenv("CHM_MARG_SUB") ? atoi(getenv("CHM_MARG_SUB")) : 32;     // lanes per pixel in the fast kernel
+        if (fast && sub == 32) hipLaunchKernelGGL(k_kde_marg_sub<32>, dim3(L.E_cnt * ((Pd + 1) / 2), nb), dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
+        else if (fast && sub == 16) hipLaunchKernelGGL(k_kde_marg_sub<16>, dim3(L.E_cnt * ((Pd + 3) / 4), nb), dim3(64), sizeof(double) * (3 * N + 3) * 4, sg, L, dp);
+        else if (fast) hipLaunchKernelGGL(k_kde_marg_fast, dim3(L.E_cnt * ((Pd + MARG_WPB - 1) / MARG_WPB), nb), dim3(64 * MARG_WPB),
                                      sizeof(double) * (3 * N + 3) * MARG_WPB, sg, L, dp);
         else { allow_lds(k_kde_marg, lds_kde); hipLaunchKernelGGL(k_kde_marg, dim3(L.E_cnt * Pd, nb), dim3(64), lds_kde, sg, L, dp); }
       } else {
@@ -502,7 +508,7 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
       HIPCHK(hipGetLastError());
       HIPCHK(hipEventRecord(c.evg[4 * g + 3], sg));
     }
-    if (ngroups > 1) { HIPCHK(hipEventRecord(c.evb[0], sB)); HIPCHK(hipStreamWaitEvent(sA, c.evb[0], 0)); }   // join the two lanes
+    if (!serial) { HIPCHK(hipEventRecord(c.evb[0], sB)); HIPCHK(hipStreamWaitEvent(sA, c.evb[0], 0)); }   // join the two lanes
     HIPCHK(hipEventRecord(c.ev[3], sA));
     // per-event log-likelihoods and their block sums
     nblk_ev = (L0.E + 255) / 256;

@@ -949,6 +949,179 @@ __global__ void __launch_bounds__(64 * MARG_WPB, 5) k_kde_marg_fast(LikeDev L, c
 }
 
 // ------------------------------------------------------------------------------------------------------
+// k_kde_marg_sub<SW>: the fast marginalized kernel with SW lanes per pixel (64/SW pixels per wave).  The per-pixel
+// set-up (histogram, prefix sums, bandwidth) is mostly wave-instruction-bound with few active lanes; sharing a wave between
+// two pixels of the same event (SW = 32) halves that cost per pixel while the grid loop keeps every lane busy.
+// Same arithmetic as k_kde_marg_fast; reductions and scans run inside each SW-lane group.
+// ------------------------------------------------------------------------------------------------------
+template <int SW> DEVFN double sg_sum(double v) {
+#pragma unroll
+  for (int o = SW / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int SW> DEVFN double sg_max(double v) {
+#pragma unroll
+  for (int o = SW / 2; o > 0; o >>= 1) v = nanmax2(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+template <int SW>
+__global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevParams* params) {
+  extern __shared__ double lds_all[];
+  constexpr int NPW = 64 / SW;                              // pixels per wave
+  constexpr int PF = 4;                                     // prefetch passes: PF * SW * 2 grid points per pixel
+  const int lane = threadIdx.x, sub = lane / SW, sl = lane % SW;
+  const int PG = (L.P + NPW - 1) / NPW;
+  const int p = (blockIdx.x % PG) * NPW + sub, e = L.e_off + blockIdx.x / PG, b = blockIdx.y;
+  const DevParams& P = params[b];
+  const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
+  double* P0 = lds_all + (size_t)sub * (3 * B + 3); double* P1 = P0 + (B + 1); double* P2 = P1 + (B + 1);
+  double* cnt = P0;
+  const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
+  const double zmin = es[0], norm = es[3], n_eff = es[4], lb = es[6], ub = es[7];
+  const bool ok = n_eff >= L.pe_neff;                       // likelihood.py:199 (same for every pixel of the event)
+  const bool live = p < L.P && p < L.neff_pixels[e];        // this lane group has a real pixel
+  const int pp = live ? p : 0;                              // idle groups shadow pixel 0 for addressing, never store
+  double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
+  double* dump = (L.p_gw_dump && p < L.P) ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
+  if (!ok || !live) {
+    if (p < L.P) { if (sl == 0) *out_like = 0.; if (dump) for (int k = sl; k < Z; k += SW) dump[k] = 0.; }
+    if (!ok) return;                                        // uniform over the wave
+  }
+  const double* zg = L.z_grids + (size_t)e * Z;
+  const double* pc = L.p_cat + ((size_t)e * L.P + pp) * Z;
+  int k_lo = (int)es[8], k_hi = (int)es[9];
+  k_lo &= ~1;
+  const bool vec2 = (Z & 1) == 0;
+  double pf0[PF], pf1[PF];
+#pragma unroll
+  for (int i = 0; i < PF; i++) {
+    int k = k_lo + 2 * SW * i + 2 * sl;
+    pf0[i] = 0.; pf1[i] = 0.;
+    if (live) {
+      if (vec2 && k + 1 <= k_hi) { double2 v = *reinterpret_cast<const double2*>(pc + k); pf0[i] = v.x; pf1[i] = v.y; }
+      else { if (k <= k_hi) pf0[i] = pc[k]; if (k + 1 <= k_hi) pf1[i] = pc[k + 1]; }
+    }
+  }
+  // histogram of the pixel's samples on [min z, max z in pixel] (math.py:32-46, likelihood.py:180-183)
+  const size_t so = ((size_t)b * L.E + e) * S;
+  const double* wz = L.ws_z + so;
+  const double* ww = L.ws_w + so;
+  const int s0 = L.seg_off[(size_t)e * (L.P + 1) + pp], s1 = live ? L.seg_off[(size_t)e * (L.P + 1) + pp + 1] : s0;
+  const double lo = zmin;
+  constexpr int NR = 256 / SW;                              // samples per lane kept in registers (covers 256 per pixel)
+  double zr[NR], wr[NR];
+#pragma unroll
+  for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; zr[i] = s < s1 ? wz[s] : lo; wr[i] = s < s1 ? ww[s] : 0.; }
+  double hi = lo;
+#pragma unroll
+  for (int i = 0; i < NR; i++) hi = nanmax2(hi, zr[i]);
+  for (int s = s0 + sl + SW * NR; s < s1; s += SW) hi = nanmax2(hi, wz[s]);
+  hi = sg_max<SW>(hi);
+  if (lo != lo) hi = lo;
+  for (int j = sl; j < B; j += SW) cnt[j] = 0.;
+  const double dbin = (hi - lo) / (double)B;                // c'_j = (j + 1/2) dbin  (see k_kde_marg_fast)
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&cnt[bin_index(zr[i], lo, hi, B)], wr[i]); }
+  for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&cnt[bin_index(wz[s], lo, hi, B)], ww[s]);
+  wave_sync();
+  // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins
+  const int per = (B + SW - 1) / SW;
+  const int j0 = sl * per < B ? sl * per : B, j1 = min(j0 + per, B);
+  double s0w = 0., s1w = 0., s2w = 0., sq = 0.;
+  for (int j = j0; j < j1; j++) { double w = cnt[j], cc = ((double)j + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
+  double x0 = s0w, x1 = s1w, x2 = s2w;
+#pragma unroll
+  for (int o = 1; o < SW; o <<= 1) {
+    double y0 = __shfl_up(x0, o, SW), y1 = __shfl_up(x1, o, SW), y2 = __shfl_up(x2, o, SW);
+    if (sl >= o) { x0 += y0; x1 += y1; x2 += y2; }
+  }
+  const double tot = __shfl(x0, SW - 1, SW);
+  const double sum2 = sg_sum<SW>(sq);
+  {
+    double r0 = x0 - s0w, r1 = x1 - s1w, r2 = x2 - s2w;
+    constexpr int MAXPER = 16;
+    double wv[MAXPER];
+    const bool small = per <= MAXPER;
+    if (small) {
+#pragma unroll
+      for (int i = 0; i < MAXPER; i++) wv[i] = (j0 + i < j1) ? cnt[j0 + i] : 0.;
+    }
+    wave_sync();
+    if (small) {
+#pragma unroll
+      for (int i = 0; i < MAXPER; i++) if (j0 + i < j1) {
+        double w = wv[i], cc = ((double)(j0 + i) + 0.5) * dbin;
+        r0 += w; r1 += w * cc; r2 += w * cc * cc;
+        P0[j0 + i + 1] = r0; P1[j0 + i + 1] = r1; P2[j0 + i + 1] = r2;
+      }
+    } else {
+      double a0 = r0, a1 = r1, a2 = r2;
+      for (int j = j0; j < j1; j++) { double w = cnt[j], cc = ((double)j + 0.5) * dbin; a1 += w * cc; a2 += w * cc * cc; P1[j + 1] = a1; P2[j + 1] = a2; }
+      a0 = r0; for (int j = j0; j < j1; j++) a0 += cnt[j];
+      for (int j = j1 - 1; j >= j0; j--) { double w = cnt[j]; P0[j + 1] = a0; a0 -= w; }
+    }
+    if (sl == 0) { P1[0] = 0.; P2[0] = 0.; }
+    wave_sync();
+    if (sl == 0) P0[0] = 0.;
+    wave_sync();
+  }
+  const double neff_k = (tot * tot) / sum2;
+  const double stdc = (hi - lo) * (sqrt(((double)B * (double)B - 1.) / 12.) / (double)B);
+  const double bw = kde_bandwidth_factor(L.bw_method, L.bw_scalar, neff_k, 1) * stdc;
+  const bool degenerate = !(dbin > 0.) || !(bw > 0.) || !(bw < 1e300) || !(tot > 0. || tot < 0.);
+  EpanCtx cx;
+  cx.P0 = P0; cx.P1 = P1; cx.P2 = P2; cx.N = B; cx.lo = lo; cx.inv_dbin = 1. / dbin; cx.bw = bw; cx.inv_bw = 1. / bw;
+  cx.scale = 0.75 * cx.inv_bw / tot;
+
+  const size_t zo = ((size_t)b * L.E + e) * Z;
+  const double* bkgA = L.bkgA + zo;
+  const double* Aw = L.Aw + zo;
+  const double* eg = L.effg + ((size_t)b * L.E + e) * G;
+  const double gwp = L.gw_pdf[(size_t)e * L.P + pp];
+  const double fR = P.fR;
+  const double inv_de = (double)(G - 1) / (ub - lb);
+  const double nan = __builtin_nan("");
+  double acc = 0.;
+  if (dump && live) { for (int k = sl; k < Z; k += SW) if (k < k_lo || k > k_hi) dump[k] = 0.; }
+#pragma unroll 1
+  for (int it = 0; k_lo + 2 * SW * it <= k_hi; it++) {      // one pass = SW lanes x 2 consecutive grid points per pixel
+    const int k = k_lo + 2 * SW * it + 2 * sl;
+    double pc0, pc1;
+    if (it < PF) {
+      pc0 = pf0[0]; pc1 = pf1[0];
+#pragma unroll
+      for (int i = 1; i < PF; i++) if (it == i) { pc0 = pf0[i]; pc1 = pf1[i]; }
+    } else {
+      pc0 = (live && k <= k_hi) ? pc[k] : 0.; pc1 = (live && k + 1 <= k_hi) ? pc[k + 1] : 0.;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int kk = k + h;
+      if (kk <= k_hi && live) {
+        const double zk = zg[kk];
+        double pgw = 0.;
+        if (zk >= lb && zk <= ub) {                         // jnp.interp(..., left=0, right=0)
+          double tp = floor((zk - lb) * inv_de);
+          tp = tp < (double)(G - 2) ? tp : (double)(G - 2);
+          const int i1 = (int)tp + 1;
+          double xa = eg[i1 - 1], xb = eg[i1];
+          double da = epan_node(cx, xa), db = epan_node(cx, xb);
+          double f = da + ((zk - xa) * inv_de) * (db - da);
+          pgw = degenerate ? nan : f * norm * gwp;          // kde_interp * norm * gw_pdf[i]    likelihood.py:194
+        } else if (zk != zk) pgw = nan;
+        if (dump) dump[kk] = pgw;
+        const double pcv = h == 0 ? pc0 : pc1;
+        if (pcv != -100.) acc += pgw * (fR * pcv + bkgA[kk]) * Aw[kk];
+      }
+    }
+  }
+  acc = sg_sum<SW>(acc);
+  if (sl == 0 && live) *out_like = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // k_kde1d: p_gw1d (likelihood.py:105-144): one block (256 threads) per (event, draw) -> pgw1d (nb,E,Z)
 // ------------------------------------------------------------------------------------------------------
 // Dynamic LDS: data[N], wgt[N], hw[3*N] (per-wave private histograms / prefix arrays), eff[G], dens[G]
