@@ -300,7 +300,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
 static void like_free_ws(chm_like* h) {
   LikeDev& L = h->L;
   (void)hipFree(L.ws_z); (void)hipFree(L.ws_w); (void)hipFree(L.part); (void)hipFree(L.jac); (void)hipFree(L.prate); (void)hipFree(L.bkgA);
-  (void)hipFree(L.pgw1d); (void)hipFree(L.like_pix); (void)hipFree(L.p_gw_dump); (void)hipFree(L.Aw); (void)hipFree(L.evstat); (void)hipFree(L.effg);
+  (void)hipFree(L.pgw1d); (void)hipFree(L.like_pix); (void)hipFree(L.p_gw_dump); (void)hipFree(L.Aw); (void)hipFree(L.evstat); (void)hipFree(L.effg); (void)hipFree(L.krange); L.krange = nullptr;
   L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.pgw1d = L.like_pix = L.p_gw_dump = L.Aw = L.evstat = L.effg = nullptr;
   h->nb_ws = 0; h->ws_dump = false;
 }
@@ -330,7 +330,11 @@ static int like_ensure_ws(chm_like* h, int nb, bool dump) {
   HIPCHK(hipMalloc(&L.jac, sizeof(double) * n * E * Z));
   HIPCHK(hipMalloc(&L.prate, sizeof(double) * n * E * Z));
   HIPCHK(hipMalloc(&L.bkgA, sizeof(double) * n * E * Z));
-  if (L.mode == CHM_MODE_1D || L.mode == CHM_MODE_APPROX) HIPCHK(hipMalloc(&L.pgw1d, sizeof(double) * n * E * Z));
+  if (L.mode == CHM_MODE_1D || L.mode == CHM_MODE_APPROX) {
+    HIPCHK(hipMalloc(&L.pgw1d, sizeof(double) * n * E * Z));
+    HIPCHK(hipMalloc(&L.Aw, sizeof(double) * n * E * Z));
+    HIPCHK(hipMalloc(&L.krange, sizeof(int) * n * E * 2));
+  }
   if (L.mode == CHM_MODE_MARG) { HIPCHK(hipMalloc(&L.Aw, sizeof(double) * n * E * Z)); HIPCHK(hipMalloc(&L.evstat, sizeof(double) * n * E * NEVSTAT));
                                  HIPCHK(hipMalloc(&L.effg, sizeof(double) * n * E * L.G)); }
   HIPCHK(hipMalloc(&L.like_pix, sizeof(double) * n * E * Pd));

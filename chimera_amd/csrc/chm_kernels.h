@@ -41,6 +41,7 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   double *Aw;                     // (nb,E,Z)  prate/jac * trapezoid weight (marginalized)
   double *evstat;                 // (nb,E,8)  per-event statistics (k_event_prep)
   double *effg;                   // (nb,E,G)  per-event effective grid (k_event_prep)
+  int *krange;                    // (nb,E,2)  first / last grid point with p_gw1d != 0 (k_kde1d; 1d / approximate)
   double *pgw1d;                  // (nb,E,Z)   1d / approximate
   double *like_pix;               // (nb,E,max(P,1))
   double *p_gw_dump;              // optional (nb,E,P,Z) or NULL
@@ -1141,7 +1142,8 @@ __global__ void __launch_bounds__(256) k_kde1d(LikeDev L, const DevParams* param
   double* out = L.pgw1d + ((size_t)b * L.E + e) * Z;
   const EvStats st = combine_stats(L.part + ((size_t)b * L.E + e) * L.NC * NPART, L.NC, S);
   const bool ok = st.n_eff >= L.pe_neff;                    // likelihood.py:133
-  if (!ok) { for (int k = t; k < Z; k += nt) out[k] = 0.; return; }
+  int* kr = L.krange + ((size_t)b * L.E + e) * 2;
+  if (!ok) { for (int k = t; k < Z; k += nt) out[k] = 0.; if (t == 0) { kr[0] = 0; kr[1] = -1; } return; }
   const double lo = st.zmin, hi = st.zmax;
   if (L.binning) {
     // per-wave private histograms (deterministic: each wave owns every 4th chunk of 64 samples), then a fixed-order sum
@@ -1195,10 +1197,15 @@ __global__ void __launch_bounds__(256) k_kde1d(LikeDev L, const DevParams* param
   }
   __syncthreads();
   // kde*norm interpolated to the event grid, left = right = 0 (likelihood.py:137)
+  double kmn = 1e300, kmx = -1.;
   for (int k = t; k < Z; k += nt) {
     double zk = L.z_grids[(size_t)e * Z + k];
-    out[k] = interp_lr0(eff, dens, G, zk, eff_guess(zk, lb, ub, G, L.has_cut, k));
+    double v = interp_lr0(eff, dens, G, zk, eff_guess(zk, lb, ub, G, L.has_cut, k));
+    out[k] = v;
+    if (v != 0.) { kmn = fmin(kmn, (double)k); kmx = fmax(kmx, (double)k); }     // NaN counts as non-zero
   }
+  kmn = block_reduce<RED_MIN>(kmn, red); kmx = block_reduce<RED_MAX>(kmx, red);
+  if (t == 0) { kr[0] = kmx >= 0. ? (int)kmn : 0; kr[1] = (int)kmx; }
 }
 
 // k_integrate_1d: one wave per (event, pixel, draw): p_gw3dapprox (likelihood.py:150-154) or the 1-D case,
@@ -1220,10 +1227,27 @@ __global__ void __launch_bounds__(64) k_integrate_1d(LikeDev L, const DevParams*
   const double gwp = pixelated ? L.gw_pdf[(size_t)e * L.P + p] : 1.;
   const size_t zo = ((size_t)b * L.E + e) * Z;
   const double* g1 = L.pgw1d + zo;
-  auto pgw_at = [&](int k, double zk) -> double { return pixelated ? g1[k] * gwp : g1[k]; };
-  double r = wave_integrate(pgw_at, L.z_grids + (size_t)e * Z, L.jac + zo, L.prate + zo, L.bkgA + zo,
-                            pixelated ? L.p_cat + ((size_t)e * L.P + p) * Z : nullptr, P.fR, Z, dump);
-  if (lane == 0) *out_like = r;
+  // p_gw1d vanishes outside [k_lo, k_hi] (found by k_kde1d): those terms of the trapezoid are exact zeros and are skipped;
+  // inside, sum_k p_gw3d[k] p_z[k]/jac[k] tw[k] with the per-z factors folded into A[k] (see k_kde_marg)
+  const int* kr = L.krange + ((size_t)b * L.E + e) * 2;
+  const int k_lo = kr[0], k_hi = kr[1];
+  const double* bkgA = L.bkgA + zo;
+  const double* Aw = L.Aw + zo;
+  const double* pc = pixelated ? L.p_cat + ((size_t)e * L.P + p) * Z : nullptr;
+  const double fR = P.fR;
+  if (dump) for (int k = lane; k < Z; k += 64) dump[k] = (k >= k_lo && k <= k_hi) ? g1[k] * gwp : 0.;
+  double acc = 0.;
+  for (int k = k_lo + lane; k <= k_hi; k += 64) {
+    double pgw = pixelated ? g1[k] * gwp : g1[k];            // p_gw1d[:,None,:] * gw_loc2d_pdf[:,:,None]   likelihood.py:153
+    if (pixelated) {
+      double pcv = pc[k];
+      if (pcv != -100.) acc += pgw * (fR * pcv + bkgA[k]) * Aw[k];      // catalog.py:202, pop_wrapper.py:87, likelihood.py:275
+    } else {
+      acc += pgw * bkgA[k] * Aw[k];                          // pop_wrapper.py:89, likelihood.py:291
+    }
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) *out_like = acc;
 }
 
 // ------------------------------------------------------------------------------------------------------
