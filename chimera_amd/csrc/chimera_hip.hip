@@ -249,7 +249,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
   if (L.mode != CHM_MODE_FULL && L.G < 2) { chm_like_destroy(h); return fail(CHM_E_ARG, "chm_like_create: Z//2 must be >= 2 when cut_grid is set"); }
 #define UP(field, src, n) do { rc = upload(h->owned, (src) ? (src) + (size_t)e0 * (n) : (src), (size_t)E * (n), &L.field, s); if (rc) { chm_like_destroy(h); return rc; } } while (0)
   std::vector<double> tmp;                                   // must outlive the async copies below
-  std::vector<std::vector<double>> sorted;
+  std::vector<std::vector<double>> sorted, logs;
   std::vector<int> seg;
   if (d->mode == CHM_MODE_MARG) {
     // marginalized: store every event's samples sorted by pixel, so that each (event, pixel) wave reads one contiguous
@@ -269,13 +269,19 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
     }
     const double** dst[4] = { &L.dL, &L.m1det, &L.m2det, &L.pe_prior };
     for (int a = 0; a < 4; a++) { rc = upload(h->owned, (const double*)sorted[a].data(), E * S, dst[a], s); if (rc) { chm_like_destroy(h); return rc; } }
+    logs.assign(2, std::vector<double>(E * S));
+    for (size_t k = 0; k < E * S; k++) { logs[0][k] = std::log(sorted[1][k]); logs[1][k] = std::log(sorted[2][k]); }
     rc = upload(h->owned, (const int*)seg.data(), E * (P + 1), &L.seg_off, s); if (rc) { chm_like_destroy(h); return rc; }
   } else {
     UP(dL, d->dL, S); UP(m1det, d->m1det, S); UP(m2det, d->m2det, S);
     tmp.resize(E * S);
     for (size_t k = 0; k < E * S; k++) tmp[k] = 1. / d->pe_prior[(size_t)e0 * S + k];          // the device keeps 1/pe_prior
     rc = upload(h->owned, (const double*)tmp.data(), E * S, &L.pe_prior, s); if (rc) { chm_like_destroy(h); return rc; }
+    logs.assign(2, std::vector<double>(E * S));
+    for (size_t k = 0; k < E * S; k++) { logs[0][k] = std::log(d->m1det[(size_t)e0 * S + k]); logs[1][k] = std::log(d->m2det[(size_t)e0 * S + k]); }
   }
+  rc = upload(h->owned, (const double*)logs[0].data(), E * S, &L.lm1det, s); if (rc) { chm_like_destroy(h); return rc; }
+  rc = upload(h->owned, (const double*)logs[1].data(), E * S, &L.lm2det, s); if (rc) { chm_like_destroy(h); return rc; }
   if (d->mode == CHM_MODE_FULL) { UP(ra, d->ra, S); UP(dec, d->dec, S); }
   UP(z_grids, d->z_grids, Z);
   // step fractions of jnp.linspace (i/div), shared by every event: bin edges (math.py:37) and effective grid (likelihood.py:188)
@@ -462,7 +468,7 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
       LikeDev L = like->L;
       if (!want_dump) L.p_gw_dump = nullptr;
       const int eb = (int)((long long)L0.E * g / ngroups), ee = (int)((long long)L0.E * (g + 1) / ngroups);
-      L.e_off = eb; L.E_cnt = ee - eb;
+      L.e_off = eb; L.E_cnt = ee - eb; L.nb = nb;
       // per-z factors of the group's events: on the other lane, concurrently with the sample stage
       hipStream_t sz = serial ? sg : ((g & 1) ? sA : sB);
       if (tab_zfac) { allow_lds(k_zfactors<true>, lds_zfac);
@@ -473,7 +479,7 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
       // sample stage
       HIPCHK(hipEventRecord(c.evg[4 * g], sg));
       const int nchunk = L.E_cnt * L.NC;
-      dim3 g1(nchunk < 1024 ? nchunk : 1024, nb);
+      dim3 g1((nchunk < 1024 ? nchunk : 1024) * nb, 1);
       const bool fullm = L.mode == CHM_MODE_FULL;
       if (tab_samp) {
         if (fullm) { allow_lds(k_samples<true, true>, lds_samp);
@@ -497,8 +503,8 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
         HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         const bool fast = L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC");
         static const int sub = getenv("CHM_MARG_SUB") ? atoi(getenv("CHM_MARG_SUB")) : 32;     // lanes per pixel in the fast kernel
-        if (fast && sub == 32) hipLaunchKernelGGL(k_kde_marg_sub<32>, dim3(L.E_cnt * ((Pd + 1) / 2), nb), dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
-        else if (fast && sub == 16) hipLaunchKernelGGL(k_kde_marg_sub<16>, dim3(L.E_cnt * ((Pd + 3) / 4), nb), dim3(64), sizeof(double) * (3 * N + 3) * 4, sg, L, dp);
+        if (fast && sub == 32) hipLaunchKernelGGL(k_kde_marg_sub<32>, dim3(L.E_cnt * ((Pd + 1) / 2) * nb, 1), dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
+        else if (fast && sub == 16) hipLaunchKernelGGL(k_kde_marg_sub<16>, dim3(L.E_cnt * ((Pd + 3) / 4) * nb, 1), dim3(64), sizeof(double) * (3 * N + 3) * 4, sg, L, dp);
         else if (fast) hipLaunchKernelGGL(k_kde_marg_fast, dim3(L.E_cnt * ((Pd + MARG_WPB - 1) / MARG_WPB), nb), dim3(64 * MARG_WPB),
                                      sizeof(double) * (3 * N + 3) * MARG_WPB, sg, L, dp);
         else { allow_lds(k_kde_marg, lds_kde); hipLaunchKernelGGL(k_kde_marg, dim3(L.E_cnt * Pd, nb), dim3(64), lds_kde, sg, L, dp); }

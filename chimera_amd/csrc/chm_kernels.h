@@ -27,9 +27,12 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   int E, S, Z, P;
   int mode, kernel, bw_method, binning, num_bins, G, has_cut, NC;
   int e_off, E_cnt;               // event group handled by this launch: events [e_off, e_off + E_cnt)
+  int nb, pad2;                   // draws in this call (hot kernels fold the draw into blockIdx.x, draw fastest, so that the
+                                  // blocks working on the same samples / p_cat rows for different draws run together and share L2)
   int dbg, pad1;                  // CHM_DEBUG_SKIP ablation bits (timing experiments only; results are wrong when set)
   double bw_scalar, cut_grid, pe_neff;
   const double *dL, *m1det, *m2det, *pe_prior, *ra, *dec;
+  const double *lm1det, *lm2det;  // log(m1det), log(m2det), formed once at upload: log(m_src) = log(m_det) - log(1+z)
   const int* seg_off;             // (E,P+1) marginalized: pixel segments of the pixel-sorted samples
   const double *z_grids, *p_cat, *P_compl, *gw_pdf, *ra_pix, *dec_pix;
   const int* neff_pixels;
@@ -283,7 +286,7 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
                                                   int TcMax, int TmMax) {
   extern __shared__ double lds[];
   __shared__ double red[4 * 16];
-  const int b = blockIdx.y, t = threadIdx.x;
+  const int b = blockIdx.x % L.nb, bx = blockIdx.x / L.nb, nbx = gridDim.x / L.nb, t = threadIdx.x;
   const DevParams& P = params[b];
   TablePtrs g = { zt_all + (size_t)b * TcMax, It_all + (size_t)b * TcMax, dLt_all + (size_t)b * TcMax,
                   mg_all + (size_t)b * TmMax, cdf_all + (size_t)b * TmMax };
@@ -291,7 +294,7 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
   const int S = L.S;
   const int nchunk = L.E_cnt * L.NC;
   const bool vec2 = ((S & 1) == 0);
-  for (int ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
+  for (int ch = bx; ch < nchunk; ch += nbx) {
     const int e = L.e_off + ch / L.NC, c = ch % L.NC;
     const size_t so = ((size_t)b * L.E + e) * S;
     const size_t eo = (size_t)e * S;
@@ -306,17 +309,20 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
     // 256 threads x 2 consecutive samples (16 B per lane per array) per pass
 #pragma unroll 1
     for (int s = c * SAMPLE_CHUNK + 2 * t; s < s_end; s += 512) {
-      double dl[2], md1[2], md2[2], ipr[2];
+      double dl[2], md1[2], md2[2], ipr[2], l1[2], l2[2];
       if (vec2) {                                 // s even, S even -> s + 1 < s_end and 16-byte aligned
         double2 a = *reinterpret_cast<const double2*>(L.dL + eo + s), bb = *reinterpret_cast<const double2*>(L.m1det + eo + s);
         double2 cc = *reinterpret_cast<const double2*>(L.m2det + eo + s), dd = *reinterpret_cast<const double2*>(L.pe_prior + eo + s);
+        double2 ee = *reinterpret_cast<const double2*>(L.lm1det + eo + s), ff = *reinterpret_cast<const double2*>(L.lm2det + eo + s);
         dl[0] = a.x; dl[1] = a.y; md1[0] = bb.x; md1[1] = bb.y; md2[0] = cc.x; md2[1] = cc.y; ipr[0] = dd.x; ipr[1] = dd.y;
+        l1[0] = ee.x; l1[1] = ee.y; l2[0] = ff.x; l2[1] = ff.y;
       } else {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
           const bool in = s + h < s_end;
           dl[h] = in ? L.dL[eo + s + h] : 1.; md1[h] = in ? L.m1det[eo + s + h] : 1.;
           md2[h] = in ? L.m2det[eo + s + h] : 1.; ipr[h] = in ? L.pe_prior[eo + s + h] : 1.;
+          l1[h] = in ? L.lm1det[eo + s + h] : 0.; l2[h] = in ? L.lm2det[eo + s + h] : 0.;
         }
       }
       double zz[2], wv[2];
@@ -326,9 +332,11 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
       for (int h = 0; h < 2; h++) {
         // m_src = m_det/(1+z) (pop_wrapper.py:70); w = p_m1m2 / pe_prior (pop_wrapper.py:79; the device array holds 1/pe_prior)
         double z = zz[h];
-        double r = 1. / (1. + z);
+        double zp1 = 1. + z;
+        double r = 1. / zp1;
         double m1 = md1[h] * r, m2 = md2[h] * r;
-        double w = ((L.dbg & 32) ? m1 * m2 : p_m1m2(P, m1, m2, T.mg, T.cdf)) * ipr[h];
+        double lz = log(zp1);                                 // log(m_src) = log(m_det) - log(1+z): one log for both masses
+        double w = ((L.dbg & 32) ? m1 * m2 : p_m1m2_l(P, m1, m2, l1[h] - lz, l2[h] - lz, T.mg, T.cdf)) * ipr[h];
         wv[h] = w;
         if (s + h < s_end) {
           double d = z - z_ref;
@@ -973,7 +981,8 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   constexpr int PF = 4;                                     // prefetch passes: PF * SW * 2 grid points per pixel
   const int lane = threadIdx.x, sub = lane / SW, sl = lane % SW;
   const int PG = (L.P + NPW - 1) / NPW;
-  const int p = (blockIdx.x % PG) * NPW + sub, e = L.e_off + blockIdx.x / PG, b = blockIdx.y;
+  const int b = blockIdx.x % L.nb, bx = blockIdx.x / L.nb;
+  const int p = (bx % PG) * NPW + sub, e = L.e_off + bx / PG;
   const DevParams& P = params[b];
   const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
   double* P0 = lds_all + (size_t)sub * (3 * B + 3); double* P1 = P0 + (B + 1); double* P2 = P1 + (B + 1);

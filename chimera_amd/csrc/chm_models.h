@@ -299,12 +299,15 @@ DEVFN double interp_mgrid(const DevParams& p, double m1, double lm1, A1 mg, A2 c
 
 // mass.py:334-341
 template <class A1, class A2>
-DEVFN double p_m1m2(const DevParams& p, double m1, double m2, A1 mg, A2 cdf) {
-  double lm1 = log(m1), lm2 = log(m2);
+DEVFN double p_m1m2_l(const DevParams& p, double m1, double m2, double lm1, double lm2, A1 mg, A2 cdf) {
   double p_m1 = primary_notnorm_l(p, m1, lm1) * p.inv_norm_p_m1;
   double p_m2m1 = secondary_notnorm_l(p, m2, lm2, m1) / interp_mgrid(p, m1, lm1, mg, cdf);
   if (p_m2m1 != p_m2m1) p_m2m1 = 0.;
   return p_m1 * p_m2m1;
+}
+template <class A1, class A2>
+DEVFN double p_m1m2(const DevParams& p, double m1, double m2, A1 mg, A2 cdf) {
+  return p_m1m2_l(p, m1, m2, log(m1), log(m2), mg, cdf);
 }
 
 // ------------------------------------------------------------------------------------------------------
