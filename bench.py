@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np
 
+KERNEL_NAMES = {'marginalized': 'k_kde_marg_sub<32>', 'full': 'k_full_kde'}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
 
 
@@ -151,7 +152,7 @@ def main():
     try:
       with open(tf) as f:
         tj = json.load(f)
-      if tj.get('E') == (like._e1 - like._e0) and tj.get('kernel') == 'k_kde_marg_fast':
+      if tj.get('E') == (like._e1 - like._e0) and tj.get('kernel') == KERNEL_NAMES.get(kind) and cfg['P'] == tj.get('P') and cfg['Z'] == tj.get('Z'):
         traffic = tj['bytes_per_draw'] * nb
     except Exception:
       traffic = None
@@ -175,7 +176,7 @@ def main():
                  "parallelism": f"events+injections sharded over {world} GPU(s)",
                  "cells_per_s": value * E * max(P, 1) * Z},
       "single_call_ms": single_ms,
-      "roofline": {"bound": "hbm", "kernel": {"marginalized": "k_kde_marg_fast", "full": "k_full_kde"}.get(kind, "k_kde1d+k_integrate_1d"),
+      "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES.get(kind, "k_kde1d+k_integrate_1d"),
                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                    "traffic": traffic, "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
                    "bytes_per_launch": kb, "kernel_ms": kde_ms,

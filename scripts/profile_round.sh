@@ -28,17 +28,18 @@ for f in glob.glob('$OUT/pmc_*/*/*counter_collection.csv'):
 json.dump(out, open('$OUT/pmc_per_launch.json', 'w'), indent=1, sort_keys=True)
 b = json.loads(open('$OUT/bench.json').read().strip().split('\n')[-1])
 nb = b['config']['nbatch']
-k = out.get('k_kde_marg_fast', {})
+KN = 'k_kde_marg_sub<32>'
+k = out.get(KN, {})
 if 'FETCH_SIZE' in k and 'WRITE_SIZE' in k:
     # gfx950: FETCH_SIZE counts 64 B per 128-B request of wide (16 B/lane) streaming reads -> doubled (MI355X_MICROARCH.md, HBM);
     # the kernel also issues 8 B/lane reads, for which the counter is uncalibrated: the doubled figure is an upper estimate.
     per_launch = (2 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024
-    json.dump({'kernel': 'k_kde_marg_fast', 'E': b['config']['E'], 'nbatch': nb, 'FETCH_SIZE_KB_per_launch': k['FETCH_SIZE'],
+    json.dump({'kernel': KN, 'E': b['config']['E'], 'P': b['config']['P'], 'Z': b['config']['Z'], 'nbatch': nb, 'FETCH_SIZE_KB_per_launch': k['FETCH_SIZE'],
                'WRITE_SIZE_KB_per_launch': k['WRITE_SIZE'], 'bytes_per_launch': per_launch, 'bytes_per_draw': per_launch / nb,
                'note': 'bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: FETCH_SIZE doubled per the gfx950 correction for wide coalesced reads'},
               open('$OUT/pmc_traffic.json', 'w'), indent=1)
 print(open('$OUT/kernel_stats.csv').read()[:3000])
-print(json.dumps(out.get('k_kde_marg_fast', {})), json.dumps(out.get('k_samples<true, false>', {})))
+print(json.dumps(out.get(KN, {})), json.dumps(out.get('k_samples<true, false>', {})))
 PY
 rm -rf $OUT/trace $OUT/pmc_*/ 2>/dev/null
 ls -la $OUT
