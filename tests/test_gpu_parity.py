@@ -291,3 +291,41 @@ def test_precompute_p_cat_matches_oracle():
       assert gc.N_gal[e] == ngal
     assert gc.P_compl.shape == (cfg['E'], 1, 96) and gc.max_npixels == cfg['P']
     np.testing.assert_array_equal(gc.neff_pixels, ev['neff_pixels'])
+
+
+# ----------------------------------------------------------------------------------------------------------
+# ragged / odd shapes: odd S and Z (scalar load paths), a single pixel, an odd pixel count (half-empty wave), many bins per
+# lane, very few bins, a single event, more than one sample chunk per event
+# ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('shape', [dict(E=3, S=101, P=5, Z=51), dict(E=1, S=64, P=1, Z=33), dict(E=4, S=2100, P=3, Z=40),
+                                   dict(E=2, S=300, P=7, Z=64)])
+@pytest.mark.parametrize('like_kw', [dict(), dict(num_bins=1100), dict(num_bins=3)])
+def test_odd_shapes(shape, like_kw):
+  cfg, ev, inj = H.small_config(I=999, seed=17, ragged=True, **shape)
+  for kind in ('marginalized', 'approximate', 'full'):
+    if kind == 'full' and like_kw:
+      continue
+    like_o, _, _ = H.build_oracle(ev, inj, kind=kind, like_kw=like_kw)
+    like_p, _, _ = H.build_product(ev, inj, kind=kind, like_kw=like_kw)
+    ro, rp = like_o.compute_all(H0=71.), like_p.compute_all(H0=71.)
+    H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
+    if np.isfinite(ro[3]):
+      np.testing.assert_allclose(rp[3], ro[3], rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
+
+
+def test_degenerate_pixels_give_minus_infinity_class(cfg_pix):
+  """A pixel whose samples all have zero weight (or that holds no sample) makes the reference's KDE 0/0 = NaN, hence the
+  event's likelihood NaN -> log-likelihood -inf (likelihood.py:180-192, 296-297).  Same on the GPU."""
+  cfg, ev, inj = cfg_pix
+  ev2 = dict(ev)
+  pe = ev['pixels_pe_opt_nside'].copy()
+  e = 1
+  victim = ev['pixels_opt_nsides'][e, 0]
+  pe[e][pe[e] == victim] = 7                     # nobody lives in pixel 0 of event 1 any more
+  ev2['pixels_pe_opt_nside'] = pe
+  like_o, _, _ = H.build_oracle(ev2, inj)
+  like_p, _, _ = H.build_product(ev2, inj)
+  ro, rp = like_o.compute_all(H0=70.), like_p.compute_all(H0=70.)
+  assert ro[0][e] == -np.inf and rp[0][e] == -np.inf
+  H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
+  assert rp[3] == -np.inf and ro[3] == -np.inf
