@@ -238,18 +238,43 @@ class hyperlikelihood(object):
       pop = self.population
       self._slots = param_slots(pop.cosmo, pop.mass, pop.rate)
       self._base_params = pop.to_params()
+      self._params_dtype = np.dtype(_lib.chm_params)
+      self._base_view = np.frombuffer(self._base_params, dtype=self._params_dtype).copy()
     nb = len(list_of_hyper_lambdas)
     arr = (_lib.chm_params * nb)()
-    sz = C.sizeof(_lib.chm_params)
-    for b, lam in enumerate(list_of_hyper_lambdas):
-      C.memmove(C.byref(arr, b * sz), C.byref(self._base_params), sz)
-      p = arr[b]
-      for k, v in lam.items():
-        for field, idx, is_int in self._slots.get(k, ()):
-          if idx is None:
-            setattr(p, field, int(v) if is_int else float(v))
-          else:
-            getattr(p, field)[idx] = float(v)
+    if nb < 8:                                                 # few draws: patch ctypes structs directly
+      sz = C.sizeof(_lib.chm_params)
+      for b, lam in enumerate(list_of_hyper_lambdas):
+        C.memmove(C.byref(arr, b * sz), C.byref(self._base_params), sz)
+        p = arr[b]
+        for k, v in lam.items():
+          for field, idx, is_int in self._slots.get(k, ()):
+            if idx is None:
+              setattr(p, field, int(v) if is_int else float(v))
+            else:
+              getattr(p, field)[idx] = float(v)
+      return arr
+    view = np.frombuffer(arr, dtype=self._params_dtype)
+    view[:] = self._base_view                                  # every draw starts from the base population
+    keys = list_of_hyper_lambdas[0].keys()
+    if all(lam.keys() == keys for lam in list_of_hyper_lambdas):
+      for k in keys:                                           # one vectorised store per hyper-parameter name
+        slots = self._slots.get(k, ())
+        if slots:
+          vals = [lam[k] for lam in list_of_hyper_lambdas]
+          for field, idx, is_int in slots:
+            if idx is None:
+              view[field] = vals
+            else:
+              view[field][:, idx] = vals
+    else:
+      for b, lam in enumerate(list_of_hyper_lambdas):
+        for k, v in lam.items():
+          for field, idx, is_int in self._slots.get(k, ()):
+            if idx is None:
+              view[field][b] = v
+            else:
+              view[field][b, idx] = v
     return arr
 
   def batch(self, list_of_hyper_lambdas):

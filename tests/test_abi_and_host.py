@@ -193,6 +193,15 @@ def test_fast_parameter_patching_equals_update():
     a = like._params_array([lam, {}])
     assert bytes(a[0]) == bytes(like.population.update(**lam).to_params())
     assert bytes(a[1]) == bytes(like.population.to_params())
+    # >= 8 draws take the vectorised path: homogeneous and heterogeneous key sets
+    lams = [dict(lam, H0=60. + i, R0=1. + i, z_grid_res=1500 + i) for i in range(11)]
+    a = like._params_array(lams)
+    for i, l in enumerate(lams):
+      assert bytes(a[i]) == bytes(like.population.update(**l).to_params())
+    het = [dict(H0=61.), dict(gamma=2.), dict(), dict(R0=3., H0=70.)] * 3
+    a = like._params_array(het)
+    for i, l in enumerate(het):
+      assert bytes(a[i]) == bytes(like.population.update(**l).to_params())
 
 
 def test_event_pixel_galaxy_selection():
