@@ -35,6 +35,18 @@ def _pix_of_sample(pe_pix, pixels):
   return out
 
 
+def _vector_length(hyper_lambdas):
+  """None for scalar hyper-parameters, else the common length of the array-valued ones."""
+  n = None
+  for k, v in hyper_lambdas.items():
+    if np.ndim(v) > 0:
+      m = np.asarray(v).size
+      if n is not None and m != n:
+        raise ValueError(f"hyper-parameter arrays must have the same length (got {n} and {m} for '{k}')")
+      n = m
+  return n
+
+
 class hyperlikelihood(object):
   def __init__(self, theta_gw_det, z_grids, population, selection_function=None, kind_p_gw3d=None, kernel='epan',
                bw_method=None, cut_grid=2.0, binning=True, num_bins=200, pe_neff=2.0, comm=None, device=None):
@@ -215,8 +227,13 @@ class hyperlikelihood(object):
 
   # -- reference surface: hyper-likelihood -------------------------------------------------------------
   def compute_log_hyperlike(self, **hyper_lambdas):
-    """likelihood.py:307-316."""
-    return self._eval(self._params_array([hyper_lambdas]))['log_hyper'][0]
+    """likelihood.py:307-316.  Array-valued hyper-parameters (the vectorised dict of the reference's sampler glue,
+    CHIMERA/utils/emcee_utils.py:54-64) evaluate every draw in one launch sequence and return an array."""
+    n = _vector_length(hyper_lambdas)
+    if n is None:
+      return self._eval(self._params_array([hyper_lambdas]))['log_hyper'][0]
+    lams = [{k: (np.asarray(v).reshape(-1)[i] if np.ndim(v) > 0 else v) for k, v in hyper_lambdas.items()} for i in range(n)]
+    return self._eval(self._params_array(lams))['log_hyper']
 
   def __call__(self, **hyper_lambdas):
     """likelihood.py:318-320."""

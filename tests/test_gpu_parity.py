@@ -329,3 +329,19 @@ def test_degenerate_pixels_give_minus_infinity_class(cfg_pix):
   assert ro[0][e] == -np.inf and rp[0][e] == -np.inf
   H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
   assert rp[3] == -np.inf and ro[3] == -np.inf
+
+
+def test_vectorised_call_and_sampler_glue(cfg_pix):
+  from chimera_amd.utils.emcee_utils import generate_dict, make_log_prob
+  cfg, ev, inj = cfg_pix
+  like, _, _ = H.build_product(ev, inj)
+  H0 = np.array([55., 65., 75.]); al = np.array([3.0, 3.4, 3.8])
+  vec = like(H0=H0, alpha=al, gamma=2.7)
+  one = np.array([like(H0=h, alpha=a, gamma=2.7) for h, a in zip(H0, al)])
+  np.testing.assert_array_equal(vec, one)
+  theta = np.stack([H0, al], axis=1)
+  assert generate_dict(theta, ['H0', 'alpha'])['alpha'].tolist() == al.tolist()
+  lp = make_log_prob(like, ['H0', 'alpha'], priors=[[20., 70.], [1., 5.]])(theta)
+  assert lp[2] == -np.inf and np.all(lp[:2] == np.array([like(H0=h, alpha=a) for h, a in zip(H0[:2], al[:2])]))
+  with pytest.raises(ValueError):
+    like(H0=np.array([60., 70.]), alpha=np.array([3., 3.1, 3.2]))
