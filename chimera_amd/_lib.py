@@ -62,7 +62,7 @@ class chm_out(C.Structure):
 SYMBOLS = ['chm_version', 'chm_device_count', 'chm_last_error', 'chm_like_create', 'chm_like_destroy',
            'chm_sel_create', 'chm_sel_destroy', 'chm_eval', 'chm_model_eval', 'chm_model_tables',
            'chm_comm_unique_id', 'chm_comm_init_rank', 'chm_comm_destroy', 'chm_comm_allreduce_sum',
-           'chm_last_timing', 'chm_pcat_compute']
+           'chm_last_timing', 'chm_pcat_compute', 'chm_kde2d_pixels']
 
 _lib = None
 
@@ -93,6 +93,7 @@ def lib():
   L.chm_comm_allreduce_sum.argtypes = [vp, c_dp, C.c_int32]
   L.chm_last_timing.argtypes = [vp, vp, c_dp]
   L.chm_pcat_compute.argtypes = [C.POINTER(chm_params), C.POINTER(chm_pcat_desc), c_dp]
+  L.chm_kde2d_pixels.argtypes = [C.c_int32, C.c_int32, C.c_int32, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, C.c_int32]
   for name in SYMBOLS:
     if name not in ('chm_version', 'chm_last_error'):
       getattr(L, name).restype = C.c_int

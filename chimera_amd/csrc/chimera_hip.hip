@@ -711,6 +711,38 @@ extern "C" int chm_pcat_compute(const chm_params* cosmo, const chm_pcat_desc* d,
   return CHM_OK;
 }
 
+extern "C" int chm_kde2d_pixels(int32_t E, int32_t S, int32_t P, const double* ra, const double* dec, const double* ra_pix,
+                                const double* dec_pix, const int32_t* npix, double* out, int32_t device) {
+  if (E <= 0 || S <= 1 || P <= 0 || !ra || !dec || !ra_pix || !dec_pix || !npix || !out)
+    return fail(CHM_E_ARG, "chm_kde2d_pixels: need E > 0, S > 1, P > 0 and all arrays");
+  int ndev = chm_device_count();
+  if (device < 0 || device >= ndev) return fail(CHM_E_HIP, "chm_kde2d_pixels: no such HIP device (is a GPU visible?)");
+  HIPCHK(hipSetDevice(device));
+  std::vector<void*> owned;
+  auto cleanup = [&]() { for (void* q : owned) (void)hipFree(q); };
+  const double *d_ra = nullptr, *d_dec = nullptr, *d_rp = nullptr, *d_dp = nullptr; const int* d_np = nullptr;
+#define CKR(x) do { int _r = (x); if (_r) { cleanup(); return _r; } } while (0)
+  CKR(upload(owned, ra, (size_t)E * S, &d_ra, (hipStream_t)0));
+  CKR(upload(owned, dec, (size_t)E * S, &d_dec, (hipStream_t)0));
+  CKR(upload(owned, ra_pix, (size_t)E * P, &d_rp, (hipStream_t)0));
+  CKR(upload(owned, dec_pix, (size_t)E * P, &d_dp, (hipStream_t)0));
+  CKR(upload(owned, (const int*)npix, (size_t)E, &d_np, (hipStream_t)0));
+#undef CKR
+  double* d_out = nullptr;
+  hipError_t he = hipMalloc(&d_out, sizeof(double) * (size_t)E * P);
+  if (he != hipSuccess) { cleanup(); return fail(CHM_E_NOMEM, std::string("chm_kde2d_pixels: ") + hipGetErrorString(he)); }
+  owned.push_back(d_out);
+  he = hipMemcpy(d_out, out, sizeof(double) * (size_t)E * P, hipMemcpyHostToDevice);     // keeps the caller's padding
+  if (he == hipSuccess) {
+    hipLaunchKernelGGL(k_kde2d, dim3(E), dim3(256), 0, (hipStream_t)0, S, P, d_ra, d_dec, d_rp, d_dp, d_np, d_out);
+    he = hipGetLastError();
+  }
+  if (he == hipSuccess) he = hipMemcpy(out, d_out, sizeof(double) * (size_t)E * P, hipMemcpyDeviceToHost);
+  cleanup();
+  if (he != hipSuccess) return fail(CHM_E_HIP, std::string("chm_kde2d_pixels: ") + hipGetErrorString(he));
+  return CHM_OK;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // RCCL communicator (one process per GPU)
 // ------------------------------------------------------------------------------------------------------

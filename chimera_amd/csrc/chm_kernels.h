@@ -1642,6 +1642,50 @@ __global__ void __launch_bounds__(256) k_pcat(PcatDev D, const DevParams* params
 }
 
 // ------------------------------------------------------------------------------------------------------
+// k_kde2d: jax_gkde_nd for d = 2 (math.py:95-148) at the pixel centres of each event; one block per event
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_kde2d(int S, int Pmax, const double* ra, const double* dec, const double* ra_pix,
+                                                const double* dec_pix, const int* npix, double* out) {
+  __shared__ double red[16];
+  __shared__ double wh[8];
+  const int e = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+  const double* x = ra + (size_t)e * S;
+  const double* y = dec + (size_t)e * S;
+  // unweighted: W = 1/S, neff = S, factor = S^(-1/6) (scott, d = 2)                      math.py:115-118
+  const double W = 1. / (double)S;
+  double sx = 0., sy = 0.;
+  for (int s = t; s < S; s += nt) { sx += W * x[s]; sy += W * y[s]; }
+  sx = block_reduce<RED_SUM>(sx, red); sy = block_reduce<RED_SUM>(sy, red);
+  double cxx = 0., cxy = 0., cyy = 0.;
+  for (int s = t; s < S; s += nt) { double rx = x[s] - sx, ry = y[s] - sy; cxx += rx * W * rx; cxy += rx * W * ry; cyy += ry * W * ry; }
+  cxx = block_reduce<RED_SUM>(cxx, red); cxy = block_reduce<RED_SUM>(cxy, red); cyy = block_reduce<RED_SUM>(cyy, red);
+  if (t == 0) {
+    double den = 1. - (double)S * (W * W);                 // 1 - sum(W^2)                      math.py:128
+    cxx /= den; cxy /= den; cyy /= den;
+    double factor = exp(log((double)S) * (-1. / 6.));
+    double det = cxx * cyy - cxy * cxy, f2 = factor * factor;
+    double ixx = cyy / det / f2, ixy = -cxy / det / f2, iyy = cxx / det / f2;      // inv_cov        math.py:129-131
+    double l00 = sqrt(ixx), l10 = ixy / l00, l11 = sqrt(iyy - l10 * l10);           // cholesky       math.py:132
+    wh[0] = l00; wh[1] = l10; wh[2] = l11;
+    wh[3] = (log(l00) + log(l11)) - 0.5 * 2. * log(2. * CHM_PI);                    // log_norm       math.py:135
+  }
+  __syncthreads();
+  const double l00 = wh[0], l10 = wh[1], l11 = wh[2], log_norm = wh[3];
+  const int np_ = npix[e];
+  for (int p = 0; p < np_ && p < Pmax; p++) {
+    const double qx = ra_pix[(size_t)e * Pmax + p], qy = dec_pix[(size_t)e * Pmax + p];
+    const double q0 = qx * l00 + qy * l10, q1 = qy * l11;  // points . L                          math.py:133
+    double acc = 0.;
+    for (int s = t; s < S; s += nt) {
+      double d0 = (x[s] * l00 + y[s] * l10) - q0, d1 = y[s] * l11 - q1;
+      acc += W * exp(log_norm - 0.5 * (d0 * d0 + d1 * d1));                          // math.py:141-146
+    }
+    acc = block_reduce<RED_SUM>(acc, red);
+    if (t == 0) out[(size_t)e * Pmax + p] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // k_model_eval: elementwise model functions for the Python free functions (cosmo.py / mass.py / rate.py)
 // ------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_model_eval(const DevParams* params, TablePtrs g, int func, const double* a, const double* bb,

@@ -75,3 +75,178 @@ def save_npz(fname, obj):
 def load_npz(fname, cls=theta_pe_det):
   with np.load(fname) as d:
     return cls(**{k: d[k] for k in d.files if k in cls._fields})
+
+
+################
+# DATA LOADING #   (reference: CHIMERA/data.py:70-236)
+################
+import ctypes as _C
+from . import _lib
+from .utils import angles
+from .utils.io import save_set, load_set, load_data_h5
+from .utils.config import logger
+
+
+def load_galaxy_catalog(file_path, parameters=['ra_gal', 'dec_gal', 'z_cgal'], units='rad', backend='numpy'):
+  """data.py:70-105."""
+  if units not in ['rad', 'deg']:
+    raise ValueError("units must be either 'rad' or 'deg'")
+  data = load_data_h5(file_path, require_keys=parameters)
+  result = {'ra': data['ra_gal'], 'dec': data['dec_gal'], 'z': data['z_cgal']}
+  if units == 'rad':
+    result['ra'] = np.deg2rad(result['ra'])
+    result['dec'] = np.deg2rad(result['dec'])
+  return result
+
+
+def _process_selection(n, max_n, name):
+  """data.py:218-233."""
+  if n is None:
+    return slice(None)
+  elif isinstance(n, (list, np.ndarray)):
+    return np.asarray(n)
+  elif isinstance(n, (int, np.integer)):
+    if n > max_n:
+      logger.warning(f"Requested more {name} than available. Using all {max_n}.")
+      return slice(None)
+    return np.sort(np.random.choice(max_n, n, replace=False))
+  raise ValueError(f"Invalid selection for {name}: must be None, list or int")
+
+
+def load_gw_pe_samples(file_ev_pe, parameters=['dL', 'm1det', 'm2det', 'phi', 'theta'], group='posteriors', nevents=None,
+                       nsamples=None, return_struct=True):
+  """data.py:107-148."""
+  data = load_data_h5(file_ev_pe, group_h5=group, require_keys=parameters)
+  event_idx = _process_selection(nevents, data['dL'].shape[0], 'events')
+  sample_idx = _process_selection(nsamples, data['dL'].shape[1], 'samples')
+  result = {k: np.asarray(data[k][event_idx][:, sample_idx]) for k in parameters}
+  if {'theta', 'phi'}.issubset(parameters):
+    ra, dec = angles.ra_dec_from_th_phi(result['theta'], result['phi'])
+    result.update(ra=ra, dec=dec)
+  return theta_pe_det(**result) if return_struct else result
+
+
+def load_injection_data(file_inj, snr_cut=None, ninj=None, group=None, key_mapping=None, return_struct=True):
+  """data.py:150-216."""
+  defaults = {'m1s': 'm1src', 'm2s': 'm2src', 'm1d': 'm1det', 'm2d': 'm2det', 'dL': 'dL', 'z': 'z', 'snr': 'SNR_net',
+              'log_pdraw': 'log_p_draw_nospin'}
+  keys = {**defaults, **(key_mapping or {})}
+  data = load_data_h5(file_inj, group_h5=group, require_keys=[keys[k] for k in ['dL', 'snr', 'log_pdraw']])
+  keep = data[keys['snr']] > snr_cut if snr_cut else slice(None)
+  m1d = data[keys['m1d']] if keys['m1d'] in data else data[keys['m1s']] * (1 + data[keys['z']])
+  m2d = data[keys['m2d']] if keys['m2d'] in data else data[keys['m2s']] * (1 + data[keys['z']])
+  assert (m1d[keep] > 0).all() and (m2d[keep] > 0).all(), "Masses must be positive"
+  assert (data[keys['dL']][keep] > 0).all(), "Distances must be positive"
+  assert (m2d[keep] <= m1d[keep]).all(), "Primary mass must be >= secondary mass"
+  inj_data = {'m1det': m1d[keep], 'm2det': m2d[keep], 'dL': data[keys['dL']][keep]}
+  inj_idx = _process_selection(ninj, len(inj_data['m1det']), 'injections')
+  result = {k: np.asarray(v[inj_idx]) for k, v in inj_data.items()}
+  prior = np.exp(data[keys['log_pdraw']][keep][inj_idx])
+  return theta_inj_det(**result, p_draw=prior) if return_struct else (result, prior)
+
+
+################
+# PIXELIZATION #   (reference: CHIMERA/data.py:239-404)
+################
+theta_pe_pixelated_groups = ['pixels_pe_all_nsides']
+
+
+def _get_threshold(norm_counts, level):
+  """data.py:239-244."""
+  prob_sorted = np.sort(norm_counts)[::-1]
+  prob_sorted_cum = np.cumsum(prob_sorted)
+  idx = np.searchsorted(prob_sorted_cum, level)
+  return prob_sorted[idx]
+
+
+def compute_sky_conf_event(healpix_pe, sky_conf, nside):
+  """data.py:246-260: pixels whose sample fraction reaches the sky-confidence threshold."""
+  unique, counts = np.unique(healpix_pe, return_counts=True)
+  p = np.zeros(angles.nside2npix(nside))
+  p[unique] = counts / healpix_pe.shape[0]
+  return np.argwhere(p >= _get_threshold(p, sky_conf)).flatten()
+
+
+def _pad_arr_list(array_list, pad_value):
+  """data.py:406-420 (1-D case)."""
+  max_rows = max(arr.shape[0] for arr in array_list)
+  padded = np.full((len(array_list), max_rows), pad_value, dtype=array_list[0].dtype)
+  for i, arr in enumerate(array_list):
+    padded[i, :arr.shape[0]] = arr
+  return padded
+
+
+def gw_loc2d_pdf_at_pixels(ra, dec, ra_pix, dec_pix, npix, device=None):
+  """2-D Gaussian KDE of each event's (ra, dec) samples at its pixel centres (data.py:343-345) on the GPU."""
+  ra, dec = _lib.as_f64(ra), _lib.as_f64(dec)
+  rp, dp = _lib.as_f64(ra_pix), _lib.as_f64(dec_pix)
+  E, S = ra.shape
+  P = rp.shape[1]
+  n = np.ascontiguousarray(npix, dtype=np.int32)
+  out = np.full((E, P), -100.)
+  dev = _lib.default_device() if device is None else device
+  _lib.check(_lib.lib().chm_kde2d_pixels(E, S, P, _lib.dptr(ra), _lib.dptr(dec), _lib.dptr(rp), _lib.dptr(dp), _lib.iptr(n),
+                                         _lib.dptr(out), dev))
+  return out
+
+
+def pixelize_gw_catalog(theta_gw, nside_list, mean_npixels_event, sky_conf, nest=False, prefix=None, ret_datastruct=True):
+  """data.py:262-392: HEALPix indices of the samples for every nside, per-event optimal nside (number of pixels inside the
+  sky-confidence area closest to ``mean_npixels_event``), the event pixels, their centres, the 2-D localisation density at
+  the centres (GPU) and the pixel of each sample (samples outside the area go to the nearest event pixel)."""
+  num_events = theta_gw.dL.shape[0]
+  ra, dec = np.asarray(theta_gw.ra, dtype=np.float64), np.asarray(theta_gw.dec, dtype=np.float64)
+  pixels_pe_all_nsides = {}
+  for nside in nside_list:
+    logger.info(f"Precomputing Healpix pixels (NSIDE={nside}, NEST={nest})")
+    pixels_pe_all_nsides[f"nside_{nside}"] = angles.find_pix_RAdec(ra, dec, nside, nest)
+  pixel_count_matrix = np.array([[len(compute_sky_conf_event(pixels_pe_all_nsides[f"nside_{nside}"][e], sky_conf, nside))
+                                  for nside in nside_list] for e in range(num_events)])
+  best = np.argmin(np.abs(pixel_count_matrix - mean_npixels_event), axis=1)
+  opt_nsides = np.array(nside_list)[best]
+  event_pixels = [compute_sky_conf_event(pixels_pe_all_nsides[f"nside_{opt_nsides[e]}"][e], sky_conf, opt_nsides[e])
+                  for e in range(num_events)]
+  pixel_ra, pixel_dec = zip(*[angles.find_ra_dec(event_pixels[e], nside=opt_nsides[e]) for e in range(num_events)])
+  pe_samples_pixels = np.zeros(ra.shape, dtype=np.int64)
+  for e in range(num_events):
+    sample_pix = pixels_pe_all_nsides[f"nside_{opt_nsides[e]}"][e]
+    valid = np.isin(sample_pix, event_pixels[e])
+    sep = angles.angular_separation_from_LOS(ra[e][:, None], dec[e][:, None], pixel_ra[e][None, :], pixel_dec[e][None, :])
+    pe_samples_pixels[e] = np.where(valid, sample_pix, event_pixels[e][np.argmin(sep, axis=1)])
+  padded_event_pixels = _pad_arr_list(event_pixels, pad_value=-100)
+  padded_pixel_ra = _pad_arr_list(list(pixel_ra), pad_value=-100.)
+  padded_pixel_dec = _pad_arr_list(list(pixel_dec), pad_value=-100.)
+  npix = np.array([len(p) for p in event_pixels], dtype=np.int32)
+  padded_pixel_probs = gw_loc2d_pdf_at_pixels(ra, dec, padded_pixel_ra, padded_pixel_dec, npix)
+  theta_gw_pixelated = theta_gw.update(pixels_pe_all_nsides=pixels_pe_all_nsides, opt_nsides=opt_nsides,
+                                       pixels_opt_nsides=padded_event_pixels, ra_pix=padded_pixel_ra, dec_pix=padded_pixel_dec,
+                                       gw_loc2d_pdf=padded_pixel_probs, pixels_pe_opt_nside=pe_samples_pixels)
+  if prefix is not None:
+    print_list = "-".join(map(str, nside_list))
+    fname = prefix + f"_pixelated_nsidelist{print_list}_meanpixels{mean_npixels_event}_skyconf{sky_conf}_nest{nest}.npz"
+    save_set(theta_gw_pixelated, fname, datasets=[d for d in theta_pe_pixelated_datasets if getattr(theta_gw_pixelated, d) is not None],
+             groups=theta_pe_pixelated_groups)
+  return theta_gw_pixelated
+
+
+def load_pixelated_gw_catalog(fname):
+  """data.py:395-404."""
+  avail = None
+  if not str(fname).endswith(('.h5', '.hdf5')):
+    with np.load(fname) as f:
+      avail = set(f.files)
+  datasets = [d for d in theta_pe_pixelated_datasets if avail is None or d in avail]
+  return load_set(theta_pe_det(), fname, attrs=[], datasets=datasets, groups=theta_pe_pixelated_groups)
+
+
+def compute_localization_areas(theta, phi, percentile=0.9, unit='deg2'):
+  """data.py:426-451."""
+  thetas, phis = np.atleast_2d(theta), np.atleast_2d(phi)
+  area = np.zeros(thetas.shape[0])
+  for e in range(thetas.shape[0]):
+    th, ph = thetas[e], phis[e]
+    s2t, s2p = np.cov(th, th)[0, 0], np.cov(ph, ph)[0, 0]
+    cov2 = np.cov(th, ph)[0, 1]**2
+    one_sigma = 2 * np.pi * np.abs(np.sin(np.mean(th))) * np.sqrt(s2t * s2p - cov2)
+    area[e] = -np.log(1 - percentile / 100) * one_sigma * (180 / np.pi)**2
+  return area

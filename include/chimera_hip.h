@@ -179,6 +179,12 @@ typedef struct chm_pcat_desc {
 } chm_pcat_desc;
 int chm_pcat_compute(const chm_params* cosmo, const chm_pcat_desc* desc, double* p_cat /* (E,P,Z) */);
 
+/* 2-D sky-localisation density at the pixel centres: jax_gkde_nd((ra, dec) samples, pixel centres) of pixelize_gw_catalog
+ * (CHIMERA/data.py:343-345, CHIMERA/utils/math.py:95-148; unweighted Gaussian KDE, Scott factor, covariance whitening).
+ * ra, dec: (E,S); ra_pix, dec_pix: (E,P) with npix[e] valid entries per event; out: (E,P), entries >= npix[e] untouched.   */
+int chm_kde2d_pixels(int32_t E, int32_t S, int32_t P, const double* ra, const double* dec, const double* ra_pix,
+                     const double* dec_pix, const int32_t* npix, double* out, int32_t device);
+
 /* Event/injection sharding across GPUs: one process per GPU, RCCL over xGMI.
  * Replaces the MPI layer CHIMERA/parallel.py:94-99,68-73,366-376 (dead code in v2.0.0).               */
 int chm_comm_unique_id(char id[128]);                       /* rank 0; broadcast the bytes out-of-band */
