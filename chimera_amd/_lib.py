@@ -17,7 +17,7 @@ NCOSMO, NMASS, NRATE = 8, 8, 4
 
 # function ids of chm_model_eval
 (F_E, F_INT_INVE, F_DCR, F_DCT, F_DL, F_DDLDZ, F_DVCDZ, F_VC, F_XI, F_Z_FROM_DGW, F_RATE, F_PM1M2, F_PRIMARY,
- F_SECONDARY, F_SMOOTHING) = range(15)
+ F_SECONDARY, F_SMOOTHING, F_PM1M2_FUSED) = range(16)
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)

@@ -373,7 +373,11 @@ extern "C" int chm_sel_create(const chm_sel_desc* d, chm_sel** out) {
   std::vector<double> ipd(n);
   for (size_t k = 0; k < n; k++) ipd[k] = 1. / d->p_draw[i0 + k];                                 // the device keeps 1/p_draw
   rc = upload(h->owned, (const double*)ipd.data(), n, &S.p_draw, s); if (rc) { chm_sel_destroy(h); return rc; }
-  long long nblk = (S.I + 255) / 256;
+  std::vector<double> l1(n), l2(n);                                                               // log(m_det), once (alive until the sync below)
+  for (size_t k = 0; k < n; k++) { l1[k] = log(d->m1det[i0 + k]); l2[k] = log(d->m2det[i0 + k]); }
+  rc = upload(h->owned, (const double*)l1.data(), n, &S.lm1det, s); if (rc) { chm_sel_destroy(h); return rc; }
+  rc = upload(h->owned, (const double*)l2.data(), n, &S.lm2det, s); if (rc) { chm_sel_destroy(h); return rc; }
+  long long nblk = (S.I + SEL_TILE - 1) / SEL_TILE;
   S.nblocks = (int)(nblk < 1 ? 1 : (nblk > 2048 ? 2048 : nblk));
   hipError_t he = hipStreamSynchronize(s);
   if (he != hipSuccess) { chm_sel_destroy(h); return fail(CHM_E_HIP, std::string("chm_sel_create: ") + hipGetErrorString(he)); }
@@ -469,13 +473,23 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
       if (!want_dump) L.p_gw_dump = nullptr;
       const int eb = (int)((long long)L0.E * g / ngroups), ee = (int)((long long)L0.E * (g + 1) / ngroups);
       L.e_off = eb; L.E_cnt = ee - eb; L.nb = nb;
-      // per-z factors of the group's events: on the other lane, concurrently with the sample stage
-      hipStream_t sz = serial ? sg : ((g & 1) ? sA : sB);
-      if (tab_zfac) { allow_lds(k_zfactors<true>, lds_zfac);
-        hipLaunchKernelGGL(k_zfactors<true>, dim3(L.E_cnt, nb), dim3(256), lds_zfac, sz, L, dp, c.zt, c.It, Tc);
-      } else hipLaunchKernelGGL(k_zfactors<false>, dim3(L.E_cnt, nb), dim3(256), 0, sz, L, dp, c.zt, c.It, Tc);
-      HIPCHK(hipGetLastError());
-      if (sz != sg) HIPCHK(hipEventRecord(c.evg[32 + g], sz));
+      // per-z factors of the group's events: on the other lane, concurrently with the sample stage -- except in marginalized
+      // mode, where they follow k_event_prep on the group's own lane and cover only the support of each event's KDE
+      const bool zf_ranged = L.mode == CHM_MODE_MARG && !getenv("CHM_ZF_FULL");
+      hipStream_t sz = (serial || zf_ranged) ? sg : ((g & 1) ? sA : sB);
+      // ~2048 blocks in all: each stages the draw's (zt, It) tables in LDS once and walks over E_cnt / gridDim.x events
+      const int zf_target = 2048 / nb > 1 ? 2048 / nb : 1;
+      const int zf_blocks = L.E_cnt < zf_target ? L.E_cnt : zf_target;
+      auto launch_zfactors = [&]() {
+        if (tab_zfac) { allow_lds(k_zfactors<true>, lds_zfac);
+          hipLaunchKernelGGL(k_zfactors<true>, dim3(zf_blocks, nb), dim3(256), lds_zfac, sz, L, dp, c.zt, c.It, Tc, zf_ranged ? 1 : 0);
+        } else hipLaunchKernelGGL(k_zfactors<false>, dim3(zf_blocks, nb), dim3(256), 0, sz, L, dp, c.zt, c.It, Tc, zf_ranged ? 1 : 0);
+      };
+      if (!zf_ranged) {
+        launch_zfactors();
+        HIPCHK(hipGetLastError());
+        if (sz != sg) HIPCHK(hipEventRecord(c.evg[32 + g], sz));
+      }
       // sample stage
       HIPCHK(hipEventRecord(c.evg[4 * g], sg));
       const int nchunk = L.E_cnt * L.NC;
@@ -500,6 +514,7 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
       } else if (L.mode == CHM_MODE_MARG) {
         hipLaunchKernelGGL(k_event_prep, dim3(L.E_cnt, nb), dim3(64), 0, sg, L);
         HIPCHK(hipGetLastError());
+        if (zf_ranged) { launch_zfactors(); HIPCHK(hipGetLastError()); }
         HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         const bool fast = L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC");
         static const int sub = getenv("CHM_MARG_SUB") ? atoi(getenv("CHM_MARG_SUB")) : 32;     // lanes per pixel in the fast kernel
@@ -620,8 +635,8 @@ static int with_tables(const chm_params* p, int device, Ctx& c) {
 extern "C" int chm_model_eval(const chm_params* p, int32_t func, const double* a, const double* b, int64_t n,
                               double* out, int32_t device) {
   if (!a || !out || n < 0) return fail(CHM_E_ARG, "chm_model_eval: null argument");
-  if (func < 0 || func > CHM_F_SMOOTHING) return fail(CHM_E_ARG, "chm_model_eval: unknown function id");
-  if ((func == CHM_F_PM1M2 || func == CHM_F_SECONDARY) && !b) return fail(CHM_E_ARG, "chm_model_eval: function needs two inputs");
+  if (func < 0 || func > CHM_F_PM1M2_FUSED) return fail(CHM_E_ARG, "chm_model_eval: unknown function id");
+  if ((func == CHM_F_PM1M2 || func == CHM_F_SECONDARY || func == CHM_F_PM1M2_FUSED) && !b) return fail(CHM_E_ARG, "chm_model_eval: function needs two inputs");
   if (n == 0) return CHM_OK;
   Ctx c;
   int rc = with_tables(p, device, c);
@@ -788,7 +803,7 @@ extern "C" int chm_comm_destroy(chm_comm* c) {
 extern "C" int chm_comm_allreduce_sum(chm_comm* c, double* buf, int32_t n) {
   if (!c || !buf || n <= 0) return fail(CHM_E_ARG, "chm_comm_allreduce_sum: bad argument");
   HIPCHK(hipSetDevice(c->device));
-  if (n > c->cap) { if (c->d_buf) hipFree(c->d_buf); c->d_buf = nullptr; HIPCHK(hipMalloc(&c->d_buf, sizeof(double) * n)); c->cap = n; }
+  if (n > c->cap) { if (c->d_buf) (void)hipFree(c->d_buf); c->d_buf = nullptr; HIPCHK(hipMalloc(&c->d_buf, sizeof(double) * n)); c->cap = n; }
   HIPCHK(hipMemcpyAsync(c->d_buf, buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   NCCLCHK(ncclAllReduce(c->d_buf, c->d_buf, (size_t)n, ncclDouble, ncclSum, c->comm, c->stream));
   HIPCHK(hipMemcpyAsync(buf, c->d_buf, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));

@@ -22,6 +22,7 @@
 // per-(draw,event,chunk) partial statistics written by k_samples; d = z - z_ref (z_ref = z of the event's first sample)
 enum { PT_SW = 0, PT_SW2, PT_SD1, PT_SD2, PT_ZMIN, PT_ZMAX, PT_WD0, PT_WD1, PT_WD2, PT_W00, PT_W01, PT_W02, PT_W11, PT_W12, PT_W22, PT_ZREF };
 #define SAMPLE_CHUNK 1024
+#define NEVSTAT 10           // doubles per (draw, event) written by k_event_prep
 
 struct LikeDev {                  // device-resident shard of events (see chm_like_desc)
   int E, S, Z, P;
@@ -336,7 +337,7 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
         double r = 1. / zp1;
         double m1 = md1[h] * r, m2 = md2[h] * r;
         double lz = log(zp1);                                 // log(m_src) = log(m_det) - log(1+z): one log for both masses
-        double w = ((L.dbg & 32) ? m1 * m2 : p_m1m2_l(P, m1, m2, l1[h] - lz, l2[h] - lz, T.mg, T.cdf)) * ipr[h];
+        double w = ((L.dbg & 32) ? m1 * m2 : p_m1m2_fused(P, m1, m2, l1[h] - lz, l2[h] - lz, T.mg, T.cdf)) * ipr[h];
         wv[h] = w;
         if (s + h < s_end) {
           double d = z - z_ref;
@@ -379,36 +380,48 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
 // ------------------------------------------------------------------------------------------------------
 template <bool LDS_TAB>
 __global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
-                                                   int TcMax) {
+                                                   int TcMax, int ranged) {
   extern __shared__ double lds[];
-  const int e = L.e_off + blockIdx.x, b = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+  const int b = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
   const DevParams& P = params[b];
   const double* zt = zt_all + (size_t)b * TcMax;
   const double* It = It_all + (size_t)b * TcMax;
-  if (LDS_TAB) {
+  if (LDS_TAB) {                                    // staged once per block; the block then walks over its events
     double* a = lds; double* c = lds + P.Tc;
     for (int i = t; i < P.Tc; i += nt) { a[i] = zt[i]; c[i] = It[i]; }
     __syncthreads();
     zt = a; It = c;
   }
   const int Z = L.Z;
-  const size_t zo = ((size_t)b * L.E + e) * Z;
-  for (int k = t; k < Z; k += nt) {
-    double z = L.z_grids[(size_t)e * Z + k];
-    double dCt = dCt_at_z(P, z, zt, It);
-    double zp1 = 1. + z;
-    double lzp1 = log(zp1);
-    double Ez = E_at_z_l(P, z, lzp1);
-    L.jac[zo + k] = ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1) * (zp1 * zp1);
-    L.prate[zo + k] = merger_rate_l(P, z, lzp1) / (1. + z);
-    double p_bkg = dVcdz_from_dCt_E(P, dCt, Ez);
-    L.bkgA[zo + k] = P.has_catalog ? (1. - L.P_compl[(size_t)e * Z + k]) * p_bkg : p_bkg;
-    if (L.Aw) {
-      // trapezoid weight of grid point k: y_k enters the two adjacent intervals (jnp.trapezoid, likelihood.py:278)
-      const double* zg = L.z_grids + (size_t)e * Z;
-      double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
-      double tw = 0.5 * ((z - zl) + (zr - z));
-      L.Aw[zo + k] = (L.prate[zo + k] / L.jac[zo + k]) * tw;
+  for (int ei = blockIdx.x; ei < L.E_cnt; ei += gridDim.x) {
+    const int e = L.e_off + ei;
+    const size_t zo = ((size_t)b * L.E + e) * Z;
+    const double* zg = L.z_grids + (size_t)e * Z;
+    // ranged (marginalized mode, after k_event_prep): only the grid points the GW kernel reads, [k_lo & ~1, k_hi] of the
+    // event (the support of its KDE, NEVSTAT slots 8-9); nothing for an event that fails the n_eff guard (likelihood.py:199)
+    int k_first = 0, k_last = Z - 1;
+    if (ranged) {
+      const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
+      if (!(es[4] >= L.pe_neff)) continue;
+      k_first = ((int)es[8]) & ~1; k_last = (int)es[9];
+    }
+    for (int k = k_first + t; k <= k_last; k += nt) {
+      double z = zg[k];
+      double dCt = dCt_at_z(P, z, zt, It);
+      double zp1 = 1. + z;
+      double lzp1 = log(zp1);
+      double Ez = E_at_z_l(P, z, lzp1);
+      double jac = ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1) * (zp1 * zp1);
+      double prate = merger_rate_l(P, z, lzp1) / (1. + z);
+      if (!ranged) { L.jac[zo + k] = jac; L.prate[zo + k] = prate; }
+      double p_bkg = dVcdz_from_dCt_E(P, dCt, Ez);
+      L.bkgA[zo + k] = P.has_catalog ? (1. - L.P_compl[(size_t)e * Z + k]) * p_bkg : p_bkg;
+      if (L.Aw) {
+        // trapezoid weight of grid point k: y_k enters the two adjacent intervals (jnp.trapezoid, likelihood.py:278)
+        double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
+        double tw = 0.5 * ((z - zl) + (zr - z));
+        L.Aw[zo + k] = (prate / jac) * tw;
+      }
     }
   }
 }
@@ -573,7 +586,6 @@ DEVFN void wave_prefix3(const double* cen, const double* wgt, int N, double c_re
 
 // k_event_prep: one wave per (event, draw): combine the chunk partials once for all the event's pixel blocks.
 // evstat (nb,E,8): zmin, zmax, std, norm, n_eff, sum w, lb, ub  (effective-grid ends, likelihood.py:186-187)
-#define NEVSTAT 10
 __global__ void __launch_bounds__(64) k_event_prep(LikeDev L) {
   const int e = L.e_off + blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const EvStats st = combine_stats(L.part + ((size_t)b * L.E + e) * L.NC * NPART, L.NC, L.S);
@@ -1433,40 +1445,74 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
 struct SelDev {
   long long I;
   const double *dL, *m1det, *m2det, *p_draw;
+  const double *lm1det, *lm2det;  // log(m1det), log(m2det), formed once at upload (as for the posterior samples)
   double N_inj, N_eff; int has_neff, pad;
   double* partial;                // (nb, nblocks, 2)
   int nblocks;
 };
 
+// one injection: dN/dtheta_det / p_draw                                     pop_wrapper.py:102-111, selection_function.py:38
+template <class A1, class A2>
+DEVFN double sel_term(const DevParams& P, double dl, double m1d, double m2d, double l1d, double l2d, double ipd, double z,
+                      A1 mg, A2 cdf) {
+  double zp1 = 1. + z;
+  double rz = 1. / zp1;
+  double m1 = m1d * rz, m2 = m2d * rz;
+  double lzp1 = log(zp1);
+  double Ez = E_at_z_l(P, z, lzp1);
+  double dCt = dL2dCt_l(P, dl, z, lzp1);                           // original distances: cosmo.py:191-192,215-216
+  double p_z = dVcdz_from_dCt_E(P, dCt, Ez);                       // gal_cat.p_bkg              pop_wrapper.py:106
+  p_z = p_z * (merger_rate_l(P, z, lzp1) / (1. + z));              //                            pop_wrapper.py:107
+  double dN = P.R0 * p_m1m2_fused(P, m1, m2, l1d - lzp1, l2d - lzp1, mg, cdf) * p_z;   //           pop_wrapper.py:108
+  double jacobian = fabs(ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1)) * (zp1 * zp1);      //           pop_wrapper.py:109
+  dN = dN / jacobian;
+  return dN * ipd;                                                 // selection_function.py:38 (array holds 1/p_draw)
+}
+
+// Blocks of 256 threads stage the draw's tables in LDS once and walk over tiles of SEL_TILE injections (tile = blockIdx.x,
+// += gridDim.x); a thread takes two consecutive injections per pass (16 B loads, lock-step table searches).
+#define SEL_TILE 1024
 template <bool LDS_TAB>
 __global__ void __launch_bounds__(256) k_selection(SelDev Sd, const DevParams* params, const double* zt_all, const double* It_all,
                                                     const double* dLt_all, const double* mg_all, const double* cdf_all,
                                                     int TcMax, int TmMax) {
   extern __shared__ double lds[];
   __shared__ double red[16];
-  const int b = blockIdx.y;
+  const int b = blockIdx.y, t = threadIdx.x;
   const DevParams& P = params[b];
   TablePtrs g = { zt_all + (size_t)b * TcMax, It_all + (size_t)b * TcMax, dLt_all + (size_t)b * TcMax,
                   mg_all + (size_t)b * TmMax, cdf_all + (size_t)b * TmMax };
   TabView T = stage_tables(P, g, LDS_TAB, lds, false);
   double s1 = 0., s2 = 0.;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < Sd.I; i += (long long)gridDim.x * blockDim.x) {
-    double dl = Sd.dL[i];
-    double z = jnp_interp(dl, T.dLt, T.zt, P.Tc, false, 0., 0.);
-    double zp1 = 1. + z;
-    double rz = 1. / zp1;
-    double m1 = Sd.m1det[i] * rz, m2 = Sd.m2det[i] * rz;
-    double lzp1 = log(zp1);
-    double Ez = E_at_z_l(P, z, lzp1);
-    double dCt = dL2dCt_l(P, dl, z, lzp1);                           // original distances: cosmo.py:191-192,215-216
-    double p_z = dVcdz_from_dCt_E(P, dCt, Ez);                       // gal_cat.p_bkg              pop_wrapper.py:106
-    p_z = p_z * (merger_rate_l(P, z, lzp1) / (1. + z));              //                            pop_wrapper.py:107
-    double dN = P.R0 * p_m1m2(P, m1, m2, T.mg, T.cdf) * p_z;         //                            pop_wrapper.py:108
-    double jacobian = fabs(ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1)) * (zp1 * zp1);   //              pop_wrapper.py:109
-    dN = dN / jacobian;
-    dN = dN * Sd.p_draw[i];                                          // selection_function.py:38 (array holds 1/p_draw)
-    if (dN == dN) s1 += dN;                                          // nansum                     selection_function.py:39
-    s2 += dN * dN;                                                   // plain sum     selection_function.py:44
+  const long long I = Sd.I;
+  for (long long base = (long long)blockIdx.x * SEL_TILE; base < I; base += (long long)gridDim.x * SEL_TILE) {
+#pragma unroll 1
+    for (int off = 2 * t; off < SEL_TILE; off += 512) {
+      const long long i = base + off;
+      if (i >= I) break;
+      const bool two = i + 1 < I;
+      double dl[2], md1[2], md2[2], ipd[2], l1[2], l2[2];
+      if (two) {                                    // i even: 16-byte aligned pairs
+        double2 a = *reinterpret_cast<const double2*>(Sd.dL + i), bb = *reinterpret_cast<const double2*>(Sd.m1det + i);
+        double2 cc = *reinterpret_cast<const double2*>(Sd.m2det + i), dd = *reinterpret_cast<const double2*>(Sd.p_draw + i);
+        double2 ee = *reinterpret_cast<const double2*>(Sd.lm1det + i), ff = *reinterpret_cast<const double2*>(Sd.lm2det + i);
+        dl[0] = a.x; dl[1] = a.y; md1[0] = bb.x; md1[1] = bb.y; md2[0] = cc.x; md2[1] = cc.y; ipd[0] = dd.x; ipd[1] = dd.y;
+        l1[0] = ee.x; l1[1] = ee.y; l2[0] = ff.x; l2[1] = ff.y;
+      } else {
+        dl[0] = dl[1] = Sd.dL[i]; md1[0] = md1[1] = Sd.m1det[i]; md2[0] = md2[1] = Sd.m2det[i]; ipd[0] = ipd[1] = Sd.p_draw[i];
+        l1[0] = l1[1] = Sd.lm1det[i]; l2[0] = l2[1] = Sd.lm2det[i];
+      }
+      double zz[2];
+      jnp_interp_x2(dl[0], dl[1], T.dLt, T.zt, P.Tc, zz[0], zz[1]);   // z = z_from_dGW(dL)   cosmo.py:260-264
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        double dN = sel_term(P, dl[h], md1[h], md2[h], l1[h], l2[h], ipd[h], zz[h], T.mg, T.cdf);
+        if (h == 0 || two) {
+          if (dN == dN) s1 += dN;                                    // nansum                     selection_function.py:39
+          s2 += dN * dN;                                             // plain sum     selection_function.py:44
+        }
+      }
+    }
   }
   s1 = block_reduce<RED_SUM>(s1, red);
   s2 = block_reduce<RED_SUM>(s2, red);
@@ -1710,6 +1756,7 @@ __global__ void __launch_bounds__(256) k_model_eval(const DevParams* params, Tab
       case 12: r = primary_notnorm(P, x); break;
       case 13: r = secondary_notnorm(P, x, bb[i]); break;
       case 14: r = smoothing(x, mass_delta_m(P), P.m[0]); break;
+      case 15: r = p_m1m2_fused(P, x, bb[i], log(x), log(bb[i]), g.mg, g.cdf); break;   // the hot loops' form of case 11
     }
     out[i] = r;
   }

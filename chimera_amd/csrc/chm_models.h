@@ -310,6 +310,70 @@ DEVFN double p_m1m2(const DevParams& p, double m1, double m2, A1 mg, A2 cdf) {
   return p_m1m2_l(p, m1, m2, log(m1), log(m2), mg, cdf);
 }
 
+// p_m1m2 (mass.py:334-341) for the per-sample hot loops, same quantity as p_m1m2_l() with the operation count cut:
+//   p_m1m2 = [Pn(m1) S(m1) / norm] [m2^beta S(m2) 1(m_low <= m2 <= m1)] / interp(m1; m_grid, cdf_m2)
+// * the two smoothing arguments x = dm (a+b)/(a b) (mass.py:261-263) share one reciprocal, and S = 1/(1 + e^x) is kept as its
+//   denominator D = 1 + e^x  (e^x = inf -> S = 0, as the reference's exp(-logaddexp(0, x)) underflows);
+// * m2^beta = e^(beta lm2) is folded into the exponents of the primary's power laws / Gaussian (one exp fewer);
+// * the cdf interpolant f0 + (dm1/dx) df is kept as (f0 dx + dm1 df)/dx, so that S(m1), S(m2), the interpolant and the
+//   final quotient need ONE division:  w = Pn norm^-1 dx / (D1 D2 (f0 dx + dm1 df)).
+// Relative difference to p_m1m2_l(): rounding only, <= ~(|beta lm2| + 8) ulp ~ 3e-15; the `p_m2m1 = NaN -> 0` rule
+// (mass.py:340) is applied to the same cases (0/0 at m1 = m2 = m_low).
+template <class A1, class A2>
+DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, double lm2, A1 mg, A2 cdf) {
+  const double m_low = p.m[0], m_high = p.m[1];
+  const bool in2 = (m_low <= m2 && m2 <= m1);               // tpl_notnorm(m2, beta, m_low, m1)   mass.py:240-245,322
+  const double e5 = in2 ? mass_beta(p) * lm2 : 0.;
+  // primary numerator (without smoothing), times m2^beta                                         mass.py:285-305
+  double Pn;
+  if (p.mass_model == 0) {
+    Pn = (m_low <= m1 && m1 <= m_high) ? exp(-p.m[2] * lm1 + e5) : 0.;
+  } else if (p.mass_model == 1) {
+    double a = (m_low <= m1 && m1 <= p.bpl_mbreak) ? exp(-p.m[2] * lm1 + e5) : 0.;
+    double b = (p.bpl_mbreak <= m1 && m1 <= m_high) ? exp(-p.m[3] * lm1 + e5) : 0.;
+    Pn = a + b * p.bpl_pl1 / p.bpl_pl2;
+  } else {
+    double Pw = (m_low <= m1 && m1 <= m_high) ? exp(-p.m[3] * lm1 + e5) * p.inv_plnorm : 0.;
+    double G = 0.;
+    if (m_low <= m1 && m1 <= p.tg_hi) { double d = m1 - p.m[6]; G = exp((p.g_c0 - (d * d) * p.inv_2s2) + e5) * p.inv_tg_norm; }
+    Pn = (1. - p.m[2]) * Pw + p.m[2] * G;
+  }
+  // smoothing denominators                                                                       mass.py:255-264
+  double D1 = 1., D2 = 1.;
+  bool zero = !in2;
+  if (p.mass_model != 0) {
+    const double dm = p.m[5], eps = 1.e-99;
+    const bool w1 = !(m1 < m_low) && !(m1 > m_low + dm), w2 = !(m2 < m_low) && !(m2 > m_low + dm);
+    zero = zero || (m1 < m_low) || (m2 < m_low);
+    double ab1 = 1., ab2 = 1., s1 = 0., s2 = 0.;
+    if (w1) { double a = m1 - m_low + eps, b = m1 - m_low - dm + eps; ab1 = a * b; s1 = a + b; }
+    if (w2) { double a = m2 - m_low + eps, b = m2 - m_low - dm + eps; ab2 = a * b; s2 = a + b; }
+    if (w1 || w2) {
+      double r = dm / (ab1 * ab2);
+      if (w1) D1 = 1. + exp((s1 * ab2) * r);
+      if (w2) D2 = 1. + exp((s2 * ab1) * r);
+    }
+  }
+  // interp(m1; m_grid, cdf_m2) as (f0 dx + (m1 - x0) df) / dx                                     mass.py:339
+  const int n = p.Tm;
+  double t = (lm1 - p.lmg0) * p.inv_dlmg;
+  int i = (t >= 0.) ? (t < (double)n ? (int)t + 1 : n - 1) : 1;
+  i = i < 1 ? 1 : (i > n - 1 ? n - 1 : i);
+  while (i > 1 && mg[i - 1] > m1) i--;
+  while (i < n - 1 && mg[i] <= m1) i++;
+  double x0 = mg[i - 1], x1 = mg[i], f0 = cdf[i - 1], f1 = cdf[i];
+  double dx = x1 - x0;
+  double cn = f0 * dx + (m1 - x0) * (f1 - f0);
+  if (fabs(dx) <= 4.930380657631324e-32) { cn = f0; dx = 1.; }
+  if (m1 < (double)mg[0]) cn = cdf[0] * dx;
+  if (m1 > (double)mg[n - 1]) cn = cdf[n - 1] * dx;
+  double w = ((Pn * p.inv_norm_p_m1) * dx) / ((D1 * D2) * cn);
+  // sec = 0 -> p_m2m1 = 0 (or 0/0 = NaN -> 0): w = p_m1 * 0
+  if (zero || (w != w && cn == 0.)) w = Pn * 0.;
+  if (m1 != m1) w = m1;
+  return w;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // rate  (population/rate.py:96-122)
 // ------------------------------------------------------------------------------------------------------

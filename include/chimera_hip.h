@@ -153,7 +153,8 @@ int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_params* par
 /* Elementwise model functions on the device (cosmo.py:122-264, mass.py:334-341, rate.py:96-122),
  * used by the Python free functions and by compute_z_grids (pop_wrapper.py:133-208).                  */
 enum { CHM_F_E = 0, CHM_F_INT_INVE, CHM_F_DCR, CHM_F_DCT, CHM_F_DL, CHM_F_DDLDZ, CHM_F_DVCDZ, CHM_F_VC,
-       CHM_F_XI, CHM_F_Z_FROM_DGW, CHM_F_RATE, CHM_F_PM1M2, CHM_F_PRIMARY, CHM_F_SECONDARY, CHM_F_SMOOTHING };
+       CHM_F_XI, CHM_F_Z_FROM_DGW, CHM_F_RATE, CHM_F_PM1M2, CHM_F_PRIMARY, CHM_F_SECONDARY, CHM_F_SMOOTHING,
+       CHM_F_PM1M2_FUSED /* the reduced-operation form of PM1M2 used inside the per-sample kernels (for tests) */ };
 /* out[i] = f(a[i] [, b[i]]):  cosmology functions take a = z and optional b = original distances
  * (cosmo.py:155-221; b may be NULL); Z_FROM_DGW takes a = dGW; RATE takes a = z; PM1M2 / SECONDARY take
  * a = m1, b = m2 (SECONDARY: a = m2, b = m1); PRIMARY / SMOOTHING take a = m.                           */

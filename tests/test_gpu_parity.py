@@ -54,6 +54,15 @@ def test_tables_and_model_functions():
     np.testing.assert_allclose(mp.norm_p_m1, mo.norm_p_m1, rtol=1e-13)
     np.testing.assert_allclose(CH.mass.p_m1m2(mp, m1, m2), O.p_m1m2(mo, m1, m2), rtol=1e-12, atol=1e-300, err_msg=mname)
     np.testing.assert_allclose(CH.mass.primary_mass_pdf_notnorm(mp, m1), O.primary_mass_pdf_notnorm(mo, m1), rtol=1e-12, atol=1e-300)
+    # the reduced-operation form used inside the per-sample kernels (p_m1m2_fused), incl. the edges of every window
+    from chimera_amd.population._base import make_params, model_eval
+    from chimera_amd import _lib
+    edge = np.array([mo.m_low, mo.m_low + getattr(mo, 'delta_m', 0.), mo.m_high, np.nextafter(mo.m_low, 0.), np.nextafter(mo.m_high, 1e3),
+                     getattr(mo, 'mu_g', 30.) + 5. * getattr(mo, 'sigma_g', 1.)])
+    M1 = np.concatenate([m1, np.repeat(edge, edge.size), edge, edge])
+    M2 = np.concatenate([m2, np.tile(edge, edge.size), edge * 0.999999, edge * 0.5])
+    pf = model_eval(make_params(mass=mp), _lib.F_PM1M2_FUSED, M1, M2)
+    np.testing.assert_allclose(pf, O.p_m1m2(mo, M1, M2), rtol=1e-12, atol=1e-300, err_msg=mname + ' (fused)')
   z = np.linspace(0., 3., 200)
   for rname in ('power_law', 'madau_dickinson', 'trunc_power_law', 'trunc_madau_dickinson'):
     np.testing.assert_allclose(CH.rate.merger_rate(getattr(CH.rate, rname)(), z), O.merger_rate(getattr(O, rname)(), z), rtol=1e-13)
