@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
       double g = P.r[0], k = P.r[1], zp = P.r[2], zmax = P.r[3];
       Pg.md_norm = 1. + pow(1. + zp, -g - k);                             // rate.py:114
       Pg.tpl_rate_norm = (pow(1. + zmax, g + 1.) - 1.) / (g + 1.);        // rate.py:105
-      Pg.l1pzp = log(1. + zp);
+      Pg.l1pzp = chm_log(1. + zp);
     }
     // zt = [0] U logspace(-10, log10 z_max, Tc-1); It = cumtrapz(1/E, zt)     cosmo.py:43-46
     const double lzmax = log10(P.z_max);
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
         double max_point = (Ps.tg_hi - mu) / (sg * sqrt(2.));
         double min_point = (m_low - mu) / (sg * sqrt(2.));
         Ps.tg_norm = 0.5 * erf(max_point) - 0.5 * erf(min_point);         // mass.py:272-274
-        Ps.g_c0 = -0.5 * log(2. * CHM_PI) - log(sg);                      // mass.py:268
+        Ps.g_c0 = -0.5 * chm_log(2. * CHM_PI) - chm_log(sg);                      // mass.py:268
         Ps.inv_plnorm = 1. / Ps.plp_plnorm; Ps.inv_tg_norm = 1. / Ps.tg_norm; Ps.inv_2s2 = 1. / (2. * (sg * sg));
         Pg.plp_plnorm = Ps.plp_plnorm; Pg.tg_hi = Ps.tg_hi; Pg.tg_norm = Ps.tg_norm; Pg.g_c0 = Ps.g_c0;
         Pg.inv_plnorm = Ps.inv_plnorm; Pg.inv_tg_norm = Ps.inv_tg_norm; Pg.inv_2s2 = Ps.inv_2s2;
@@ -213,8 +213,8 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
         Ps.bpl_pl2 = tpl_notnorm(mb, -P.m[3], mb, m_high);
         Pg.bpl_mbreak = Ps.bpl_mbreak; Pg.bpl_pl1 = Ps.bpl_pl1; Pg.bpl_pl2 = Ps.bpl_pl2;
       }
-      Pg.lmg0 = log(m_low);
-      Pg.inv_dlmg = (double)(P.Tm - 1) / (log(m_high) - log(m_low));
+      Pg.lmg0 = chm_log(m_low);
+      Pg.inv_dlmg = (double)(P.Tm - 1) / (chm_log(m_high) - chm_log(m_low));
     }
     __syncthreads();
     // m_grid = logspace(log10 m_low, log10 m_high, Tm); cdf = cumtrapz(secondary(m_grid; m_high))   mass.py:45-49
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
         double zp1 = 1. + z;
         double r = 1. / zp1;
         double m1 = md1[h] * r, m2 = md2[h] * r;
-        double lz = log(zp1);                                 // log(m_src) = log(m_det) - log(1+z): one log for both masses
+        double lz = chm_log_pos(zp1);                             // log(m_src) = log(m_det) - log(1+z): one log for both masses
         double w = ((L.dbg & 32) ? m1 * m2 : p_m1m2_fused(P, m1, m2, l1[h] - lz, l2[h] - lz, T.mg, T.cdf)) * ipr[h];
         wv[h] = w;
         if (s + h < s_end) {
@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* pa
       double z = zg[k];
       double dCt = dCt_at_z(P, z, zt, It);
       double zp1 = 1. + z;
-      double lzp1 = log(zp1);
+      double lzp1 = chm_log_pos(zp1);
       double Ez = E_at_z_l(P, z, lzp1);
       double jac = ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1) * (zp1 * zp1);
       double prate = merger_rate_l(P, z, lzp1) / (1. + z);
@@ -440,8 +440,8 @@ DEVFN int bin_index(double z, double lo, double hi, int B) {
 DEVFN double kde_bandwidth_factor(int bw_method, double bw_scalar, double neff, int d) {
   // math.py:65-73 (d = 1), :178-183 (d = 3)
   // x^y as exp(y log x): |y log x| eps ~ 1e-16 away from pow()
-  if (bw_method == 0) return exp(log(neff) * (-1. / (double)(d + 4)));
-  if (bw_method == 1) return exp(log(neff * (double)(d + 2) / 4.0) * (-1. / (double)(d + 4)));
+  if (bw_method == 0) return chm_exp(chm_log(neff) * (-1. / (double)(d + 4)));
+  if (bw_method == 1) return chm_exp(chm_log(neff * (double)(d + 2) / 4.0) * (-1. / (double)(d + 4)));
   return bw_scalar;
 }
 
@@ -489,7 +489,7 @@ DEVFN double kde_dense_eval(double g, const double* data, const double* wgt, int
     const double isq = 1. / sqrt(2. * CHM_PI);
     for (int j = 0; j < N; j++) {
       double u = (g - data[j]) * inv_bw;
-      acc += wgt[j] * (exp(-0.5 * (u * u)) * isq);
+      acc += wgt[j] * (chm_exp(-0.5 * (u * u)) * isq);
     }
   }
   return acc / bw;
@@ -1333,7 +1333,7 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
     double l11 = sqrt(i11 - l10 * l10), l21 = (i12 - l20 * l10) / l11;
     double l22 = sqrt(i22 - l20 * l20 - l21 * l21);
     wh[0] = l00; wh[1] = l10; wh[2] = l11; wh[3] = l20; wh[4] = l21; wh[5] = l22;
-    wh[6] = (log(l00) + log(l11) + log(l22)) - 0.5 * 3. * log(2. * CHM_PI);      // log_norm  math.py:215
+    wh[6] = (chm_log(l00) + chm_log(l11) + chm_log(l22)) - 0.5 * 3. * chm_log(2. * CHM_PI);      // log_norm  math.py:215
   }
   __syncthreads();
   const double l00 = wh[0], l10 = wh[1], l11 = wh[2], l20 = wh[3], l21 = wh[4], l22 = wh[5], log_norm = wh[6];
@@ -1371,7 +1371,7 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
       }
       t0 = z0 * l00 + t_base; D = dz * l00;
     }
-    const double rho = exp(-(D * D)), hD2 = 0.5 * D * D;
+    const double rho = chm_exp(-(D * D)), hD2 = 0.5 * D * D;
     double acc[FULL_LK];
 #pragma unroll
     for (int i = 0; i < FULL_LK; i++) acc[i] = 0.;
@@ -1382,15 +1382,15 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
         double x0 = wz[s0 + s], x1 = L.ra[eo + s0 + s], x2 = L.dec[eo + s0 + s];
         double d1 = (x1 * l11 + x2 * l21) - q1, d2 = x2 * l22 - q2;
         sa[s] = x0 * l00 + x1 * l10 + x2 * l20;
-        sc[s] = (ww[s0 + s] / st.sumw) * exp(log_norm - 0.5 * (d1 * d1 + d2 * d2));
+        sc[s] = (ww[s0 + s] / st.sumw) * chm_exp(log_norm - 0.5 * (d1 * d1 + d2 * d2));
       }
       __syncthreads();
       if (has && any) {
         if (uni) {
           for (int s = sl; s < ns; s += NS) {
             double d = sa[s] - t0;
-            double g = sc[s] * exp(-0.5 * (d * d));
-            double r = exp(d * D - hD2);
+            double g = sc[s] * chm_exp(-0.5 * (d * d));
+            double r = chm_exp(d * D - hD2);
 #pragma unroll
             for (int i = 0; i < FULL_LK; i++) { acc[i] += g; g *= r; r *= rho; }
           }
@@ -1401,7 +1401,7 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
             for (int i = 0; i < FULL_LK; i++) {
               double ti = (i < nk ? zg[k0 + i] : zg[k0]) * l00 + t_base;
               double d = a0 - ti;
-              acc[i] += cj * exp(-0.5 * (d * d));
+              acc[i] += cj * chm_exp(-0.5 * (d * d));
             }
           }
         }
@@ -1458,7 +1458,7 @@ DEVFN double sel_term(const DevParams& P, double dl, double m1d, double m2d, dou
   double zp1 = 1. + z;
   double rz = 1. / zp1;
   double m1 = m1d * rz, m2 = m2d * rz;
-  double lzp1 = log(zp1);
+  double lzp1 = chm_log_pos(zp1);
   double Ez = E_at_z_l(P, z, lzp1);
   double dCt = dL2dCt_l(P, dl, z, lzp1);                           // original distances: cosmo.py:191-192,215-216
   double p_z = dVcdz_from_dCt_E(P, dCt, Ez);                       // gal_cat.p_bkg              pop_wrapper.py:106
@@ -1667,13 +1667,13 @@ __global__ void __launch_bounds__(256) k_pcat(PcatDev D, const DevParams* params
     double part = 0.;
     for (int k = t; k < Z - 1; k += nt) {
       double u0 = (zz[k] - mu) / sg, u1 = (zz[k + 1] - mu) / sg;
-      double y0 = pref * exp(-0.5 * (u0 * u0)) * dv[k], y1 = pref * exp(-0.5 * (u1 * u1)) * dv[k + 1];
+      double y0 = pref * chm_exp(-0.5 * (u0 * u0)) * dv[k], y1 = pref * chm_exp(-0.5 * (u1 * u1)) * dv[k + 1];
       part += (zz[k + 1] - zz[k]) * (y1 + y0);
     }
     const double norm = 0.5 * block_reduce<RED_SUM>(part, red);
     for (int k = t; k < Z; k += nt) {
       double u = (zz[k] - mu) / sg;
-      double y = pref * exp(-0.5 * (u * u)) * dv[k];
+      double y = pref * chm_exp(-0.5 * (u * u)) * dv[k];
       acc[k] += w * y / norm;                                          // np.sum(weights * gauss / norm, axis=1)   :221
     }
     sw += w;
@@ -1708,12 +1708,12 @@ __global__ void __launch_bounds__(256) k_kde2d(int S, int Pmax, const double* ra
   if (t == 0) {
     double den = 1. - (double)S * (W * W);                 // 1 - sum(W^2)                      math.py:128
     cxx /= den; cxy /= den; cyy /= den;
-    double factor = exp(log((double)S) * (-1. / 6.));
+    double factor = chm_exp(chm_log((double)S) * (-1. / 6.));
     double det = cxx * cyy - cxy * cxy, f2 = factor * factor;
     double ixx = cyy / det / f2, ixy = -cxy / det / f2, iyy = cxx / det / f2;      // inv_cov        math.py:129-131
     double l00 = sqrt(ixx), l10 = ixy / l00, l11 = sqrt(iyy - l10 * l10);           // cholesky       math.py:132
     wh[0] = l00; wh[1] = l10; wh[2] = l11;
-    wh[3] = (log(l00) + log(l11)) - 0.5 * 2. * log(2. * CHM_PI);                    // log_norm       math.py:135
+    wh[3] = (chm_log(l00) + chm_log(l11)) - 0.5 * 2. * chm_log(2. * CHM_PI);                    // log_norm       math.py:135
   }
   __syncthreads();
   const double l00 = wh[0], l10 = wh[1], l11 = wh[2], log_norm = wh[3];
@@ -1724,7 +1724,7 @@ __global__ void __launch_bounds__(256) k_kde2d(int S, int Pmax, const double* ra
     double acc = 0.;
     for (int s = t; s < S; s += nt) {
       double d0 = (x[s] * l00 + y[s] * l10) - q0, d1 = y[s] * l11 - q1;
-      acc += W * exp(log_norm - 0.5 * (d0 * d0 + d1 * d1));                          // math.py:141-146
+      acc += W * chm_exp(log_norm - 0.5 * (d0 * d0 + d1 * d1));                          // math.py:141-146
     }
     acc = block_reduce<RED_SUM>(acc, red);
     if (t == 0) out[(size_t)e * Pmax + p] = acc;
@@ -1756,7 +1756,7 @@ __global__ void __launch_bounds__(256) k_model_eval(const DevParams* params, Tab
       case 12: r = primary_notnorm(P, x); break;
       case 13: r = secondary_notnorm(P, x, bb[i]); break;
       case 14: r = smoothing(x, mass_delta_m(P), P.m[0]); break;
-      case 15: r = p_m1m2_fused(P, x, bb[i], log(x), log(bb[i]), g.mg, g.cdf); break;   // the hot loops' form of case 11
+      case 15: r = p_m1m2_fused(P, x, bb[i], chm_log(x), chm_log(bb[i]), g.mg, g.cdf); break;   // the hot loops' form of case 11
     }
     out[i] = r;
   }

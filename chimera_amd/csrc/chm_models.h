@@ -38,12 +38,13 @@ struct TablePtrs {                       // per-draw tables (global memory)
 };
 
 #define DEVFN __device__ __forceinline__
+#include "chm_math.h"
 
 // x^y for x > 0 as exp(y log x).  The reference's jnp.power is correctly rounded to ~1 ulp; this form is within
 // (|y ln x| + 2) ulp of it -- <= 2e-15 relative for every use below (|y ln x| <= 16) -- and costs a third of ocml's pow().
 // Callers that already hold log(x) pass it in and share it between several powers.
-DEVFN double pow_l(double lx, double y) { return exp(y * lx); }
-DEVFN double pow_el(double x, double y) { return exp(y * log(x)); }
+DEVFN double pow_l(double lx, double y) { return chm_exp(y * lx); }
+DEVFN double pow_el(double x, double y) { return chm_exp(y * chm_log(x)); }
 
 // ------------------------------------------------------------------------------------------------------
 // jax.numpy semantics
@@ -116,7 +117,7 @@ DEVFN void jnp_interp_x2(double xa, double xb, AccX xp, AccF fp, int n, double& 
 DEVFN double logaddexp0(double x) {
   double amax = x > 0. ? x : 0.;
   if (x != x) return x;
-  return amax + log1p(exp(-fabs(x)));
+  return amax + log1p(chm_exp(-fabs(x)));
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -136,14 +137,14 @@ DEVFN double E_at_z_l(const DevParams& p, double z, double lzp1) {
 }
 DEVFN bool de_needs_log(const DevParams& p) { return !(p.wa == 0. && p.w0 == -1.); }
 DEVFN double E_at_z(const DevParams& p, double z) {
-  return E_at_z_l(p, z, de_needs_log(p) ? log(1. + z) : 0.);
+  return E_at_z_l(p, z, de_needs_log(p) ? chm_log(1. + z) : 0.);
 }
 
 // cosmo.py:225-228
 DEVFN double Xi_at_z_l(const DevParams& p, double lzp1) {
   return p.Xi0 + (1. - p.Xi0) / pow_l(lzp1, p.n_mg);
 }
-DEVFN double Xi_at_z(const DevParams& p, double z) { return Xi_at_z_l(p, log(1. + z)); }
+DEVFN double Xi_at_z(const DevParams& p, double z) { return Xi_at_z_l(p, chm_log(1. + z)); }
 
 // cosmo.py:141-153 given dCr
 DEVFN double dCt_from_dCr(const DevParams& p, double dCr) {
@@ -166,7 +167,7 @@ DEVFN double dL2dCt_l(const DevParams& p, double dist, double z, double lzp1) {
   return dist / (1. + z);
 }
 DEVFN double dL2dCt(const DevParams& p, double dist, double z) {
-  return dL2dCt_l(p, dist, z, p.cosmo_model == 1 ? log(1. + z) : 0.);
+  return dL2dCt_l(p, dist, z, p.cosmo_model == 1 ? chm_log(1. + z) : 0.);
 }
 
 // cosmo.py:205-210, 237-243 given dCt
@@ -188,7 +189,7 @@ DEVFN double ddLdz_from_dCt_E(const DevParams& p, double dCt, double z, double E
   return ddLflrw;
 }
 DEVFN double ddLdz_from_dCt(const DevParams& p, double dCt, double z) {
-  double l = (p.cosmo_model == 1 || de_needs_log(p)) ? log(1. + z) : 0.;
+  double l = (p.cosmo_model == 1 || de_needs_log(p)) ? chm_log(1. + z) : 0.;
   return ddLdz_from_dCt_E(p, dCt, z, E_at_z_l(p, z, l), l);
 }
 
@@ -226,8 +227,8 @@ DEVFN double smoothing(double m, double delta_m, double m_low) {
   double x = delta_m * ((a + b) / (a * b));                  // = delta_m/a + delta_m/b with one division
   // exp(-logaddexp(0, x)) = 1/(1 + e^x), evaluated without overflow; equal to the reference's form to ~2 ulp
   if (x != x) return x;
-  if (x > 0.) { double t = exp(-x); return t / (1. + t); }
-  return 1. / (1. + exp(x));
+  if (x > 0.) { double t = chm_exp(-x); return t / (1. + t); }
+  return 1. / (1. + chm_exp(x));
 }
 
 // mass.py:240-245; lm = log(m)
@@ -240,7 +241,7 @@ DEVFN double tpl_notnorm(double m, double alpha, double m_low, double m_high) {
 
 // mass.py:247-252
 DEVFN double tpl_cdf(double alpha, double m_low, double m) {
-  if (alpha == -1.) return log(m_low) - log(m);
+  if (alpha == -1.) return chm_log(m_low) - chm_log(m);
   return (pow(m, 1. + alpha) - pow(m_low, 1. + alpha)) / (1. + alpha);
 }
 
@@ -259,14 +260,14 @@ DEVFN double primary_notnorm_l(const DevParams& p, double m, double lm) {
     double G = 0.;
     if (m_low <= m && m <= p.tg_hi) {
       double d = m - mu;
-      G = exp(p.g_c0 - (d * d) * p.inv_2s2) * p.inv_tg_norm;       // mass.py:267-279 (divisions by constants as reciprocals)
+      G = chm_exp(p.g_c0 - (d * d) * p.inv_2s2) * p.inv_tg_norm;       // mass.py:267-279 (divisions by constants as reciprocals)
     }
     double pdf = (1. - lam) * P + lam * G;
     return pdf * smoothing(m, p.m[5], m_low);
   }
 }
 
-DEVFN double primary_notnorm(const DevParams& p, double m) { return primary_notnorm_l(p, m, log(m)); }
+DEVFN double primary_notnorm(const DevParams& p, double m) { return primary_notnorm_l(p, m, chm_log(m)); }
 
 DEVFN double mass_beta(const DevParams& p) { return p.mass_model == 0 ? p.m[3] : (p.mass_model == 1 ? p.m[4] : p.m[4]); }
 DEVFN double mass_delta_m(const DevParams& p) { return p.m[5]; }
@@ -277,7 +278,7 @@ DEVFN double secondary_notnorm_l(const DevParams& p, double m2, double lm2, doub
   if (p.mass_model == 0) return pdf;
   return pdf * smoothing(m2, mass_delta_m(p), p.m[0]);
 }
-DEVFN double secondary_notnorm(const DevParams& p, double m2, double m1) { return secondary_notnorm_l(p, m2, log(m2), m1); }
+DEVFN double secondary_notnorm(const DevParams& p, double m2, double m1) { return secondary_notnorm_l(p, m2, chm_log(m2), m1); }
 
 // jnp.interp(m1, m_grid, cdf) (mass.py:339) with the bracket found from log(m1): m_grid is a logspace (mass.py:46), so
 // the index is floor((log10 m1 - l0)/(l1 - l0) (Tm-1)) up to rounding; the fix-up loops restore searchsorted exactly.
@@ -307,7 +308,7 @@ DEVFN double p_m1m2_l(const DevParams& p, double m1, double m2, double lm1, doub
 }
 template <class A1, class A2>
 DEVFN double p_m1m2(const DevParams& p, double m1, double m2, A1 mg, A2 cdf) {
-  return p_m1m2_l(p, m1, m2, log(m1), log(m2), mg, cdf);
+  return p_m1m2_l(p, m1, m2, chm_log(m1), chm_log(m2), mg, cdf);
 }
 
 // p_m1m2 (mass.py:334-341) for the per-sample hot loops, same quantity as p_m1m2_l() with the operation count cut:
@@ -327,15 +328,15 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
   // primary numerator (without smoothing), times m2^beta                                         mass.py:285-305
   double Pn;
   if (p.mass_model == 0) {
-    Pn = (m_low <= m1 && m1 <= m_high) ? exp(-p.m[2] * lm1 + e5) : 0.;
+    Pn = (m_low <= m1 && m1 <= m_high) ? chm_exp(-p.m[2] * lm1 + e5) : 0.;
   } else if (p.mass_model == 1) {
-    double a = (m_low <= m1 && m1 <= p.bpl_mbreak) ? exp(-p.m[2] * lm1 + e5) : 0.;
-    double b = (p.bpl_mbreak <= m1 && m1 <= m_high) ? exp(-p.m[3] * lm1 + e5) : 0.;
+    double a = (m_low <= m1 && m1 <= p.bpl_mbreak) ? chm_exp(-p.m[2] * lm1 + e5) : 0.;
+    double b = (p.bpl_mbreak <= m1 && m1 <= m_high) ? chm_exp(-p.m[3] * lm1 + e5) : 0.;
     Pn = a + b * p.bpl_pl1 / p.bpl_pl2;
   } else {
-    double Pw = (m_low <= m1 && m1 <= m_high) ? exp(-p.m[3] * lm1 + e5) * p.inv_plnorm : 0.;
+    double Pw = (m_low <= m1 && m1 <= m_high) ? chm_exp(-p.m[3] * lm1 + e5) * p.inv_plnorm : 0.;
     double G = 0.;
-    if (m_low <= m1 && m1 <= p.tg_hi) { double d = m1 - p.m[6]; G = exp((p.g_c0 - (d * d) * p.inv_2s2) + e5) * p.inv_tg_norm; }
+    if (m_low <= m1 && m1 <= p.tg_hi) { double d = m1 - p.m[6]; G = chm_exp((p.g_c0 - (d * d) * p.inv_2s2) + e5) * p.inv_tg_norm; }
     Pn = (1. - p.m[2]) * Pw + p.m[2] * G;
   }
   // smoothing denominators                                                                       mass.py:255-264
@@ -350,8 +351,8 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
     if (w2) { double a = m2 - m_low + eps, b = m2 - m_low - dm + eps; ab2 = a * b; s2 = a + b; }
     if (w1 || w2) {
       double r = dm / (ab1 * ab2);
-      if (w1) D1 = 1. + exp((s1 * ab2) * r);
-      if (w2) D2 = 1. + exp((s2 * ab1) * r);
+      if (w1) D1 = 1. + chm_exp((s1 * ab2) * r);
+      if (w2) D2 = 1. + chm_exp((s2 * ab1) * r);
     }
   }
   // interp(m1; m_grid, cdf_m2) as (f0 dx + (m1 - x0) df) / dx                                     mass.py:339
@@ -390,7 +391,7 @@ DEVFN double merger_rate_l(const DevParams& p, double z, double lzp1) {
   if (p.rate_model == 1) return p.md_norm * md;
   return z < p.r[3] ? p.md_norm * md : 0.;
 }
-DEVFN double merger_rate(const DevParams& p, double z) { return merger_rate_l(p, z, log(1. + z)); }
+DEVFN double merger_rate(const DevParams& p, double z) { return merger_rate_l(p, z, chm_log(1. + z)); }
 
 // ------------------------------------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)

@@ -1,0 +1,92 @@
+#include <cstdio>
+#include <cmath>
+#include <random>
+// host build of chimera_amd/csrc/chm_math.h's algorithms (rcp emulated in fp32):  g++ -O2 -ffp-contract=off scripts/check_fastmath.cpp && ./a.out
+#define DEVFN static inline
+static inline double FM_RCP(double x) { return (double)(1.0f / (float)x); }
+static inline double FM_FREXP_M(double x) { int e; return std::frexp(x, &e); }
+static inline int FM_FREXP_E(double x) { int e; std::frexp(x, &e); return e; }
+DEVFN double chm_exp(double x) {
+  const double L2E = 1.44269504088896338700e+00, LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10;
+  double n = __builtin_rint(x * L2E);
+  double r = __builtin_fma(-n, LN2HI, x);
+  r = __builtin_fma(-n, LN2LO, r);
+  double p = 1.6059043836821613e-10;                 // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878681e-09);     // 1/12!
+  p = __builtin_fma(p, r, 2.505210838544172e-08);    // 1/11!
+  p = __builtin_fma(p, r, 2.755731922398589e-07);    // 1/10!
+  p = __builtin_fma(p, r, 2.7557319223985893e-06);   // 1/9!
+  p = __builtin_fma(p, r, 2.48015873015873e-05);     // 1/8!
+  p = __builtin_fma(p, r, 0.0001984126984126984);    // 1/7!
+  p = __builtin_fma(p, r, 0.001388888888888889);     // 1/6!
+  p = __builtin_fma(p, r, 0.008333333333333333);     // 1/5!
+  p = __builtin_fma(p, r, 0.041666666666666664);     // 1/4!
+  p = __builtin_fma(p, r, 0.16666666666666666);      // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  int k = (int)n;
+  double v = __builtin_ldexp(p, k);
+  if (x > 709.782712893384) v = __builtin_inf();
+  if (x < -745.1332191019412) v = 0.;
+  return v;
+}
+
+// log(x) for finite x > 0 (NaN propagates); fdlibm e_log.c scheme, < 1 ulp
+DEVFN double chm_log_pos(double x) {
+  const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+               Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+               Lg7 = 1.479819860511658591e-01;
+  double m = FM_FREXP_M(x);
+  int e = FM_FREXP_E(x);
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  double f = m - 1.0;
+  double d = 2.0 + f;
+  double r = FM_RCP(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  double s = f * r;
+  s = __builtin_fma(__builtin_fma(-d, s, f), r, s);
+  double z = s * s, w = z * z;
+  double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
+  double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+  double R = t2 + t1;
+  double hfsq = 0.5 * f * f;
+  double dk = (double)e;
+  return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+DEVFN double chm_log(double x) {
+  double v = chm_log_pos(x);
+  if (x == 0.) v = -__builtin_inf();
+  if (x < 0.) v = __builtin_nan("");
+  if (x == __builtin_inf()) v = x;
+  return v;
+}
+
+int main() {
+  std::mt19937_64 g(1);
+  std::uniform_real_distribution<double> ue(-745, 709), ul(-700, 700), us(-1, 1);
+  double maxe = 0, maxl = 0; double we=0, wl=0;
+  for (int i = 0; i < 20000000; i++) {
+    double x = i % 3 == 0 ? ue(g) : (i % 3 == 1 ? us(g) * 40 : us(g));
+    long double ref = expl((long double)x);
+    double v = chm_exp(x);
+    double err = fabs((double)(((long double)v - ref) / ref));
+    if (x > -708 && err > maxe) { maxe = err; we = x; }
+    double y = i % 2 ? exp(ul(g)) : 1.0 + fabs(us(g)) * 6;
+    long double rl = logl((long double)y);
+    double vl = chm_log(y);
+    double el = rl != 0 ? fabs((double)(((long double)vl - rl) / rl)) : fabs(vl);
+    if (el > maxl) { maxl = el; wl = y; }
+  }
+  printf("exp max rel err %.3e (at %g) = %.2f ulp; log max rel err %.3e (at %g) = %.2f ulp\n", maxe, we, maxe / 1.11e-16, maxl, wl, maxl / 1.11e-16);
+  printf("specials: exp(-inf)=%g exp(inf)=%g exp(nan)=%g exp(-746)=%g exp(-740)=%g (ref %g) exp(710)=%g log(0)=%g log(-1)=%g log(inf)=%g log(nan)=%g log(1)=%g log(5e-324)=%g (ref %g)\n",
+    chm_exp(-INFINITY), chm_exp(INFINITY), chm_exp(NAN), chm_exp(-746), chm_exp(-740), exp(-740.), chm_exp(710), chm_log(0.), chm_log(-1.), chm_log(INFINITY), chm_log(NAN), chm_log(1.), chm_log(5e-324), log(5e-324));
+  // near 1
+  double mx = 0;
+  for (int i = -2000; i <= 2000; i++) { double y = 1.0 + i * 1e-7; long double rl = logl((long double)y); double vl = chm_log(y); if (rl != 0) { double el = fabs((double)(((long double)vl - rl) / rl)); if (el > mx) mx = el; } }
+  printf("log near 1 max rel err %.3e\n", mx);
+}
