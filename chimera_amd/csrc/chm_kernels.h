@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
   extern __shared__ double lds[];
   __shared__ double red[4 * 16];
   const int b = blockIdx.x % L.nb, bx = blockIdx.x / L.nb, nbx = gridDim.x / L.nb, t = threadIdx.x;
-  const DevParams& P = params[b];
+  const DevParams P = params[b];      // by value: uniform loads at kernel start -> scalar registers, nothing re-read in the loops
   TablePtrs g = { zt_all + (size_t)b * TcMax, It_all + (size_t)b * TcMax, dLt_all + (size_t)b * TcMax,
                   mg_all + (size_t)b * TmMax, cdf_all + (size_t)b * TmMax };
   TabView T = stage_tables(P, g, LDS_TAB, lds, false);
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* pa
                                                    int TcMax, int ranged) {
   extern __shared__ double lds[];
   const int b = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
-  const DevParams& P = params[b];
+  const DevParams P = params[b];      // by value: uniform loads at kernel start -> scalar registers, nothing re-read in the loops
   const double* zt = zt_all + (size_t)b * TcMax;
   const double* It = It_all + (size_t)b * TcMax;
   if (LDS_TAB) {                                    // staged once per block; the block then walks over its events
@@ -1479,7 +1479,7 @@ __global__ void __launch_bounds__(256) k_selection(SelDev Sd, const DevParams* p
   extern __shared__ double lds[];
   __shared__ double red[16];
   const int b = blockIdx.y, t = threadIdx.x;
-  const DevParams& P = params[b];
+  const DevParams P = params[b];      // by value: uniform loads at kernel start -> scalar registers, nothing re-read in the loops
   TablePtrs g = { zt_all + (size_t)b * TcMax, It_all + (size_t)b * TcMax, dLt_all + (size_t)b * TcMax,
                   mg_all + (size_t)b * TmMax, cdf_all + (size_t)b * TmMax };
   TabView T = stage_tables(P, g, LDS_TAB, lds, false);

@@ -15,6 +15,14 @@
 #define FM_RCP(x) __builtin_amdgcn_rcp(x)
 #define FM_FREXP_M(x) __builtin_amdgcn_frexp_mant(x)
 #define FM_FREXP_E(x) __builtin_amdgcn_frexp_exp(x)
+// a*b + c as ONE three-address v_fma_f64 with the coefficient c held in a VGPR pair.  In the large kernels the compiler turns a
+// Horner step with a register-resident coefficient into v_mov_b64 + v_fmac_f64 (two issue slots, seen in the gfx950 ISA of
+// k_samples: 260 of 1134 VALU instructions in the loop were such copies); spelling the instruction out halves the polynomial cost.
+DEVFN double FM_FMA(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 
 DEVFN double chm_exp(double x) {
   const double L2E = 1.44269504088896338700e+00, LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10;
@@ -22,16 +30,16 @@ DEVFN double chm_exp(double x) {
   double r = __builtin_fma(-n, LN2HI, x);
   r = __builtin_fma(-n, LN2LO, r);
   double p = 1.6059043836821613e-10;                 // 1/13!
-  p = __builtin_fma(p, r, 2.08767569878681e-09);     // 1/12!
-  p = __builtin_fma(p, r, 2.505210838544172e-08);    // 1/11!
-  p = __builtin_fma(p, r, 2.755731922398589e-07);    // 1/10!
-  p = __builtin_fma(p, r, 2.7557319223985893e-06);   // 1/9!
-  p = __builtin_fma(p, r, 2.48015873015873e-05);     // 1/8!
-  p = __builtin_fma(p, r, 0.0001984126984126984);    // 1/7!
-  p = __builtin_fma(p, r, 0.001388888888888889);     // 1/6!
-  p = __builtin_fma(p, r, 0.008333333333333333);     // 1/5!
-  p = __builtin_fma(p, r, 0.041666666666666664);     // 1/4!
-  p = __builtin_fma(p, r, 0.16666666666666666);      // 1/3!
+  p = FM_FMA(p, r, 2.08767569878681e-09);     // 1/12!
+  p = FM_FMA(p, r, 2.505210838544172e-08);    // 1/11!
+  p = FM_FMA(p, r, 2.755731922398589e-07);    // 1/10!
+  p = FM_FMA(p, r, 2.7557319223985893e-06);   // 1/9!
+  p = FM_FMA(p, r, 2.48015873015873e-05);     // 1/8!
+  p = FM_FMA(p, r, 0.0001984126984126984);    // 1/7!
+  p = FM_FMA(p, r, 0.001388888888888889);     // 1/6!
+  p = FM_FMA(p, r, 0.008333333333333333);     // 1/5!
+  p = FM_FMA(p, r, 0.041666666666666664);     // 1/4!
+  p = FM_FMA(p, r, 0.16666666666666666);      // 1/3!
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
@@ -61,8 +69,8 @@ DEVFN double chm_log_pos(double x) {
   double s = f * r;
   s = __builtin_fma(__builtin_fma(-d, s, f), r, s);
   double z = s * s, w = z * z;
-  double t1 = w * __builtin_fma(w, __builtin_fma(w, Lg6, Lg4), Lg2);
-  double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, Lg7, Lg5), Lg3), Lg1);
+  double t1 = w * FM_FMA(w, FM_FMA(w, Lg6, Lg4), Lg2);
+  double t2 = z * FM_FMA(w, FM_FMA(w, FM_FMA(w, Lg7, Lg5), Lg3), Lg1);
   double R = t2 + t1;
   double hfsq = 0.5 * f * f;
   double dk = (double)e;
