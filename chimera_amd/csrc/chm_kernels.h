@@ -990,15 +990,15 @@ template <int SW>
 __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevParams* params) {
   extern __shared__ double lds_all[];
   constexpr int NPW = 64 / SW;                              // pixels per wave
-  constexpr int PF = 4;                                     // prefetch passes: PF * SW * 2 grid points per pixel
+  constexpr int PF = 4;                                     // p_cat prefetch passes: PF * SW * 2 grid points per pixel
   const int lane = threadIdx.x, sub = lane / SW, sl = lane % SW;
   const int PG = (L.P + NPW - 1) / NPW;
   const int b = blockIdx.x % L.nb, bx = blockIdx.x / L.nb;
   const int p = (bx % PG) * NPW + sub, e = L.e_off + bx / PG;
-  const DevParams& P = params[b];
   const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
-  double* P0 = lds_all + (size_t)sub * (3 * B + 3); double* P1 = P0 + (B + 1); double* P2 = P1 + (B + 1);
-  double* cnt = P0;
+  // LDS slice of this pixel: Q[3 j + c], j = 0..B, c = 0,1,2: prefix sums of (w, w c', w c'^2) interleaved, so that one
+  // address serves the three reads of a bin boundary; the bin counts live in the c = 0 slots until the prefix pass
+  double* Q = lds_all + (size_t)sub * (3 * B + 3);
   const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
   const double zmin = es[0], norm = es[3], n_eff = es[4], lb = es[6], ub = es[7];
   const bool ok = n_eff >= L.pe_neff;                       // likelihood.py:199 (same for every pixel of the event)
@@ -1012,19 +1012,26 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   }
   const double* zg = L.z_grids + (size_t)e * Z;
   const double* pc = L.p_cat + ((size_t)e * L.P + pp) * Z;
+  const size_t zo = ((size_t)b * L.E + e) * Z;
+  const double* bkgA = L.bkgA + zo;
+  const double* Aw = L.Aw + zo;
   int k_lo = (int)es[8], k_hi = (int)es[9];
   k_lo &= ~1;
-  const bool vec2 = (Z & 1) == 0;
+  const bool vec2 = (Z & 1) == 0;                           // then every pair (k, k+1), k even, is 16-byte aligned and in bounds
+  // two consecutive grid points of one array for this lane
+  auto load2 = [&](const double* a, int k, double& v0, double& v1) {
+    v0 = 0.; v1 = 0.;
+    if (live && k <= k_hi) {
+      if (vec2) { double2 v = *reinterpret_cast<const double2*>(a + k); v0 = v.x; v1 = v.y; }
+      else { v0 = a[k]; if (k + 1 <= k_hi) v1 = a[k + 1]; }
+    }
+  };
   double pf0[PF], pf1[PF];
 #pragma unroll
-  for (int i = 0; i < PF; i++) {
-    int k = k_lo + 2 * SW * i + 2 * sl;
-    pf0[i] = 0.; pf1[i] = 0.;
-    if (live) {
-      if (vec2 && k + 1 <= k_hi) { double2 v = *reinterpret_cast<const double2*>(pc + k); pf0[i] = v.x; pf1[i] = v.y; }
-      else { if (k <= k_hi) pf0[i] = pc[k]; if (k + 1 <= k_hi) pf1[i] = pc[k + 1]; }
-    }
-  }
+  for (int i = 0; i < PF; i++) load2(pc, k_lo + 2 * SW * i + 2 * sl, pf0[i], pf1[i]);
+  // grid, background and trapezoid factors of the first pass: in flight during the histogram phase
+  double zc0, zc1, bc0, bc1, ac0, ac1;
+  load2(zg, k_lo + 2 * sl, zc0, zc1); load2(bkgA, k_lo + 2 * sl, bc0, bc1); load2(Aw, k_lo + 2 * sl, ac0, ac1);
   // histogram of the pixel's samples on [min z, max z in pixel] (math.py:32-46, likelihood.py:180-183)
   const size_t so = ((size_t)b * L.E + e) * S;
   const double* wz = L.ws_z + so;
@@ -1041,18 +1048,18 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   for (int s = s0 + sl + SW * NR; s < s1; s += SW) hi = nanmax2(hi, wz[s]);
   hi = sg_max<SW>(hi);
   if (lo != lo) hi = lo;
-  for (int j = sl; j < B; j += SW) cnt[j] = 0.;
+  for (int j = sl; j < B; j += SW) Q[3 * j] = 0.;
   const double dbin = (hi - lo) / (double)B;                // c'_j = (j + 1/2) dbin  (see k_kde_marg_fast)
   wave_sync();
 #pragma unroll
-  for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&cnt[bin_index(zr[i], lo, hi, B)], wr[i]); }
-  for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&cnt[bin_index(wz[s], lo, hi, B)], ww[s]);
+  for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q[3 * bin_index(zr[i], lo, hi, B)], wr[i]); }
+  for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q[3 * bin_index(wz[s], lo, hi, B)], ww[s]);
   wave_sync();
   // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins
   const int per = (B + SW - 1) / SW;
   const int j0 = sl * per < B ? sl * per : B, j1 = min(j0 + per, B);
   double s0w = 0., s1w = 0., s2w = 0., sq = 0.;
-  for (int j = j0; j < j1; j++) { double w = cnt[j], cc = ((double)j + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
+  for (int j = j0; j < j1; j++) { double w = Q[3 * j], cc = ((double)j + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
   double x0 = s0w, x1 = s1w, x2 = s2w;
 #pragma unroll
   for (int o = 1; o < SW; o <<= 1) {
@@ -1068,7 +1075,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
     const bool small = per <= MAXPER;
     if (small) {
 #pragma unroll
-      for (int i = 0; i < MAXPER; i++) wv[i] = (j0 + i < j1) ? cnt[j0 + i] : 0.;
+      for (int i = 0; i < MAXPER; i++) wv[i] = (j0 + i < j1) ? Q[3 * (j0 + i)] : 0.;
     }
     wave_sync();
     if (small) {
@@ -1076,68 +1083,84 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
       for (int i = 0; i < MAXPER; i++) if (j0 + i < j1) {
         double w = wv[i], cc = ((double)(j0 + i) + 0.5) * dbin;
         r0 += w; r1 += w * cc; r2 += w * cc * cc;
-        P0[j0 + i + 1] = r0; P1[j0 + i + 1] = r1; P2[j0 + i + 1] = r2;
+        double* q = Q + 3 * (j0 + i + 1);
+        q[0] = r0; q[1] = r1; q[2] = r2;
       }
-    } else {
+    } else {                                                // many bins per lane: the count of bin j+1 shares the slot of P0[j+1]
       double a0 = r0, a1 = r1, a2 = r2;
-      for (int j = j0; j < j1; j++) { double w = cnt[j], cc = ((double)j + 0.5) * dbin; a1 += w * cc; a2 += w * cc * cc; P1[j + 1] = a1; P2[j + 1] = a2; }
-      a0 = r0; for (int j = j0; j < j1; j++) a0 += cnt[j];
-      for (int j = j1 - 1; j >= j0; j--) { double w = cnt[j]; P0[j + 1] = a0; a0 -= w; }
+      for (int j = j0; j < j1; j++) { double w = Q[3 * j], cc = ((double)j + 0.5) * dbin; a1 += w * cc; a2 += w * cc * cc; Q[3 * (j + 1) + 1] = a1; Q[3 * (j + 1) + 2] = a2; }
+      a0 = r0; for (int j = j0; j < j1; j++) a0 += Q[3 * j];
+      for (int j = j1 - 1; j >= j0; j--) { double w = Q[3 * j]; Q[3 * (j + 1)] = a0; a0 -= w; }
     }
-    if (sl == 0) { P1[0] = 0.; P2[0] = 0.; }
+    if (sl == 0) { Q[1] = 0.; Q[2] = 0.; }
     wave_sync();
-    if (sl == 0) P0[0] = 0.;
+    if (sl == 0) Q[0] = 0.;
     wave_sync();
   }
   const double neff_k = (tot * tot) / sum2;
   const double stdc = (hi - lo) * (sqrt(((double)B * (double)B - 1.) / 12.) / (double)B);
   const double bw = kde_bandwidth_factor(L.bw_method, L.bw_scalar, neff_k, 1) * stdc;
   const bool degenerate = !(dbin > 0.) || !(bw > 0.) || !(bw < 1e300) || !(tot > 0. || tot < 0.);
-  EpanCtx cx;
-  cx.P0 = P0; cx.P1 = P1; cx.P2 = P2; cx.N = B; cx.lo = lo; cx.inv_dbin = 1. / dbin; cx.bw = bw; cx.inv_bw = 1. / bw;
-  cx.scale = 0.75 * cx.inv_bw / tot;
-
-  const size_t zo = ((size_t)b * L.E + e) * Z;
-  const double* bkgA = L.bkgA + zo;
-  const double* Aw = L.Aw + zo;
-  const double* eg = L.effg + ((size_t)b * L.E + e) * G;
-  const double gwp = L.gw_pdf[(size_t)e * L.P + pp];
-  const double fR = P.fR;
+  // Per-pixel constants of the node evaluation.  A node g of the effective grid sees the bins [ja, jb) with |g - c_j| <= h,
+  // c_j = lo + (j + 1/2) dbin:  ja = ceil(t - hb), jb = floor(t + hb) + 1 with t = (g - lo)/dbin - 1/2, hb = h/dbin; the next
+  // node is t + dd, dd = de/dbin.  A bin whose |u| is within rounding of 1 may land on either side (kernel value < 1e-12).
+  const double inv_dbin = 1. / dbin, inv_bw = 1. / bw, inv_bw2 = inv_bw * inv_bw;
+  const double scale = 0.75 * inv_bw / tot;
+  const double hb = bw * inv_dbin;
   const double inv_de = (double)(G - 1) / (ub - lb);
+  const double de = (ub - lb) / (double)(G - 1);            // spacing of jnp.linspace(lb, ub, G)   likelihood.py:188
+  const double dd = de * inv_dbin;
+  const double dB = (double)B, dG2 = (double)(G - 2);
+  const double lbl = lb - lo;
+  const double ng = norm * L.gw_pdf[(size_t)e * L.P + pp]; // kde_interp * norm * gw_pdf[i]    likelihood.py:194
+  const double fR = params[b].fR;
   const double nan = __builtin_nan("");
+  // density (without the common factor `scale`) at the node with g' = g - lo and bin position t
+  auto node = [&](double gp, double t) {
+    double fa = __builtin_fmin(__builtin_fmax(ceil(t - hb), 0.), dB);
+    double fb = __builtin_fmin(__builtin_fmax(floor(t + hb) + 1., fa), dB);
+    const int ia = 3 * (int)fa, ib = 3 * (int)fb;
+    double S0 = Q[ib] - Q[ia], S1 = Q[ib + 1] - Q[ia + 1], S2 = Q[ib + 2] - Q[ia + 2];
+    double qq = fma(gp, fma(gp, S0, -2. * S1), S2);         // sum W (g' - c')^2 over the support
+    return S0 - qq * inv_bw2;
+  };
   double acc = 0.;
   if (dump && live) { for (int k = sl; k < Z; k += SW) if (k < k_lo || k > k_hi) dump[k] = 0.; }
 #pragma unroll 1
   for (int it = 0; k_lo + 2 * SW * it <= k_hi; it++) {      // one pass = SW lanes x 2 consecutive grid points per pixel
     const int k = k_lo + 2 * SW * it + 2 * sl;
-    double pc0, pc1;
-    if (it < PF) {
-      pc0 = pf0[0]; pc1 = pf1[0];
+    // software pipeline: the loads of the next pass are issued before the arithmetic of this one
+    double zn0, zn1, bn0, bn1, an0, an1, pn0 = 0., pn1 = 0.;
+    const int kn = k + 2 * SW;
+    load2(zg, kn, zn0, zn1); load2(bkgA, kn, bn0, bn1); load2(Aw, kn, an0, an1);
+    if (it + 1 >= PF) load2(pc, kn, pn0, pn1);
+    double pc0 = pf0[0], pc1 = pf1[0];                      // this pass's p_cat: prefetched at kernel start or by the previous pass
 #pragma unroll
-      for (int i = 1; i < PF; i++) if (it == i) { pc0 = pf0[i]; pc1 = pf1[i]; }
-    } else {
-      pc0 = (live && k <= k_hi) ? pc[k] : 0.; pc1 = (live && k + 1 <= k_hi) ? pc[k + 1] : 0.;
-    }
+    for (int i = 1; i < PF; i++) if (it == i) { pc0 = pf0[i]; pc1 = pf1[i]; }
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int kk = k + h;
       if (kk <= k_hi && live) {
-        const double zk = zg[kk];
+        const double zk = h == 0 ? zc0 : zc1;
         double pgw = 0.;
         if (zk >= lb && zk <= ub) {                         // jnp.interp(..., left=0, right=0)
-          double tp = floor((zk - lb) * inv_de);
-          tp = tp < (double)(G - 2) ? tp : (double)(G - 2);
-          const int i1 = (int)tp + 1;
-          double xa = eg[i1 - 1], xb = eg[i1];
-          double da = epan_node(cx, xa), db = epan_node(cx, xb);
-          double f = da + ((zk - xa) * inv_de) * (db - da);
-          pgw = degenerate ? nan : f * norm * gwp;          // kde_interp * norm * gw_pdf[i]    likelihood.py:194
+          // bracket on the uniform effective grid: nodes x_i = lb + i de; a z within rounding of a node may pick either
+          // neighbouring segment -- the interpolant is continuous there
+          double tp = __builtin_fmin(floor((zk - lb) * inv_de), dG2);
+          double ga = fma(tp, de, lbl);                     // x_a - lo
+          double ta = fma(ga, inv_dbin, -0.5);
+          double da = node(ga, ta), db = node(ga + de, ta + dd);
+          double wgt = ((zk - lb) - tp * de) * inv_de;      // (z - x_a)/dx
+          double f = (da + wgt * (db - da)) * scale;
+          pgw = degenerate ? nan : f * ng;
         } else if (zk != zk) pgw = nan;
         if (dump) dump[kk] = pgw;
         const double pcv = h == 0 ? pc0 : pc1;
-        if (pcv != -100.) acc += pgw * (fR * pcv + bkgA[kk]) * Aw[kk];
+        if (pcv != -100.) acc += pgw * (fR * pcv + (h == 0 ? bc0 : bc1)) * (h == 0 ? ac0 : ac1);   // catalog.py:202, likelihood.py:275
       }
     }
+    zc0 = zn0; zc1 = zn1; bc0 = bn0; bc1 = bn1; ac0 = an0; ac1 = an1;
+    if (it + 1 >= PF) { pf0[0] = pn0; pf1[0] = pn1; }
   }
   acc = sg_sum<SW>(acc);
   if (sl == 0 && live) *out_like = acc;
