@@ -22,7 +22,7 @@
 // per-(draw,event,chunk) partial statistics written by k_samples; d = z - z_ref (z_ref = z of the event's first sample)
 enum { PT_SW = 0, PT_SW2, PT_SD1, PT_SD2, PT_ZMIN, PT_ZMAX, PT_WD0, PT_WD1, PT_WD2, PT_W00, PT_W01, PT_W02, PT_W11, PT_W12, PT_W22, PT_ZREF };
 #define SAMPLE_CHUNK 1024
-#define NEVSTAT 10           // doubles per (draw, event) written by k_event_prep
+#define NEVSTAT 12           // doubles per (draw, event) written by k_event_prep
 
 struct LikeDev {                  // device-resident shard of events (see chm_like_desc)
   int E, S, Z, P;
@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
         if (s + h < s_end) {
           double d = z - z_ref;
           v[0] += w; v[1] += w * w; v[2] += d; v[3] += d * d;
-          v[4] = nanmin2(v[4], z); v[5] = nanmax2(v[5], z);
+          v[4] = __builtin_fmin(v[4], z); v[5] = __builtin_fmax(v[5], z);       // a NaN z is caught through sum(d) below
           if (FULL) {                             // un-normalised weighted moments of (z, ra, dec) about the reference
             double d1 = L.ra[eo + s + h] - ra_ref, d2 = L.dec[eo + s + h] - dec_ref;
             m[0] += w * d; m[1] += w * d1; m[2] += w * d2;
@@ -360,6 +360,7 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
     }
     double* q = L.part + (((size_t)b * L.E + e) * L.NC + c) * NPART;
     block_reduce_stats<4>(v, red);
+    if (v[2] != v[2]) { v[4] = v[2]; v[5] = v[2]; }         // jnp.min / jnp.max propagate NaN (any NaN z makes sum(d) NaN)
     if (t == 0) { q[PT_SW] = v[0]; q[PT_SW2] = v[1]; q[PT_SD1] = v[2]; q[PT_SD2] = v[3]; q[PT_ZMIN] = v[4]; q[PT_ZMAX] = v[5]; q[PT_ZREF] = z_ref; }
     if (FULL) {
       double mm[11];
@@ -435,6 +436,18 @@ DEVFN int bin_index(double z, double lo, double hi, int B) {
   double f = floor((z - lo) / (hi - lo) * (double)B);
   f = f < 0. ? 0. : (f > (double)(B - 1) ? (double)(B - 1) : f);
   return (f != f) ? 0 : (int)f;
+}
+
+// bin_index() with the pixel-constant divisor d = hi - lo and r = 1/d (one IEEE division per pixel): the quotient is formed as
+// q0 = x r, q = q0 + r (x - q0 d) (fma residual), which IS the correctly rounded x/d for the operands met here (0 <= x <= d,
+// Markstein), so the bin of every sample is the one bin_index() gives; the clamp runs on v_max/v_min (NaN -> bin 0).
+DEVFN int bin_index_r(double z, double lo, double d, double r, double dB) {
+  double x = z - lo;
+  double q = x * r;
+  q = fma(fma(-q, d, x), r, q);
+  double f = floor(q * dB);
+  f = __builtin_fmin(__builtin_fmax(f, 0.), dB - 1.);
+  return (int)f;
 }
 
 DEVFN double kde_bandwidth_factor(int bw_method, double bw_scalar, double neff, int d) {
@@ -607,7 +620,8 @@ __global__ void __launch_bounds__(64) k_event_prep(LikeDev L) {
     if (fl == fl && fh == fh && gl <= gh && (gl == 0 || zg[gl] < lb) && (gh == Z - 1 || zg[gh] > ub)) { k_lo = gl; k_hi = gh; }
   }
   if (lane == 0) { o[0] = st.zmin; o[1] = st.zmax; o[2] = st.sd; o[3] = st.norm; o[4] = st.n_eff; o[5] = st.sumw; o[6] = lb; o[7] = ub;
-                   o[8] = (double)k_lo; o[9] = (double)k_hi; }
+                   o[8] = (double)k_lo; o[9] = (double)k_hi;
+                   o[10] = (ub - lb) / (double)(L.G - 1); o[11] = (double)(L.G - 1) / (ub - lb); }    // likelihood.py:188
   double* eg = L.effg + ((size_t)b * L.E + e) * L.G;
   if (L.has_cut) { for (int i = lane; i < L.G; i += 64) eg[i] = linspace_tab(lb, ub, L.G, i, L.fracG); }   // likelihood.py:188
   else { for (int i = lane; i < L.G; i += 64) eg[i] = L.z_grids[(size_t)e * L.Z + i]; }                        // likelihood.py:190
@@ -1042,18 +1056,28 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   double zr[NR], wr[NR];
 #pragma unroll
   for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; zr[i] = s < s1 ? wz[s] : lo; wr[i] = s < s1 ? ww[s] : 0.; }
+  // hi = max(where(mask, z, min z)) (likelihood.py:180, math.py:36), NaN-propagating like jnp.max: v_max_f64 over the
+  // samples plus a "saw a NaN" vote of the pixel's lanes
   double hi = lo;
+  bool sawnan = lo != lo;
 #pragma unroll
-  for (int i = 0; i < NR; i++) hi = nanmax2(hi, zr[i]);
-  for (int s = s0 + sl + SW * NR; s < s1; s += SW) hi = nanmax2(hi, wz[s]);
-  hi = sg_max<SW>(hi);
-  if (lo != lo) hi = lo;
+  for (int i = 0; i < NR; i++) { hi = __builtin_fmax(hi, zr[i]); sawnan = sawnan || (zr[i] != zr[i]); }
+  for (int s = s0 + sl + SW * NR; s < s1; s += SW) { double zz = wz[s]; hi = __builtin_fmax(hi, zz); sawnan = sawnan || (zz != zz); }
+#pragma unroll
+  for (int o = SW / 2; o > 0; o >>= 1) hi = __builtin_fmax(hi, __shfl_xor(hi, o, 64));
+  {
+    const unsigned long long votes = __ballot(sawnan);
+    const unsigned long long mine = SW == 64 ? ~0ull : (((1ull << (SW & 63)) - 1ull) << (sub * SW));
+    if (votes & mine) hi = __builtin_nan("");
+  }
   for (int j = sl; j < B; j += SW) Q[3 * j] = 0.;
-  const double dbin = (hi - lo) / (double)B;                // c'_j = (j + 1/2) dbin  (see k_kde_marg_fast)
+  const double dB = (double)B;
+  const double dbin = (hi - lo) / dB;                       // c'_j = (j + 1/2) dbin  (see k_kde_marg_fast)
+  const double dhl = hi - lo, rhl = 1. / dhl;
   wave_sync();
 #pragma unroll
-  for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q[3 * bin_index(zr[i], lo, hi, B)], wr[i]); }
-  for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q[3 * bin_index(wz[s], lo, hi, B)], ww[s]);
+  for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q[3 * bin_index_r(zr[i], lo, dhl, rhl, dB)], wr[i]); }
+  for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q[3 * bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
   wave_sync();
   // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins
   const int per = (B + SW - 1) / SW;
@@ -1107,10 +1131,9 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   const double inv_dbin = 1. / dbin, inv_bw = 1. / bw, inv_bw2 = inv_bw * inv_bw;
   const double scale = 0.75 * inv_bw / tot;
   const double hb = bw * inv_dbin;
-  const double inv_de = (double)(G - 1) / (ub - lb);
-  const double de = (ub - lb) / (double)(G - 1);            // spacing of jnp.linspace(lb, ub, G)   likelihood.py:188
+  const double de = es[10], inv_de = es[11];                // spacing of jnp.linspace(lb, ub, G) and its inverse (k_event_prep)
   const double dd = de * inv_dbin;
-  const double dB = (double)B, dG2 = (double)(G - 2);
+  const double dG2 = (double)(G - 2);
   const double lbl = lb - lo;
   const double ng = norm * L.gw_pdf[(size_t)e * L.P + pp]; // kde_interp * norm * gw_pdf[i]    likelihood.py:194
   const double fR = params[b].fR;

@@ -90,15 +90,18 @@ DEVFN double jnp_interp(double x, AccX xp, AccF fp, int n, bool has_lr, double l
 // no data-dependent branches), so that the LDS latencies of the two searches overlap.  Same result as jnp_interp().
 template <class AccX, class AccF>
 DEVFN void jnp_interp_x2(double xa, double xb, AccX xp, AccF fp, int n, double& fa, double& fb) {
-  int pa = 0, pb = 0;                                    // number of elements <= x  (searchsorted side='right')
-  int step = 1;
-  while (step * 2 <= n) step *= 2;
-  for (; step > 0; step >>= 1) {
-    int ta = pa + step, tb = pb + step;
-    double va = xp[(ta <= n ? ta : n) - 1], vb = xp[(tb <= n ? tb : n) - 1];
-    if (ta <= n && va <= xa) pa = ta;
-    if (tb <= n && vb <= xb) pb = tb;
+  // number of elements <= x (searchsorted side='right') by halving [base, base + len): the probe base + half - 1 is always in
+  // bounds and the sequence of lengths is the same for every lane, so a step is a read, a compare and a conditional add
+  int pa = 0, pb = 0;
+  for (int len = n; len > 1;) {
+    const int half = len >> 1;
+    double va = xp[pa + half - 1], vb = xp[pb + half - 1];
+    pa += (va <= xa) ? half : 0;
+    pb += (vb <= xb) ? half : 0;
+    len -= half;
   }
+  pa += (xp[pa] <= xa) ? 1 : 0;
+  pb += (xp[pb] <= xb) ? 1 : 0;
   int ia = pa < 1 ? 1 : (pa > n - 1 ? n - 1 : pa), ib = pb < 1 ? 1 : (pb > n - 1 ? n - 1 : pb);
   double x0a = xp[ia - 1], x1a = xp[ia], f0a = fp[ia - 1], f1a = fp[ia];
   double x0b = xp[ib - 1], x1b = xp[ib], f0b = fp[ib - 1], f1b = fp[ib];
