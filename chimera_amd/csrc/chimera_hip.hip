@@ -476,14 +476,17 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
       // per-z factors of the group's events: on the other lane, concurrently with the sample stage -- except in marginalized
       // mode, where they follow k_event_prep on the group's own lane and cover only the support of each event's KDE
       const bool zf_ranged = L.mode == CHM_MODE_MARG && !getenv("CHM_ZF_FULL");
+      static const int marg_sub = getenv("CHM_MARG_SUB") ? atoi(getenv("CHM_MARG_SUB")) : 32;   // lanes per pixel in the standard kernel
+      const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC") && (marg_sub == 32 || marg_sub == 16);
+      const int zf_mode = zf_ranged ? 1 : 0;
       hipStream_t sz = (serial || zf_ranged) ? sg : ((g & 1) ? sA : sB);
       // ~2048 blocks in all: each stages the draw's (zt, It) tables in LDS once and walks over E_cnt / gridDim.x events
       const int zf_target = 2048 / nb > 1 ? 2048 / nb : 1;
       const int zf_blocks = L.E_cnt < zf_target ? L.E_cnt : zf_target;
       auto launch_zfactors = [&]() {
         if (tab_zfac) { allow_lds(k_zfactors<true>, lds_zfac);
-          hipLaunchKernelGGL(k_zfactors<true>, dim3(zf_blocks, nb), dim3(256), lds_zfac, sz, L, dp, c.zt, c.It, Tc, zf_ranged ? 1 : 0);
-        } else hipLaunchKernelGGL(k_zfactors<false>, dim3(zf_blocks, nb), dim3(256), 0, sz, L, dp, c.zt, c.It, Tc, zf_ranged ? 1 : 0);
+          hipLaunchKernelGGL(k_zfactors<true>, dim3(zf_blocks, nb), dim3(256), lds_zfac, sz, L, dp, c.zt, c.It, Tc, zf_mode);
+        } else hipLaunchKernelGGL(k_zfactors<false>, dim3(zf_blocks, nb), dim3(256), 0, sz, L, dp, c.zt, c.It, Tc, zf_mode);
       };
       if (!zf_ranged) {
         launch_zfactors();
@@ -493,6 +496,8 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
       // sample stage
       HIPCHK(hipEventRecord(c.evg[4 * g], sg));
       const int nchunk = L.E_cnt * L.NC;
+      // up to 1024 blocks per draw, each staging the draw's tables in LDS (40 KB) and walking over its chunks (fewer, longer
+      // blocks measured slower at C3: 1.13 ms at 1024 blocks in all against 1.04 ms; dynamic balance matters more than staging)
       dim3 g1((nchunk < 1024 ? nchunk : 1024) * nb, 1);
       const bool fullm = L.mode == CHM_MODE_FULL;
       if (tab_samp) {
@@ -512,12 +517,12 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
         HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         hipLaunchKernelGGL(k_full_kde, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp);
       } else if (L.mode == CHM_MODE_MARG) {
-        hipLaunchKernelGGL(k_event_prep, dim3(L.E_cnt, nb), dim3(64), 0, sg, L);
+        hipLaunchKernelGGL(k_event_prep, dim3(L.E_cnt, nb), dim3(64), 0, sg, L, marg_std ? 0 : 1);
         HIPCHK(hipGetLastError());
         if (zf_ranged) { launch_zfactors(); HIPCHK(hipGetLastError()); }
         HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         const bool fast = L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC");
-        static const int sub = getenv("CHM_MARG_SUB") ? atoi(getenv("CHM_MARG_SUB")) : 32;     // lanes per pixel in the fast kernel
+        const int sub = marg_sub;
         if (fast && sub == 32) hipLaunchKernelGGL(k_kde_marg_sub<32>, dim3(L.E_cnt * ((Pd + 1) / 2) * nb, 1), dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
         else if (fast && sub == 16) hipLaunchKernelGGL(k_kde_marg_sub<16>, dim3(L.E_cnt * ((Pd + 3) / 4) * nb, 1), dim3(64), sizeof(double) * (3 * N + 3) * 4, sg, L, dp);
         else if (fast) hipLaunchKernelGGL(k_kde_marg_fast, dim3(L.E_cnt * ((Pd + MARG_WPB - 1) / MARG_WPB), nb), dim3(64 * MARG_WPB),

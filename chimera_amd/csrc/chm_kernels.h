@@ -375,59 +375,6 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_zfactors: per-z factors of the integrand on each event grid; one block per (event, draw)
-//   jac = ddL/dz (1+z)^2 (likelihood.py:272);  prate = merger_rate/(1+z) (pop_wrapper.py:85);
-//   bkgA = (1 - P_compl) p_bkg (catalog.py:202)  or  p_bkg for the empty catalogue (catalog.py:43)
-// ------------------------------------------------------------------------------------------------------
-template <bool LDS_TAB>
-__global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
-                                                   int TcMax, int ranged) {
-  extern __shared__ double lds[];
-  const int b = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
-  const DevParams P = params[b];      // by value: uniform loads at kernel start -> scalar registers, nothing re-read in the loops
-  const double* zt = zt_all + (size_t)b * TcMax;
-  const double* It = It_all + (size_t)b * TcMax;
-  if (LDS_TAB) {                                    // staged once per block; the block then walks over its events
-    double* a = lds; double* c = lds + P.Tc;
-    for (int i = t; i < P.Tc; i += nt) { a[i] = zt[i]; c[i] = It[i]; }
-    __syncthreads();
-    zt = a; It = c;
-  }
-  const int Z = L.Z;
-  for (int ei = blockIdx.x; ei < L.E_cnt; ei += gridDim.x) {
-    const int e = L.e_off + ei;
-    const size_t zo = ((size_t)b * L.E + e) * Z;
-    const double* zg = L.z_grids + (size_t)e * Z;
-    // ranged (marginalized mode, after k_event_prep): only the grid points the GW kernel reads, [k_lo & ~1, k_hi] of the
-    // event (the support of its KDE, NEVSTAT slots 8-9); nothing for an event that fails the n_eff guard (likelihood.py:199)
-    int k_first = 0, k_last = Z - 1;
-    if (ranged) {
-      const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
-      if (!(es[4] >= L.pe_neff)) continue;
-      k_first = ((int)es[8]) & ~1; k_last = (int)es[9];
-    }
-    for (int k = k_first + t; k <= k_last; k += nt) {
-      double z = zg[k];
-      double dCt = dCt_at_z(P, z, zt, It);
-      double zp1 = 1. + z;
-      double lzp1 = chm_log_pos(zp1);
-      double Ez = E_at_z_l(P, z, lzp1);
-      double jac = ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1) * (zp1 * zp1);
-      double prate = merger_rate_l(P, z, lzp1) / (1. + z);
-      if (!ranged) { L.jac[zo + k] = jac; L.prate[zo + k] = prate; }
-      double p_bkg = dVcdz_from_dCt_E(P, dCt, Ez);
-      L.bkgA[zo + k] = P.has_catalog ? (1. - L.P_compl[(size_t)e * Z + k]) * p_bkg : p_bkg;
-      if (L.Aw) {
-        // trapezoid weight of grid point k: y_k enters the two adjacent intervals (jnp.trapezoid, likelihood.py:278)
-        double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
-        double tw = 0.5 * ((z - zl) + (zr - z));
-        L.Aw[zo + k] = (prate / jac) * tw;
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------------
 // KDE building blocks shared by k_kde_marg (one wave) and k_kde1d (one block)
 // ------------------------------------------------------------------------------------------------------
 // bin index of binning1d (math.py:41): clip(floor((x - lo)/(hi - lo) * B), 0, B-1); a NaN index (hi == lo) -> 0,
@@ -597,12 +544,11 @@ DEVFN void wave_prefix3(const double* cen, const double* wgt, int N, double c_re
   }
 }
 
-// k_event_prep: one wave per (event, draw): combine the chunk partials once for all the event's pixel blocks.
-// evstat (nb,E,8): zmin, zmax, std, norm, n_eff, sum w, lb, ub  (effective-grid ends, likelihood.py:186-187)
-__global__ void __launch_bounds__(64) k_event_prep(LikeDev L) {
-  const int e = L.e_off + blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+// Per-(draw, event) statistics for the marginalized kernels: the chunk partials of k_samples combined once for all the event's
+// pixels.  es[NEVSTAT]: zmin, zmax, std, norm, n_eff, sum w, lb, ub (effective-grid ends, likelihood.py:186-187), k_lo, k_hi
+// (event-grid points inside [lb, ub]), de, 1/de (spacing of jnp.linspace(lb, ub, G), likelihood.py:188)
+DEVFN void event_stats(const LikeDev& L, int b, int e, double* es) {
   const EvStats st = combine_stats(L.part + ((size_t)b * L.E + e) * L.NC * NPART, L.NC, L.S);
-  double* o = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
   double lb = 0., ub = 0.;
   if (L.has_cut) eff_bounds(L.mode == 2, st.zmin, st.zmax, st.sd, L.cut_grid, lb, ub);
   else { lb = L.z_grids[(size_t)e * L.Z]; ub = L.z_grids[(size_t)e * L.Z + L.Z - 1]; }
@@ -619,12 +565,82 @@ __global__ void __launch_bounds__(64) k_event_prep(LikeDev L) {
     int gh = fh < (double)(Z - 1) ? (fh > 0. ? (int)fh : 0) : Z - 1;
     if (fl == fl && fh == fh && gl <= gh && (gl == 0 || zg[gl] < lb) && (gh == Z - 1 || zg[gh] > ub)) { k_lo = gl; k_hi = gh; }
   }
-  if (lane == 0) { o[0] = st.zmin; o[1] = st.zmax; o[2] = st.sd; o[3] = st.norm; o[4] = st.n_eff; o[5] = st.sumw; o[6] = lb; o[7] = ub;
-                   o[8] = (double)k_lo; o[9] = (double)k_hi;
-                   o[10] = (ub - lb) / (double)(L.G - 1); o[11] = (double)(L.G - 1) / (ub - lb); }    // likelihood.py:188
+  es[0] = st.zmin; es[1] = st.zmax; es[2] = st.sd; es[3] = st.norm; es[4] = st.n_eff; es[5] = st.sumw; es[6] = lb; es[7] = ub;
+  es[8] = (double)k_lo; es[9] = (double)k_hi;
+  es[10] = (ub - lb) / (double)(L.G - 1); es[11] = (double)(L.G - 1) / (ub - lb);
+}
+
+// k_event_prep: one wave per (event, draw): event_stats -> evstat (nb,E,NEVSTAT) and, for the general kernels (k_kde_marg,
+// k_kde_marg_fast), the effective grid effg (nb,E,G); the standard kernel (k_kde_marg_sub) forms its nodes arithmetically.
+__global__ void __launch_bounds__(64) k_event_prep(LikeDev L, int write_effg) {
+  const int e = L.e_off + blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  double es[NEVSTAT];
+  event_stats(L, b, e, es);
+  double* o = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
+  if (lane < NEVSTAT) {
+    double v = es[0];
+#pragma unroll
+    for (int i = 1; i < NEVSTAT; i++) if (lane == i) v = es[i];
+    o[lane] = v;
+  }
+  if (!write_effg) return;
+  const double lb = es[6], ub = es[7];
   double* eg = L.effg + ((size_t)b * L.E + e) * L.G;
   if (L.has_cut) { for (int i = lane; i < L.G; i += 64) eg[i] = linspace_tab(lb, ub, L.G, i, L.fracG); }   // likelihood.py:188
   else { for (int i = lane; i < L.G; i += 64) eg[i] = L.z_grids[(size_t)e * L.Z + i]; }                        // likelihood.py:190
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_zfactors: per-z factors of the integrand on each event grid; one block per (event, draw)
+//   jac = ddL/dz (1+z)^2 (likelihood.py:272);  prate = merger_rate/(1+z) (pop_wrapper.py:85);
+//   bkgA = (1 - P_compl) p_bkg (catalog.py:202)  or  p_bkg for the empty catalogue (catalog.py:43)
+// ------------------------------------------------------------------------------------------------------
+template <bool LDS_TAB>
+__global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
+                                                   int TcMax, int ranged) {
+  extern __shared__ double lds[];
+  const int b = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+  const DevParams P = params[b];      // by value: uniform loads at kernel start -> scalar registers, nothing re-read in the loops
+  const double* zt = zt_all + (size_t)b * TcMax;
+  const double* It = It_all + (size_t)b * TcMax;
+  if (LDS_TAB) {                                    // staged once per block; the block then walks over its events
+    double* a = lds; double* c = lds + P.Tc;
+    for (int i = t; i < P.Tc; i += nt) { a[i] = zt[i]; c[i] = It[i]; }
+    __syncthreads();
+    zt = a; It = c;
+  }
+  const int Z = L.Z;
+  for (int ei = blockIdx.x; ei < L.E_cnt; ei += gridDim.x) {
+    const int e = L.e_off + ei;
+    const size_t zo = ((size_t)b * L.E + e) * Z;
+    const double* zg = L.z_grids + (size_t)e * Z;
+    // ranged (marginalized mode, after k_samples / k_event_prep): only the grid points the GW kernel reads, [k_lo & ~1, k_hi] of the
+    // event (the support of its KDE, NEVSTAT slots 8-9); nothing for an event that fails the n_eff guard (likelihood.py:199)
+    int k_first = 0, k_last = Z - 1;
+    if (ranged) {
+      const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
+      if (!(es[4] >= L.pe_neff)) continue;
+      k_first = ((int)es[8]) & ~1; k_last = (int)es[9];
+    }
+    for (int k = k_first + t; k <= k_last; k += nt) {
+      double z = zg[k];
+      double dCt = dCt_at_z(P, z, zt, It);
+      double zp1 = 1. + z;
+      double lzp1 = chm_log_pos(zp1);
+      double Ez = E_at_z_l(P, z, lzp1);
+      double jac = ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1) * (zp1 * zp1);
+      double prate = merger_rate_l(P, z, lzp1) / (1. + z);
+      if (!ranged) { L.jac[zo + k] = jac; L.prate[zo + k] = prate; }
+      double p_bkg = dVcdz_from_dCt_E(P, dCt, Ez);
+      L.bkgA[zo + k] = P.has_catalog ? (1. - L.P_compl[(size_t)e * Z + k]) * p_bkg : p_bkg;
+      if (L.Aw) {
+        // trapezoid weight of grid point k: y_k enters the two adjacent intervals (jnp.trapezoid, likelihood.py:278)
+        double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
+        double tw = 0.5 * ((z - zl) + (zr - z));
+        L.Aw[zo + k] = (prate / jac) * tw;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1571,6 +1587,22 @@ __global__ void __launch_bounds__(256) k_selection(SelDev Sd, const DevParams* p
 // ------------------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------------------
+// L_i = sum over the pixels of one event, in pixel order (jnp.sum over axis 1, likelihood.py:280); the loads of 8 pixels are
+// issued together so that a thread waits for 4 memory round trips per 32 pixels instead of 32
+DEVFN double pixel_sum(const double* lp, int Pd) {
+  double Li = 0.;
+  int p = 0;
+  for (; p + 8 <= Pd; p += 8) {
+    double v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = lp[p + i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) Li += v[i];
+  }
+  for (; p < Pd; p++) Li += lp[p];
+  return Li;
+}
+
 // k_reduce_events: one thread per event: L_i = sum_p like_pix (likelihood.py:280), log, nan_to_num (:296-297); block sums
 __global__ void __launch_bounds__(256) k_reduce_events(int E, int Pd, const double* like_pix, double* ev_partial /* (nb, nblk) */,
                                                         double* log_like_evs, double* numlike_evs) {
@@ -1579,8 +1611,7 @@ __global__ void __launch_bounds__(256) k_reduce_events(int E, int Pd, const doub
   double ll = 0.;
   if (e < E) {
     const double* lp = like_pix + ((size_t)b * E + e) * Pd;
-    double Li = 0.;
-    for (int p = 0; p < Pd; p++) Li += lp[p];
+    double Li = pixel_sum(lp, Pd);
     ll = log(Li);
     // jnp.nan_to_num(x, nan=-inf): NaN -> -inf, -inf -> -DBL_MAX, +inf -> DBL_MAX   
     if (ll != ll) ll = -__builtin_inf();
@@ -1647,8 +1678,7 @@ __global__ void __launch_bounds__(1024) k_reduce_final(int E, int Pd, const doub
   double acc = 0., s1 = 0., s2 = 0.;
   for (int e = t; e < E; e += blockDim.x) {
     const double* lp = like_pix + ((size_t)b * E + e) * Pd;
-    double Li = 0.;
-    for (int p = 0; p < Pd; p++) Li += lp[p];                      // jnp.sum over pixels          likelihood.py:280
+    double Li = pixel_sum(lp, Pd);                                   // jnp.sum over pixels          likelihood.py:280
     double ll = log(Li);                                             // likelihood.py:296,329
     if (ll != ll) ll = -__builtin_inf();                             // nan_to_num(nan=-inf)        
     else if (ll == -__builtin_inf()) ll = -1.7976931348623157e308;
