@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- hyper-likelihood throughput on MI355X (BASELINE.json metric).
 
-A step = one call of ``hyperlikelihood.batch`` with ``--nbatch`` (default 16) different hyper-parameter draws, i.e. nbatch
+A step = one call of ``hyperlikelihood.batch`` with ``--nbatch`` (default 64) different hyper-parameter draws, i.e. nbatch
 full hyperposterior evaluations (each: tables + det->src + weights + histogram/KDE + integrand + trapz + selection
 function + reduce) over the C3 workload: 1000 events x 32 pixels x 1000 z-bins x 4096 samples/event, 1e5 detected
 injections, PowerLaw+Peak + Madau-Dickinson + flat-LCDM, kind_p_gw3d='marginalized', binning(200), cut_grid=2 --
@@ -13,7 +13,7 @@ the latency of a single-draw call (nbatch = 1, the reference's scalar call) is r
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 N > 1: events and injections are sharded across ranks (strong scaling: the total workload is fixed), one RCCL
-all-reduce of 3 doubles per step inside chm_eval.  Rank 0 prints ONE JSON line.
+all-reduce of 3 * nbatch doubles per step inside chm_eval.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -50,12 +50,12 @@ def main():
   ap.add_argument('--warmup', type=int, default=3)
   ap.add_argument('--config', default='C3')
   ap.add_argument('--mode', default='marginalized')
-  ap.add_argument('--nbatch', type=int, default=16, help='hyper-parameter draws per chm_eval call (hyperlikelihood.batch)')
+  ap.add_argument('--nbatch', type=int, default=64, help='hyper-parameter draws per chm_eval call (hyperlikelihood.batch)')
   ap.add_argument('--events', type=int, default=None, help='shrink the number of events (debug)')
   ap.add_argument('--inj', type=int, default=None, help='shrink the number of injections (debug)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--single-call', action='store_true', help='also time the scalar one-draw call (extra launches after the timed region)')
-  ap.add_argument('--cpu-events', type=int, default=24)
+  ap.add_argument('--cpu-events', type=int, default=1000, help='events of the workload the CPU baseline evaluates (1000 = all of C3, ~15 s)')
   args = ap.parse_args()
 
   rank = int(os.environ.get('RANK', 0))
@@ -188,7 +188,11 @@ def main():
       "last_log_hyper": float(np.asarray(vals[-1]).ravel()[-1]),
     }
     if world == 1 and not args.no_cpu_baseline:
-      out["cpu_baseline"] = cpu_baseline(cfg, ev, inj, kind, args.cpu_events)
+      out["cpu_baseline"] = cb = cpu_baseline(cfg, ev, inj, kind, args.cpu_events)
+      if cb.get("log_hyper_H0_67") is not None:      # full-size parity check of the timed path against the CPU port
+        g = float(like(H0=67.))
+        out["parity_full_size"] = {"H0": 67., "log_hyper_hip": g, "log_hyper_cpu_port": cb["log_hyper_H0_67"],
+                                   "abs_diff": abs(g - cb["log_hyper_H0_67"]), "tolerance": 1e-7 * float(np.sqrt(E))}
     print(json.dumps(out), flush=True)
   like.close()
   sel.close()
@@ -199,30 +203,55 @@ def main():
     dist.destroy_process_group()
 
 
-def cpu_baseline(cfg, ev, inj, kind, n_ev):
-  """The oracle (NumPy restatement of the reference algorithm, one core) on a bounded sample of the same workload:
-  the first n_ev events + all injections, one evaluation; scaled linearly in the number of events."""
+def cpu_baseline(cfg, ev, inj, kind, n_ev, threads=None, numpy_events=48):
+  """CPU baselines on this host, same workload, same algorithm as the reference (dense G x B kernel sums):
+  * value: the plain-C / OpenMP restatement (oracle/chimera_oracle_c.c) on `threads` cores (the GPU box's CPU share is 16),
+    n_ev events (default: the whole workload) + all injections, 2 evaluations with different H0 (tables rebuilt each time);
+  * numpy_1core: the NumPy restatement (oracle/chimera_oracle.py) on one core, on the first `numpy_events` events, scaled."""
   for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
     os.environ.setdefault(k, '1')
   from oracle import chimera_oracle as O
   E = cfg['E']
-  n_ev = min(n_ev, E)
-  sub = {k: (v[:n_ev] if hasattr(v, 'shape') and v.shape[:1] == (E,) else v) for k, v in ev.items()}
   fields = ('m1det', 'm2det', 'dL', 'ra', 'dec', 'pe_prior', 'pixels_opt_nsides', 'ra_pix', 'dec_pix', 'gw_loc2d_pdf',
             'pixels_pe_opt_nside')
-  th = O.theta_pe_det(**{k: sub[k] for k in fields if k in sub})
-  gc = O.pixelated_catalog(O.dVdz_completeness(), sub['p_cat'], sub['z_grids'], sub['neff_pixels']) if cfg['pixelated'] else None
-  pop = O.population(O.flrw(H0=70., Om0=0.25, z_max=5.), O.plp(), O.madau_dickinson(), gal_cat=gc)
-  sel = O.selection_function(O.theta_inj_det(**{k: inj[k] for k in ('m1det', 'm2det', 'dL', 'p_draw')}), inj['N_inj'])
-  like = O.hyperlikelihood(th, sub['z_grids'], pop, sel, kind_p_gw3d=kind)
+
+  def build(n):
+    n = min(n, E)
+    sub = {k: (v[:n] if hasattr(v, 'shape') and v.shape[:1] == (E,) else v) for k, v in ev.items()}
+    th = O.theta_pe_det(**{k: sub[k] for k in fields if k in sub})
+    gc = O.pixelated_catalog(O.dVdz_completeness(), sub['p_cat'], sub['z_grids'], sub['neff_pixels']) if cfg['pixelated'] else None
+    pop = O.population(O.flrw(H0=70., Om0=0.25, z_max=5.), O.plp(), O.madau_dickinson(), gal_cat=gc)
+    sel = O.selection_function(O.theta_inj_det(**{k: inj[k] for k in ('m1det', 'm2det', 'dL', 'p_draw')}), inj['N_inj'])
+    return n, O.hyperlikelihood(th, sub['z_grids'], pop, sel, kind_p_gw3d=kind), pop, sel
+
+  out = {}
+  # NumPy, one core, bounded sample
+  n_np, like, pop, sel = build(numpy_events)
   popu = pop.update(H0=67.)
   t0 = time.perf_counter(); like.compute_log_likenum(popu); t_ev = time.perf_counter() - t0
   t0 = time.perf_counter(); sel.N_exp(popu); t_sel = time.perf_counter() - t0
-  t_full = t_ev * E / n_ev + t_sel
-  return {"value": 1.0 / t_full, "unit": "evals/s", "cores": 1, "kind": "port",
-          "sample": f"oracle (NumPy), first {n_ev} of {E} events ({t_ev:.2f} s) + all {cfg['I']} injections ({t_sel:.3f} s), "
-                    f"1 evaluation, event time scaled x{E / n_ev:.1f}",
-          "host_cpus": os.cpu_count()}
+  np1 = {"value": 1.0 / (t_ev * E / n_np + t_sel), "cores": 1,
+         "sample": f"oracle/chimera_oracle.py, first {n_np} of {E} events ({t_ev:.2f} s) + all {cfg['I']} injections ({t_sel:.3f} s), "
+                   f"1 evaluation, event time scaled x{E / n_np:.1f}"}
+  if kind != 'marginalized':
+    out = dict(np1, unit="evals/s", kind="port", host_cpus=os.cpu_count())
+    return out
+  # C / OpenMP, `threads` cores, the whole workload
+  from oracle import oracle_c as OC
+  threads = threads or min(16, os.cpu_count() or 1)
+  n_c, like, pop, sel = build(n_ev)
+  OC.numlike_marg(like, pop.update(H0=70.), nthreads=threads) if n_c <= 64 else None      # warm the library on small runs only
+  H0s = (67., 61., 73., 79.)                       # different H0 per evaluation: the tables are rebuilt each time
+  t0 = time.perf_counter()
+  vals = [OC.compute_all(like, dict(H0=h), nthreads=threads)[3] for h in H0s]
+  t_c = (time.perf_counter() - t0) / len(H0s)
+  val = vals[0]
+  t_full = t_c * (E / n_c) if n_c < E else t_c
+  out = {"value": 1.0 / t_full, "unit": "evals/s", "cores": threads, "kind": "port",
+         "sample": f"oracle/chimera_oracle_c.c (C + OpenMP, {threads} threads), {n_c} of {E} events + all {cfg['I']} injections, "
+                   f"{len(H0s)} evaluations at different H0 ({t_c:.2f} s each; {len(H0s) * t_c * threads:.0f} core-seconds in all)",
+         "host_cpus": os.cpu_count(), "numpy_1core": np1, "log_hyper_H0_67": float(val) if n_c == E else None}
+  return out
 
 
 if __name__ == '__main__':
