@@ -496,9 +496,12 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
       // sample stage
       HIPCHK(hipEventRecord(c.evg[4 * g], sg));
       const int nchunk = L.E_cnt * L.NC;
-      // up to 1024 blocks per draw, each staging the draw's tables in LDS (40 KB) and walking over its chunks (fewer, longer
-      // blocks measured slower at C3: 1.13 ms at 1024 blocks in all against 1.04 ms; dynamic balance matters more than staging)
-      dim3 g1((nchunk < 1024 ? nchunk : 1024) * nb, 1);
+      // blocks stage the draw's tables in LDS (40 KB) once and walk over their chunks: 8 chunks per block amortise the staging
+      // while leaving enough blocks for dynamic balance (measured, 64 draws: 1 chunk per block 0.582 ms at 125 events, 8 per block 0.536 ms; 3.99 -> 3.93 ms at 1000 events)
+      static const int cpb = getenv("CHM_SAMP_CPB") ? atoi(getenv("CHM_SAMP_CPB")) : 8;
+      int samp_blocks = (nchunk + cpb - 1) / cpb;
+      samp_blocks = samp_blocks < 1 ? 1 : (samp_blocks > 1024 ? 1024 : samp_blocks);
+      dim3 g1(samp_blocks * nb, 1);
       const bool fullm = L.mode == CHM_MODE_FULL;
       if (tab_samp) {
         if (fullm) { allow_lds(k_samples<true, true>, lds_samp);
