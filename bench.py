@@ -152,7 +152,8 @@ def main():
     try:
       with open(tf) as f:
         tj = json.load(f)
-      if tj.get('E') == (like._e1 - like._e0) and tj.get('kernel') == KERNEL_NAMES.get(kind) and cfg['P'] == tj.get('P') and cfg['Z'] == tj.get('Z'):
+      if (tj.get('E') == (like._e1 - like._e0) and tj.get('kernel') == KERNEL_NAMES.get(kind) and cfg['P'] == tj.get('P')
+          and cfg['Z'] == tj.get('Z') and tj.get('nbatch') == nb):      # measured on this workload, this many draws per call
         traffic = tj['bytes_per_draw'] * nb
     except Exception:
       traffic = None

@@ -11,6 +11,10 @@ timeout 900 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 # 2. kernel trace + stats of the same command
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
+# 2b. the same with every kernel on ONE stream (CHM_SERIAL=1): standalone durations (in the default run k_selection and
+#     k_zfactors overlap the sample stage on their own streams, so their trace durations are stretched)
+CHM_SERIAL=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -- python3 bench.py --no-cpu-baseline > $OUT/bench_serial_under_rocprof.json 2> $OUT/trace_serial.err
+cp $OUT/trace_serial/*/*kernel_stats.csv $OUT/kernel_stats_serial.csv 2>/dev/null
 # 3. PMC passes (separate runs, counters only)
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
   tag=$(echo $c | tr ' ' '_' | cut -c1-24)
@@ -41,5 +45,5 @@ if 'FETCH_SIZE' in k and 'WRITE_SIZE' in k:
 print(open('$OUT/kernel_stats.csv').read()[:3000])
 print(json.dumps(out.get(KN, {})), json.dumps(out.get('k_samples<true, false>', {})))
 PY
-rm -rf $OUT/trace $OUT/pmc_*/ 2>/dev/null
+rm -rf $OUT/trace $OUT/trace_serial $OUT/pmc_*/ 2>/dev/null
 ls -la $OUT
