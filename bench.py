@@ -83,7 +83,8 @@ def main():
   t_gen = time.time() - t0
 
   comm = Comm(world, rank, local_rank) if world > 1 else None
-  cosmo = CH.cosmo.flrw(H0=70., Om0=0.25, z_max=5.)
+  mg = args.config == 'C5'                      # BASELINE.json configs[4]: modified GW propagation (Xi0, n)
+  cosmo = CH.cosmo.mg_flrw(H0=70., Om0=0.25, z_max=5., Xi0=1.8, n=1.9) if mg else CH.cosmo.flrw(H0=70., Om0=0.25, z_max=5.)
   mass = CH.mass.plp()
   rate = CH.rate.madau_dickinson(gamma=2.7, kappa=3., zp=2.)
   pe_fields = ('m1det', 'm2det', 'dL', 'ra', 'dec', 'pe_prior', 'pixels_opt_nsides', 'ra_pix', 'dec_pix',
@@ -105,7 +106,11 @@ def main():
   nb = args.nbatch
   H0s = np.linspace(55., 95., 4099)          # a different H0 for every draw of every step
 
+  Xi0s = np.linspace(0.6, 3.0, 4099)
+
   def lambdas(step):
+    if mg:                                        # a different (Xi0, H0) for every draw
+      return [dict(Xi0=float(Xi0s[(step * nb + j) % len(Xi0s)]), H0=float(H0s[(7 * (step * nb + j)) % len(H0s)])) for j in range(nb)]
     return [dict(H0=float(H0s[(step * nb + j) % len(H0s)])) for j in range(nb)]
 
   def sync():
@@ -172,7 +177,7 @@ def main():
       "ms_per_step": 1e3 * dt / max(args.steps, 1), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
       "dtype": "f64", "data": "synthetic (seed 20250926; chimera_amd/synth.py)",
       "config": {"workload": f"{args.config}: {E} events x {P} pixels x {Z} z-bins, {S} samples/event, {I} detected injections, "
-                             f"PLP + Madau-Dickinson + flat-LCDM, {kind or '1d'}, binning 200, cut_grid 2",
+                             f"PLP + Madau-Dickinson + {'modified-GW-propagation (Xi0, n) flat-LCDM' if mg else 'flat-LCDM'}, {kind or '1d'}, binning 200, cut_grid 2",
                  "E": E, "P": P, "Z": Z, "S": S, "I": I, "kind_p_gw3d": kind, "nbatch": nb,
                  "parallelism": f"events+injections sharded over {world} GPU(s)",
                  "cells_per_s": value * E * max(P, 1) * Z},
