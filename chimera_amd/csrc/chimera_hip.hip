@@ -475,10 +475,10 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
       L.e_off = eb; L.E_cnt = ee - eb; L.nb = nb;
       // per-z factors of the group's events: on the other lane, concurrently with the sample stage -- except in marginalized
       // mode, where they follow k_event_prep on the group's own lane and cover only the support of each event's KDE
-      const bool zf_ranged = L.mode == CHM_MODE_MARG && !getenv("CHM_ZF_FULL");
+      const bool zf_ranged = (L.mode == CHM_MODE_MARG || L.mode == CHM_MODE_1D || L.mode == CHM_MODE_APPROX) && !getenv("CHM_ZF_FULL");
       static const int marg_sub = getenv("CHM_MARG_SUB") ? atoi(getenv("CHM_MARG_SUB")) : 32;   // lanes per pixel in the standard kernel
       const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC") && (marg_sub == 32 || marg_sub == 16);
-      const int zf_mode = zf_ranged ? 1 : 0;
+      const int zf_mode = !zf_ranged ? 0 : (L.mode == CHM_MODE_MARG ? 1 : 2);
       hipStream_t sz = (serial || zf_ranged) ? sg : ((g & 1) ? sA : sB);
       // ~2048 blocks in all: each stages the draw's (zt, It) tables in LDS once and walks over E_cnt / gridDim.x events
       const int zf_target = 2048 / nb > 1 ? 2048 / nb : 1;
@@ -536,6 +536,7 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
         allow_lds(k_kde1d, lds_kde);
         hipLaunchKernelGGL(k_kde1d, dim3(L.E_cnt, nb), dim3(256), lds_kde, sg, L, dp);
         HIPCHK(hipGetLastError());
+        if (zf_ranged) { launch_zfactors(); HIPCHK(hipGetLastError()); }
         hipLaunchKernelGGL(k_integrate_1d, dim3(L.E_cnt * Pd, nb), dim3(64), 0, sg, L, dp);
       }
       HIPCHK(hipGetLastError());

@@ -614,13 +614,17 @@ __global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* pa
     const int e = L.e_off + ei;
     const size_t zo = ((size_t)b * L.E + e) * Z;
     const double* zg = L.z_grids + (size_t)e * Z;
-    // ranged (marginalized mode, after k_samples / k_event_prep): only the grid points the GW kernel reads, [k_lo & ~1, k_hi] of the
-    // event (the support of its KDE, NEVSTAT slots 8-9); nothing for an event that fails the n_eff guard (likelihood.py:199)
+    // ranged: only the grid points the GW kernel reads -- 1 (marginalized, after k_event_prep): [k_lo & ~1, k_hi] of the event,
+    // the support of its KDE (NEVSTAT slots 8-9), nothing for an event that fails the n_eff guard (likelihood.py:199);
+    // 2 (1d / approximate, after k_kde1d): the range where p_gw1d is non-zero
     int k_first = 0, k_last = Z - 1;
-    if (ranged) {
+    if (ranged == 1) {
       const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
       if (!(es[4] >= L.pe_neff)) continue;
       k_first = ((int)es[8]) & ~1; k_last = (int)es[9];
+    } else if (ranged == 2) {                       // 1d / approximate: the grid points where p_gw1d != 0 (k_kde1d)
+      const int* kr = L.krange + ((size_t)b * L.E + e) * 2;
+      k_first = kr[0]; k_last = kr[1];
     }
     for (int k = k_first + t; k <= k_last; k += nt) {
       double z = zg[k];

@@ -357,6 +357,25 @@ def test_degenerate_pixels_give_minus_infinity_class(cfg_pix):
   assert rp[3] == -np.inf and ro[3] == -np.inf
 
 
+@pytest.mark.parametrize('kind', ['marginalized', 'approximate'])
+def test_nan_and_out_of_range_samples_behave_like_the_reference(cfg_pix, kind):
+  """A NaN distance makes the event's z statistics NaN (jnp.min / max / std propagate it), hence L_i = NaN -> -inf; samples
+  with masses outside the population's range simply carry zero weight.  The v_max/v_min + NaN-vote forms must agree."""
+  cfg, ev, inj = cfg_pix
+  ev2 = dict(ev)
+  dL = ev['dL'].copy(); m1 = ev['m1det'].copy()
+  dL[0, 5] = np.nan                              # event 0: one NaN distance
+  m1[2, :40] = 1e4                               # event 2: forty samples far above m_high -> weight 0
+  m1[3, 7] = np.nan                              # event 3: one NaN mass -> NaN weight -> sums NaN
+  ev2['dL'], ev2['m1det'] = dL, m1
+  like_o, _, _ = H.build_oracle(ev2, inj, kind=kind)
+  like_p, _, _ = H.build_product(ev2, inj, kind=kind)
+  with np.errstate(all='ignore'):
+    ro, rp = like_o.compute_all(H0=70.), like_p.compute_all(H0=70.)
+  assert H.neginf_class(ro[0][0]) and H.neginf_class(ro[0][3]) and np.isfinite(ro[0][2])
+  H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
+
+
 def test_vectorised_call_and_sampler_glue(cfg_pix):
   from chimera_amd.utils.emcee_utils import generate_dict, make_log_prob
   cfg, ev, inj = cfg_pix
