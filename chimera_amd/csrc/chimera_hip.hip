@@ -244,8 +244,8 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
   L.has_cut = std::isnan(d->cut_grid) ? 0 : 1;
   L.G = L.has_cut ? d->Z / 2 : d->Z;                         // likelihood.py:121,188
   L.NC = (int)((S + SAMPLE_CHUNK - 1) / SAMPLE_CHUNK);
-  { const char* dbg = getenv("CHM_DEBUG_SKIP"); L.dbg = dbg ? atoi(dbg) : 0; }
   L.bw_scalar = d->bw_scalar; L.cut_grid = d->cut_grid; L.pe_neff = d->pe_neff;
+  { const double B = (double)(d->num_bins > 0 ? d->num_bins : 1); L.inv_B = 1. / B; L.std_unit = sqrt((B * B - 1.) / 12.) / B; }   // math.py:67 on uniform centres
   if (L.mode != CHM_MODE_FULL && L.G < 2) { chm_like_destroy(h); return fail(CHM_E_ARG, "chm_like_create: Z//2 must be >= 2 when cut_grid is set"); }
 #define UP(field, src, n) do { rc = upload(h->owned, (src) ? (src) + (size_t)e0 * (n) : (src), (size_t)E * (n), &L.field, s); if (rc) { chm_like_destroy(h); return rc; } } while (0)
   std::vector<double> tmp;                                   // must outlive the async copies below
@@ -524,12 +524,10 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
         HIPCHK(hipGetLastError());
         if (zf_ranged) { launch_zfactors(); HIPCHK(hipGetLastError()); }
         HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
-        const bool fast = L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC");
+        const bool fast = marg_std;
         const int sub = marg_sub;
         if (fast && sub == 32) hipLaunchKernelGGL(k_kde_marg_sub<32>, dim3(L.E_cnt * ((Pd + 1) / 2) * nb, 1), dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
         else if (fast && sub == 16) hipLaunchKernelGGL(k_kde_marg_sub<16>, dim3(L.E_cnt * ((Pd + 3) / 4) * nb, 1), dim3(64), sizeof(double) * (3 * N + 3) * 4, sg, L, dp);
-        else if (fast) hipLaunchKernelGGL(k_kde_marg_fast, dim3(L.E_cnt * ((Pd + MARG_WPB - 1) / MARG_WPB), nb), dim3(64 * MARG_WPB),
-                                     sizeof(double) * (3 * N + 3) * MARG_WPB, sg, L, dp);
         else { allow_lds(k_kde_marg, lds_kde); hipLaunchKernelGGL(k_kde_marg, dim3(L.E_cnt * Pd, nb), dim3(64), lds_kde, sg, L, dp); }
       } else {
         HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));

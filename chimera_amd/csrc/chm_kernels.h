@@ -30,8 +30,8 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   int e_off, E_cnt;               // event group handled by this launch: events [e_off, e_off + E_cnt)
   int nb, pad2;                   // draws in this call (hot kernels fold the draw into blockIdx.x, draw fastest, so that the
                                   // blocks working on the same samples / p_cat rows for different draws run together and share L2)
-  int dbg, pad1;                  // CHM_DEBUG_SKIP ablation bits (timing experiments only; results are wrong when set)
   double bw_scalar, cut_grid, pe_neff;
+  double inv_B, std_unit;         // 1/num_bins; std of num_bins uniform bin centres per unit range, sqrt((B^2-1)/12)/B (host, once)
   const double *dL, *m1det, *m2det, *pe_prior, *ra, *dec;
   const double *lm1det, *lm2det;  // log(m1det), log(m2det), formed once at upload: log(m_src) = log(m_det) - log(1+z)
   const int* seg_off;             // (E,P+1) marginalized: pixel segments of the pixel-sorted samples
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
         double r = 1. / zp1;
         double m1 = md1[h] * r, m2 = md2[h] * r;
         double lz = chm_log_pos(zp1);                             // log(m_src) = log(m_det) - log(1+z): one log for both masses
-        double w = ((L.dbg & 32) ? m1 * m2 : p_m1m2_fused(P, m1, m2, l1[h] - lz, l2[h] - lz, T.mg, T.cdf)) * ipr[h];
+        double w = p_m1m2_fused(P, m1, m2, l1[h] - lz, l2[h] - lz, T.mg, T.cdf) * ipr[h];
         wv[h] = w;
         if (s + h < s_end) {
           double d = z - z_ref;
@@ -570,8 +570,8 @@ DEVFN void event_stats(const LikeDev& L, int b, int e, double* es) {
   es[10] = (ub - lb) / (double)(L.G - 1); es[11] = (double)(L.G - 1) / (ub - lb);
 }
 
-// k_event_prep: one wave per (event, draw): event_stats -> evstat (nb,E,NEVSTAT) and, for the general kernels (k_kde_marg,
-// k_kde_marg_fast), the effective grid effg (nb,E,G); the standard kernel (k_kde_marg_sub) forms its nodes arithmetically.
+// k_event_prep: one wave per (event, draw): event_stats -> evstat (nb,E,NEVSTAT) and, for the general kernel (k_kde_marg),
+// the effective grid effg (nb,E,G); the standard kernel (k_kde_marg_sub) forms its nodes arithmetically.
 __global__ void __launch_bounds__(64) k_event_prep(LikeDev L, int write_effg) {
   const int e = L.e_off + blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   double es[NEVSTAT];
@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
   k_lo &= ~1;                                               // 16-byte aligned pairs
   // prefetch the first pass of the p_cat segment: lane owns grid points k_lo + 128*i + 2*lane + {0,1}
   double pf0[MARG_PF], pf1[MARG_PF];
-  if (ok && !(L.dbg & 8)) {
+  if (ok) {
 #pragma unroll
     for (int i = 0; i < MARG_PF; i++) {
       int k = k_lo + 128 * i + 2 * lane;
@@ -710,7 +710,7 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
     }
   }
 
-  if (ok && !(L.dbg & 16)) {
+  if (ok) {
     const int s0 = L.seg_off[(size_t)e * (L.P + 1) + p], s1 = L.seg_off[(size_t)e * (L.P + 1) + p + 1];
     const double lo = zmin;
     // hi = max(where(mask, z, min z))  (likelihood.py:180, math.py:36)
@@ -725,7 +725,7 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
         wgt[j] = 0.;
       }
       __syncthreads();
-      if (!(L.dbg & 1)) for (int s = s0 + lane; s < s1; s += 64) atomicAdd(&wgt[bin_index(wz[s], lo, hi, B)], ww[s]);
+      for (int s = s0 + lane; s < s1; s += 64) atomicAdd(&wgt[bin_index(wz[s], lo, hi, B)], ww[s]);
       __syncthreads();
     } else {
       for (int s = lane; s < S; s += 64) {
@@ -758,7 +758,7 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
     if (fast) {
       wave_prefix3(data, wgt, N, lo, P0, P1, P2);
       __syncthreads();
-      if (!(L.dbg & 2)) for (int i = lane; i < G; i += 64) dens[i] = epan_prefix_eval(eff[i], data, P0, P1, P2, N, lo, 1. / dbin, bw, inv_bw, lo);
+      for (int i = lane; i < G; i += 64) dens[i] = epan_prefix_eval(eff[i], data, P0, P1, P2, N, lo, 1. / dbin, bw, inv_bw, lo);
     } else {
       for (int i = lane; i < G; i += 64) dens[i] = kde_dense_eval(eff[i], data, wgt, N, true, bw, inv_bw);
     }
@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
   const bool has_cut = L.has_cut;
   double acc = 0.;
   if (dump) { for (int k = lane; k < Z; k += 64) if (!ok || k < k_lo || k > k_hi) dump[k] = 0.; }
-  if (ok && !(L.dbg & 4)) {
+  if (ok) {
     for (int kb = k_lo; kb <= k_hi; kb += 128 * MARG_PF) {
 #pragma unroll
       for (int i = 0; i < MARG_PF; i++) {
@@ -805,18 +805,6 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
   if (lane == 0) *out_like = acc;
 }
 
-// ------------------------------------------------------------------------------------------------------
-// k_kde_marg_fast: the marginalized GW kernel for the standard configuration (binning=True, cut_grid set):
-// one wave per (event, pixel, draw).  Same quantity as k_kde_marg, organised for latency and occupancy:
-//   * LDS holds only the bin centres and the three prefix-sum arrays (6.4 KB at 200 bins -> 20+ waves per CU);
-//   * the KDE is evaluated on demand at the two effective-grid nodes that bracket each event-grid point (the values
-//     jnp.interp combines, likelihood.py:193) instead of on the whole effective grid first;
-//   * weights stay un-normalised in the prefix sums, 1/sum(w) is applied at the end; std of the bin centres is the
-//     closed form for a uniform grid, (hi-lo) sqrt((B^2-1)/12)/B (math.py:67 evaluates it numerically: same to ~1e-16).
-// Degenerate pixels (no in-pixel weight, zero-width histogram, zero bandwidth) give NaN, as the reference's 0/0 does.
-// ------------------------------------------------------------------------------------------------------
-#define FAST_PF 4
-#define MARG_WPB 1
 // ordering point for LDS traffic inside ONE wave (its lanes exchange data through the wave's private LDS slice): LDS
 // instructions of a wave execute in issue order, so only the compiler has to be kept from moving accesses across it
 DEVFN void wave_sync() {
@@ -824,190 +812,18 @@ DEVFN void wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-struct EpanCtx { const double* P0; const double* P1; const double* P2; int N; double lo, inv_dbin, bw, inv_bw, scale; };
-
-// Index range [ja, jb) of the bins with |g - c_j| <= h straight from the uniform spacing c_j = lo + (j + 1/2) dbin.  A bin
-// whose |u| is within rounding of 1 may land on either side; its kernel value 3/4 (1 - u^2) is then < 1e-12, far below the
-// stated tolerance (k_kde_marg keeps the exact predicate of math.py:85).
-DEVFN double epan_node(const EpanCtx& c, double g) {
-  double fa = ceil((g - c.bw - c.lo) * c.inv_dbin - 0.5), fb = floor((g + c.bw - c.lo) * c.inv_dbin - 0.5) + 1.;
-  const double dN = (double)c.N;
-  fa = fa > 0. ? (fa < dN ? fa : dN) : 0.;
-  fb = fb > fa ? (fb < dN ? fb : dN) : fa;
-  const int ja = (int)fa, jb = (int)fb;
-  double S0 = c.P0[jb] - c.P0[ja], S1 = c.P1[jb] - c.P1[ja], S2 = c.P2[jb] - c.P2[ja];
-  double gp = g - c.lo;
-  double qq = fma(gp, fma(gp, S0, -2. * S1), S2);
-  return (S0 - qq * (c.inv_bw * c.inv_bw)) * c.scale;
-}
-
-__global__ void __launch_bounds__(64 * MARG_WPB, 5) k_kde_marg_fast(LikeDev L, const DevParams* params) {
-  extern __shared__ double lds_all[];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int PG = (L.P + MARG_WPB - 1) / MARG_WPB;            // pixel groups per event: one wave per pixel, MARG_WPB waves per block
-  const int p = (blockIdx.x % PG) * MARG_WPB + wid, e = L.e_off + blockIdx.x / PG, b = blockIdx.y;
-  if (p >= L.P) return;
-  double* lds = lds_all + (size_t)wid * (3 * L.num_bins + 3);   // each wave works in its own LDS slice: no block barriers
-  const DevParams& P = params[b];
-  const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
-  double* P0 = lds; double* P1 = P0 + (B + 1); double* P2 = P1 + (B + 1);
-  double* cnt = P0;                                         // bin counts live in P0[0..B) until the prefix pass
-  double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
-  double* dump = L.p_gw_dump ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
-  if (p >= L.neff_pixels[e]) {
-    if (lane == 0) *out_like = 0.;
-    if (dump) for (int k = lane; k < Z; k += 64) dump[k] = 0.;
-    return;
-  }
-  const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
-  const double zmin = es[0], norm = es[3], n_eff = es[4], lb = es[6], ub = es[7];
-  const bool ok = n_eff >= L.pe_neff;                       // likelihood.py:199
-  if (!ok) {
-    if (lane == 0) *out_like = 0.;
-    if (dump) for (int k = lane; k < Z; k += 64) dump[k] = 0.;
-    return;
-  }
-  const double* zg = L.z_grids + (size_t)e * Z;
-  const double* pc = L.p_cat + ((size_t)e * L.P + p) * Z;
-  // k-range of the event grid inside [lb, ub], found once per event by k_event_prep
-  int k_lo = (int)es[8], k_hi = (int)es[9];
-  k_lo &= ~1;
-  const bool vec2 = (Z & 1) == 0;
-  double pf0[FAST_PF], pf1[FAST_PF];
-#pragma unroll
-  for (int i = 0; i < FAST_PF; i++) {
-    int k = k_lo + 128 * i + 2 * lane;
-    pf0[i] = 0.; pf1[i] = 0.;
-    if (vec2 && k + 1 <= k_hi) { double2 v = *reinterpret_cast<const double2*>(pc + k); pf0[i] = v.x; pf1[i] = v.y; }
-    else { if (k <= k_hi) pf0[i] = pc[k]; if (k + 1 <= k_hi) pf1[i] = pc[k + 1]; }
-  }
-
-  // histogram of this pixel's samples on [min z, max z in pixel] (math.py:32-46, likelihood.py:180-183)
-  if (L.dbg & 16) { double a = 0.; for (int i = 0; i < FAST_PF; i++) a += pf0[i] + pf1[i]; a = wave_sum(a); if (lane == 0) *out_like = a; return; }
-  const size_t so = ((size_t)b * L.E + e) * S;
-  const double* wz = L.ws_z + so;
-  const double* ww = L.ws_w + so;
-  const int s0 = L.seg_off[(size_t)e * (L.P + 1) + p], s1 = L.seg_off[(size_t)e * (L.P + 1) + p + 1];
-  const double lo = zmin;
-  double zr[2], wr[2];                                      // first two samples per lane stay in registers
-#pragma unroll
-  for (int i = 0; i < 2; i++) { int s = s0 + lane + 64 * i; zr[i] = s < s1 ? wz[s] : lo; wr[i] = s < s1 ? ww[s] : 0.; }
-  double hi = nanmax2(nanmax2(lo, zr[0]), zr[1]);
-  for (int s = s0 + lane + 128; s < s1; s += 64) hi = nanmax2(hi, wz[s]);
-  hi = wave_max(hi);
-  if (lo != lo) hi = lo;
-  for (int j = lane; j < B; j += 64) cnt[j] = 0.;
-  // bin centres relative to the lower edge: c'_j = c_j - lo = (j + 1/2) dbin for the uniform edges of math.py:37-39
-  // (the linspace form differs from this by rounding of order eps*lo, i.e. 1e-13 of a bin width)
-  const double dbin = (hi - lo) / (double)B;
-  wave_sync();
-#pragma unroll
-  for (int i = 0; i < 2; i++) { int s = s0 + lane + 64 * i; if (s < s1 && !(L.dbg & 1)) atomicAdd(&cnt[bin_index(zr[i], lo, hi, B)], wr[i]); }
-  for (int s = s0 + lane + 128; s < s1; s += 64) atomicAdd(&cnt[bin_index(wz[s], lo, hi, B)], ww[s]);
-  wave_sync();
-  // sum w, sum w^2 over the bins; prefix sums of (w, w c', w c'^2), c' = centre - lo
-  const int per = (B + 63) / 64;
-  const int j0 = lane * per, j1 = min(j0 + per, B);
-  double s0w = 0., s1w = 0., s2w = 0., sq = 0.;
-  for (int j = j0; j < j1; j++) { double w = cnt[j], cc = ((double)j + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
-  double x0 = s0w, x1 = s1w, x2 = s2w;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    double y0 = __shfl_up(x0, o, 64), y1 = __shfl_up(x1, o, 64), y2 = __shfl_up(x2, o, 64);
-    if (lane >= o) { x0 += y0; x1 += y1; x2 += y2; }
-  }
-  const double tot = __shfl(x0, 63, 64);
-  const double sum2 = wave_sum(sq);
-  {
-    double r0 = x0 - s0w, r1 = x1 - s1w, r2 = x2 - s2w;
-    double wv[8];                                           // the lane's counts, read before P0 overwrites them
-    const bool small = per <= 8;
-    if (small) {
-#pragma unroll
-      for (int i = 0; i < 8; i++) wv[i] = (j0 + i < j1) ? cnt[j0 + i] : 0.;
-    }
-    wave_sync();
-    if (small) {
-#pragma unroll
-      for (int i = 0; i < 8; i++) if (j0 + i < j1) {
-        double w = wv[i], cc = ((double)(j0 + i) + 0.5) * dbin;
-        r0 += w; r1 += w * cc; r2 += w * cc * cc;
-        P0[j0 + i + 1] = r0; P1[j0 + i + 1] = r1; P2[j0 + i + 1] = r2;
-      }
-    } else {                                                // many bins per lane: walk backwards so that cnt[j] is read before P0[j+1] lands on cnt[j+1]
-      // recompute from the top: P0[j+1] for j descending needs the inclusive value; do a forward pass into P1/P2 first
-      double a0 = r0, a1 = r1, a2 = r2;
-      for (int j = j0; j < j1; j++) { double w = cnt[j], cc = ((double)j + 0.5) * dbin; a1 += w * cc; a2 += w * cc * cc; P1[j + 1] = a1; P2[j + 1] = a2; }
-      a0 = r0; for (int j = j0; j < j1; j++) a0 += cnt[j];
-      for (int j = j1 - 1; j >= j0; j--) { double w = cnt[j]; P0[j + 1] = a0; a0 -= w; }
-    }
-    if (lane == 0) { P1[0] = 0.; P2[0] = 0.; }
-    wave_sync();
-    if (lane == 0) P0[0] = 0.;
-    wave_sync();
-  }
-  // bandwidth: neff = 1/sum(W^2), W = w/tot (math.py:62-64); std of the uniform centres; factor (math.py:65-73)
-  const double neff_k = (tot * tot) / sum2;
-  const double stdc = (hi - lo) * (sqrt(((double)B * (double)B - 1.) / 12.) / (double)B);
-  const double bw = kde_bandwidth_factor(L.bw_method, L.bw_scalar, neff_k, 1) * stdc;
-  const bool degenerate = !(dbin > 0.) || !(bw > 0.) || !(bw < 1e300) || !(tot > 0. || tot < 0.);
-  EpanCtx cx;
-  cx.P0 = P0; cx.P1 = P1; cx.P2 = P2; cx.N = B; cx.lo = lo; cx.inv_dbin = 1. / dbin; cx.bw = bw; cx.inv_bw = 1. / bw;
-  cx.scale = 0.75 * cx.inv_bw / tot;
-
-  const size_t zo = ((size_t)b * L.E + e) * Z;
-  const double* bkgA = L.bkgA + zo;
-  const double* Aw = L.Aw + zo;
-  const double* eg = L.effg + ((size_t)b * L.E + e) * G;
-  const double gwp = L.gw_pdf[(size_t)e * L.P + p];
-  const double fR = P.fR;
-  const double inv_de = (double)(G - 1) / (ub - lb);
-  const double nan = __builtin_nan("");
-  double acc = 0.;
-  if (dump) { for (int k = lane; k < Z; k += 64) if (k < k_lo || k > k_hi) dump[k] = 0.; }
-#pragma unroll 1
-  for (int it = 0; k_lo + 128 * it <= k_hi && !(L.dbg & 4); it++) {         // one pass = 64 lanes x 2 consecutive grid points
-    const int k = k_lo + 128 * it + 2 * lane;
-    double pc0, pc1;
-    if (it < FAST_PF) {                                     // prefetched at kernel start (uniform select)
-      pc0 = pf0[0]; pc1 = pf1[0];
-#pragma unroll
-      for (int i = 1; i < FAST_PF; i++) if (it == i) { pc0 = pf0[i]; pc1 = pf1[i]; }
-    } else {
-      pc0 = k <= k_hi ? pc[k] : 0.; pc1 = k + 1 <= k_hi ? pc[k + 1] : 0.;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int kk = k + h;
-      if (kk <= k_hi) {
-        const double zk = zg[kk];
-        double pgw = 0.;
-        if (zk >= lb && zk <= ub) {                         // jnp.interp(..., left=0, right=0)
-          // bracket on the uniform effective grid: i1 - 1 = floor((z - lb)/de); a z within rounding of a node may pick
-          // either neighbouring segment -- the interpolant is continuous there
-          double tp = floor((zk - lb) * inv_de);
-          tp = tp < (double)(G - 2) ? tp : (double)(G - 2);
-          const int i1 = (int)tp + 1;
-          double xa = eg[i1 - 1], xb = eg[i1];
-          double da = epan_node(cx, xa), db = epan_node(cx, xb);
-          double f = da + ((zk - xa) * inv_de) * (db - da);             // (z - x0)/dx with dx = (ub - lb)/(G - 1)
-          pgw = degenerate ? nan : f * norm * gwp;          // kde_interp * norm * gw_pdf[i]    likelihood.py:194
-        } else if (zk != zk) pgw = nan;
-        if (dump) dump[kk] = pgw;
-        const double pcv = h == 0 ? pc0 : pc1;
-        if (pcv != -100.) acc += pgw * (fR * pcv + bkgA[kk]) * Aw[kk];
-      }
-    }
-  }
-  acc = wave_sum(acc);
-  if (lane == 0) *out_like = acc;
-}
 
 // ------------------------------------------------------------------------------------------------------
-// k_kde_marg_sub<SW>: the fast marginalized kernel with SW lanes per pixel (64/SW pixels per wave).  The per-pixel
-// set-up (histogram, prefix sums, bandwidth) is mostly wave-instruction-bound with few active lanes; sharing a wave between
-// two pixels of the same event (SW = 32) halves that cost per pixel while the grid loop keeps every lane busy.
-// Same arithmetic as k_kde_marg_fast; reductions and scans run inside each SW-lane group.
+// k_kde_marg_sub<SW>: the marginalized GW kernel for the standard configuration (binning=True, cut_grid set), SW lanes per
+// pixel (64/SW pixels per wave; SW = 32 in production).  Same quantity as k_kde_marg, organised for latency and occupancy:
+//   * LDS holds only the three prefix-sum arrays, interleaved (9.6 KB per wave at 200 bins -> 16 waves per CU);
+//   * the KDE is evaluated on demand at the two effective-grid nodes that bracket each event-grid point (the values
+//     jnp.interp combines, likelihood.py:193) instead of on the whole effective grid first;
+//   * weights stay un-normalised in the prefix sums, 1/sum(w) is applied at the end; std of the bin centres is the
+//     closed form for a uniform grid, (hi-lo) sqrt((B^2-1)/12)/B (math.py:67 evaluates it numerically: same to ~1e-16);
+//   * the per-pixel set-up (histogram, prefix sums, bandwidth) is wave-instruction-bound with few active lanes: sharing a wave
+//     between two pixels of the same event halves that cost per pixel while the grid loop keeps every lane busy.
+// Degenerate pixels (no in-pixel weight, zero-width histogram, zero bandwidth) give NaN, as the reference's 0/0 does.
 // ------------------------------------------------------------------------------------------------------
 template <int SW> DEVFN double sg_sum(double v) {
 #pragma unroll
@@ -1092,8 +908,8 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   }
   for (int j = sl; j < B; j += SW) Q[3 * j] = 0.;
   const double dB = (double)B;
-  const double dbin = (hi - lo) / dB;                       // c'_j = (j + 1/2) dbin  (see k_kde_marg_fast)
   const double dhl = hi - lo, rhl = 1. / dhl;
+  const double dbin = dhl * L.inv_B;                        // c'_j = c_j - lo = (j + 1/2) dbin for the uniform edges of math.py:37-39
   wave_sync();
 #pragma unroll
   for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q[3 * bin_index_r(zr[i], lo, dhl, rhl, dB)], wr[i]); }
@@ -1142,14 +958,16 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
     wave_sync();
   }
   const double neff_k = (tot * tot) / sum2;
-  const double stdc = (hi - lo) * (sqrt(((double)B * (double)B - 1.) / 12.) / (double)B);
+  const double stdc = dhl * L.std_unit;
   const double bw = kde_bandwidth_factor(L.bw_method, L.bw_scalar, neff_k, 1) * stdc;
   const bool degenerate = !(dbin > 0.) || !(bw > 0.) || !(bw < 1e300) || !(tot > 0. || tot < 0.);
   // Per-pixel constants of the node evaluation.  A node g of the effective grid sees the bins [ja, jb) with |g - c_j| <= h,
   // c_j = lo + (j + 1/2) dbin:  ja = ceil(t - hb), jb = floor(t + hb) + 1 with t = (g - lo)/dbin - 1/2, hb = h/dbin; the next
   // node is t + dd, dd = de/dbin.  A bin whose |u| is within rounding of 1 may land on either side (kernel value < 1e-12).
-  const double inv_dbin = 1. / dbin, inv_bw = 1. / bw, inv_bw2 = inv_bw * inv_bw;
-  const double scale = 0.75 * inv_bw / tot;
+  // one reciprocal serves 1/bw and the normalisation 3/4 / (bw sum w); 1/dbin = B / (hi - lo) re-uses the histogram's reciprocal
+  const double rbt = 1. / (bw * tot);
+  const double inv_dbin = dB * rhl, inv_bw = rbt * tot, inv_bw2 = inv_bw * inv_bw;
+  const double scale = 0.75 * rbt;
   const double hb = bw * inv_dbin;
   const double de = es[10], inv_de = es[11];                // spacing of jnp.linspace(lb, ub, G) and its inverse (k_event_prep)
   const double dd = de * inv_dbin;
