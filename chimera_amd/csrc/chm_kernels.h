@@ -598,6 +598,7 @@ __global__ void __launch_bounds__(64) k_event_prep(LikeDev L, int write_effg) {
 template <bool LDS_TAB>
 __global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
                                                    int TcMax, int ranged) {
+#pragma clang fp contract(fast)                  // smooth per-z factors: a*b+c may fuse (jnp_interp keeps the default, off)
   extern __shared__ double lds[];
   const int b = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
   const DevParams P = params[b];      // by value: uniform loads at kernel start -> scalar registers, nothing re-read in the loops
@@ -838,6 +839,7 @@ template <int SW> DEVFN double sg_max(double v) {
 
 template <int SW>
 __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevParams* params) {
+#pragma clang fp contract(fast)                  // a*b+c may fuse in this body; the bin index lives in bin_index_r() (contract off)
   extern __shared__ double lds_all[];
   constexpr int NPW = 64 / SW;                              // pixels per wave
   constexpr int PF = 4;                                     // p_cat prefetch passes: PF * SW * 2 grid points per pixel
@@ -1339,6 +1341,7 @@ struct SelDev {
 template <class A1, class A2>
 DEVFN double sel_term(const DevParams& P, double dl, double m1d, double m2d, double l1d, double l2d, double ipd, double z,
                       A1 mg, A2 cdf) {
+#pragma clang fp contract(fast)                  // smooth arithmetic only: a*b+c may fuse (the translation unit default is off)
   double zp1 = 1. + z;
   double rz = 1. / zp1;
   double m1 = m1d * rz, m2 = m2d * rz;

@@ -325,6 +325,7 @@ DEVFN double p_m1m2(const DevParams& p, double m1, double m2, A1 mg, A2 cdf) {
 // (mass.py:340) is applied to the same cases (0/0 at m1 = m2 = m_low).
 template <class A1, class A2>
 DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, double lm2, A1 mg, A2 cdf) {
+#pragma clang fp contract(fast)                  // smooth arithmetic only (no rounding-sensitive predicate): a*b+c may fuse
   const double m_low = p.m[0], m_high = p.m[1];
   const bool in2 = (m_low <= m2 && m2 <= m1);               // tpl_notnorm(m2, beta, m_low, m1)   mass.py:240-245,322
   const double e5 = in2 ? mass_beta(p) * lm2 : 0.;
