@@ -133,6 +133,11 @@ static void fill_dev_params(const chm_params* p, DevParams* d) {
   for (int i = 0; i < 8; i++) d->m[i] = p->mass[i];
   for (int i = 0; i < 4; i++) d->r[i] = p->rate[i];
   d->R0 = p->R0; d->Tobs = p->Tobs; d->zc0 = p->compl_z0; d->zc1 = p->compl_z1;
+  // End nodes of the mass grid, jnp.logspace(log10 m_low, log10 m_high)[0], [-1] (mass.py:46).  Whether they pass the
+  // `m_low <= m <= m_high` test of tpl_notnorm (mass.py:240-245) decides if the first / last trapezoid node of cdf_m2 and
+  // norm_p_m1 counts -- an O(1e-3) effect hanging on the last bit of pow().  The host's libm forms them (as NumPy / the CPU
+  // back-end of the reference does), so the decision is the CPU reference's for every (m_low, m_high), not only the defaults.
+  d->mg_first = pow(10., log10(p->mass[CHM_M_MLOW])); d->mg_last = pow(10., log10(p->mass[CHM_M_MHIGH]));
 }
 
 // upload nb draws and build their tables on c.stream

@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
     // m_grid = logspace(log10 m_low, log10 m_high, Tm); cdf = cumtrapz(secondary(m_grid; m_high))   mass.py:45-49
     const double l0 = log10(P.m[0]), l1 = log10(P.m[1]);
     for (int i = t; i < Tm; i += nt) {
-      double m = pow(10., jnp_linspace_at(l0, l1, Tm, i));
+      double m = i == 0 ? P.mg_first : (i == Tm - 1 ? P.mg_last : pow(10., jnp_linspace_at(l0, l1, Tm, i)));   // end nodes: host libm (DevParams)
       mg[i] = m;
       tmp[i] = secondary_notnorm(P, m, P.m[1]);
     }
@@ -285,6 +285,7 @@ template <bool LDS_TAB, bool FULL>
 __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
                                                   const double* dLt_all, const double* mg_all, const double* cdf_all,
                                                   int TcMax, int TmMax) {
+#pragma clang fp contract(fast)                  // sums of products may fuse; z comes from jnp_interp_x2 (contract off) untouched
   extern __shared__ double lds[];
   __shared__ double red[4 * 16];
   const int b = blockIdx.x % L.nb, bx = blockIdx.x / L.nb, nbx = gridDim.x / L.nb, t = threadIdx.x;

@@ -17,6 +17,7 @@ struct DevParams {
   double m[8];                           // chm_params.mass
   double r[4];                           // chm_params.rate
   double R0, Tobs, zc0, zc1;
+  double mg_first, mg_last;              // 10**log10(m_low), 10**log10(m_high) formed by the HOST's libm (see k_tables, mass grid)
   // constants derived once per draw by k_tables (same expressions the reference re-evaluates per element)
   double plp_plnorm;                     // tpl_cdf(-alpha, m_low, m_high)           mass.py:301
   double tg_norm;                        // truncated_gaussian norm                   mass.py:272-274

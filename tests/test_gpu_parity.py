@@ -357,6 +357,43 @@ def test_degenerate_pixels_give_minus_infinity_class(cfg_pix):
   assert rp[3] == -np.inf and ro[3] == -np.inf
 
 
+@pytest.mark.parametrize('mass,cosmo', [('plp', 'flrw'), ('tpl', 'flrw'), ('bpl', 'mg_flrw'), ('plp', 'mg_flrw')])
+def test_random_hyperparameter_draws_against_the_c_oracle(mass, cosmo):
+  """Twelve random draws over every free hyper-parameter of the models (cosmology, mass, rate), evaluated in one batch on the
+  GPU and one by one by the C oracle: per-event log-likelihoods and the hyper-likelihood must agree for each draw."""
+  import os
+  from oracle import oracle_c as OC
+  cfg, ev, inj = H.small_config(E=24, S=1024, P=6, Z=200, I=20000, seed=23, ragged=True)
+  models = dict(mass=mass, cosmo=cosmo)
+  like_p, _, _ = H.build_product(ev, inj, models=models)
+  like_o, _, _ = H.build_oracle(ev, inj, models=models)
+  rng = np.random.default_rng(99)
+  lams = []
+  for _ in range(12):
+    lam = dict(H0=rng.uniform(55., 95.), Om0=rng.uniform(0.15, 0.45), gamma=rng.uniform(1., 4.), kappa=rng.uniform(2., 5.),
+               zp=rng.uniform(1., 3.), m_low=rng.uniform(3.5, 6.), m_high=rng.uniform(70., 110.), beta=rng.uniform(0., 2.5))
+    if cosmo == 'mg_flrw':
+      lam.update(Xi0=rng.uniform(0.5, 3.), n=rng.uniform(0.5, 3.))
+    if mass == 'plp':
+      lam.update(alpha=rng.uniform(2., 4.5), lambda_peak=rng.uniform(0.01, 0.2), mu_g=rng.uniform(28., 40.), sigma_g=rng.uniform(2., 6.),
+                 delta_m=rng.uniform(2., 7.))
+    elif mass == 'bpl':
+      lam.update(alpha_1=rng.uniform(1., 2.5), alpha_2=rng.uniform(3., 7.), break_fraction=rng.uniform(0.2, 0.7), delta_m=rng.uniform(2., 7.))
+    else:
+      lam.update(alpha=rng.uniform(1.5, 4.))
+    lams.append(lam)
+  got = like_p.batch(lams)
+  nthr = min(16, os.cpu_count() or 1)
+  for i, lam in enumerate(lams):
+    rc = OC.compute_all(like_o, lam, nthreads=nthr)
+    if np.isfinite(rc[3]):
+      np.testing.assert_allclose(got[i], rc[3], rtol=0, atol=1e-7 * np.sqrt(cfg['E']), err_msg=str(lam))
+    else:
+      assert not np.isfinite(got[i]) or got[i] < -1e300
+    if i % 4 == 0:
+      H.assert_loglike_close(like_p.compute_all(**lam)[0], rc[0], rtol=RTOL_L, atol=1e-9)
+
+
 @pytest.mark.parametrize('kind', ['marginalized', 'approximate'])
 def test_nan_and_out_of_range_samples_behave_like_the_reference(cfg_pix, kind):
   """A NaN distance makes the event's z statistics NaN (jnp.min / max / std propagate it), hence L_i = NaN -> -inf; samples
