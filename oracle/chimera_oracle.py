@@ -19,6 +19,7 @@ Third-party semantics restated here (the reference executes through ``jax.numpy`
 """
 import numpy as np
 from math import erf as _erf_scalar
+import math as _math
 
 FLT_MIN_NEG = -np.finfo(np.float64).max     # jnp.nan_to_num default for -inf
 
@@ -249,6 +250,14 @@ class _mass_base(_Params):
   def _setup(self):
     """get_normalizations, mass.py:45-52."""
     self.m_grid = jnp_logspace(np.log10(self.m_low), np.log10(self.m_high), self.grid_res)
+    # The end nodes 10**log10(m_low), 10**log10(m_high) are tested against `m_low <= m <= m_high` by tpl_notnorm (mass.py:240-245):
+    # whether the first / last trapezoid node counts (an O(1e-3) effect on norm_p_m1 / cdf_m2) hangs on the last bit of the
+    # platform's log10 and pow.  NumPy's AVX-512 loops and the C library disagree there for some masses (e.g. m_low = 3.760945123513589:
+    # 3.7609451235135896 vs 3.7609451235135887), as XLA's CPU and GPU back-ends may.  The oracle pins the two nodes to the C
+    # library's values (math.pow / math.log10 = glibc), which the C oracle and the product's host code use as well, so that all
+    # three take the same branch on every host; the defaults (5.1, 87) are unaffected.
+    self.m_grid[0] = _math.pow(10., _math.log10(self.m_low))
+    self.m_grid[-1] = _math.pow(10., _math.log10(self.m_high))
     p_values = secondary_mass_conditioned_pdf_notnorm(self, self.m_grid, self.m_high)
     self.cdf_m2_conditioned = cumtrapz(p_values, self.m_grid)
     self.norm_p_m1 = trapz(primary_mass_pdf_notnorm(self, self.m_grid), self.m_grid)

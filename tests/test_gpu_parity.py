@@ -394,6 +394,49 @@ def test_random_hyperparameter_draws_against_the_c_oracle(mass, cosmo):
       H.assert_loglike_close(like_p.compute_all(**lam)[0], rc[0], rtol=RTOL_L, atol=1e-9)
 
 
+@pytest.mark.parametrize('seed', range(6))
+def test_random_configurations_against_the_numpy_oracle(seed):
+  """Random shapes, modes, KDE options, models and hyper-parameters (five configurations per seed) against the NumPy oracle."""
+  rng = np.random.default_rng(1000 + seed)
+  for _ in range(5):
+    pixelated = rng.random() < 0.8
+    kind = rng.choice(['marginalized', 'marginalized', 'approximate', 'full']) if pixelated else None
+    E, S = int(rng.integers(1, 6)), int(rng.integers(40, 700))
+    P, Z = int(rng.integers(1, 7)), int(rng.integers(12, 90))
+    cfg, ev, inj = H.small_config(E=E, S=S, P=P, Z=Z, I=int(rng.integers(300, 3000)), seed=int(rng.integers(1, 10**6)),
+                                  ragged=bool(rng.random() < 0.5), pixelated=pixelated)
+    like_kw = dict(num_bins=int(rng.choice([3, 17, 64, 200, 333])), pe_neff=float(rng.choice([2., 5., 50.])))
+    if kind != 'full':
+      like_kw['cut_grid'] = [None, 1.0, 2.0, 3.5][int(rng.integers(0, 4))]
+      like_kw['bw_method'] = [None, 'scott', 'silverman', 0.25][int(rng.integers(0, 4))]
+      like_kw['binning'] = bool(rng.random() < 0.75)
+    if kind in (None, 'approximate'):
+      like_kw['kernel'] = str(rng.choice(['epan', 'gauss']))
+    models = dict(mass=str(rng.choice(['plp', 'tpl', 'bpl'])), cosmo=str(rng.choice(['flrw', 'mg_flrw'])),
+                  rate=str(rng.choice(['power_law', 'madau_dickinson', 'trunc_power_law', 'trunc_madau_dickinson'])))
+    if models['rate'].startswith('trunc'):
+      models['rate_kw'] = dict(zmax=float(rng.uniform(1.5, 4.)))
+    pop_kw = dict(scale_free=bool(rng.random() < 0.7), R0=float(rng.uniform(5., 40.)), Tobs=float(rng.uniform(0.5, 3.)))
+    N_eff = [None, 5.][int(rng.integers(0, 2))]
+    lam = dict(H0=float(rng.uniform(55., 95.)), Om0=float(rng.uniform(0.2, 0.4)), gamma=float(rng.uniform(1., 3.5)),
+               m_low=float(rng.uniform(3.5, 6.)), m_high=float(rng.uniform(75., 110.)), beta=float(rng.uniform(0., 2.)))
+    if models['cosmo'] == 'mg_flrw':
+      lam.update(Xi0=float(rng.uniform(0.6, 2.5)), n=float(rng.uniform(0.5, 2.5)))
+    desc = f"kind={kind} shape=({E},{S},{P},{Z}) like_kw={like_kw} models={models} pop_kw={pop_kw} N_eff={N_eff} lam={lam}"
+    like_o, _, _ = H.build_oracle(ev, inj, pixelated=pixelated, kind=kind, models=models, like_kw=like_kw, pop_kw=pop_kw, N_eff=N_eff)
+    like_p, _, _ = H.build_product(ev, inj, pixelated=pixelated, kind=kind, models=models, like_kw=like_kw, pop_kw=pop_kw, N_eff=N_eff)
+    with np.errstate(all='ignore'):
+      ro, rp = like_o.compute_all(**lam), like_p.compute_all(**lam)
+    try:
+      H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
+      if np.isfinite(ro[3]):
+        np.testing.assert_allclose(rp[2], ro[2], rtol=1e-10)
+        np.testing.assert_allclose(rp[3], ro[3], rtol=1e-12, atol=1e-7 * np.sqrt(E))
+    except AssertionError as err:
+      raise AssertionError(desc + '\n' + str(err))
+    like_p.close()
+
+
 @pytest.mark.parametrize('kind', ['marginalized', 'approximate'])
 def test_nan_and_out_of_range_samples_behave_like_the_reference(cfg_pix, kind):
   """A NaN distance makes the event's z statistics NaN (jnp.min / max / std propagate it), hence L_i = NaN -> -inf; samples
