@@ -103,6 +103,10 @@ def main():
   like = CH.hyperlikelihood(th, ev['z_grids'], pop, sel, kind_p_gw3d=kind, kernel='epan', bw_method=None, cut_grid=2,
                             binning=True, num_bins=200, comm=comm)
 
+  # one-time hand-over of the host buffers (pixel sort + H2D copies in chm_like_create / chm_sel_create); NOT part of `value`
+  t0 = time.time()
+  like._handle(); sel._handle()
+  t_upload = time.time() - t0
   nb = args.nbatch
   H0s = np.linspace(55., 95., 4099)          # a different H0 for every draw of every step
 
@@ -190,7 +194,9 @@ def main():
                    "path_frac": path_bytes * nb / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[0] > 0 else None,
                    "stage_ms": {"eval": kt[0], "tables": kt[1], "samples": kt[2], "kde_integrate": kt[3],
                                 "selection": kt[4], "reduce": kt[5], "events_wall": kt[6], "event_groups": kt[7]}},
-      "setup_s": {"synthetic": t_gen},
+      "setup_s": {"synthetic": t_gen, "upload_once": t_upload,
+                  "note": "upload_once = chm_like_create + chm_sel_create (host pixel sort, log(m_det), H2D of the shard); every "
+                          "evaluation afterwards moves ~350 B of parameters per draw host->device and 24 B back"},
       "last_log_hyper": float(np.asarray(vals[-1]).ravel()[-1]),
     }
     if world == 1 and not args.no_cpu_baseline:

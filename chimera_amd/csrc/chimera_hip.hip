@@ -525,7 +525,7 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
         HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         hipLaunchKernelGGL(k_full_kde, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp);
       } else if (L.mode == CHM_MODE_MARG) {
-        hipLaunchKernelGGL(k_event_prep, dim3(L.E_cnt, nb), dim3(64), 0, sg, L, marg_std ? 0 : 1);
+        hipLaunchKernelGGL(k_event_prep, dim3((L.E_cnt + 3) / 4, nb), dim3(256), 0, sg, L, marg_std ? 0 : 1);
         HIPCHK(hipGetLastError());
         if (zf_ranged) { launch_zfactors(); HIPCHK(hipGetLastError()); }
         HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));

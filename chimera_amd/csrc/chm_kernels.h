@@ -571,10 +571,12 @@ DEVFN void event_stats(const LikeDev& L, int b, int e, double* es) {
   es[10] = (ub - lb) / (double)(L.G - 1); es[11] = (double)(L.G - 1) / (ub - lb);
 }
 
-// k_event_prep: one wave per (event, draw): event_stats -> evstat (nb,E,NEVSTAT) and, for the general kernel (k_kde_marg),
+// k_event_prep: one wave per (event, draw), four waves per block: event_stats -> evstat (nb,E,NEVSTAT) and, for the general kernel (k_kde_marg),
 // the effective grid effg (nb,E,G); the standard kernel (k_kde_marg_sub) forms its nodes arithmetically.
-__global__ void __launch_bounds__(64) k_event_prep(LikeDev L, int write_effg) {
-  const int e = L.e_off + blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+__global__ void __launch_bounds__(256) k_event_prep(LikeDev L, int write_effg) {
+  const int lane = threadIdx.x & 63, ei = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;     // four events (waves) per block
+  if (ei >= L.E_cnt) return;
+  const int e = L.e_off + ei;
   double es[NEVSTAT];
   event_stats(L, b, e, es);
   double* o = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
