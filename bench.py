@@ -55,9 +55,15 @@ def main():
   ap.add_argument('--inj', type=int, default=None, help='shrink the number of injections (debug)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--single-call', action='store_true', help='also time the scalar one-draw call (extra launches after the timed region)')
+  ap.add_argument('--force-comm', action='store_true', help='build the gloo group and the RCCL communicator even for one rank (rehearses the N > 1 path)')
   ap.add_argument('--cpu-events', type=int, default=1000, help='events of the workload the CPU baseline evaluates (1000 = all of C3, ~15 s)')
   args = ap.parse_args()
 
+  # stdout must carry ONE JSON line: gloo ("[Gloo] Rank 0 is connected ...") and RCCL (its version banner) print to fd 1 when
+  # they come up, so fd 1 points at stderr for the whole run and the JSON line goes to the saved descriptor
+  sys.stdout.flush()
+  real_stdout = os.dup(1)
+  os.dup2(2, 1)
   rank = int(os.environ.get('RANK', 0))
   world = int(os.environ.get('WORLD_SIZE', 1))
   local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -66,9 +72,11 @@ def main():
   os.environ.setdefault('CHIMERA_DEVICE', str(local_rank))
 
   dist = None
-  if world > 1:
+  if world > 1 or args.force_comm:
     import torch
     import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
     dist.init_process_group('gloo', rank=rank, world_size=world)      # control plane only (barrier, max-of-times, id exchange)
 
   import chimera_amd as CH
@@ -82,7 +90,7 @@ def main():
   pixelated = cfg['pixelated']
   t_gen = time.time() - t0
 
-  comm = Comm(world, rank, local_rank) if world > 1 else None
+  comm = Comm(world, rank, local_rank) if (world > 1 or args.force_comm) else None
   mg = args.config == 'C5'                      # BASELINE.json configs[4]: modified GW propagation (Xi0, n)
   cosmo = CH.cosmo.mg_flrw(H0=70., Om0=0.25, z_max=5., Xi0=1.8, n=1.9) if mg else CH.cosmo.flrw(H0=70., Om0=0.25, z_max=5.)
   mass = CH.mass.plp()
@@ -205,7 +213,8 @@ def main():
         g = float(like(H0=67.))
         out["parity_full_size"] = {"H0": 67., "log_hyper_hip": g, "log_hyper_cpu_port": cb["log_hyper_H0_67"],
                                    "abs_diff": abs(g - cb["log_hyper_H0_67"]), "tolerance": 1e-7 * float(np.sqrt(E))}
-    print(json.dumps(out), flush=True)
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(out) + '\n').encode())
   like.close()
   sel.close()
   if comm is not None:

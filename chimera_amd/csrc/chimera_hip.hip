@@ -562,7 +562,8 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
   const size_t El = like ? like->L.E : 0;
   if (like && out->log_like_evs) HIPCHK(hipMalloc(&d_lle, sizeof(double) * nb * El));
   if (like && out->numlike_evs) HIPCHK(hipMalloc(&d_nle, sizeof(double) * nb * El));
-  const bool multi = comm && comm->nranks > 1;
+  const bool multi = comm != nullptr;       // with a communicator the partials always go through ncclAllReduce + k_combine (also for
+                                            // one rank, so that a single GPU exercises the very path the multi-GPU run takes)
   double Etot = comm ? (double)E_total : (like ? (double)like->L.E : 0.);
   const bool one_kernel = !like || like->L.E <= 4096;
   if (like && !one_kernel) {
