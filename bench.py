@@ -55,6 +55,7 @@ def main():
   ap.add_argument('--inj', type=int, default=None, help='shrink the number of injections (debug)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--single-call', action='store_true', help='also time the scalar one-draw call (extra launches after the timed region)')
+  ap.add_argument('--host-comm', action='store_true', help='reduce the partial sums through the host (gloo) instead of RCCL')
   ap.add_argument('--force-comm', action='store_true', help='build the gloo group and the RCCL communicator even for one rank (rehearses the N > 1 path)')
   ap.add_argument('--cpu-events', type=int, default=1000, help='events of the workload the CPU baseline evaluates (1000 = all of C3, ~15 s)')
   args = ap.parse_args()
@@ -69,7 +70,14 @@ def main():
   local_rank = int(os.environ.get('LOCAL_RANK', 0))
   if world != args.gpus and world > 1:
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-  os.environ.setdefault('CHIMERA_DEVICE', str(local_rank))
+  # one rank per GPU; on a box with fewer GPUs than ranks (a rehearsal with --host-comm) the ranks wrap around the devices
+  try:
+    import torch
+    ndev = torch.cuda.device_count()              # counting devices does not initialise the GPU
+  except ImportError:
+    ndev = 0
+  device = local_rank % ndev if ndev > 0 else local_rank
+  os.environ.setdefault('CHIMERA_DEVICE', str(device))
 
   dist = None
   if world > 1 or args.force_comm:
@@ -90,7 +98,25 @@ def main():
   pixelated = cfg['pixelated']
   t_gen = time.time() - t0
 
-  comm = Comm(world, rank, local_rank) if (world > 1 or args.force_comm) else None
+  comm, comm_kind = None, None
+  if world > 1 or args.force_comm:
+    from chimera_amd.parallel import HostComm
+    err = None
+    try:
+      comm = None if args.host_comm else Comm(world, rank, device)          # one RCCL rank per GPU
+    except Exception as e:                                                        # noqa: BLE001 -- any failure -> host fallback
+      err = e
+    import torch
+    flag = torch.tensor([0 if comm is not None else 1], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.SUM)                                   # every rank must take the same branch
+    if int(flag[0]) > 0:
+      if comm is not None:
+        comm.close()
+      if err is not None:
+        print(f"[bench] rank {rank}: RCCL communicator failed ({err}); partial sums go through the host (gloo)", file=sys.stderr)
+      comm, comm_kind = HostComm(world, rank, device), "host (gloo) all-reduce of 3*nbatch doubles"
+    else:
+      comm_kind = "RCCL all-reduce of 3*nbatch doubles inside chm_eval"
   mg = args.config == 'C5'                      # BASELINE.json configs[4]: modified GW propagation (Xi0, n)
   cosmo = CH.cosmo.mg_flrw(H0=70., Om0=0.25, z_max=5., Xi0=1.8, n=1.9) if mg else CH.cosmo.flrw(H0=70., Om0=0.25, z_max=5.)
   mass = CH.mass.plp()
@@ -129,7 +155,7 @@ def main():
     try:
       import torch
       if torch.cuda.is_available():
-        torch.cuda.synchronize(local_rank)
+        torch.cuda.synchronize(device)
     except ImportError:
       pass
     if dist is not None:
@@ -191,7 +217,7 @@ def main():
       "config": {"workload": f"{args.config}: {E} events x {P} pixels x {Z} z-bins, {S} samples/event, {I} detected injections, "
                              f"PLP + Madau-Dickinson + {'modified-GW-propagation (Xi0, n) flat-LCDM' if mg else 'flat-LCDM'}, {kind or '1d'}, binning 200, cut_grid 2",
                  "E": E, "P": P, "Z": Z, "S": S, "I": I, "kind_p_gw3d": kind, "nbatch": nb,
-                 "parallelism": f"events+injections sharded over {world} GPU(s)",
+                 "parallelism": f"events+injections sharded over {world} GPU(s)" + (f"; {comm_kind}" if comm_kind else ""),
                  "cells_per_s": value * E * max(P, 1) * Z},
       "single_call_ms": single_ms,
       "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES.get(kind, "k_kde1d+k_integrate_1d"),

@@ -189,7 +189,19 @@ class hyperlikelihood(object):
       res['partials'] = np.empty((nb, 3)); out.partials = _lib.dptr(res['partials'])
     sel = self.selection_function._handle() if (with_sel and self.selection_function is not None) else None
     comm_h = getattr(self.comm, 'handle', None) if self.comm is not None else None       # RCCL all-reduce inside chm_eval
+    host_reduce = (self.comm is not None and comm_h is None and self.comm.nranks > 1 and hasattr(self.comm, 'allreduce_sum'))
+    if host_reduce and 'partials' not in res:               # HostComm: the partial sums are reduced and combined on the host
+      res['partials'] = np.empty((nb, 3)); out.partials = _lib.dptr(res['partials'])
     _lib.check(_lib.lib().chm_eval(h, sel, comm_h, params, nb, self.nevents, C.byref(out)))
+    if host_reduce:
+      from .parallel import combine_partials
+      tot = self.comm.allreduce_sum(res['partials']).reshape(nb, 3)
+      sf = self.selection_function if with_sel else None
+      for b in range(nb):
+        p = params[b]
+        res['log_hyper'][b], res['log_num'][b], res['N_exp'][b] = combine_partials(
+          tot[b], self.nevents, sf.N_inj if sf is not None else 1., sf.N_eff if sf is not None else None,
+          bool(p.scale_free), p.R0, p.Tobs, has_like=True, has_sel=sf is not None)
     return res
 
   def last_timing(self):

@@ -62,6 +62,55 @@ class Comm(object):
       pass
 
 
+class HostComm(object):
+  """Fallback communicator for hosts where RCCL cannot bring up a communicator: the ``3 * nbatch`` partial sums travel through
+  ``torch.distributed`` (any initialised backend, e.g. gloo) on the host and the combination (likelihood.py:298-316,
+  selection_function.py:38-47) is formed by :func:`combine_partials` instead of ``k_combine``.  Same sharding, same sums; only the
+  transport differs (an extra D2H/H2D of 3 doubles per draw per call)."""
+  handle = None
+
+  def __init__(self, nranks, rank, device=None):
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+      raise RuntimeError("HostComm needs an initialised torch.distributed process group")
+    self.nranks, self.rank = int(nranks), int(rank)
+    self.device = _lib.default_device() if device is None else int(device)
+
+  def allreduce_sum(self, x):
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(_lib.as_f64(x).copy())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy()
+
+  def close(self):
+    pass
+
+
+def combine_partials(partials, E_total, N_inj, N_eff, scale_free, R0, Tobs, has_like=True, has_sel=True):
+  """Host form of the device's ``combine_one``: [sum_i log L_i, nansum dN, sum dN^2] (summed over ranks) ->
+  (log_hyper, log_num, N_exp)   (selection_function.py:38-47, likelihood.py:298-300, 313-316)."""
+  log_num, s1, s2 = (float(v) for v in partials)
+  with np.errstate(all='ignore'):
+    Nexp = np.nan
+    if has_sel:
+      xi = s1 / N_inj
+      Nexp = Tobs * xi
+      if N_eff is not None:
+        variance2 = s2 / N_inj**2 - xi**2 / N_inj
+        if xi**2 / variance2 < N_eff:
+          Nexp = 0.0
+    log_hyper = np.nan
+    if has_like:
+      if not scale_free:
+        log_num = log_num + E_total * np.log(R0 * Tobs)
+      if has_sel:
+        log_hyper = log_num - E_total * np.log(Nexp) if scale_free else log_num - Nexp
+    else:
+      log_num = np.nan
+  return log_hyper, log_num, Nexp
+
+
 def new_unique_id():
   buf = C.create_string_buffer(128)
   _lib.check(_lib.lib().chm_comm_unique_id(buf))

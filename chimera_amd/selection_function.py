@@ -63,7 +63,15 @@ class selection_function(object):
     out = _lib.chm_out()
     out.N_exp = _lib.dptr(nexp)
     comm_h = getattr(self.comm, 'handle', None) if self.comm is not None else None
+    host_reduce = self.comm is not None and comm_h is None and self.comm.nranks > 1 and hasattr(self.comm, 'allreduce_sum')
+    part = np.empty(3)
+    if host_reduce:
+      out.partials = _lib.dptr(part)
     _lib.check(_lib.lib().chm_eval(None, self._handle(), comm_h, C.byref(p), 1, 0, C.byref(out)))
+    if host_reduce:                                           # HostComm: reduce the two selection sums on the host
+      from .parallel import combine_partials
+      return combine_partials(self.comm.allreduce_sum(part), 0, self.N_inj, self.N_eff, bool(p.scale_free), p.R0, p.Tobs,
+                              has_like=False, has_sel=True)[2]
     return nexp[0]
 
   def __call__(self, pop_lambdas):

@@ -215,6 +215,46 @@ def test_rccl_single_rank_communicator(cfg_pix):
   comm.close()
 
 
+def _hostcomm_worker(rank, world, port, outdir):
+  import os, sys
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  import torch.distributed as dist
+  from chimera_amd.parallel import HostComm
+  from tests import helpers as HH
+  os.environ['MASTER_ADDR'] = '127.0.0.1'
+  os.environ['MASTER_PORT'] = str(port)
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  cfg, ev, inj = HH.small_config(E=9, S=300, P=4, Z=60, I=3001, seed=41, ragged=True)
+  comm = HostComm(world, rank, device=0)
+  out = []
+  for pop_kw in ({}, dict(scale_free=False, R0=12., Tobs=1.5)):
+    like, pop, sel = HH.build_product(ev, inj, comm=comm, pop_kw=pop_kw)
+    lams = [dict(H0=64.), dict(H0=70., alpha=3.0), dict(H0=81., gamma=2.0)]
+    out.append(np.concatenate([like.batch(lams), [like(**lams[1]), sel.N_exp(pop.update(**lams[2]))]]))
+    like.close(); sel.close()
+  np.save(os.path.join(outdir, f'rank{rank}.npy'), np.array(out))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_share_one_gpu_through_the_host_communicator(tmp_path):
+  """The N > 1 path end to end on the device: two processes shard events and injections (both on GPU 0), reduce the three
+  partial sums per draw through the host communicator (gloo) and must each obtain the single-process result."""
+  import socket
+  import torch.multiprocessing as mp
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  mp.spawn(_hostcomm_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  r0, r1 = np.load(tmp_path / 'rank0.npy'), np.load(tmp_path / 'rank1.npy')
+  np.testing.assert_array_equal(r0, r1)
+  cfg, ev, inj = H.small_config(E=9, S=300, P=4, Z=60, I=3001, seed=41, ragged=True)
+  for k, pop_kw in enumerate(({}, dict(scale_free=False, R0=12., Tobs=1.5))):
+    like, pop, sel = H.build_product(ev, inj, pop_kw=pop_kw)
+    lams = [dict(H0=64.), dict(H0=70., alpha=3.0), dict(H0=81., gamma=2.0)]
+    ref = np.concatenate([like.batch(lams), [like(**lams[1]), sel.N_exp(pop.update(**lams[2]))]])
+    np.testing.assert_allclose(r0[k], ref, rtol=1e-12)
+
+
 # ----------------------------------------------------------------------------------------------------------
 # size-independent properties at a BASELINE-sized shape (300 events x 32 pixels x 1000 z-bins x 4096 samples)
 # ----------------------------------------------------------------------------------------------------------
