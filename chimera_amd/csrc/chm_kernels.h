@@ -406,6 +406,27 @@ DEVFN double kde_bandwidth_factor(int bw_method, double bw_scalar, double neff, 
   return bw_scalar;
 }
 
+// x^(-1/5) for the bandwidth rules (math.py:65-73, d = 1) without fp64 log/exp: fp32 hardware log2/exp2 give a seed good to
+// ~1e-7, two Newton steps y <- y (6 - x y^5)/5 (error -> 3 e^2) bring it to fp64 rounding (~20 instructions instead of ~70).
+// x = 0, inf, NaN give inf / 0 / NaN as exp(-log(x)/5) does; used by the standard GW kernel, whose support test is tolerant
+// of the last bits of the bandwidth.
+DEVFN double pow_m1_5(double x) {
+  double y = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)x));
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    double y2 = y * y, y5 = (y2 * y2) * y;
+    y = y * ((6. - x * y5) * 0.2);
+  }
+  if (x == 0.) y = __builtin_inf();
+  if (x == __builtin_inf()) y = 0.;
+  return y;
+}
+DEVFN double kde_bandwidth_factor_fast(int bw_method, double bw_scalar, double neff) {
+  if (bw_method == 0) return pow_m1_5(neff);
+  if (bw_method == 1) return pow_m1_5(neff * 3. / 4.0);
+  return bw_scalar;
+}
+
 // lower/upper ends of the effective grid (likelihood.py:119-120 for p_gw1d, :186-187 for p_gw3dmarg)
 DEVFN void eff_bounds(bool marg, double zmin, double zmax, double sd, double cut, double& lb, double& ub) {
   lb = zmin - cut * sd;
@@ -964,7 +985,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   }
   const double neff_k = (tot * tot) / sum2;
   const double stdc = dhl * L.std_unit;
-  const double bw = kde_bandwidth_factor(L.bw_method, L.bw_scalar, neff_k, 1) * stdc;
+  const double bw = kde_bandwidth_factor_fast(L.bw_method, L.bw_scalar, neff_k) * stdc;
   const bool degenerate = !(dbin > 0.) || !(bw > 0.) || !(bw < 1e300) || !(tot > 0. || tot < 0.);
   // Per-pixel constants of the node evaluation.  A node g of the effective grid sees the bins [ja, jb) with |g - c_j| <= h,
   // c_j = lo + (j + 1/2) dbin:  ja = ceil(t - hb), jb = floor(t + hb) + 1 with t = (g - lo)/dbin - 1/2, hb = h/dbin; the next
