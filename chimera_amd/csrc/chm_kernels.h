@@ -850,6 +850,48 @@ DEVFN void wave_sync() {
 //     between two pixels of the same event halves that cost per pixel while the grid loop keeps every lane busy.
 // Degenerate pixels (no in-pixel weight, zero-width histogram, zero bandwidth) give NaN, as the reference's 0/0 does.
 // ------------------------------------------------------------------------------------------------------
+// Cross-lane steps of the scans / reductions inside a lane group as DPP moves (two v_mov_b32_dpp per double) instead of
+// ds_bpermute shuffles: row_shr:n inside rows of 16 lanes, row_bcast:15 / row_bcast:31 across rows (gfx9 DPP controls).
+// FILL0: lanes without a source lane receive 0 (neutral for a sum); otherwise they keep their own value (neutral for a max).
+template <int CTRL, int ROW_MASK, bool FILL0>
+DEVFN double dpp_move(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  int lo2 = __builtin_amdgcn_update_dpp(FILL0 ? 0 : lo, lo, CTRL, ROW_MASK, 0xf, false);
+  int hi2 = __builtin_amdgcn_update_dpp(FILL0 ? 0 : hi, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi2, lo2);
+}
+// inclusive prefix sum over each group of SW consecutive lanes (SW = 16, 32 or 64)
+template <int SW> DEVFN double sg_scan_add(double x) {
+  x += dpp_move<0x111, 0xf, true>(x);
+  x += dpp_move<0x112, 0xf, true>(x);
+  x += dpp_move<0x114, 0xf, true>(x);
+  x += dpp_move<0x118, 0xf, true>(x);
+  if (SW >= 32) x += dpp_move<0x142, 0xa, true>(x);       // row_bcast:15 into rows 1 and 3
+  if (SW >= 64) x += dpp_move<0x143, 0xc, true>(x);       // row_bcast:31 into rows 2 and 3
+  return x;
+}
+// value of the LAST lane of this lane's group, for every lane (the group total after sg_scan_add / sg_scan_max)
+template <int SW> DEVFN double sg_last(double x, int sub) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  int rl = __builtin_amdgcn_readlane(lo, SW - 1), rh = __builtin_amdgcn_readlane(hi, SW - 1);
+#pragma unroll
+  for (int g = 1; g < 64 / SW; g++) {
+    int l2 = __builtin_amdgcn_readlane(lo, (g + 1) * SW - 1), h2 = __builtin_amdgcn_readlane(hi, (g + 1) * SW - 1);
+    if (sub == g) { rl = l2; rh = h2; }
+  }
+  return __hiloint2double(rh, rl);
+}
+// running maximum towards the last lane of the group (v_max_f64: NaN-ignoring; callers vote on NaNs separately)
+template <int SW> DEVFN double sg_scan_max(double x) {
+  x = __builtin_fmax(x, dpp_move<0x111, 0xf, false>(x));
+  x = __builtin_fmax(x, dpp_move<0x112, 0xf, false>(x));
+  x = __builtin_fmax(x, dpp_move<0x114, 0xf, false>(x));
+  x = __builtin_fmax(x, dpp_move<0x118, 0xf, false>(x));
+  if (SW >= 32) x = __builtin_fmax(x, dpp_move<0x142, 0xa, false>(x));
+  if (SW >= 64) x = __builtin_fmax(x, dpp_move<0x143, 0xc, false>(x));
+  return x;
+}
+
 template <int SW> DEVFN double sg_sum(double v) {
 #pragma unroll
   for (int o = SW / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -925,8 +967,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
 #pragma unroll
   for (int i = 0; i < NR; i++) { hi = __builtin_fmax(hi, zr[i]); sawnan = sawnan || (zr[i] != zr[i]); }
   for (int s = s0 + sl + SW * NR; s < s1; s += SW) { double zz = wz[s]; hi = __builtin_fmax(hi, zz); sawnan = sawnan || (zz != zz); }
-#pragma unroll
-  for (int o = SW / 2; o > 0; o >>= 1) hi = __builtin_fmax(hi, __shfl_xor(hi, o, 64));
+  hi = sg_last<SW>(sg_scan_max<SW>(hi), sub);
   {
     const unsigned long long votes = __ballot(sawnan);
     const unsigned long long mine = SW == 64 ? ~0ull : (((1ull << (SW & 63)) - 1ull) << (sub * SW));
@@ -946,14 +987,9 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   const int j0 = sl * per < B ? sl * per : B, j1 = min(j0 + per, B);
   double s0w = 0., s1w = 0., s2w = 0., sq = 0.;
   for (int j = j0; j < j1; j++) { double w = Q[3 * j], cc = ((double)j + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
-  double x0 = s0w, x1 = s1w, x2 = s2w;
-#pragma unroll
-  for (int o = 1; o < SW; o <<= 1) {
-    double y0 = __shfl_up(x0, o, SW), y1 = __shfl_up(x1, o, SW), y2 = __shfl_up(x2, o, SW);
-    if (sl >= o) { x0 += y0; x1 += y1; x2 += y2; }
-  }
-  const double tot = __shfl(x0, SW - 1, SW);
-  const double sum2 = sg_sum<SW>(sq);
+  const double x0 = sg_scan_add<SW>(s0w), x1 = sg_scan_add<SW>(s1w), x2 = sg_scan_add<SW>(s2w);
+  const double tot = sg_last<SW>(x0, sub);
+  const double sum2 = sg_last<SW>(sg_scan_add<SW>(sq), sub);
   {
     double r0 = x0 - s0w, r1 = x1 - s1w, r2 = x2 - s2w;
     constexpr int MAXPER = 16;
@@ -1049,8 +1085,8 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
     zc0 = zn0; zc1 = zn1; bc0 = bn0; bc1 = bn1; ac0 = an0; ac1 = an1;
     if (it + 1 >= PF) { pf0[0] = pn0; pf1[0] = pn1; }
   }
-  acc = sg_sum<SW>(acc);
-  if (sl == 0 && live) *out_like = acc;
+  acc = sg_scan_add<SW>(acc);                               // the group's last lane holds the pixel's integral
+  if (sl == SW - 1 && live) *out_like = acc;
 }
 
 // ------------------------------------------------------------------------------------------------------
