@@ -266,8 +266,8 @@ template <int NS>
 DEVFN void block_reduce_stats(double* v, double* scratch /* 4 x (NS+2) */) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
-  for (int i = 0; i < NS; i++) v[i] = wave_sum(v[i]);
-  v[NS] = wave_min(v[NS]); v[NS + 1] = wave_max(v[NS + 1]);
+  for (int i = 0; i < NS; i++) v[i] = wave_sum_dpp(v[i]);                     // every lane of the block is active here
+  v[NS] = wave_min_dpp(v[NS]); v[NS + 1] = wave_max_dpp(v[NS + 1]);         // NaN-ignoring; the caller restores NaN from the sums
   __syncthreads();
   if (lane == 0) {
 #pragma unroll
@@ -850,16 +850,6 @@ DEVFN void wave_sync() {
 //     between two pixels of the same event halves that cost per pixel while the grid loop keeps every lane busy.
 // Degenerate pixels (no in-pixel weight, zero-width histogram, zero bandwidth) give NaN, as the reference's 0/0 does.
 // ------------------------------------------------------------------------------------------------------
-// Cross-lane steps of the scans / reductions inside a lane group as DPP moves (two v_mov_b32_dpp per double) instead of
-// ds_bpermute shuffles: row_shr:n inside rows of 16 lanes, row_bcast:15 / row_bcast:31 across rows (gfx9 DPP controls).
-// FILL0: lanes without a source lane receive 0 (neutral for a sum); otherwise they keep their own value (neutral for a max).
-template <int CTRL, int ROW_MASK, bool FILL0>
-DEVFN double dpp_move(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  int lo2 = __builtin_amdgcn_update_dpp(FILL0 ? 0 : lo, lo, CTRL, ROW_MASK, 0xf, false);
-  int hi2 = __builtin_amdgcn_update_dpp(FILL0 ? 0 : hi, hi, CTRL, ROW_MASK, 0xf, false);
-  return __hiloint2double(hi2, lo2);
-}
 // inclusive prefix sum over each group of SW consecutive lanes (SW = 16, 32 or 64)
 template <int SW> DEVFN double sg_scan_add(double x) {
   x += dpp_move<0x111, 0xf, true>(x);

@@ -420,6 +420,39 @@ DEVFN double wave_max(double v) {
   return v;
 }
 
+// Cross-lane steps of the scans / reductions inside a lane group as DPP moves (two v_mov_b32_dpp per double) instead of
+// ds_bpermute shuffles: row_shr:n inside rows of 16 lanes, row_bcast:15 / row_bcast:31 across rows (gfx9 DPP controls).
+// FILL0: lanes without a source lane receive 0 (neutral for a sum); otherwise they keep their own value (neutral for a max).
+template <int CTRL, int ROW_MASK, bool FILL0>
+DEVFN double dpp_move(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  int lo2 = __builtin_amdgcn_update_dpp(FILL0 ? 0 : lo, lo, CTRL, ROW_MASK, 0xf, false);
+  int hi2 = __builtin_amdgcn_update_dpp(FILL0 ? 0 : hi, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi2, lo2);
+}
+// 64-lane reductions on DPP moves; the result is read from lane 63 and is uniform.  ALL 64 lanes must be active at the call.
+DEVFN double lane63(double x) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(x), 63), hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
+  return __hiloint2double(hi, lo);
+}
+DEVFN double wave_sum_dpp(double v) {
+  v += dpp_move<0x111, 0xf, true>(v); v += dpp_move<0x112, 0xf, true>(v); v += dpp_move<0x114, 0xf, true>(v);
+  v += dpp_move<0x118, 0xf, true>(v); v += dpp_move<0x142, 0xa, true>(v); v += dpp_move<0x143, 0xc, true>(v);
+  return lane63(v);
+}
+DEVFN double wave_max_dpp(double v) {                      // v_max_f64: NaN-ignoring
+  v = __builtin_fmax(v, dpp_move<0x111, 0xf, false>(v)); v = __builtin_fmax(v, dpp_move<0x112, 0xf, false>(v));
+  v = __builtin_fmax(v, dpp_move<0x114, 0xf, false>(v)); v = __builtin_fmax(v, dpp_move<0x118, 0xf, false>(v));
+  v = __builtin_fmax(v, dpp_move<0x142, 0xa, false>(v)); v = __builtin_fmax(v, dpp_move<0x143, 0xc, false>(v));
+  return lane63(v);
+}
+DEVFN double wave_min_dpp(double v) {
+  v = __builtin_fmin(v, dpp_move<0x111, 0xf, false>(v)); v = __builtin_fmin(v, dpp_move<0x112, 0xf, false>(v));
+  v = __builtin_fmin(v, dpp_move<0x114, 0xf, false>(v)); v = __builtin_fmin(v, dpp_move<0x118, 0xf, false>(v));
+  v = __builtin_fmin(v, dpp_move<0x142, 0xa, false>(v)); v = __builtin_fmin(v, dpp_move<0x143, 0xc, false>(v));
+  return lane63(v);
+}
+
 // block-wide reductions for blockDim.x <= 1024; scratch: >= 16 doubles of LDS; result broadcast to all threads.
 enum { RED_SUM = 0, RED_MIN = 1, RED_MAX = 2 };
 template <int OP>
