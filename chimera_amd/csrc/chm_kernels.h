@@ -3,7 +3,7 @@
 // One evaluation (nb = draws in the batch, blockIdx.y = draw).  Stream A: k_tables -> k_samples -> GW-kernel -> reduce;
 // stream B (forked after k_tables): k_zfactors, k_selection.
 //   k_tables        1 block / draw            per-draw tables + constants            cosmo.py:43-46,263, mass.py:45-52
-//   k_samples       1 block / 1024 samples    det->src, weights, partial statistics  pop_wrapper.py:67-80, likelihood.py:111-118
+//   k_samples       blocks walk over chunks   det->src, weights, partial statistics  pop_wrapper.py:67-80, likelihood.py:111-118
 //   k_zfactors      1 block / event           per-z factors of the integrand          likelihood.py:270-272, pop_wrapper.py:82-90
 //   k_kde_marg      1 wave  / (event,pixel)   histogram, KDE, interp, integrand, trapz  math.py:32-89, likelihood.py:160-205,266-281
 //   k_kde1d         1 block / event           1-D GW kernel p_gw(z)                   likelihood.py:105-144
@@ -21,7 +21,7 @@
 #define NPART 16
 // per-(draw,event,chunk) partial statistics written by k_samples; d = z - z_ref (z_ref = z of the event's first sample)
 enum { PT_SW = 0, PT_SW2, PT_SD1, PT_SD2, PT_ZMIN, PT_ZMAX, PT_WD0, PT_WD1, PT_WD2, PT_W00, PT_W01, PT_W02, PT_W11, PT_W12, PT_W22, PT_ZREF };
-#define SAMPLE_CHUNK 1024
+#define SAMPLE_CHUNK 4096
 #define NEVSTAT 12           // doubles per (draw, event) written by k_event_prep
 
 struct LikeDev {                  // device-resident shard of events (see chm_like_desc)
