@@ -1028,6 +1028,11 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   const double ng = norm * L.gw_pdf[(size_t)e * L.P + pp]; // kde_interp * norm * gw_pdf[i]    likelihood.py:194
   const double fR = params[b].fR;
   const double nan = __builtin_nan("");
+  // Support of THIS pixel's interpolated KDE on the event grid: the bin centres lie in [lo + dbin/2, hi - dbin/2], a node sees
+  // none of them beyond bw, and an event-grid point combines the two nodes within de of it -- so p_gw is an exact zero for
+  // z outside (lo - bw - de, hi + bw + de), typically a third of the event's range [lb, ub] (every pixel's histogram starts
+  // at the event's min z but ends at the pixel's own max z, likelihood.py:180).  Degenerate pixels keep [lb, ub] (NaN there).
+  const double zlo = degenerate ? lb : __builtin_fmax(lb, lo - bw - de), zhi = degenerate ? ub : __builtin_fmin(ub, hi + bw + de);
   // density (without the common factor `scale`) at the node with g' = g - lo and bin position t
   auto node = [&](double gp, double t) {
     double fa = __builtin_fmin(__builtin_fmax(ceil(t - hb), 0.), dB);
@@ -1056,7 +1061,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
       if (kk <= k_hi && live) {
         const double zk = h == 0 ? zc0 : zc1;
         double pgw = 0.;
-        if (zk >= lb && zk <= ub) {                         // jnp.interp(..., left=0, right=0)
+        if (zk >= zlo && zk <= zhi) {                       // inside: jnp.interp on the nodes; outside: 0 (left=0, right=0 or no bin in reach)
           // bracket on the uniform effective grid: nodes x_i = lb + i de; a z within rounding of a node may pick either
           // neighbouring segment -- the interpolant is continuous there
           double tp = __builtin_fmin(floor((zk - lb) * inv_de), dG2);
