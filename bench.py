@@ -224,6 +224,11 @@ def main():
                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                    "traffic": traffic, "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
                    "bytes_per_launch": kb, "kernel_ms": kde_ms,
+                   "note": "achieved = ALGORITHMIC bytes of the launch (every input of the kernel once: 370.7 MB per draw at C3) / its "
+                           "HIP-event duration; the kernel moves far fewer bytes than that (see traffic): it reads only the part of "
+                           "each p_cat row inside the KDE's support, and the draws of a call share p_cat and samples through L2 / "
+                           "Infinity Cache -- so frac can approach or exceed 1 without the HBM being saturated; the kernel is "
+                           "fp64-VALU / latency bound (DESIGN.md section 4)",
                    "path_bytes_per_eval": path_bytes,
                    "path_frac": path_bytes * nb / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[0] > 0 else None,
                    "stage_ms": {"eval": kt[0], "tables": kt[1], "samples": kt[2], "kde_integrate": kt[3],
