@@ -487,7 +487,8 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
       hipStream_t sz = (serial || zf_ranged) ? sg : ((g & 1) ? sA : sB);
       // ~2048 blocks in all: each stages the draw's (zt, It) tables in LDS once and walks over E_cnt / gridDim.x events
       const int zf_target = 2048 / nb > 1 ? 2048 / nb : 1;
-      const int zf_blocks = L.E_cnt < zf_target ? L.E_cnt : zf_target;
+      const int zf_units = zf_mode ? (L.E_cnt + 3) / 4 : L.E_cnt;     // ranged: four events (waves) per block pass
+      const int zf_blocks = zf_units < zf_target ? zf_units : zf_target;
       auto launch_zfactors = [&]() {
         if (tab_zfac) { allow_lds(k_zfactors<true>, lds_zfac);
           hipLaunchKernelGGL(k_zfactors<true>, dim3(zf_blocks, nb), dim3(256), lds_zfac, sz, L, dp, c.zt, c.It, Tc, zf_mode);

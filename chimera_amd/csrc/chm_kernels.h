@@ -635,7 +635,11 @@ __global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* pa
     zt = a; It = c;
   }
   const int Z = L.Z;
-  for (int ei = blockIdx.x; ei < L.E_cnt; ei += gridDim.x) {
+  // ranged: a WAVE per event (the support of an event's KDE is ~Z/3 points: 64-lane passes waste less than 256-thread ones);
+  // whole grids: the block walks over the events
+  const int lane0 = ranged ? (t & 63) : t, stride = ranged ? 64 : nt;
+  const int ev_first = ranged ? blockIdx.x * (nt >> 6) + (t >> 6) : blockIdx.x, ev_step = ranged ? gridDim.x * (nt >> 6) : gridDim.x;
+  for (int ei = ev_first; ei < L.E_cnt; ei += ev_step) {
     const int e = L.e_off + ei;
     const size_t zo = ((size_t)b * L.E + e) * Z;
     const double* zg = L.z_grids + (size_t)e * Z;
@@ -651,7 +655,7 @@ __global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* pa
       const int* kr = L.krange + ((size_t)b * L.E + e) * 2;
       k_first = kr[0]; k_last = kr[1];
     }
-    for (int k = k_first + t; k <= k_last; k += nt) {
+    for (int k = k_first + lane0; k <= k_last; k += stride) {
       double z = zg[k];
       double dCt = dCt_at_z(P, z, zt, It);
       double zp1 = 1. + z;
