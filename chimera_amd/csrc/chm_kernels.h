@@ -1290,18 +1290,25 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
   const size_t zo = ((size_t)b * L.E + e) * Z;
   const double* pc = L.p_cat + ((size_t)e * L.P + p) * Z;
 
+  // Only the grid points inside the mask [zlo, zhi] carry a KDE value (likelihood.py:225-226, 248-250); they form one
+  // contiguous stretch [k_first, k_last] of the event grid, and only that stretch is chunked -- with the whole grid half the
+  // threads held chunks outside the mask and idled while the others worked.
+  double kf = 1e300, kl = -1.;
+  for (int k = t; k < Z; k += nt) { double z = zg[k]; if (z <= zhi && z >= zlo) { kf = fmin(kf, (double)k); kl = fmax(kl, (double)k); } }
+  kf = block_reduce<RED_MIN>(kf, red); kl = block_reduce<RED_MAX>(kl, red);
+  const int k_first = kl >= 0. ? (int)kf : 0, k_last = (int)kl;
   // chunks of FULL_LK grid points; NS threads (a power of two, adjacent lanes) share a chunk and split the samples
-  const int nch = (Z + FULL_LK - 1) / FULL_LK;
+  const int nch = k_last >= k_first ? (k_last - k_first + FULL_LK) / FULL_LK : 0;
   int NS = 1;
   while (NS < 16 && nch * NS * 2 <= nt) NS *= 2;
   const int cpp = nt / NS;                                // chunks per pass
   double accl = 0.;
-  if (dump && !ok) for (int k = t; k < Z; k += nt) dump[k] = 0.;
+  if (dump) for (int k = t; k < Z; k += nt) if (!ok || k < k_first || k > k_last) dump[k] = 0.;
   for (int cb = 0; cb < nch && ok; cb += cpp) {
     const int c = cb + t / NS, sl = t % NS;
     const bool has = c < nch;
-    const int k0 = has ? c * FULL_LK : 0;
-    const int nk = has ? min(FULL_LK, Z - k0) : 0;
+    const int k0 = has ? k_first + c * FULL_LK : 0;
+    const int nk = has ? min(FULL_LK, k_last + 1 - k0) : 0;
     // the chunk's grid in the first whitened coordinate; uniform?
     double t0 = 0., D = 0.;
     bool uni = false, any = false;
