@@ -59,3 +59,27 @@ def test_partials_with_zero_likelihood_events_overflow_like_the_reference():
   """Two events with L_i = 0 contribute -1.797e308 each; their sum is -inf on one rank or across ranks."""
   big = -np.finfo(np.float64).max
   assert big + big == -np.inf and (big + 1.0) + (big - 2.0) == -np.inf
+
+
+def test_host_combination_of_all_reduced_partials():
+  """parallel.combine_partials (the host form of the device's combination, used by HostComm) against the reference formulas
+  (selection_function.py:38-47, likelihood.py:298-300, 313-316), including the N_eff guard and the non-scale-free branch."""
+  sys.path.insert(0, ROOT)
+  from chimera_amd.parallel import combine_partials
+  from tests import helpers as H
+  from oracle import chimera_oracle as O
+  rng = np.random.default_rng(3)
+  for _ in range(50):
+    E, N_inj = int(rng.integers(1, 2000)), float(rng.integers(10**4, 10**7))
+    s1 = float(rng.uniform(1., 1e4)); s2 = float(s1**2 / rng.uniform(2., 2000.))
+    part = np.array([float(rng.uniform(-5e3, 0.)), s1, s2])
+    scale_free, N_eff = bool(rng.random() < 0.5), [None, 5., 1e9][int(rng.integers(0, 3))]
+    pop = O.population(O.flrw(), O.plp(), O.madau_dickinson(), R0=float(rng.uniform(1., 50.)), Tobs=float(rng.uniform(0.5, 3.)),
+                       scale_free=scale_free)
+    with np.errstate(all='ignore'):
+      want = H.combine_partials(part, E, pop, N_inj, N_eff)
+      got = combine_partials(part, E, N_inj, N_eff, scale_free, pop.R0, pop.Tobs)
+    if np.isfinite(want):
+      np.testing.assert_allclose(got[0], want, rtol=1e-14)
+    else:
+      assert got[0] == want or (np.isnan(got[0]) and np.isnan(want))
