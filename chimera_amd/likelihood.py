@@ -245,7 +245,7 @@ class hyperlikelihood(object):
     if n is None:
       return self._eval(self._params_array([hyper_lambdas]))['log_hyper'][0]
     lams = [{k: (np.asarray(v).reshape(-1)[i] if np.ndim(v) > 0 else v) for k, v in hyper_lambdas.items()} for i in range(n)]
-    return self._eval(self._params_array(lams))['log_hyper']
+    return self.batch(lams)
 
   def __call__(self, **hyper_lambdas):
     """likelihood.py:318-320."""
@@ -306,6 +306,14 @@ class hyperlikelihood(object):
               view[field][b, idx] = v
     return arr
 
+  #: draws evaluated per launch sequence; longer lists are processed in slices (the per-draw workspaces -- source-frame
+  #: z and weights of every sample, per-z factors -- take ~16 B x samples per draw: 65 MB per draw at 1000 events x 4096)
+  max_draws_per_call = 256
+
   def batch(self, list_of_hyper_lambdas):
     """log-hyperlikelihood of several draws in one launch sequence: array of len(list)."""
-    return self._eval(self._params_array(list_of_hyper_lambdas))['log_hyper']
+    lams = list(list_of_hyper_lambdas)
+    m = max(1, int(self.max_draws_per_call))
+    if len(lams) <= m:
+      return self._eval(self._params_array(lams))['log_hyper']
+    return np.concatenate([self._eval(self._params_array(lams[i:i + m]))['log_hyper'] for i in range(0, len(lams), m)])

@@ -163,6 +163,16 @@ def test_batch_matches_single(cfg_pix):
   np.testing.assert_array_equal(batched, single)
 
 
+def test_long_batches_are_sliced(cfg_pix):
+  cfg, ev, inj = cfg_pix
+  like, _, _ = H.build_product(ev, inj)
+  lams = [dict(H0=float(h)) for h in np.linspace(60., 80., 23)]
+  whole = like.batch(lams)
+  like.max_draws_per_call = 5                     # 23 draws -> slices of 5, 5, 5, 5, 3
+  np.testing.assert_array_equal(like.batch(lams), whole)
+  np.testing.assert_array_equal(like(H0=np.linspace(60., 80., 23)), whole)
+
+
 def test_compute_z_grids(cfg_pix):
   import chimera_amd as CH
   cfg, ev, inj = cfg_pix
