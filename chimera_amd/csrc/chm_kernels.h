@@ -1231,6 +1231,7 @@ __global__ void __launch_bounds__(64) k_integrate_1d(LikeDev L, const DevParams*
 #define FULL_LK 16
 __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* params) {
   __shared__ double sa[FULL_TILE], sc[FULL_TILE];
+  __shared__ double racc[256 * FULL_LK];                   // per-thread partial sums of a pass (blockDim.x = 256)
   __shared__ double red[16];
   __shared__ double wh[12];
   const int t = threadIdx.x, nt = blockDim.x;
@@ -1297,16 +1298,16 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
   for (int k = t; k < Z; k += nt) { double z = zg[k]; if (z <= zhi && z >= zlo) { kf = fmin(kf, (double)k); kl = fmax(kl, (double)k); } }
   kf = block_reduce<RED_MIN>(kf, red); kl = block_reduce<RED_MAX>(kl, red);
   const int k_first = kl >= 0. ? (int)kf : 0, k_last = (int)kl;
-  // chunks of FULL_LK grid points; NS threads (a power of two, adjacent lanes) share a chunk and split the samples
+  // chunks of FULL_LK grid points; NS threads share a chunk and split the samples (any NS: their partial sums meet in LDS)
   const int nch = k_last >= k_first ? (k_last - k_first + FULL_LK) / FULL_LK : 0;
-  int NS = 1;
-  while (NS < 16 && nch * NS * 2 <= nt) NS *= 2;
+  int NS = nch > 0 ? nt / nch : 1;
+  NS = NS < 1 ? 1 : (NS > 32 ? 32 : NS);
   const int cpp = nt / NS;                                // chunks per pass
   double accl = 0.;
   if (dump) for (int k = t; k < Z; k += nt) if (!ok || k < k_first || k > k_last) dump[k] = 0.;
   for (int cb = 0; cb < nch && ok; cb += cpp) {
     const int c = cb + t / NS, sl = t % NS;
-    const bool has = c < nch;
+    const bool has = c < nch && t < cpp * NS;
     const int k0 = has ? k_first + c * FULL_LK : 0;
     const int nk = has ? min(FULL_LK, k_last + 1 - k0) : 0;
     // the chunk's grid in the first whitened coordinate; uniform?
@@ -1359,32 +1360,32 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
         }
       }
     }
-    // sum over the NS sample slices (adjacent lanes)
-    for (int o = 1; o < NS; o <<= 1) {
+    // the NS partial sums of every grid point meet in LDS; then one thread per grid point forms p_gw and the integrand
+    __syncthreads();
 #pragma unroll
-      for (int i = 0; i < FULL_LK; i++) acc[i] += __shfl_xor(acc[i], o, 64);
-    }
-    if (has && sl == 0) {
-#pragma unroll
-      for (int i = 0; i < FULL_LK; i++) {
-        if (i < nk) {
-          const int k = k0 + i;
-          const double z = zg[k];
-          const bool inm = (z <= zhi) && (z >= zlo);
-          double pgw = inm ? acc[i] * st.norm : 0.;       // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
-          if (dump) dump[k] = pgw;
-          double pcv = pc[k];
-          double y = 0.;
-          if (pcv != -100.) {
-            double p_gal = P.fR * pcv + L.bkgA[zo + k];
-            double p_z = p_gal * L.prate[zo + k];
-            y = (p_z != -100.) ? pgw * p_z / L.jac[zo + k] : 0.;
-          }
-          // trapezoid: y_k enters the two adjacent intervals
-          double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
-          accl += y * ((z - zl) + (zr - z));
-        }
+    for (int i = 0; i < FULL_LK; i++) racc[t * FULL_LK + i] = acc[i];
+    __syncthreads();
+    const int npts = min(cpp, nch - cb) * FULL_LK;
+    for (int idx = t; idx < npts; idx += nt) {
+      const int cl = idx / FULL_LK, i = idx % FULL_LK;
+      const int k = k_first + (cb + cl) * FULL_LK + i;
+      if (k > k_last) continue;
+      double v = 0.;
+      for (int q = 0; q < NS; q++) v += racc[(cl * NS + q) * FULL_LK + i];
+      const double z = zg[k];
+      const bool inm = (z <= zhi) && (z >= zlo);
+      double pgw = inm ? v * st.norm : 0.;              // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
+      if (dump) dump[k] = pgw;
+      double pcv = pc[k];
+      double y = 0.;
+      if (pcv != -100.) {
+        double p_gal = P.fR * pcv + L.bkgA[zo + k];
+        double p_z = p_gal * L.prate[zo + k];
+        y = (p_z != -100.) ? pgw * p_z / L.jac[zo + k] : 0.;
       }
+      // trapezoid: y_k enters the two adjacent intervals
+      double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
+      accl += y * ((z - zl) + (zr - z));
     }
   }
   accl = block_reduce<RED_SUM>(accl, red);
