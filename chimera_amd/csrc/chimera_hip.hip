@@ -481,8 +481,9 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
       // per-z factors of the group's events: on the other lane, concurrently with the sample stage -- except in marginalized
       // mode, where they follow k_event_prep on the group's own lane and cover only the support of each event's KDE
       const bool zf_ranged = (L.mode == CHM_MODE_MARG || L.mode == CHM_MODE_1D || L.mode == CHM_MODE_APPROX) && !getenv("CHM_ZF_FULL");
-      static const int marg_sub = getenv("CHM_MARG_SUB") ? atoi(getenv("CHM_MARG_SUB")) : 32;   // lanes per pixel in the standard kernel
-      const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC") && (marg_sub == 32 || marg_sub == 16);
+      // standard configuration (binning, cut_grid set) -> k_kde_marg_sub<32>, two pixels per wave (16 lanes per pixel measured
+      // 30 % slower: 19 KB of LDS per wave halve the occupancy); anything else, or CHM_MARG_GENERIC=1, -> the general kernel
+      const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC");
       const int zf_mode = !zf_ranged ? 0 : (L.mode == CHM_MODE_MARG ? 1 : 2);
       hipStream_t sz = (serial || zf_ranged) ? sg : ((g & 1) ? sA : sB);
       // ~2048 blocks in all: each stages the draw's (zt, It) tables in LDS once and walks over E_cnt / gridDim.x events
@@ -538,9 +539,7 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
         if (zf_ranged) { launch_zfactors(); HIPCHK(hipGetLastError()); }
         HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         const bool fast = marg_std;
-        const int sub = marg_sub;
-        if (fast && sub == 32) hipLaunchKernelGGL(k_kde_marg_sub<32>, dim3(L.E_cnt * ((Pd + 1) / 2) * nb, 1), dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
-        else if (fast && sub == 16) hipLaunchKernelGGL(k_kde_marg_sub<16>, dim3(L.E_cnt * ((Pd + 3) / 4) * nb, 1), dim3(64), sizeof(double) * (3 * N + 3) * 4, sg, L, dp);
+        if (fast) hipLaunchKernelGGL(k_kde_marg_sub<32>, dim3(L.E_cnt * ((Pd + 1) / 2) * nb, 1), dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
         else { allow_lds(k_kde_marg, lds_kde); hipLaunchKernelGGL(k_kde_marg, dim3(L.E_cnt * Pd, nb), dim3(64), lds_kde, sg, L, dp); }
       } else {
         HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
