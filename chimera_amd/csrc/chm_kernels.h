@@ -172,6 +172,13 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
     if (LDS_ARR) __syncthreads(); else gsync();
     block_cumtrapz(tmp, zt, It, Tc, sh);
     if (!LDS_ARR) gsync();
+    {                                               // first non-finite node of the table -> z_bad (grid_is_poisoned)
+      double first = 1e300;
+      for (int i = t; i < Tc; i += nt) if (!(fabs(It[i]) <= 1.7976931348623157e308)) first = fmin(first, (double)i);
+      first = block_reduce<RED_MIN>(first, sh);
+      if (t == 0) { int j = (int)fmin(first, 1e9); Pg.z_bad = first < 1e299 ? zt[j > 0 ? j - 1 : 0] : __builtin_inf(); }
+      __syncthreads();
+    }
     // dL table of z_from_dGW: dL_at_z(cosmo, z_grid_interp) (cosmo.py:263).  jnp.interp evaluated AT its own nodes returns
     // It[i] exactly for i < Tc-1 (delta = 0) and It[Tc-2] + (dx/dx) dI at the last node.
     for (int i = t; i < Tc; i += nt) {
@@ -180,6 +187,14 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
       if (i == Tc - 1) { double dx = zt[i] - zt[i - 1]; ii = It[i - 1] + (dx / dx) * (It[i] - It[i - 1]); }
       dLt[i] = dL_from_dCt(P, dCt_from_dCr(P, P.dH * ii), z);
       if (LDS_ARR) { g_zt[i] = z; g_It[i] = It[i]; }
+    }
+    // is the dL table non-decreasing?  (decides the search used by the sample / injection kernels, see z_from_dGW_x2)
+    gsync();
+    {
+      int bad = 0;
+      for (int i = t + 1; i < Tc; i += nt) bad |= (dLt[i] < dLt[i - 1]) || (dLt[i] != dLt[i]) ? 1 : 0;
+      bad = __syncthreads_or(bad);
+      if (t == 0) Pg.dl_sorted = bad ? 0. : 1.;
     }
     // fR = Vc(z1) - Vc(z0)                                                       completeness.py:54-58
     double i0 = block_interp(P.zc0, zt, It, Tc, sh);
@@ -329,7 +344,7 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
       }
       double zz[2], wv[2];
       // z = z_from_dGW(dL) (cosmo.py:260-264) for the two samples together
-      jnp_interp_x2(dl[0], dl[1], T.dLt, T.zt, P.Tc, zz[0], zz[1]);
+      z_from_dGW_x2(P, dl[0], dl[1], T.dLt, T.zt, zz[0], zz[1]);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         // m_src = m_det/(1+z) (pop_wrapper.py:70); w = p_m1m2 / pe_prior (pop_wrapper.py:79; the device array holds 1/pe_prior)
@@ -712,6 +727,7 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
   const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
   const double zmin = es[0], norm = es[3], n_eff = es[4], lb = es[6], ub = es[7];
   const bool ok = n_eff >= L.pe_neff;                       // lax.cond(n_eff >= pe_neff, ...)   likelihood.py:199
+  const bool poisoned = grid_is_poisoned(P.z_bad, L.z_grids + (size_t)e * Z, Z);
   const double* zg = L.z_grids + (size_t)e * Z;
   const double* pc = L.p_cat + ((size_t)e * L.P + p) * Z;
 
@@ -831,7 +847,7 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
     }
   }
   acc = wave_sum(acc);
-  if (lane == 0) *out_like = acc;
+  if (lane == 0) *out_like = poisoned ? __builtin_nan("") : acc;     // NaN factors somewhere on the grid: 0 * NaN (see grid_is_poisoned)
 }
 
 // ordering point for LDS traffic inside ONE wave (its lanes exchange data through the wave's private LDS slice): LDS
@@ -918,11 +934,12 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   const int pp = live ? p : 0;                              // idle groups shadow pixel 0 for addressing, never store
   double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
   double* dump = (L.p_gw_dump && p < L.P) ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
+  const double* zg = L.z_grids + (size_t)e * Z;
+  const bool poisoned = grid_is_poisoned(params[b].z_bad, zg, Z);   // NaN factors somewhere on the grid: every live pixel is 0 * NaN
   if (!ok || !live) {
-    if (p < L.P) { if (sl == 0) *out_like = 0.; if (dump) for (int k = sl; k < Z; k += SW) dump[k] = 0.; }
+    if (p < L.P) { if (sl == 0) *out_like = (live && poisoned) ? __builtin_nan("") : 0.; if (dump) for (int k = sl; k < Z; k += SW) dump[k] = 0.; }
     if (!ok) return;                                        // uniform over the wave
   }
-  const double* zg = L.z_grids + (size_t)e * Z;
   const double* pc = L.p_cat + ((size_t)e * L.P + pp) * Z;
   const size_t zo = ((size_t)b * L.E + e) * Z;
   const double* bkgA = L.bkgA + zo;
@@ -1085,7 +1102,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
     if (it + 1 >= PF) { pf0[0] = pn0; pf1[0] = pn1; }
   }
   acc = sg_scan_add<SW>(acc);                               // the group's last lane holds the pixel's integral
-  if (sl == SW - 1 && live) *out_like = acc;
+  if (sl == SW - 1 && live) *out_like = poisoned ? nan : acc;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1192,6 +1209,7 @@ __global__ void __launch_bounds__(64) k_integrate_1d(LikeDev L, const DevParams*
   }
   const double gwp = pixelated ? L.gw_pdf[(size_t)e * L.P + p] : 1.;
   const size_t zo = ((size_t)b * L.E + e) * Z;
+  const bool poisoned = grid_is_poisoned(P.z_bad, L.z_grids + (size_t)e * Z, Z);
   const double* g1 = L.pgw1d + zo;
   // p_gw1d vanishes outside [k_lo, k_hi] (found by k_kde1d): those terms of the trapezoid are exact zeros and are skipped;
   // inside, sum_k p_gw3d[k] p_z[k]/jac[k] tw[k] with the per-z factors folded into A[k] (see k_kde_marg)
@@ -1213,7 +1231,7 @@ __global__ void __launch_bounds__(64) k_integrate_1d(LikeDev L, const DevParams*
     }
   }
   acc = wave_sum(acc);
-  if (lane == 0) *out_like = acc;
+  if (lane == 0) *out_like = poisoned ? __builtin_nan("") : acc;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1389,7 +1407,7 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
     }
   }
   accl = block_reduce<RED_SUM>(accl, red);
-  if (t == 0) *out_like = 0.5 * accl;
+  if (t == 0) *out_like = grid_is_poisoned(P.z_bad, zg, Z) ? __builtin_nan("") : 0.5 * accl;   // NaN factors on the grid: 0 * NaN
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1457,7 +1475,7 @@ __global__ void __launch_bounds__(256) k_selection(SelDev Sd, const DevParams* p
         l1[0] = l1[1] = Sd.lm1det[i]; l2[0] = l2[1] = Sd.lm2det[i];
       }
       double zz[2];
-      jnp_interp_x2(dl[0], dl[1], T.dLt, T.zt, P.Tc, zz[0], zz[1]);   // z = z_from_dGW(dL)   cosmo.py:260-264
+      z_from_dGW_x2(P, dl[0], dl[1], T.dLt, T.zt, zz[0], zz[1]);      // z = z_from_dGW(dL)   cosmo.py:260-264
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         double dN = sel_term(P, dl[h], md1[h], md2[h], l1[h], l2[h], ipd[h], zz[h], T.mg, T.cdf);

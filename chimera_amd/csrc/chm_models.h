@@ -31,6 +31,8 @@ struct DevParams {
   double inv_plnorm, inv_tg_norm, inv_2s2;   // reciprocals of plp_plnorm, tg_norm, 2 sigma_g^2
   double norm_p_m1, inv_norm_p_m1;       // mass.py:51
   double fR;                             // completeness.py:54-58
+  double z_bad;                          // first z at which the comoving-distance table is non-finite (+inf: nowhere), see grid_is_poisoned
+  double dl_sorted;                      // 1 if the dL table of z_from_dGW is non-decreasing (k_tables), else 0: see z_from_dGW_x2
 };
 
 struct TablePtrs {                       // per-draw tables (global memory)
@@ -115,6 +117,26 @@ DEVFN void jnp_interp_x2(double xa, double xb, AccX xp, AccF fp, int n, double& 
   if (xa > xlast) fa = fp[n - 1];
   if (xb < xfirst) fb = fp[0];
   if (xb > xlast) fb = fp[n - 1];
+}
+
+// z = z_from_dGW(dL) (cosmo.py:260-264) for two samples.  jnp_interp_x2's halving search returns searchsorted's answer on a sorted
+// table; on a NON-monotonic dL table (modified propagation with Xi(z) falling fast, or a closed universe past the antipode) the
+// result of a binary search depends on its probe sequence, so the reference's own bisection (jnp.searchsorted, method 'scan')
+// is followed step by step there -- flagged per draw by k_tables, never taken for sensible parameters.
+template <class AccX, class AccF>
+DEVFN void z_from_dGW_x2(const DevParams& p, double xa, double xb, AccX dLt, AccF zt, double& za, double& zb) {
+  if (p.dl_sorted != 0.) { jnp_interp_x2(xa, xb, dLt, zt, p.Tc, za, zb); return; }
+  za = jnp_interp(xa, dLt, zt, p.Tc, false, 0., 0.);
+  zb = jnp_interp(xb, dLt, zt, p.Tc, false, 0., 0.);
+}
+
+// An unphysical draw (E(z)^2 < 0 somewhere, e.g. a strongly closed universe) leaves NaNs in the cumulative table of 1/E from
+// some node on; every event grid reaching that far has NaN Jacobian / background factors there, and the reference's integrand
+// 0 * NaN = NaN makes L_i NaN -> log L_i = -inf for EVERY live pixel, also where p_gw is zero (likelihood.py:274-278, 296-297).
+// The kernels skip grid points outside the KDE's support, so they test this condition explicitly.
+DEVFN bool grid_is_poisoned(double z_bad, const double* zg, int Z) {
+  double a = zg[0], b = zg[Z - 1];
+  return (a > b ? a : b) >= z_bad;
 }
 
 // jnp.logaddexp(0, x) = max(0,x) + log1p(exp(-|x|))
