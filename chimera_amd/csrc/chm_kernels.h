@@ -1341,6 +1341,7 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
         if (z <= zhi && z >= zlo) any = true;
       }
       t0 = z0 * l00 + t_base; D = dz * l00;
+      if (!(fabs(D) <= 1.)) uni = false;                  // grid coarser than the kernel width: one exp per pair (no recurrence)
     }
     const double rho = chm_exp(-(D * D)), hD2 = 0.5 * D * D;
     double acc[FULL_LK];
@@ -1360,8 +1361,12 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
         if (uni) {
           for (int s = sl; s < ns; s += NS) {
             double d = sa[s] - t0;
-            double g = sc[s] * chm_exp(-0.5 * (d * d));
-            double r = chm_exp(d * D - hD2);
+            const double e1 = -0.5 * (d * d);
+            // a sample more than 37 kernel widths from the chunk's first point is left out: exp(e1) underflows (and the step
+            // factor may overflow: 0 * inf); with |D| <= 1 it stays >= 22 widths from every point of the chunk, i.e. it would add
+            // < 1e-105 of its own weight
+            double g = e1 > -700. ? sc[s] * chm_exp(e1) : 0.;
+            double r = e1 > -700. ? chm_exp(d * D - hD2) : 0.;
 #pragma unroll
             for (int i = 0; i < FULL_LK; i++) { acc[i] += g; g *= r; r *= rho; }
           }
