@@ -680,7 +680,8 @@ __global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* pa
       double prate = merger_rate_l(P, z, lzp1) / (1. + z);
       if (!ranged) { L.jac[zo + k] = jac; L.prate[zo + k] = prate; }
       double p_bkg = dVcdz_from_dCt_E(P, dCt, Ez);
-      L.bkgA[zo + k] = P.has_catalog ? (1. - L.P_compl[(size_t)e * Z + k]) * p_bkg : p_bkg;
+      // a 1-D handle built from a catalogue population (hyperlikelihood.p_gw1d on a pixelated object) carries no P_compl
+      L.bkgA[zo + k] = (P.has_catalog && L.P_compl) ? (1. - L.P_compl[(size_t)e * Z + k]) * p_bkg : p_bkg;
       if (L.Aw) {
         // trapezoid weight of grid point k: y_k enters the two adjacent intervals (jnp.trapezoid, likelihood.py:278)
         double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;

@@ -163,6 +163,17 @@ def test_batch_matches_single(cfg_pix):
   np.testing.assert_array_equal(batched, single)
 
 
+def test_p_gw1d_of_a_pixelated_likelihood(cfg_pix):
+  """hyperlikelihood.p_gw1d on an object built with a galaxy catalogue (likelihood.py:105-144 needs the samples only): the 1-D
+  handle carries no completeness array -- this used to dereference a null pointer on the device."""
+  cfg, ev, inj = cfg_pix
+  for kind in ('approximate', 'marginalized'):
+    like_o, pop_o, _ = H.build_oracle(ev, inj, kind=kind)
+    like_p, pop_p, _ = H.build_product(ev, inj, kind=kind)
+    a, b = like_o.p_gw1d(pop_o.update(H0=71.)), like_p.p_gw1d(pop_p.update(H0=71.))
+    np.testing.assert_allclose(b, a, rtol=1e-9, atol=1e-9 * np.max(a))
+
+
 def test_long_batches_are_sliced(cfg_pix):
   cfg, ev, inj = cfg_pix
   like, _, _ = H.build_product(ev, inj)
