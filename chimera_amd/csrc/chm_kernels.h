@@ -470,7 +470,8 @@ DEVFN double epan_prefix_eval(double g, const double* cen, const double* P0, con
   double S0 = P0[jb] - P0[ja], S1 = P1[jb] - P1[ja], S2 = P2[jb] - P2[ja];
   double gp = g - c_ref;
   double qq = fma(gp, fma(gp, S0, -2. * S1), S2);                // sum W (g' - c')^2
-  return 0.75 * (S0 - qq * (inv_bw * inv_bw)) * inv_bw;
+  // a sum of non-negative kernel values: rounding of the prefix-sum form (~1e-14 of the peak) must not make it negative
+  return __builtin_fmax(0.75 * (S0 - qq * (inv_bw * inv_bw)) * inv_bw, 0.);
 }
 
 // dense density at g (math.py:77-81), used for the Gaussian kernel, for binning=False and for degenerate bandwidths
@@ -1062,7 +1063,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
     const int ia = 3 * (int)fa, ib = 3 * (int)fb;
     double S0 = Q[ib] - Q[ia], S1 = Q[ib + 1] - Q[ia + 1], S2 = Q[ib + 2] - Q[ia + 2];
     double qq = fma(gp, fma(gp, S0, -2. * S1), S2);         // sum W (g' - c')^2 over the support
-    return S0 - qq * inv_bw2;
+    return __builtin_fmax(S0 - qq * inv_bw2, 0.);           // a sum of non-negative kernel values (rounding may leave -1e-14 of the peak)
   };
   double acc = 0.;
   if (dump && live) { for (int k = sl; k < Z; k += SW) if (k < k_lo || k > k_hi) dump[k] = 0.; }
