@@ -172,29 +172,35 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
     if (LDS_ARR) __syncthreads(); else gsync();
     block_cumtrapz(tmp, zt, It, Tc, sh);
     if (!LDS_ARR) gsync();
-    {                                               // first non-finite node of the table -> z_bad (grid_is_poisoned)
-      double first = 1e300;
-      for (int i = t; i < Tc; i += nt) if (!(fabs(It[i]) <= 1.7976931348623157e308)) first = fmin(first, (double)i);
-      first = block_reduce<RED_MIN>(first, sh);
-      if (t == 0) { int j = (int)fmin(first, 1e9); Pg.z_bad = first < 1e299 ? zt[j > 0 ? j - 1 : 0] : __builtin_inf(); }
-      __syncthreads();
-    }
     // dL table of z_from_dGW: dL_at_z(cosmo, z_grid_interp) (cosmo.py:263).  jnp.interp evaluated AT its own nodes returns
-    // It[i] exactly for i < Tc-1 (delta = 0) and It[Tc-2] + (dx/dx) dI at the last node.
+    // It[i] exactly for i < Tc-1 (delta = 0) and It[Tc-2] + (dx/dx) dI at the last node.  The values also go into `tmp` (free
+    // after the cumulative integral) for the monotonicity check below.
     for (int i = t; i < Tc; i += nt) {
       double z = zt[i];
       double ii = It[i];
       if (i == Tc - 1) { double dx = zt[i] - zt[i - 1]; ii = It[i - 1] + (dx / dx) * (It[i] - It[i - 1]); }
-      dLt[i] = dL_from_dCt(P, dCt_from_dCr(P, P.dH * ii), z);
+      double dl = dL_from_dCt(P, dCt_from_dCr(P, P.dH * ii), z);
+      dLt[i] = dl;
+      tmp[i] = dl;
       if (LDS_ARR) { g_zt[i] = z; g_It[i] = It[i]; }
     }
-    // is the dL table non-decreasing?  (decides the search used by the sample / injection kernels, see z_from_dGW_x2)
-    gsync();
+    if (LDS_ARR) __syncthreads(); else gsync();
+    // one pass over the table for two per-draw flags: z_bad, the last finite stretch of the cumulative integral (first non-finite
+    // node -> grid_is_poisoned), and dl_sorted, whether the dL table is non-decreasing (-> z_from_dGW_x2)
     {
+      double first = 1e300;
       int bad = 0;
-      for (int i = t + 1; i < Tc; i += nt) bad |= (dLt[i] < dLt[i - 1]) || (dLt[i] != dLt[i]) ? 1 : 0;
+      for (int i = t; i < Tc; i += nt) {
+        if (!(fabs(It[i]) <= 1.7976931348623157e308)) first = fmin(first, (double)i);
+        if (i > 0) bad |= ((tmp[i] < tmp[i - 1]) || (tmp[i] != tmp[i])) ? 1 : 0;
+      }
+      first = block_reduce<RED_MIN>(first, sh);
       bad = __syncthreads_or(bad);
-      if (t == 0) Pg.dl_sorted = bad ? 0. : 1.;
+      if (t == 0) {
+        int j = (int)fmin(first, 1e9);
+        Pg.z_bad = first < 1e299 ? zt[j > 0 ? j - 1 : 0] : __builtin_inf();
+        Pg.dl_sorted = bad ? 0. : 1.;
+      }
     }
     // fR = Vc(z1) - Vc(z0)                                                       completeness.py:54-58
     double i0 = block_interp(P.zc0, zt, It, Tc, sh);
