@@ -59,8 +59,14 @@ class chm_out(C.Structure):
               ('numlike_evs', c_dp), ('p_gw', c_dp), ('partials', c_dp)]
 
 
+class chm_tab(C.Structure):
+  """Caller-evaluated plug-in models of one call (include/chimera_hip.h: struct chm_tab)."""
+  _fields_ = [('pm_samples', c_dp), ('pm_inj', c_dp), ('rate_grid', c_dp), ('rate_inj', c_dp), ('bkg_grid', c_dp),
+              ('bkg_inj', c_dp), ('fR', c_dp)]
+
+
 SYMBOLS = ['chm_version', 'chm_device_count', 'chm_last_error', 'chm_like_create', 'chm_like_destroy',
-           'chm_sel_create', 'chm_sel_destroy', 'chm_eval', 'chm_model_eval', 'chm_model_tables',
+           'chm_sel_create', 'chm_sel_destroy', 'chm_eval', 'chm_eval_tabulated', 'chm_model_eval', 'chm_model_tables',
            'chm_comm_unique_id', 'chm_comm_init_rank', 'chm_comm_destroy', 'chm_comm_allreduce_sum',
            'chm_last_timing', 'chm_pcat_compute', 'chm_kde2d_pixels']
 
@@ -85,6 +91,7 @@ def lib():
   L.chm_sel_create.argtypes = [C.POINTER(chm_sel_desc), C.POINTER(vp)]
   L.chm_sel_destroy.argtypes = [vp]
   L.chm_eval.argtypes = [vp, vp, vp, C.POINTER(chm_params), C.c_int32, C.c_int64, C.POINTER(chm_out)]
+  L.chm_eval_tabulated.argtypes = [vp, vp, vp, C.POINTER(chm_params), C.c_int32, C.c_int64, C.POINTER(chm_tab), C.POINTER(chm_out)]
   L.chm_model_eval.argtypes = [C.POINTER(chm_params), C.c_int32, c_dp, c_dp, C.c_int64, c_dp, C.c_int32]
   L.chm_model_tables.argtypes = [C.POINTER(chm_params), c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int32]
   L.chm_comm_unique_id.argtypes = [C.c_char_p]

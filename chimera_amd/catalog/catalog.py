@@ -20,9 +20,13 @@ class empty_catalog(object):
     self.p_cat = 0.
     self.N_gal = 0.
     self.P_compl = 0.
-    if p_bkg != "dVdz":
-      raise ValueError("only the 'dVdz' background is built into the HIP path")
-    self.p_bkg = dVcdz_at_z
+    if callable(p_bkg):                 # plug-in background p_bkg(cosmo, z): evaluated on the host (population/plugins.py)
+      self.p_bkg = p_bkg
+      self.p_bkg_is_plugin = True
+    elif p_bkg == "dVdz":
+      self.p_bkg = dVcdz_at_z
+    else:
+      raise ValueError("p_bkg must be 'dVdz' (built into the HIP path) or a callable p_bkg(cosmo, z)")
     self.max_npixels = None
     self.neff_pixels = None
     self.z_range = (0.073, 1.3)

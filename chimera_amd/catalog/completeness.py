@@ -9,6 +9,8 @@ from ..data import theta_src
 
 
 class dVdz_completeness(object):
+  builtin = True                  # evaluated inside the kernels; any other completeness object is a host plug-in (population/plugins.py)
+
   def __init__(self, z_range=(0.073, 1.3), kind="step", z_sig=None):
     self.z_range = np.asarray(z_range, dtype=np.float64)
     if kind != "step":

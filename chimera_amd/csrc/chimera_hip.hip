@@ -141,7 +141,7 @@ static void fill_dev_params(const chm_params* p, DevParams* d) {
 }
 
 // upload nb draws and build their tables on c.stream
-static int ctx_tables(Ctx& c, const chm_params* params, int nb) {
+static int ctx_tables(Ctx& c, const chm_params* params, int nb, const double* fR_given = nullptr) {
   int Tc = 0, Tm = 0;
   for (int b = 0; b < nb; b++) {
     int rc = check_params(&params[b]); if (rc) return rc;
@@ -149,7 +149,10 @@ static int ctx_tables(Ctx& c, const chm_params* params, int nb) {
     Tm = params[b].mass_grid_res > Tm ? params[b].mass_grid_res : Tm;
   }
   int rc = ctx_ensure(c, nb, Tc, Tm); if (rc) return rc;
-  for (int b = 0; b < nb; b++) fill_dev_params(&params[b], &c.h_params[b]);
+  for (int b = 0; b < nb; b++) {
+    fill_dev_params(&params[b], &c.h_params[b]);
+    if (fR_given) { c.h_params[b].fR = fR_given[b]; c.h_params[b].fR_given = 1.; }     // plug-in completeness (chm_tab.fR)
+  }
   HIPCHK(hipMemcpyAsync(c.d_params, c.h_params, sizeof(DevParams) * nb, hipMemcpyHostToDevice, c.stream));
   const size_t tl = sizeof(double) * 3 * (size_t)(Tc > Tm ? Tc : Tm);
   if (tl <= 120 * 1024) {
@@ -255,7 +258,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
 #define UP(field, src, n) do { rc = upload(h->owned, (src) ? (src) + (size_t)e0 * (n) : (src), (size_t)E * (n), &L.field, s); if (rc) { chm_like_destroy(h); return rc; } } while (0)
   std::vector<double> tmp;                                   // must outlive the async copies below
   std::vector<std::vector<double>> sorted, logs;
-  std::vector<int> seg;
+  std::vector<int> seg, perm_all;                            // perm_all: original index of every pixel-sorted sample (for chm_tab)
   if (d->mode == CHM_MODE_MARG) {
     // marginalized: store every event's samples sorted by pixel, so that each (event, pixel) wave reads one contiguous
     // segment (the device-side form of `pe_pix == pixels[i]`, likelihood.py:179)
@@ -263,8 +266,10 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
     const double* src[4] = { d->dL, d->m1det, d->m2det, d->pe_prior };
     sorted.assign(4, std::vector<double>(E * S));
     std::vector<int> perm;
+    perm_all.resize(E * S);
     for (size_t e = 0; e < E; e++) {
       pixel_sort(d->pix_of_sample + (size_t)(e0 + e) * S, (int)S, (int)P, perm, &seg[e * (P + 1)]);
+      for (size_t k = 0; k < S; k++) perm_all[e * S + k] = perm[k];
       for (int a = 0; a < 4; a++) {
         const double* in = src[a] + (size_t)(e0 + e) * S;
         double* o = sorted[a].data() + e * S;
@@ -277,6 +282,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
     logs.assign(2, std::vector<double>(E * S));
     for (size_t k = 0; k < E * S; k++) { logs[0][k] = std::log(sorted[1][k]); logs[1][k] = std::log(sorted[2][k]); }
     rc = upload(h->owned, (const int*)seg.data(), E * (P + 1), &L.seg_off, s); if (rc) { chm_like_destroy(h); return rc; }
+    rc = upload(h->owned, (const int*)perm_all.data(), E * S, &L.perm, s); if (rc) { chm_like_destroy(h); return rc; }
   } else {
     UP(dL, d->dL, S); UP(m1det, d->m1det, S); UP(m2det, d->m2det, S);
     tmp.resize(E * S);
@@ -420,8 +426,33 @@ static void allow_lds(K kernel, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// device copies of the caller's tables for one call (plug-in models, chm_tab); freed when the call returns
+struct TabDev {
+  double *pm_s = nullptr, *pm_i = nullptr, *rate_g = nullptr, *rate_i = nullptr, *bkg_g = nullptr, *bkg_i = nullptr;
+  ~TabDev() { (void)hipFree(pm_s); (void)hipFree(pm_i); (void)hipFree(rate_g); (void)hipFree(rate_i); (void)hipFree(bkg_g); (void)hipFree(bkg_i); }
+};
+static int tab_upload(double** dst, const double* src, size_t n, hipStream_t s) {
+  if (!src || n == 0) return CHM_OK;
+  HIPCHK(hipMalloc(dst, sizeof(double) * n));
+  HIPCHK(hipMemcpyAsync(*dst, src, sizeof(double) * n, hipMemcpyHostToDevice, s));
+  return CHM_OK;
+}
+
+static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_params* params, int32_t nb,
+                     int64_t E_total, const chm_tab* tab, chm_out* out);
+
 extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_params* params, int32_t nb,
                         int64_t E_total, chm_out* out) {
+  return eval_impl(like, sel, comm, params, nb, E_total, nullptr, out);
+}
+
+extern "C" int chm_eval_tabulated(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_params* params, int32_t nb,
+                                  int64_t E_total, const chm_tab* tab, chm_out* out) {
+  return eval_impl(like, sel, comm, params, nb, E_total, tab, out);
+}
+
+static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_params* params, int32_t nb,
+                     int64_t E_total, const chm_tab* tab, chm_out* out) {
   if ((!like && !sel) || !params || !out || nb <= 0) return fail(CHM_E_ARG, "chm_eval: need a handle, params, out and nb > 0");
   if (like && sel && like->ctx.device != sel->ctx.device) return fail(CHM_E_ARG, "chm_eval: like and sel live on different devices");
   Ctx& c = like ? like->ctx : sel->ctx;
@@ -434,8 +465,23 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
   if (like) { rc = like_ensure_ws(like, nb, want_dump); if (rc) return rc; }
   if (sel) { rc = sel_ensure_ws(sel, nb); if (rc) return rc; }
 
+  TabDev td;
+  if (tab) {                                                  // plug-in models: the caller's tables of this call, host -> device
+    if (like) {
+      const size_t ES = (size_t)nb * like->L.E * like->L.S, EZ = (size_t)nb * like->L.E * like->L.Z;
+      rc = tab_upload(&td.pm_s, tab->pm_samples, ES, sA); if (rc) return rc;
+      rc = tab_upload(&td.rate_g, tab->rate_grid, EZ, sA); if (rc) return rc;
+      rc = tab_upload(&td.bkg_g, tab->bkg_grid, EZ, sA); if (rc) return rc;
+    }
+    if (sel) {
+      const size_t NI = (size_t)nb * (size_t)sel->S.I;
+      rc = tab_upload(&td.pm_i, tab->pm_inj, NI, sA); if (rc) return rc;
+      rc = tab_upload(&td.rate_i, tab->rate_inj, NI, sA); if (rc) return rc;
+      rc = tab_upload(&td.bkg_i, tab->bkg_inj, NI, sA); if (rc) return rc;
+    }
+  }
   HIPCHK(hipEventRecord(c.ev[0], sA));
-  rc = ctx_tables(c, params, nb); if (rc) return rc;
+  rc = ctx_tables(c, params, nb, tab ? tab->fR : nullptr); if (rc) return rc;
   HIPCHK(hipEventRecord(c.ev[1], sA));
   HIPCHK(hipStreamWaitEvent(sB, c.ev[1], 0));               // fork: the other lanes start after the tables
   HIPCHK(hipStreamWaitEvent(sC, c.ev[1], 0));
@@ -449,6 +495,7 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
   // ---- selection function on its own stream
   if (sel) {
     SelDev S = sel->S;
+    S.tab_pm = td.pm_i; S.tab_rate = td.rate_i; S.tab_bkg = td.bkg_i;
     HIPCHK(hipEventRecord(c.evb[1], sC));
     if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
       hipLaunchKernelGGL(k_selection<true>, dim3(S.nblocks, nb), dim3(256), lds_samp, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
@@ -475,6 +522,7 @@ extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_
     for (int g = 0; g < ngroups; g++) {
       hipStream_t sg = (g & 1) ? sB : sA;
       LikeDev L = like->L;
+      L.tab_pm = td.pm_s; L.tab_rate = td.rate_g; L.tab_bkg = td.bkg_g;
       if (!want_dump) L.p_gw_dump = nullptr;
       const int eb = (int)((long long)L0.E * g / ngroups), ee = (int)((long long)L0.E * (g + 1) / ngroups);
       L.e_off = eb; L.E_cnt = ee - eb; L.nb = nb;

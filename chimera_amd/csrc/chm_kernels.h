@@ -37,6 +37,8 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   const int* seg_off;             // (E,P+1) marginalized: pixel segments of the pixel-sorted samples
   const double *z_grids, *p_cat, *P_compl, *gw_pdf, *ra_pix, *dec_pix;
   const int* neff_pixels;
+  const int* perm;                // (E,S) marginalized: original index of the pixel-sorted sample (for caller-tabulated values)
+  const double *tab_pm, *tab_rate, *tab_bkg;   // plug-in models evaluated by the caller (chm_tab), device copies; NULL = built-in
   const double *fracB, *fracG;    // i/num_bins (num_bins+1), i/(G-1) (G): the step fractions of jnp.linspace
   // workspaces (nb-major)
   double *ws_z, *ws_w;            // (nb,E,S)
@@ -208,7 +210,7 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
     if (t == 0) {
       double v0 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * i0));
       double v1 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * i1));
-      Pg.fR = v1 - v0;
+      Pg.fR = P.fR_given != 0. ? P.fR : v1 - v0;      // a plug-in completeness hands its own fR(cosmo) over (chm_tab.fR)
     }
   } else {
     double* mg = LDS_ARR ? larr : g_mg;
@@ -359,7 +361,12 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
         double r = 1. / zp1;
         double m1 = md1[h] * r, m2 = md2[h] * r;
         double lz = chm_log_pos(zp1);                             // log(m_src) = log(m_det) - log(1+z): one log for both masses
-        double w = p_m1m2_fused(P, m1, m2, l1[h] - lz, l2[h] - lz, T.mg, T.cdf) * ipr[h];
+        double pm;
+        if (L.tab_pm) {                                       // plug-in mass model: p_m1m2 tabulated by the caller (original sample order)
+          const int si = s + h < s_end ? s + h : s;
+          pm = L.tab_pm[so + (L.perm ? L.perm[eo + si] : si)];
+        } else pm = p_m1m2_fused(P, m1, m2, l1[h] - lz, l2[h] - lz, T.mg, T.cdf);
+        double w = pm * ipr[h];
         wv[h] = w;
         if (s + h < s_end) {
           double d = z - z_ref;
@@ -684,9 +691,9 @@ __global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* pa
       double lzp1 = chm_log_pos(zp1);
       double Ez = E_at_z_l(P, z, lzp1);
       double jac = ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1) * (zp1 * zp1);
-      double prate = merger_rate_l(P, z, lzp1) / (1. + z);
+      double prate = (L.tab_rate ? L.tab_rate[zo + k] : merger_rate_l(P, z, lzp1)) / (1. + z);      // plug-in rate model: tabulated
       if (!ranged) { L.jac[zo + k] = jac; L.prate[zo + k] = prate; }
-      double p_bkg = dVcdz_from_dCt_E(P, dCt, Ez);
+      double p_bkg = L.tab_bkg ? L.tab_bkg[zo + k] : dVcdz_from_dCt_E(P, dCt, Ez);                   // plug-in completeness: tabulated
       // a 1-D handle built from a catalogue population (hyperlikelihood.p_gw1d on a pixelated object) carries no P_compl
       L.bkgA[zo + k] = (P.has_catalog && L.P_compl) ? (1. - L.P_compl[(size_t)e * Z + k]) * p_bkg : p_bkg;
       if (L.Aw) {
@@ -1430,6 +1437,7 @@ struct SelDev {
   long long I;
   const double *dL, *m1det, *m2det, *p_draw;
   const double *lm1det, *lm2det;  // log(m1det), log(m2det), formed once at upload (as for the posterior samples)
+  const double *tab_pm, *tab_rate, *tab_bkg;   // (nb,I) plug-in models evaluated by the caller (chm_tab); NULL = built-in
   double N_inj, N_eff; int has_neff, pad;
   double* partial;                // (nb, nblocks, 2)
   int nblocks;
@@ -1438,7 +1446,7 @@ struct SelDev {
 // one injection: dN/dtheta_det / p_draw                                     pop_wrapper.py:102-111, selection_function.py:38
 template <class A1, class A2>
 DEVFN double sel_term(const DevParams& P, double dl, double m1d, double m2d, double l1d, double l2d, double ipd, double z,
-                      A1 mg, A2 cdf) {
+                      A1 mg, A2 cdf, const double* tpm, const double* trate, const double* tbkg) {
 #pragma clang fp contract(fast)                  // smooth arithmetic only: a*b+c may fuse (the translation unit default is off)
   double zp1 = 1. + z;
   double rz = 1. / zp1;
@@ -1446,9 +1454,9 @@ DEVFN double sel_term(const DevParams& P, double dl, double m1d, double m2d, dou
   double lzp1 = chm_log_pos(zp1);
   double Ez = E_at_z_l(P, z, lzp1);
   double dCt = dL2dCt_l(P, dl, z, lzp1);                           // original distances: cosmo.py:191-192,215-216
-  double p_z = dVcdz_from_dCt_E(P, dCt, Ez);                       // gal_cat.p_bkg              pop_wrapper.py:106
-  p_z = p_z * (merger_rate_l(P, z, lzp1) / (1. + z));              //                            pop_wrapper.py:107
-  double dN = P.R0 * p_m1m2_fused(P, m1, m2, l1d - lzp1, l2d - lzp1, mg, cdf) * p_z;   //           pop_wrapper.py:108
+  double p_z = tbkg ? *tbkg : dVcdz_from_dCt_E(P, dCt, Ez);        // gal_cat.p_bkg              pop_wrapper.py:106
+  p_z = p_z * ((trate ? *trate : merger_rate_l(P, z, lzp1)) / (1. + z));              //         pop_wrapper.py:107
+  double dN = P.R0 * (tpm ? *tpm : p_m1m2_fused(P, m1, m2, l1d - lzp1, l2d - lzp1, mg, cdf)) * p_z;   // pop_wrapper.py:108
   double jacobian = fabs(ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1)) * (zp1 * zp1);      //           pop_wrapper.py:109
   dN = dN / jacobian;
   return dN * ipd;                                                 // selection_function.py:38 (array holds 1/p_draw)
@@ -1491,7 +1499,9 @@ __global__ void __launch_bounds__(256) k_selection(SelDev Sd, const DevParams* p
       z_from_dGW_x2(P, dl[0], dl[1], T.dLt, T.zt, zz[0], zz[1]);      // z = z_from_dGW(dL)   cosmo.py:260-264
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        double dN = sel_term(P, dl[h], md1[h], md2[h], l1[h], l2[h], ipd[h], zz[h], T.mg, T.cdf);
+        const size_t ti = (size_t)b * (size_t)I + (size_t)(i + (two ? h : 0));      // plug-in models: (nb,I) tables of the caller
+        double dN = sel_term(P, dl[h], md1[h], md2[h], l1[h], l2[h], ipd[h], zz[h], T.mg, T.cdf, Sd.tab_pm ? Sd.tab_pm + ti : nullptr,
+                             Sd.tab_rate ? Sd.tab_rate + ti : nullptr, Sd.tab_bkg ? Sd.tab_bkg + ti : nullptr);
         if (h == 0 || two) {
           if (dN == dN) s1 += dN;                                    // nansum                     selection_function.py:39
           s2 += dN * dN;                                             // plain sum     selection_function.py:44

@@ -31,6 +31,7 @@ struct DevParams {
   double inv_plnorm, inv_tg_norm, inv_2s2;   // reciprocals of plp_plnorm, tg_norm, 2 sigma_g^2
   double norm_p_m1, inv_norm_p_m1;       // mass.py:51
   double fR;                             // completeness.py:54-58
+  double fR_given;                       // != 0: fR was supplied by the caller (plug-in completeness), k_tables keeps it
   double z_bad;                          // first z at which the comoving-distance table is non-finite (+inf: nowhere), see grid_is_poisoned
   double dl_sorted;                      // 1 if the dL table of z_from_dGW is non-decreasing (k_tables), else 0: see z_from_dGW_x2
 };

@@ -92,6 +92,10 @@ class hyperlikelihood(object):
     else:
       self._e0, self._e1 = 0, self.nevents
     self._handles = {}
+    from .population.plugins import population_plugins
+    self._plugins = population_plugins(self.population)        # (mass, rate, completeness) evaluated on the host?
+    if any(self._plugins):
+      self.max_draws_per_call = 4                              # the caller-evaluated tables are (draws, events, samples) arrays
     logger.info(f'Created hyperlikelihood model. Using {self.nevents} GW events.')
 
   # -- device handles ----------------------------------------------------------------------------------
@@ -168,10 +172,20 @@ class hyperlikelihood(object):
   def _eval(self, pops, want=(), mode=None, with_sel=True):
     """Evaluate a list of population draws.  ``want`` subset of {'log_like_evs','numlike_evs','p_gw','partials'}."""
     nb = len(pops)
+    tab, tab_keep = None, None
     if isinstance(pops, C.Array):
+      if any(self._plugins):
+        raise RuntimeError("plug-in population models need population objects, not a packed chm_params array")
       params = pops
     else:
       params = (_lib.chm_params * nb)(*[p.to_params() for p in pops])
+      if any(self._plugins):                                   # plug-in models: evaluate them on the host for this shard
+        from .population.plugins import build_tab
+        th, e0, e1 = self.theta_gw_det, self._e0, self._e1
+        evd = dict(dL=_lib.as_f64(th.dL)[e0:e1], m1det=_lib.as_f64(th.m1det)[e0:e1], m2det=_lib.as_f64(th.m2det)[e0:e1],
+                   z_grids=self.z_grids[e0:e1])
+        injd = self.selection_function._inj_shard() if (with_sel and self.selection_function is not None) else None
+        tab, tab_keep = build_tab(pops, self._plugins, ev=evd, inj=injd)
     h = self._handle(mode)
     El = self._e1 - self._e0
     res = {'log_hyper': np.empty(nb), 'log_num': np.empty(nb), 'N_exp': np.empty(nb)}
@@ -192,7 +206,10 @@ class hyperlikelihood(object):
     host_reduce = (self.comm is not None and comm_h is None and self.comm.nranks > 1 and hasattr(self.comm, 'allreduce_sum'))
     if host_reduce and 'partials' not in res:               # HostComm: the partial sums are reduced and combined on the host
       res['partials'] = np.empty((nb, 3)); out.partials = _lib.dptr(res['partials'])
-    _lib.check(_lib.lib().chm_eval(h, sel, comm_h, params, nb, self.nevents, C.byref(out)))
+    if tab is not None:
+      _lib.check(_lib.lib().chm_eval_tabulated(h, sel, comm_h, params, nb, self.nevents, C.byref(tab), C.byref(out)))
+    else:
+      _lib.check(_lib.lib().chm_eval(h, sel, comm_h, params, nb, self.nevents, C.byref(out)))
     if host_reduce:
       from .parallel import combine_partials
       tot = self.comm.allreduce_sum(res['partials']).reshape(nb, 3)
@@ -243,7 +260,7 @@ class hyperlikelihood(object):
     CHIMERA/utils/emcee_utils.py:54-64) evaluate every draw in one launch sequence and return an array."""
     n = _vector_length(hyper_lambdas)
     if n is None:
-      return self._eval(self._params_array([hyper_lambdas]))['log_hyper'][0]
+      return self.batch([hyper_lambdas])[0]
     lams = [{k: (np.asarray(v).reshape(-1)[i] if np.ndim(v) > 0 else v) for k, v in hyper_lambdas.items()} for i in range(n)]
     return self.batch(lams)
 
@@ -314,6 +331,7 @@ class hyperlikelihood(object):
     """log-hyperlikelihood of several draws in one launch sequence: array of len(list)."""
     lams = list(list_of_hyper_lambdas)
     m = max(1, int(self.max_draws_per_call))
+    pack = (lambda ls: [self.population.update(**l) for l in ls]) if any(self._plugins) else self._params_array
     if len(lams) <= m:
-      return self._eval(self._params_array(lams))['log_hyper']
-    return np.concatenate([self._eval(self._params_array(lams[i:i + m]))['log_hyper'] for i in range(0, len(lams), m)])
+      return self._eval(pack(lams))['log_hyper']
+    return np.concatenate([self._eval(pack(lams[i:i + m]))['log_hyper'] for i in range(0, len(lams), m)])

@@ -41,8 +41,8 @@ def make_params(cosmo=None, mass=None, rate=None, R0=1., Tobs=1., scale_free=Tru
   """Fill one ``chm_params`` (include/chimera_hip.h) from model objects."""
   p = _lib.chm_params()
   c = cosmo._pack() if cosmo is not None else _DEF_COSMO
-  m = mass._pack() if mass is not None else _DEF_MASS
-  r = rate._pack() if rate is not None else _DEF_RATE
+  m = mass._pack() if (mass is not None and hasattr(mass, '_pack')) else _DEF_MASS        # plug-in models (population/plugins.py):
+  r = rate._pack() if (rate is not None and hasattr(rate, '_pack')) else _DEF_RATE        # their values come from the host
   p.cosmo_model, p.mass_model, p.rate_model = c['model'], m['model'], r['model']
   p.z_grid_res, p.mass_grid_res = int(c['z_grid_res']), int(m['grid_res'])
   p.scale_free, p.has_catalog = int(bool(scale_free)), int(bool(has_catalog))

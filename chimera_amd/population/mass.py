@@ -80,4 +80,6 @@ def p_m1m2(mass, m1, m2=None):
   """mass.py:334-345 (array and theta_src overloads)."""
   if isinstance(m1, theta_src):
     m1, m2 = m1.m1src, m1.m2src
+  if not hasattr(mass, '_pack'):                 # plug-in mass model (population/plugins.py): its own host function
+    return np.asarray(mass.p_m1m2(np.asarray(m1, dtype=np.float64), np.asarray(m2, dtype=np.float64)), dtype=np.float64)
   return model_eval(make_params(mass=mass), _lib.F_PM1M2, m1, m2)

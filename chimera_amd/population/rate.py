@@ -1,4 +1,5 @@
 """Merger-rate models (reference: CHIMERA/population/rate.py): four closed-form models evaluated on the GPU."""
+import numpy as np
 from .. import _lib
 from ..data import theta_src
 from ._base import base_struct, make_params, model_eval
@@ -48,4 +49,6 @@ def merger_rate(rate, z):
   """rate.py:96-129."""
   if isinstance(z, theta_src):
     z = z.z
+  if not hasattr(rate, '_pack'):                 # plug-in rate model (population/plugins.py): its own host function
+    return np.asarray(rate.merger_rate(np.asarray(z, dtype=np.float64)), dtype=np.float64)
   return model_eval(make_params(rate=rate), _lib.F_RATE, z)

@@ -55,10 +55,20 @@ class selection_function(object):
     except Exception:
       pass
 
+  def _inj_shard(self):
+    """This rank's injections (dL, m1det, m2det) -- what a plug-in model is evaluated on (population/plugins.py)."""
+    th = self.theta_inj_det
+    n = np.size(th.dL)
+    i0, i1 = chunk_bounds(n, self.comm.nranks, self.comm.rank) if (self.comm is not None and self.comm.nranks > 1) else (0, n)
+    return {k: _lib.as_f64(getattr(th, k)).ravel()[i0:i1] for k in ('dL', 'm1det', 'm2det')}
+
   # -- reference surface -------------------------------------------------------------------------------
   def N_exp(self, pop_lambdas):
     """selection_function.py:34-48."""
     p = pop_lambdas.to_params()
+    from .population.plugins import population_plugins, build_tab
+    plugins = population_plugins(pop_lambdas)
+    tab, tab_keep = build_tab([pop_lambdas], plugins, inj=self._inj_shard()) if any(plugins) else (None, None)
     nexp = np.empty(1)
     out = _lib.chm_out()
     out.N_exp = _lib.dptr(nexp)
@@ -67,7 +77,10 @@ class selection_function(object):
     part = np.empty(3)
     if host_reduce:
       out.partials = _lib.dptr(part)
-    _lib.check(_lib.lib().chm_eval(None, self._handle(), comm_h, C.byref(p), 1, 0, C.byref(out)))
+    if tab is not None:
+      _lib.check(_lib.lib().chm_eval_tabulated(None, self._handle(), comm_h, C.byref(p), 1, 0, C.byref(tab), C.byref(out)))
+    else:
+      _lib.check(_lib.lib().chm_eval(None, self._handle(), comm_h, C.byref(p), 1, 0, C.byref(out)))
     if host_reduce:                                           # HostComm: reduce the two selection sums on the host
       from .parallel import combine_partials
       return combine_partials(self.comm.allreduce_sum(part), 0, self.N_inj, self.N_eff, bool(p.scale_free), p.R0, p.Tobs,

@@ -126,6 +126,21 @@ typedef struct chm_out {
   double* partials;      /* (nb,3)      this shard's [sum_i log L_i, nansum dN, sum dN^2]             */
 } chm_out;
 
+/* Plug-in models ("plugin fallback").  The reference's population pieces are open classes: a user adds a mass,
+ * rate or completeness model by writing a new struct and new plum overloads of p_m1m2 (mass.py:334-345), merger_rate
+ * (rate.py:96-122) or p_bkg / fR (completeness.py:43-67).  Such Python functions cannot run inside a kernel; the caller
+ * evaluates them on the host and hands the values over per draw.  Every pointer may be NULL (= the built-in model selected by
+ * chm_params is used for that piece); arrays are for THIS shard, C-contiguous, in the caller's original sample order.        */
+typedef struct chm_tab {
+  const double* pm_samples;    /* (nb,E_loc,S)  p_m1m2(m1src, m2src) of every posterior sample      pop_wrapper.py:79          */
+  const double* pm_inj;        /* (nb,I_loc)    p_m1m2 of every injection                           pop_wrapper.py:108         */
+  const double* rate_grid;     /* (nb,E_loc,Z)  merger_rate(z) on the event grids                   pop_wrapper.py:85          */
+  const double* rate_inj;      /* (nb,I_loc)    merger_rate(z_inj)                                  pop_wrapper.py:107         */
+  const double* bkg_grid;      /* (nb,E_loc,Z)  completeness.p_bkg(cosmo, z) on the event grids     catalog.py:200             */
+  const double* bkg_inj;       /* (nb,I_loc)    p_bkg(cosmo, z_inj, original distances)             pop_wrapper.py:106         */
+  const double* fR;            /* (nb,)         completeness.fR(cosmo)                              catalog.py:199             */
+} chm_tab;
+
 typedef struct chm_like chm_like;
 typedef struct chm_sel  chm_sel;
 typedef struct chm_comm chm_comm;
@@ -149,6 +164,11 @@ int chm_sel_destroy(chm_sel* h);
  * E_total is the number of events over all shards (ignored when comm == NULL).                        */
 int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_params* params, int32_t nb,
              int64_t E_total, chm_out* out);
+/* chm_eval with plug-in pieces evaluated by the caller (tab may be NULL = chm_eval).  Slow path: the tables travel host ->
+ * device on every call.  Source-frame quantities for the caller's functions: z = chm_model_eval(CHM_F_Z_FROM_DGW, dL),
+ * m_src = m_det / (1 + z).                                                                                               */
+int chm_eval_tabulated(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_params* params, int32_t nb,
+                       int64_t E_total, const chm_tab* tab, chm_out* out);
 
 /* Elementwise model functions on the device (cosmo.py:122-264, mass.py:334-341, rate.py:96-122),
  * used by the Python free functions and by compute_z_grids (pop_wrapper.py:133-208).                  */

@@ -35,7 +35,8 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_ctypes_structs_match_c_layout(lib, tmp_path):
-  structs = {'chm_params': lib.chm_params, 'chm_like_desc': lib.chm_like_desc, 'chm_sel_desc': lib.chm_sel_desc, 'chm_out': lib.chm_out}
+  structs = {'chm_params': lib.chm_params, 'chm_like_desc': lib.chm_like_desc, 'chm_sel_desc': lib.chm_sel_desc, 'chm_out': lib.chm_out,
+             'chm_tab': lib.chm_tab}
   prog = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
   for sname, cls in structs.items():
     prog.append(f'  printf("{sname} size %zu\\n", sizeof({sname}));')
