@@ -595,7 +595,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         hipLaunchKernelGGL(k_kde1d, dim3(L.E_cnt, nb), dim3(256), lds_kde, sg, L, dp);
         HIPCHK(hipGetLastError());
         if (zf_ranged) { launch_zfactors(); HIPCHK(hipGetLastError()); }
-        hipLaunchKernelGGL(k_integrate_1d, dim3(L.E_cnt * Pd, nb), dim3(64), 0, sg, L, dp);
+        hipLaunchKernelGGL(k_integrate_1d, dim3(L.E_cnt * nb, 1), dim3(256), 0, sg, L, dp);
       }
       HIPCHK(hipGetLastError());
       HIPCHK(hipEventRecord(c.evg[4 * g + 3], sg));

@@ -1206,23 +1206,16 @@ __global__ void __launch_bounds__(256) k_kde1d(LikeDev L, const DevParams* param
   if (t == 0) { kr[0] = kmx >= 0. ? (int)kmn : 0; kr[1] = (int)kmx; }
 }
 
-// k_integrate_1d: one wave per (event, pixel, draw): p_gw3dapprox (likelihood.py:150-154) or the 1-D case,
-// integrand and trapezoid (likelihood.py:266-292)
-__global__ void __launch_bounds__(64) k_integrate_1d(LikeDev L, const DevParams* params) {
-  const int lane = threadIdx.x;
+// k_integrate_1d: one block (four waves) per (event, draw); a wave walks over the event's pixels p = wave, wave + 4, ...:
+// p_gw3dapprox (likelihood.py:150-154) or the 1-D case, integrand and trapezoid (likelihood.py:266-292).  (One wave per
+// (event, pixel, draw) was dispatch-bound: 2 M waves of five short passes each took 1.46 ms at C3 / 64 draws.)
+__global__ void __launch_bounds__(256) k_integrate_1d(LikeDev L, const DevParams* params) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int Pd = L.P > 0 ? L.P : 1;
-  const int p = blockIdx.x % Pd, e = L.e_off + blockIdx.x / Pd, b = blockIdx.y;
+  const int b = blockIdx.x % L.nb, e = L.e_off + blockIdx.x / L.nb;    // draw fastest: the draws of an event share its p_cat rows in L2
   const DevParams& P = params[b];
   const int Z = L.Z;
   const bool pixelated = L.mode != 0;
-  double* out_like = L.like_pix + ((size_t)b * L.E + e) * Pd + p;
-  double* dump = (L.p_gw_dump && pixelated) ? L.p_gw_dump + (((size_t)b * L.E + e) * Pd + p) * Z : nullptr;
-  if (pixelated && p >= L.neff_pixels[e]) {
-    if (lane == 0) *out_like = 0.;
-    if (dump) for (int k = lane; k < Z; k += 64) dump[k] = 0.;
-    return;
-  }
-  const double gwp = pixelated ? L.gw_pdf[(size_t)e * L.P + p] : 1.;
   const size_t zo = ((size_t)b * L.E + e) * Z;
   const bool poisoned = grid_is_poisoned(P.z_bad, L.z_grids + (size_t)e * Z, Z);
   const double* g1 = L.pgw1d + zo;
@@ -1232,21 +1225,55 @@ __global__ void __launch_bounds__(64) k_integrate_1d(LikeDev L, const DevParams*
   const int k_lo = kr[0], k_hi = kr[1];
   const double* bkgA = L.bkgA + zo;
   const double* Aw = L.Aw + zo;
-  const double* pc = pixelated ? L.p_cat + ((size_t)e * L.P + p) * Z : nullptr;
   const double fR = P.fR;
-  if (dump) for (int k = lane; k < Z; k += 64) dump[k] = (k >= k_lo && k <= k_hi) ? g1[k] * gwp : 0.;
-  double acc = 0.;
-  for (int k = k_lo + lane; k <= k_hi; k += 64) {
-    double pgw = pixelated ? g1[k] * gwp : g1[k];            // p_gw1d[:,None,:] * gw_loc2d_pdf[:,:,None]   likelihood.py:153
-    if (pixelated) {
-      double pcv = pc[k];
-      if (pcv != -100.) acc += pgw * (fR * pcv + bkgA[k]) * Aw[k];      // catalog.py:202, pop_wrapper.py:87, likelihood.py:275
-    } else {
-      acc += pgw * bkgA[k] * Aw[k];                          // pop_wrapper.py:89, likelihood.py:291
-    }
+  const int npix = pixelated ? L.neff_pixels[e] : 1;
+  // The event's own factors on [k_lo, k_hi] are the same for all its pixels: when the range fits IG_NP passes of 64 lanes
+  // (512 grid points) they are loaded once into registers, and a pixel costs one batch of independent p_cat loads.
+  constexpr int IG_NP = 8;
+  const bool short_range = k_hi - k_lo < 64 * IG_NP;
+  double gv[IG_NP], bv[IG_NP], av[IG_NP];
+#pragma unroll
+  for (int i = 0; i < IG_NP; i++) {
+    const int k = k_lo + 64 * i + lane;
+    const bool in = short_range && k <= k_hi;
+    gv[i] = in ? g1[k] : 0.; bv[i] = in ? bkgA[k] : 0.; av[i] = in ? Aw[k] : 0.;
   }
-  acc = wave_sum(acc);
-  if (lane == 0) *out_like = poisoned ? __builtin_nan("") : acc;
+  for (int p = wid; p < Pd; p += nw) {
+    double* out_like = L.like_pix + ((size_t)b * L.E + e) * Pd + p;
+    double* dump = (L.p_gw_dump && pixelated) ? L.p_gw_dump + (((size_t)b * L.E + e) * Pd + p) * Z : nullptr;
+    if (pixelated && p >= npix) {                           // padded pixel: p_cat == -100, masked to 0 (likelihood.py:274-277)
+      if (lane == 0) *out_like = 0.;
+      if (dump) for (int k = lane; k < Z; k += 64) dump[k] = 0.;
+      continue;
+    }
+    const double gwp = pixelated ? L.gw_pdf[(size_t)e * L.P + p] : 1.;
+    const double* pc = pixelated ? L.p_cat + ((size_t)e * L.P + p) * Z : nullptr;
+    if (dump) for (int k = lane; k < Z; k += 64) dump[k] = (k >= k_lo && k <= k_hi) ? g1[k] * gwp : 0.;
+    double acc = 0.;
+    if (short_range) {
+      double pv[IG_NP];
+#pragma unroll
+      for (int i = 0; i < IG_NP; i++) { const int k = k_lo + 64 * i + lane; pv[i] = (pixelated && k <= k_hi) ? pc[k] : 0.; }
+#pragma unroll
+      for (int i = 0; i < IG_NP; i++) {
+        double pgw = pixelated ? gv[i] * gwp : gv[i];        // p_gw1d[:,None,:] * gw_loc2d_pdf[:,:,None]   likelihood.py:153
+        if (pixelated) { if (pv[i] != -100.) acc += pgw * (fR * pv[i] + bv[i]) * av[i]; }   // catalog.py:202, pop_wrapper.py:87, likelihood.py:275
+        else acc += pgw * bv[i] * av[i];                     // pop_wrapper.py:89, likelihood.py:291
+      }
+    } else {
+      for (int k = k_lo + lane; k <= k_hi; k += 64) {
+        double pgw = pixelated ? g1[k] * gwp : g1[k];
+        if (pixelated) {
+          double pcv = pc[k];
+          if (pcv != -100.) acc += pgw * (fR * pcv + bkgA[k]) * Aw[k];
+        } else {
+          acc += pgw * bkgA[k] * Aw[k];
+        }
+      }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) *out_like = poisoned ? __builtin_nan("") : acc;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
