@@ -1153,7 +1153,8 @@ __global__ void __launch_bounds__(256) k_kde1d(LikeDev L, const DevParams* param
     }
     __syncthreads();
     double* mine = wid == 0 ? wgt : hw + (size_t)(wid - 1) * N;
-    for (int s = t; s < S; s += nt) atomicAdd(&mine[bin_index(wz[s], lo, hi, B)], ww[s]);
+    const double dhl = hi - lo, rhl = 1. / dhl, dB = (double)B;       // same bins as bin_index(), one division per event (see bin_index_r)
+    for (int s = t; s < S; s += nt) atomicAdd(&mine[bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
     __syncthreads();
     for (int j = t; j < B; j += nt) wgt[j] = ((wgt[j] + hw[j]) + hw[N + j]) + hw[2 * N + j];
     __syncthreads();
@@ -1198,7 +1199,8 @@ __global__ void __launch_bounds__(256) k_kde1d(LikeDev L, const DevParams* param
   double kmn = 1e300, kmx = -1.;
   for (int k = t; k < Z; k += nt) {
     double zk = L.z_grids[(size_t)e * Z + k];
-    double v = interp_lr0(eff, dens, G, zk, eff_guess(zk, lb, ub, G, L.has_cut, k));
+    // left = right = 0 outside the effective grid: most of the event grid, decided before any bracket search
+    double v = (zk < eff[0] || zk > eff[G - 1]) ? 0. : interp_lr0(eff, dens, G, zk, eff_guess(zk, lb, ub, G, L.has_cut, k));
     out[k] = v;
     if (v != 0.) { kmn = fmin(kmn, (double)k); kmx = fmax(kmx, (double)k); }     // NaN counts as non-zero
   }

@@ -481,7 +481,7 @@ enum { RED_SUM = 0, RED_MIN = 1, RED_MAX = 2 };
 template <int OP>
 DEVFN double block_reduce(double v, double* scratch) {
   int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-  v = OP == RED_SUM ? wave_sum(v) : (OP == RED_MIN ? wave_min(v) : wave_max(v));
+  v = OP == RED_SUM ? wave_sum_dpp(v) : (OP == RED_MIN ? wave_min(v) : wave_max(v));     // every thread of the block reaches this call
   __syncthreads();
   if (lane == 0) scratch[wid] = v;
   __syncthreads();
