@@ -291,6 +291,17 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
     logs.assign(2, std::vector<double>(E * S));
     for (size_t k = 0; k < E * S; k++) { logs[0][k] = std::log(d->m1det[(size_t)e0 * S + k]); logs[1][k] = std::log(d->m2det[(size_t)e0 * S + k]); }
   }
+  // smallest / largest finite distance of every event: the bracket of its table searches (k_samples)
+  std::vector<double> dlo(E), dhi(E);
+  for (size_t e = 0; e < E; e++) {
+    const double* x = d->dL + (size_t)(e0 + e) * S;
+    double lo = INFINITY, hi = -INFINITY;
+    for (size_t k = 0; k < S; k++) if (std::isfinite(x[k])) { lo = x[k] < lo ? x[k] : lo; hi = x[k] > hi ? x[k] : hi; }
+    if (!(lo <= hi)) { lo = NAN; hi = NAN; }                                     // no finite sample: the kernel searches the whole table
+    dlo[e] = lo; dhi[e] = hi;
+  }
+  rc = upload(h->owned, (const double*)dlo.data(), E, &L.dl_lo, s); if (rc) { chm_like_destroy(h); return rc; }
+  rc = upload(h->owned, (const double*)dhi.data(), E, &L.dl_hi, s); if (rc) { chm_like_destroy(h); return rc; }
   rc = upload(h->owned, (const double*)logs[0].data(), E * S, &L.lm1det, s); if (rc) { chm_like_destroy(h); return rc; }
   rc = upload(h->owned, (const double*)logs[1].data(), E * S, &L.lm2det, s); if (rc) { chm_like_destroy(h); return rc; }
   if (d->mode == CHM_MODE_FULL) { UP(ra, d->ra, S); UP(dec, d->dec, S); }
@@ -523,6 +534,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       hipStream_t sg = (g & 1) ? sB : sA;
       LikeDev L = like->L;
       L.tab_pm = td.pm_s; L.tab_rate = td.rate_g; L.tab_bkg = td.bkg_g;
+      if (getenv("CHM_NO_BRACKET")) L.dl_lo = nullptr;       // diagnostics: table searches over the whole table
       if (!want_dump) L.p_gw_dump = nullptr;
       const int eb = (int)((long long)L0.E * g / ngroups), ee = (int)((long long)L0.E * (g + 1) / ngroups);
       L.e_off = eb; L.E_cnt = ee - eb; L.nb = nb;

@@ -37,6 +37,7 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   const int* seg_off;             // (E,P+1) marginalized: pixel segments of the pixel-sorted samples
   const double *z_grids, *p_cat, *P_compl, *gw_pdf, *ra_pix, *dec_pix;
   const int* neff_pixels;
+  const double *dl_lo, *dl_hi;    // (E,) smallest / largest finite dL of each event (set at upload): brackets its table searches
   const int* perm;                // (E,S) marginalized: original index of the pixel-sorted sample (for caller-tabulated values)
   const double *tab_pm, *tab_rate, *tab_bkg;   // plug-in models evaluated by the caller (chm_tab), device copies; NULL = built-in
   const double *fracB, *fracG;    // i/num_bins (num_bins+1), i/(G-1) (G): the step fractions of jnp.linspace
@@ -311,6 +312,7 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
 #pragma clang fp contract(fast)                  // sums of products may fuse; z comes from jnp_interp_x2 (contract off) untouched
   extern __shared__ double lds[];
   __shared__ double red[4 * 16];
+  __shared__ int ired[8];
   const int b = blockIdx.x % L.nb, bx = blockIdx.x / L.nb, nbx = gridDim.x / L.nb, t = threadIdx.x;
   const DevParams P = params[b];      // by value: uniform loads at kernel start -> scalar registers, nothing re-read in the loops
   TablePtrs g = { zt_all + (size_t)b * TcMax, It_all + (size_t)b * TcMax, dLt_all + (size_t)b * TcMax,
@@ -327,6 +329,23 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
     double* ww = L.ws_w + so;
     // reference point of the shifted sums: the event's first sample
     const double z_ref = jnp_interp(L.dL[eo], T.dLt, T.zt, P.Tc, false, 0., 0.);
+    // Bracket of the event's distances on the (sorted) dL table, counted by the whole block: every sample's  #entries <= dL  lies
+    // in [c_lo, c_hi], so its halving search runs over c_hi - c_lo entries (~7 steps) instead of the table (11 steps).
+    int s_base = 0, s_len = P.Tc;
+    if (P.dl_sorted != 0. && L.dl_lo) {
+      const double xlo = L.dl_lo[e], xhi = L.dl_hi[e];
+      int c_lo = 0, c_hi = 0;
+      for (int j0 = 0; j0 < P.Tc; j0 += 256) {
+        const int j = j0 + t;
+        const double v = j < P.Tc ? T.dLt[j] : __builtin_inf();
+        c_lo += __popcll(__ballot(v <= xlo)); c_hi += __popcll(__ballot(v <= xhi));        // per wave, uniform
+      }
+      __syncthreads();
+      if ((t & 63) == 0) { ired[(t >> 6) * 2] = c_lo; ired[(t >> 6) * 2 + 1] = c_hi; }
+      __syncthreads();
+      c_lo = ired[0] + ired[2] + ired[4] + ired[6]; c_hi = ired[1] + ired[3] + ired[5] + ired[7];
+      if (xlo == xlo && xhi == xhi && c_hi >= c_lo) { s_base = c_lo; s_len = c_hi - c_lo; }
+    }
     const double ra_ref = FULL ? L.ra[eo] : 0., dec_ref = FULL ? L.dec[eo] : 0.;
     double v[6] = { 0., 0., 0., 0., __builtin_inf(), -__builtin_inf() };     // sw, sw2, sd1, sd2, zmin, zmax
     double m[9] = { 0., 0., 0., 0., 0., 0., 0., 0., 0. };
@@ -352,13 +371,14 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
       }
       double zz[2], wv[2];
       // z = z_from_dGW(dL) (cosmo.py:260-264) for the two samples together
-      z_from_dGW_x2(P, dl[0], dl[1], T.dLt, T.zt, zz[0], zz[1]);
+      if (P.dl_sorted != 0.) jnp_interp_x2_range(dl[0], dl[1], T.dLt, T.zt, P.Tc, s_base, s_len, zz[0], zz[1]);
+      else z_from_dGW_x2(P, dl[0], dl[1], T.dLt, T.zt, zz[0], zz[1]);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         // m_src = m_det/(1+z) (pop_wrapper.py:70); w = p_m1m2 / pe_prior (pop_wrapper.py:79; the device array holds 1/pe_prior)
         double z = zz[h];
         double zp1 = 1. + z;
-        double r = 1. / zp1;
+        double r = chm_div(1., zp1);
         double m1 = md1[h] * r, m2 = md2[h] * r;
         double lz = chm_log_pos(zp1);                             // log(m_src) = log(m_det) - log(1+z): one log for both masses
         double pm;

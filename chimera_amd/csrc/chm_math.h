@@ -24,6 +24,18 @@ DEVFN double FM_FMA(double a, double b, double c) {
   return d;
 }
 
+// a / b without the IEEE special-case scaffolding (v_div_scale / v_div_fmas / v_div_fixup): reciprocal seed, two Newton steps,
+// quotient and one residual correction -- 8 instructions instead of 11, the correctly rounded quotient except for rare last-bit
+// cases.  For operands well inside the normal range (no denormals, no overflow in 1/b); inf and NaN still propagate.  Used only
+// where the quotient feeds smooth arithmetic (never the z interpolation or a bin index).
+DEVFN double chm_div(double a, double b) {
+  double r = FM_RCP(b);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  double q = a * r;
+  return __builtin_fma(__builtin_fma(-b, q, a), r, q);
+}
+
 DEVFN double chm_exp(double x) {
   const double L2E = 1.44269504088896338700e+00, LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10;
   double n = __builtin_rint(x * L2E);

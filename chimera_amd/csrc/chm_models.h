@@ -120,6 +120,36 @@ DEVFN void jnp_interp_x2(double xa, double xb, AccX xp, AccF fp, int n, double& 
   if (xb > xlast) fb = fp[n - 1];
 }
 
+// jnp_interp_x2 restricted to the table entries [base, base + len): for callers that know  #entries <= x  lies in
+// [base, base + len] for both arguments (all entries before `base` are <= x, all from base + len on are > x).
+template <class AccX, class AccF>
+DEVFN void jnp_interp_x2_range(double xa, double xb, AccX xp, AccF fp, int n, int base, int len, double& fa, double& fb) {
+  int pa = base, pb = base;
+  if (len > 0) {
+    for (int l = len; l > 1;) {
+      const int half = l >> 1;
+      double va = xp[pa + half - 1], vb = xp[pb + half - 1];
+      pa += (va <= xa) ? half : 0;
+      pb += (vb <= xb) ? half : 0;
+      l -= half;
+    }
+    pa += (xp[pa] <= xa) ? 1 : 0;
+    pb += (xp[pb] <= xb) ? 1 : 0;
+  }
+  int ia = pa < 1 ? 1 : (pa > n - 1 ? n - 1 : pa), ib = pb < 1 ? 1 : (pb > n - 1 ? n - 1 : pb);
+  double x0a = xp[ia - 1], x1a = xp[ia], f0a = fp[ia - 1], f1a = fp[ia];
+  double x0b = xp[ib - 1], x1b = xp[ib], f0b = fp[ib - 1], f1b = fp[ib];
+  const double epsilon = 4.930380657631324e-32;
+  double dxa = x1a - x0a, dxb = x1b - x0b;
+  fa = (fabs(dxa) <= epsilon) ? f0a : f0a + ((xa - x0a) / dxa) * (f1a - f0a);
+  fb = (fabs(dxb) <= epsilon) ? f0b : f0b + ((xb - x0b) / dxb) * (f1b - f0b);
+  double xfirst = xp[0], xlast = xp[n - 1];
+  if (xa < xfirst) fa = fp[0];
+  if (xa > xlast) fa = fp[n - 1];
+  if (xb < xfirst) fb = fp[0];
+  if (xb > xlast) fb = fp[n - 1];
+}
+
 // z = z_from_dGW(dL) (cosmo.py:260-264) for two samples.  jnp_interp_x2's halving search returns searchsorted's answer on a sorted
 // table; on a NON-monotonic dL table (modified propagation with Xi(z) falling fast, or a closed universe past the antipode) the
 // result of a binary search depends on its probe sequence, so the reference's own bisection (jnp.searchsorted, method 'scan')
@@ -378,7 +408,7 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
     if (w1) { double a = m1 - m_low + eps, b = m1 - m_low - dm + eps; ab1 = a * b; s1 = a + b; }
     if (w2) { double a = m2 - m_low + eps, b = m2 - m_low - dm + eps; ab2 = a * b; s2 = a + b; }
     if (w1 || w2) {
-      double r = dm / (ab1 * ab2);
+      double r = chm_div(dm, ab1 * ab2);
       if (w1) D1 = 1. + chm_exp((s1 * ab2) * r);
       if (w2) D2 = 1. + chm_exp((s2 * ab1) * r);
     }
@@ -396,7 +426,7 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
   if (fabs(dx) <= 4.930380657631324e-32) { cn = f0; dx = 1.; }
   if (m1 < (double)mg[0]) cn = cdf[0] * dx;
   if (m1 > (double)mg[n - 1]) cn = cdf[n - 1] * dx;
-  double w = ((Pn * p.inv_norm_p_m1) * dx) / ((D1 * D2) * cn);
+  double w = ((Pn * p.inv_norm_p_m1) * dx) / ((D1 * D2) * cn);      // IEEE division: the denominator is inf where a smoothing factor is 0
   // sec = 0 -> p_m2m1 = 0 (or 0/0 = NaN -> 0): w = p_m1 * 0
   if (zero || (w != w && cn == 0.)) w = Pn * 0.;
   if (m1 != m1) w = m1;
