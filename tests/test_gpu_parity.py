@@ -522,7 +522,7 @@ def test_unphysical_cosmology_behaves_like_the_reference(kind):
   """A strongly closed universe with E(z)^2 < 0 beyond z ~ 2: the distance tables carry NaNs and dL(z) is not monotonic.  The
   reference's integrand is 0 * NaN = NaN wherever the event grid reaches the NaN region -- also outside the KDE's support,
   which the kernels skip -- so those events are -inf; the table search must follow the reference's bisection on the
-  unsorted table.  (Found by scripts/fuzz_extreme.py.)"""
+  unsorted table.  (Found by tests/tools/fuzz_extreme.py.)"""
   lam = {'H0': 20.475122477377834, 'Om0': 0.04178692963304655, 'Ok0': -0.27540350807880004, 'Xi0': 0.28514090098152856,
          'n': 2.349145907232978, 'gamma': 1.54, 'kappa': 4.18, 'zp': 4.63, 'm_low': 6.16, 'm_high': 163.4, 'beta': -2.9,
          'alpha': 2.86, 'lambda_peak': 0.91, 'mu_g': 42.2, 'sigma_g': 6.9, 'delta_m': 6.7}

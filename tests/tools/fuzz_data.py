@@ -1,7 +1,7 @@
 """One-off: hostile DATA (not parameters): non-uniform event grids, distances outside the table, masses outside the population,
 zero / huge priors, zero draw probabilities, -100 rows, empty pixels -- HIP vs the NumPy oracle, all modes."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tests import helpers as H
 

@@ -1,6 +1,6 @@
 """One-off: hyper-parameters drawn from wide / extreme ranges (flat priors far beyond the sensible ones), HIP vs the C oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tests import helpers as H
 from oracle import oracle_c as OC

@@ -1,6 +1,6 @@
 """One-off: extreme hyper-parameters in the 1d / approximate / full modes (and marginalized without binning / cut), HIP vs NumPy oracle."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tests import helpers as H
 

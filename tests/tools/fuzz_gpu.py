@@ -1,6 +1,6 @@
 """One-off wider fuzz: the random-configuration and random-draw parity tests of tests/test_gpu_parity.py over many more seeds."""
 import sys, os, traceback
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tests import test_gpu_parity as T
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
