@@ -51,7 +51,7 @@ struct Ctx {
   hipEvent_t ev[8] = {};                // timing on `stream`
   hipEvent_t evb[4] = {};               // fork/join + timing on `stream2`
   double ms[8] = {};
-  int t_ngroups = 0; bool t_like = false, t_sel = false, t_valid = false;
+  int t_ngroups = 0; bool t_like = false, t_sel = false, t_valid = false, t_all = false;
   bool init = false;
 };
 
@@ -491,7 +491,11 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       rc = tab_upload(&td.bkg_i, tab->bkg_inj, NI, sA); if (rc) return rc;
     }
   }
-  HIPCHK(hipEventRecord(c.ev[0], sA));
+  static const bool timing = getenv("CHM_NO_TIMING") == nullptr;      // CHM_NO_TIMING=1: no timing events in the streams (chm_last_timing returns zeros)
+  // with a communicator (multi-GPU shards: short calls) only the whole evaluation and the GW kernel are timed: each event record
+  // costs ~3 us of stream time (measured: 35 us per call for the full set)
+  const bool timing_all = timing && !comm;
+  if (timing) HIPCHK(hipEventRecord(c.ev[0], sA));
   rc = ctx_tables(c, params, nb, tab ? tab->fR : nullptr); if (rc) return rc;
   HIPCHK(hipEventRecord(c.ev[1], sA));
   HIPCHK(hipStreamWaitEvent(sB, c.ev[1], 0));               // fork: the other lanes start after the tables
@@ -507,7 +511,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   if (sel) {
     SelDev S = sel->S;
     S.tab_pm = td.pm_i; S.tab_rate = td.rate_i; S.tab_bkg = td.bkg_i;
-    HIPCHK(hipEventRecord(c.evb[1], sC));
+    if (timing_all) HIPCHK(hipEventRecord(c.evb[1], sC));
     if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
       hipLaunchKernelGGL(k_selection<true>, dim3(S.nblocks, nb), dim3(256), lds_samp, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
     } else hipLaunchKernelGGL(k_selection<false>, dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
@@ -561,7 +565,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         if (sz != sg) HIPCHK(hipEventRecord(c.evg[32 + g], sz));
       }
       // sample stage
-      HIPCHK(hipEventRecord(c.evg[4 * g], sg));
+      if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g], sg));
       const int nchunk = L.E_cnt * L.NC;
       // blocks stage the draw's tables in LDS (40 KB) once and walk over their chunks of SAMPLE_CHUNK = 4096 samples (one set
       // of block-reduced statistics per chunk: 1024-sample chunks cost 3.68 ms at C3 / 64 draws, 2048: 3.33 ms, 4096: 2.98 ms);
@@ -587,22 +591,22 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         else hipLaunchKernelGGL((k_samples<false, false>), g1, dim3(256), 0, sg, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
       }
       HIPCHK(hipGetLastError());
-      HIPCHK(hipEventRecord(c.evg[4 * g + 1], sg));
+      if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g + 1], sg));
       // GW kernel + integrand (needs the per-z factors)
       if (sz != sg) HIPCHK(hipStreamWaitEvent(sg, c.evg[32 + g], 0));
       if (L.mode == CHM_MODE_FULL) {
-        HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
+        if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         hipLaunchKernelGGL(k_full_kde, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp);
       } else if (L.mode == CHM_MODE_MARG) {
         hipLaunchKernelGGL(k_event_prep, dim3((L.E_cnt + 3) / 4, nb), dim3(256), 0, sg, L, marg_std ? 0 : 1);
         HIPCHK(hipGetLastError());
         if (zf_ranged) { launch_zfactors(); HIPCHK(hipGetLastError()); }
-        HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
+        if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         const bool fast = marg_std;
         if (fast) hipLaunchKernelGGL(k_kde_marg_sub<32>, dim3(L.E_cnt * ((Pd + 1) / 2) * nb, 1), dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
         else { allow_lds(k_kde_marg, lds_kde); hipLaunchKernelGGL(k_kde_marg, dim3(L.E_cnt * Pd, nb), dim3(64), lds_kde, sg, L, dp); }
       } else {
-        HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
+        if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         allow_lds(k_kde1d, lds_kde);
         hipLaunchKernelGGL(k_kde1d, dim3(L.E_cnt, nb), dim3(256), lds_kde, sg, L, dp);
         HIPCHK(hipGetLastError());
@@ -610,10 +614,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         hipLaunchKernelGGL(k_integrate_1d, dim3(L.E_cnt * nb, 1), dim3(256), 0, sg, L, dp);
       }
       HIPCHK(hipGetLastError());
-      HIPCHK(hipEventRecord(c.evg[4 * g + 3], sg));
+      if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 3], sg));
     }
     if (!serial) { HIPCHK(hipEventRecord(c.evb[0], sB)); HIPCHK(hipStreamWaitEvent(sA, c.evb[0], 0)); }   // join the two lanes
-    HIPCHK(hipEventRecord(c.ev[3], sA));
+    if (timing_all) HIPCHK(hipEventRecord(c.ev[3], sA));
     // per-event log-likelihoods and their block sums
     nblk_ev = (L0.E + 255) / 256;
     if (nb * nblk_ev > c.evpart_cap) {
@@ -623,7 +627,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       c.evpart_cap = nb * nblk_ev;
     }
   } else {
-    HIPCHK(hipEventRecord(c.ev[3], sA));
+    if (timing_all) HIPCHK(hipEventRecord(c.ev[3], sA));
   }
   double* d_lle = nullptr; double* d_nle = nullptr;
   const size_t El = like ? like->L.E : 0;
@@ -658,7 +662,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipMemcpyAsync(c.h_out, c.d_out3, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
-  HIPCHK(hipEventRecord(c.ev[5], sA));
+  if (timing) HIPCHK(hipEventRecord(c.ev[5], sA));
   if (d_lle) HIPCHK(hipMemcpyAsync(out->log_like_evs, d_lle, sizeof(double) * nb * El, hipMemcpyDeviceToHost, sA));
   if (d_nle) HIPCHK(hipMemcpyAsync(out->numlike_evs, d_nle, sizeof(double) * nb * El, hipMemcpyDeviceToHost, sA));
   if (want_dump) {
@@ -675,7 +679,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     if (out->N_exp) out->N_exp[b] = c.h_out[b * 3 + 2];
     if (out->partials) for (int k = 0; k < 3; k++) out->partials[b * 3 + k] = c.h_out[3 * nb + b * 3 + k];
   }
-  c.t_ngroups = ngroups; c.t_like = like != nullptr; c.t_sel = sel != nullptr; c.t_valid = true;
+  c.t_ngroups = ngroups; c.t_like = like != nullptr; c.t_sel = sel != nullptr; c.t_valid = timing; c.t_all = timing_all;
   return CHM_OK;
 }
 
@@ -688,12 +692,12 @@ extern "C" int chm_last_timing(chm_like* like, chm_sel* sel, double msout[8]) {
     if (hipEventElapsedTime(&ms, c.ev[0], c.ev[5]) == hipSuccess) c.ms[0] = ms;       // whole evaluation
     if (hipEventElapsedTime(&ms, c.ev[0], c.ev[1]) == hipSuccess) c.ms[1] = ms;       // tables
     for (int g = 0; g < c.t_ngroups; g++) {                                            // summed over the event groups
-      if (hipEventElapsedTime(&ms, c.evg[4 * g], c.evg[4 * g + 1]) == hipSuccess) c.ms[2] += ms;       // sample stage
+      if (c.t_all && hipEventElapsedTime(&ms, c.evg[4 * g], c.evg[4 * g + 1]) == hipSuccess) c.ms[2] += ms;       // sample stage
       if (hipEventElapsedTime(&ms, c.evg[4 * g + 2], c.evg[4 * g + 3]) == hipSuccess) c.ms[3] += ms;   // GW kernel + integrand
     }
-    if (c.t_sel && hipEventElapsedTime(&ms, c.evb[1], c.evb[2]) == hipSuccess) c.ms[4] = ms;   // selection (own stream)
-    if (hipEventElapsedTime(&ms, c.ev[3], c.ev[5]) == hipSuccess) c.ms[5] = ms;       // reduce + combine (+ all-reduce)
-    if (c.t_like && hipEventElapsedTime(&ms, c.ev[1], c.ev[3]) == hipSuccess) c.ms[6] = ms;    // all event groups, wall
+    if (c.t_all && c.t_sel && hipEventElapsedTime(&ms, c.evb[1], c.evb[2]) == hipSuccess) c.ms[4] = ms;   // selection (own stream)
+    if (c.t_all && hipEventElapsedTime(&ms, c.ev[3], c.ev[5]) == hipSuccess) c.ms[5] = ms;       // reduce + combine (+ all-reduce)
+    if (c.t_all && c.t_like && hipEventElapsedTime(&ms, c.ev[1], c.ev[3]) == hipSuccess) c.ms[6] = ms;    // all event groups, wall
     c.ms[7] = (double)c.t_ngroups;
   }
   for (int i = 0; i < 8; i++) msout[i] = c.ms[i];
