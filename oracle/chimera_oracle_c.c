@@ -13,7 +13,8 @@
  * standard deviations, jnp.interp / jnp.linspace / jnp.trapezoid forms).
  *
  * Scope: flrw / mg_flrw cosmology, tpl / bpl / plp mass models, the four rate models, the pixelated catalogue with
- * step completeness, kind_p_gw3d = 'marginalized' (likelihood.py:160-205, 266-281) and the injection selection
+ * step completeness, kind_p_gw3d = 'marginalized' (likelihood.py:160-205, 266-281), the 1-D and 'approximate' modes
+ * (likelihood.py:105-154, 283-292) and the injection selection
  * function (selection_function.py:34-48, pop_wrapper.py:102-111).  Parameter block: `chm_params` of
  * include/chimera_hip.h (plain data; the same struct the product's C ABI takes).
  *
@@ -277,9 +278,9 @@ static double two_pass_std(const double* x, int n) {   /* jnp.std, ddof = 0 */
   return sqrt(var / (double)n);
 }
 
-/* kde1d (math.py:52-81), Epanechnikov kernel (math.py:83-85); the marginalized path never passes `kernel` */
-static void kde1d_epan(const double* data, const double* wgt_in, int N, const double* grid, int G, int bw_method, double bw_scalar,
-                       double* Wn, double* out) {
+/* kde1d (math.py:52-81); the marginalized path never passes `kernel` and so always gets Epanechnikov */
+static void kde1d(const double* data, const double* wgt_in, int N, const double* grid, int G, int bw_method, double bw_scalar,
+                  int gauss, double* Wn, double* out) {
   double tot = 0., s2 = 0.;
   for (int j = 0; j < N; j++) tot += wgt_in[j];
   for (int j = 0; j < N; j++) { Wn[j] = wgt_in[j] / tot; s2 += Wn[j] * Wn[j]; }
@@ -293,7 +294,8 @@ static void kde1d_epan(const double* data, const double* wgt_in, int N, const do
     double acc = 0.;
     for (int j = 0; j < N; j++) {
       double u = (grid[g] - data[j]) / bw;
-      double kv = fabs(u) <= 1. ? 3. / 4. * (1. - u * u) : 0.;
+      double kv = gauss ? exp(-0.5 * (u * u)) / sqrt(2. * ORC_PI)                  /* _gaussian_kernel, math.py:87-89 */
+                        : (fabs(u) <= 1. ? 3. / 4. * (1. - u * u) : 0.);           /* _epan_kernel,     math.py:83-85 */
       acc += Wn[j] * kv;
     }
     out[g] = acc / bw;
@@ -363,7 +365,7 @@ static double event_numlike(const orc_model* m, const orc_like* L, int ev, doubl
       }
       data = cen; wgt = cnt;
     }
-    kde1d_epan(data, wgt, N, eff, G, L->bw_method, L->bw_scalar, Wn, dens);        /* :192 */
+    kde1d(data, wgt, N, eff, G, L->bw_method, L->bw_scalar, 0, Wn, dens);          /* :192 */
     const double gwp = L->gw_pdf[(size_t)ev * P + i];
     /* integrand and trapezoid                                                      :193-194, 270-278 */
     double acc = 0., yprev = 0.;
@@ -408,6 +410,122 @@ int orc_numlike_marg(const chm_params* p, int E, int S, int P, int Z, const doub
     }
 #pragma omp for schedule(dynamic, 1)
     for (int ev = 0; ev < E; ev++) if (scratch) like_evs[ev] = event_numlike(&m, &L, ev, scratch);
+    free(scratch);
+  }
+  model_free(&m);
+  return fail ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------
+ * p_gw1d (likelihood.py:105-144) and the 1-D / approximate numerators (likelihood.py:150-154, 266-292), one event.
+ * P = 0: no catalogue (p_z = p_bkg * rate / (1+z), likelihood.py:283-292); P > 0: p_gw3dapprox = p_gw1d x gw_loc2d_pdf.
+ * ---------------------------------------------------------------------------------------------------- */
+static double event_numlike_1d(const orc_model* m, const orc_like* L, int gauss, const int32_t* neff_pixels, int ev, double* scratch) {
+  const int S = L->S, P = L->P, Z = L->Z, B = L->num_bins;
+  const int G = L->has_cut ? Z / 2 : Z;
+  const int N = L->binning ? B : S;
+  double* z = scratch;           double* w = z + S;
+  double* cen = w + S;           double* cnt = cen + N;      double* Wn = cnt + N;
+  double* eff = Wn + N;          double* dens = eff + G;
+  double* pz = dens + G;         double* jac = pz + Z;       double* bkg = jac + Z;     double* pg = bkg + Z;
+  const double* zg = L->z_grids + (size_t)ev * Z;
+  const size_t eo = (size_t)ev * S;
+  double sw = 0., sw2 = 0.;
+  for (int s = 0; s < S; s++) {                                                     /* pop_wrapper.py:67-80 */
+    double zz = interp1(L->dL[eo + s], m->dLt, m->zt, m->Tc, 0, 0., 0.);
+    z[s] = zz;
+    w[s] = p_m1m2(m, L->m1det[eo + s] / (1. + zz), L->m2det[eo + s] / (1. + zz)) / L->pe_prior[eo + s];
+    sw += w[s]; sw2 += w[s] * w[s];
+  }
+  double norm = sw / (double)S, n_eff = (sw * sw) / sw2;                             /* likelihood.py:111-112 */
+  for (int k = 0; k < Z; k++) pg[k] = 0.;
+  if (n_eff >= L->pe_neff) {                                                        /* lax.cond, :133-139 */
+    double zmin = z[0], zmax = z[0];
+    for (int s = 1; s < S; s++) { if (z[s] < zmin || z[s] != z[s]) zmin = z[s]; if (z[s] > zmax || z[s] != z[s]) zmax = z[s]; }
+    if (L->has_cut) {
+      double sd = two_pass_std(z, S);
+      double lb = zmin - L->cut_grid * sd; lb = lb > 0. ? lb : 1.e-8;               /* jnp.where(. > 0, ., 1e-8), :119 */
+      double ub = zmax + L->cut_grid * sd;
+      for (int i = 0; i < G; i++) eff[i] = lin_at(lb, ub, G, i);                    /* :121 */
+    } else {
+      for (int i = 0; i < G; i++) eff[i] = zg[i];
+    }
+    const double* data = z; const double* wgt = w;
+    if (L->binning) {                                                               /* binning1d, math.py:32-46 */
+      for (int j = 0; j < B; j++) { cen[j] = (lin_at(zmin, zmax, B + 1, j) + lin_at(zmin, zmax, B + 1, j + 1)) / 2.; cnt[j] = 0.; }
+      for (int s = 0; s < S; s++) {
+        double f = floor((z[s] - zmin) / (zmax - zmin) * (double)B);
+        f = f < 0. ? 0. : (f > (double)(B - 1) ? (double)(B - 1) : f);
+        cnt[(f != f) ? 0 : (int)f] += w[s];
+      }
+      data = cen; wgt = cnt;
+    }
+    kde1d(data, wgt, N, eff, G, L->bw_method, L->bw_scalar, gauss, Wn, dens);
+    for (int i = 0; i < G; i++) dens[i] *= norm;                                    /* kde * norm, :136 */
+    for (int k = 0; k < Z; k++) pg[k] = interp1(zg[k], eff, dens, G, 1, 0., 0.);    /* :137 */
+  }
+  for (int k = 0; k < Z; k++) {                                                     /* p_cbc / jacobian on the event grid */
+    double dCt = dCt_at_z(m, zg[k]);
+    pz[k] = merger_rate(m->p, zg[k]) / (1. + zg[k]);
+    jac[k] = ddLdz(m, dCt, zg[k]) * ((1. + zg[k]) * (1. + zg[k]));
+    bkg[k] = dVcdz(m, dCt, zg[k]);
+  }
+  if (P == 0) {                                                                     /* likelihood.py:283-292 */
+    double acc = 0., yprev = 0.;
+    for (int k = 0; k < Z; k++) {
+      double y = pg[k] * (bkg[k] * pz[k]) / jac[k];
+      if (k > 0) acc += (zg[k] - zg[k - 1]) * (y + yprev);
+      yprev = y;
+    }
+    return 0.5 * acc;
+  }
+  double Li = 0.;
+  for (int i = 0; i < P; i++) {                                                     /* likelihood.py:150-154, 266-281 */
+    const double* pc = L->p_cat + ((size_t)ev * P + i) * Z;
+    const double gwp = L->gw_pdf[(size_t)ev * P + i];
+    double acc = 0., yprev = 0.;
+    for (int k = 0; k < Z; k++) {
+      double pg3 = pg[k] * gwp;
+      double P_compl = (zg[k] > m->p->compl_z0 && zg[k] < m->p->compl_z1) ? 1. : 0.;
+      double p_gal = (pc[k] != -100.) ? m->fR * pc[k] + (1. - P_compl) * bkg[k] : -100.;
+      double p_z = (p_gal != -100.) ? p_gal * pz[k] : -100.;
+      double y = (p_z != -100.) ? pg3 * p_z / jac[k] : 0.;
+      if (k > 0) acc += (zg[k] - zg[k - 1]) * (y + yprev);
+      yprev = y;
+    }
+    Li += 0.5 * acc;
+  }
+  (void)neff_pixels;
+  return Li;
+}
+
+/* like_evs[ev] = L_i in the 1-D (P = 0, p_cat / gw_pdf NULL) or approximate (P > 0) mode; kernel: 0 = 'epan', 1 = 'gauss' */
+int orc_numlike_1d(const chm_params* p, int E, int S, int P, int Z, const double* dL, const double* m1det, const double* m2det,
+                   const double* pe_prior, const double* z_grids, const double* p_cat, const double* gw_pdf, double cut_grid,
+                   int binning, int num_bins, double pe_neff, int bw_method, double bw_scalar, int kernel, int nthreads,
+                   double* like_evs) {
+  orc_model m;
+  if (model_init(&m, p)) return -1;
+  orc_like L;
+  memset(&L, 0, sizeof(L));
+  L.E = E; L.S = S; L.P = P; L.Z = Z; L.num_bins = num_bins; L.binning = binning; L.has_cut = !(cut_grid != cut_grid);
+  L.bw_method = bw_method; L.cut_grid = cut_grid; L.pe_neff = pe_neff; L.bw_scalar = bw_scalar;
+  L.dL = dL; L.m1det = m1det; L.m2det = m2det; L.pe_prior = pe_prior; L.z_grids = z_grids; L.p_cat = p_cat; L.gw_pdf = gw_pdf;
+  const int N = binning ? num_bins : S;
+  const size_t nscr = (size_t)2 * S + 3 * N + 2 * Z + 4 * Z;
+  int fail = 0;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+  {
+    double* scratch = malloc(sizeof(double) * nscr);
+    if (!scratch) {
+#pragma omp atomic write
+      fail = 1;
+    }
+#pragma omp for schedule(dynamic, 1)
+    for (int ev = 0; ev < E; ev++) if (scratch) like_evs[ev] = event_numlike_1d(&m, &L, kernel, NULL, ev, scratch);
     free(scratch);
   }
   model_free(&m);

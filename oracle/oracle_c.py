@@ -44,6 +44,9 @@ def lib():
     L.orc_numlike_marg.argtypes = [C.POINTER(chm_params), C.c_int, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_lp, c_lp,
                                    c_dp, c_dp, c_dp, C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, c_dp]
     L.orc_numlike_marg.restype = C.c_int
+    L.orc_numlike_1d.argtypes = [C.POINTER(chm_params), C.c_int, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp,
+                                 C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, c_dp]
+    L.orc_numlike_1d.restype = C.c_int
     L.orc_nexp.argtypes = [C.POINTER(chm_params), C.c_longlong, c_dp, c_dp, c_dp, c_dp, C.c_double, C.c_double, C.c_int, c_dp]
     L.orc_nexp.restype = C.c_int
     L.orc_max_threads.restype = C.c_int
@@ -124,6 +127,39 @@ def numlike_marg(like, pop, nthreads=0):
   return out
 
 
+def numlike_1d(like, pop, nthreads=0):
+  """L_i of every event for an oracle ``hyperlikelihood`` in the 1-D (no catalogue) or 'approximate' mode."""
+  assert (not like.pixelated) or like.kind_p_gw3d == 'approximate'
+  th = like.theta_gw_det
+  p = pack_params(pop)
+  dL, m1, m2, pr = _f64(th.dL), _f64(th.m1det), _f64(th.m2det), _f64(th.pe_prior)
+  E, S = dL.shape
+  zg = _f64(like.z_grids)
+  Z = zg.shape[1]
+  if like.pixelated:
+    pc, gw = _f64(pop.gal_cat.p_cat), _f64(th.gw_loc2d_pdf)
+    P = pc.shape[1]
+    pcp, gwp = _dp(pc), _dp(gw)
+  else:
+    P, pcp, gwp = 0, None, None
+  bw = like.bw_method
+  bw_method, bw_scalar = (0, 0.) if bw in (None, 'scott') else ((1, 0.) if bw == 'silverman' else (2, float(bw)))
+  cut = float('nan') if like.cut_grid is None else float(like.cut_grid)
+  out = np.zeros(E)
+  rc = lib().orc_numlike_1d(C.byref(p), E, S, P, Z, _dp(dL), _dp(m1), _dp(m2), _dp(pr), _dp(zg), pcp, gwp, cut,
+                            int(bool(like.binning)), int(like.num_bins), float(like.pe_neff), bw_method, bw_scalar,
+                            1 if like.kernel == 'gauss' else 0, int(nthreads), _dp(out))
+  if rc:
+    raise MemoryError('orc_numlike_1d')
+  return out
+
+
+def numlike(like, pop, nthreads=0):
+  if like.pixelated and like.kind_p_gw3d == 'marginalized':
+    return numlike_marg(like, pop, nthreads)
+  return numlike_1d(like, pop, nthreads)
+
+
 def n_exp(sel, pop, nthreads=0):
   """(N_exp, xi, n_eff) of an oracle ``selection_function``."""
   th = sel.theta_inj_det
@@ -140,7 +176,7 @@ def compute_all(like, lam, nthreads=0):
   """(log_like_evs, log_like_num, log N_exp, log_hyper) as hyperlikelihood.compute_all (likelihood.py:326-338)."""
   pop = like.population.update(**lam)
   with np.errstate(all='ignore'):
-    ll = O.nan_to_num_neginf(np.log(numlike_marg(like, pop, nthreads)))
+    ll = O.nan_to_num_neginf(np.log(numlike(like, pop, nthreads)))
     log_num = np.sum(ll)
     Nexp = n_exp(like.selection_function, pop, nthreads)[0]
     if not pop.scale_free:

@@ -336,14 +336,15 @@ def test_full_size_against_oracle_sample(cfg_big):
     H.assert_loglike_close(like_p.compute_all(**lam)[0][:n], like_o.compute_all(**lam)[0], rtol=1e-9, atol=1e-9)
 
 
-def test_full_size_every_event_against_the_c_oracle(cfg_big):
+@pytest.mark.parametrize('kind', ['marginalized', 'approximate'])
+def test_full_size_every_event_against_the_c_oracle(cfg_big, kind):
   """All 300 events x 32 pixels x 1000 z-bins x 4096 samples + 1e5 injections against the plain-C restatement
   (oracle/chimera_oracle_c.c, OpenMP; itself checked against the NumPy oracle in tests/test_oracle_c.py)."""
   import os
   from oracle import oracle_c as OC
   cfg, ev, inj = cfg_big
-  like_p, _, _ = H.build_product(ev, inj)
-  like_o, _, _ = H.build_oracle(ev, inj)
+  like_p, _, _ = H.build_product(ev, inj, kind=kind)
+  like_o, _, _ = H.build_oracle(ev, inj, kind=kind)
   nthr = min(16, os.cpu_count() or 1)
   for lam in (dict(H0=67.), dict(H0=88., lambda_peak=0.08, gamma=2.0)):
     rp = like_p.compute_all(**lam)

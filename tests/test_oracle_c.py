@@ -62,3 +62,23 @@ def test_selection_guard_and_thread_count_do_not_change_the_result():
   sel_none = O.selection_function(sel.theta_inj_det, sel.N_inj, N_eff=None)
   np.testing.assert_allclose(OC.n_exp(sel_none, pop)[0], sel_none.N_exp(pop), rtol=1e-12)
   assert OC.max_threads() >= 1
+
+
+@pytest.mark.parametrize('pixelated,like_kw,models,lam', [
+  (False, dict(), dict(), dict(H0=67.)),
+  (False, dict(kernel='gauss'), dict(mass='tpl'), dict(H0=74., alpha=2.2)),
+  (False, dict(binning=False, cut_grid=None), dict(), dict(H0=70.)),
+  (True, dict(), dict(), dict(H0=69.)),
+  (True, dict(kernel='gauss', bw_method='silverman', num_bins=40), dict(mass='bpl', cosmo='mg_flrw', cosmo_kw=dict(Xi0=1.4, n=1.7)), dict(H0=72.)),
+  (True, dict(cut_grid=None, bw_method=0.3), dict(rate='power_law'), dict(gamma=2.0)),
+])
+def test_1d_and_approximate_modes_match_numpy_oracle(pixelated, like_kw, models, lam):
+  cfg, ev, inj = H.small_config(E=5, S=160, P=3, Z=40, I=1200, seed=13, ragged=True, pixelated=pixelated)
+  like, pop, sel = H.build_oracle(ev, inj, pixelated=pixelated, kind='approximate' if pixelated else None, models=models, like_kw=like_kw)
+  ro = like.compute_all(**lam)
+  rc = OC.compute_all(like, lam, nthreads=2)
+  H.assert_loglike_close(rc[0], ro[0], rtol=RT, atol=1e-11)
+  popu = pop.update(**lam)
+  np.testing.assert_allclose(OC.numlike(like, popu, nthreads=1), like.compute_numlike_evs(popu), rtol=RT, atol=1e-300)
+  if np.isfinite(ro[3]):
+    np.testing.assert_allclose(rc[3], ro[3], rtol=0, atol=1e-9)
