@@ -46,8 +46,8 @@ def kde_kernel_bytes(E, S, P, Z):
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=20)
-  ap.add_argument('--warmup', type=int, default=3)
+  ap.add_argument('--steps', type=int, default=50)
+  ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--config', default='C3')
   ap.add_argument('--mode', default='marginalized')
   ap.add_argument('--nbatch', type=int, default=64, help='hyper-parameter draws per chm_eval call (hyperlikelihood.batch)')
