@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- hyper-likelihood throughput on MI355X (BASELINE.json metric).
 
-A step = one call of ``hyperlikelihood.batch`` with ``--nbatch`` (default 64) different hyper-parameter draws, i.e. nbatch
+A step = one call of ``hyperlikelihood.batch`` with ``--nbatch`` (default 128) different hyper-parameter draws, i.e. nbatch
 full hyperposterior evaluations (each: tables + det->src + weights + histogram/KDE + integrand + trapz + selection
 function + reduce) over the C3 workload: 1000 events x 32 pixels x 1000 z-bins x 4096 samples/event, 1e5 detected
 injections, PowerLaw+Peak + Madau-Dickinson + flat-LCDM, kind_p_gw3d='marginalized', binning(200), cut_grid=2 --
@@ -50,7 +50,7 @@ def main():
   ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--config', default='C3')
   ap.add_argument('--mode', default='marginalized')
-  ap.add_argument('--nbatch', type=int, default=64, help='hyper-parameter draws per chm_eval call (hyperlikelihood.batch)')
+  ap.add_argument('--nbatch', type=int, default=128, help='hyper-parameter draws per chm_eval call (hyperlikelihood.batch)')
   ap.add_argument('--events', type=int, default=None, help='shrink the number of events (debug)')
   ap.add_argument('--inj', type=int, default=None, help='shrink the number of injections (debug)')
   ap.add_argument('--no-cpu-baseline', action='store_true')

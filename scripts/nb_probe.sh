@@ -4,7 +4,7 @@ OUT=gpurun_out/nb_probe.txt
 : > $OUT
 for cfg in "1000 100000" "125 12500"; do
   set -- $cfg
-  for nb in 16 64; do
+  for nb in 16 64 128; do
     timeout -k 10 200 python3 bench.py --events $1 --inj $2 --nbatch $nb --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null | python3 -c "
 import sys, json
 j = json.loads(sys.stdin.read().strip().split('\n')[-1])
