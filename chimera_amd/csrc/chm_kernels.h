@@ -92,7 +92,11 @@ DEVFN double block_excl_scan(double v, double* sh) {
   __syncthreads();
   double off = 0.;
   for (int w = 0; w < wid && w < nw; w++) off += sh[w];
-  return off + (x - v);
+  // exclusive prefix = the inclusive value of the previous lane (not x - v: a NaN value of THIS thread -- an unphysical draw's
+  // 1/E -- must not reach the entries before it, jnp.cumsum turns NaN only from the first NaN term on)
+  double ex = __shfl_up(x, 1, 64);
+  if (lane == 0) ex = 0.;
+  return off + ex;
 }
 
 // cumtrapz(y, x) (math.py:22-26) of n points in global memory by one block: thread t owns a contiguous chunk of
@@ -175,13 +179,16 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
     if (LDS_ARR) __syncthreads(); else gsync();
     block_cumtrapz(tmp, zt, It, Tc, sh);
     if (!LDS_ARR) gsync();
-    // dL table of z_from_dGW: dL_at_z(cosmo, z_grid_interp) (cosmo.py:263).  jnp.interp evaluated AT its own nodes returns
-    // It[i] exactly for i < Tc-1 (delta = 0) and It[Tc-2] + (dx/dx) dI at the last node.  The values also go into `tmp` (free
+    // dL table of z_from_dGW: dL_at_z(cosmo, z_grid_interp) (cosmo.py:263): jnp.interp evaluated AT its own nodes (below; the last
+    // node is bracketed from the left: It[Tc-2] + (dx/dx) dI).  The values also go into `tmp` (free
     // after the cumulative integral) for the monotonicity check below.
     for (int i = t; i < Tc; i += nt) {
       double z = zt[i];
-      double ii = It[i];
+      // interp AT node i brackets it with node i+1:  It[i] + (0/dx) (It[i+1] - It[i])  -- It[i] when the next node is finite, NaN
+      // when it is not (an unphysical draw: the dL table turns NaN one node before the integral does, as the reference's)
+      double ii;
       if (i == Tc - 1) { double dx = zt[i] - zt[i - 1]; ii = It[i - 1] + (dx / dx) * (It[i] - It[i - 1]); }
+      else ii = It[i] + (0. / (zt[i + 1] - zt[i])) * (It[i + 1] - It[i]);
       double dl = dL_from_dCt(P, dCt_from_dCr(P, P.dH * ii), z);
       dLt[i] = dl;
       tmp[i] = dl;
@@ -489,8 +496,11 @@ DEVFN void eff_bounds(bool marg, double zmin, double zmax, double sd, double cut
 // S_k = P_k[jb] - P_k[ja], P_k = prefix sums of W c'^k, c' = c - c_ref, g' = g - c_ref.  The range is found from the
 // bin spacing and fixed up with the reference's own predicate |(g - c_j)/h| <= 1 (math.py:78,85).
 // Differs from the dense left-to-right sum by rounding only (~(R/h)^2 eps, R = span of the bins).
+// jl1 (wave_prefix3): one past the last lane chunk of bins that holds any weight.  The prefix values after it stem from
+// different summation trees and agree only to an ulp, so a node whose support holds nothing but empty bins above the data would get
+// 1e-16 of the peak instead of the dense sum's exact zero; the range is clipped to jl1, where the values are consistent.
 DEVFN double epan_prefix_eval(double g, const double* cen, const double* P0, const double* P1, const double* P2, int N,
-                              double lo, double inv_dbin, double bw, double inv_bw, double c_ref) {
+                              double lo, double inv_dbin, double bw, double inv_bw, double c_ref, int jl1) {
   double fa = ceil((g - bw - lo) * inv_dbin - 0.5), fb = floor((g + bw - lo) * inv_dbin - 0.5) + 1.;
   int ja = fa > 0. ? (fa < (double)N ? (int)fa : N) : 0;
   int jb = fb > 0. ? (fb < (double)N ? (int)fb : N) : 0;
@@ -500,6 +510,8 @@ DEVFN double epan_prefix_eval(double g, const double* cen, const double* P0, con
   if (jb < ja) jb = ja;
   while (jb < N && fabs((g - cen[jb]) * inv_bw) <= 1.) jb++;
   while (jb > ja && !(fabs((g - cen[jb - 1]) * inv_bw) <= 1.)) jb--;
+  if (jb > jl1) jb = jl1;
+  if (ja > jl1) ja = jl1;
   double S0 = P0[jb] - P0[ja], S1 = P1[jb] - P1[ja], S2 = P2[jb] - P2[ja];
   double gp = g - c_ref;
   double qq = fma(gp, fma(gp, S0, -2. * S1), S2);                // sum W (g' - c')^2
@@ -592,8 +604,9 @@ DEVFN double wave_integrate(PGW pgw_at, const double* zg, const double* jac, con
   return 0.5 * wave_sum(acc);
 }
 
-// inclusive->exclusive prefix sums of W, W c', W c'^2 over N bins by one wave; P*[0..N]
-DEVFN void wave_prefix3(const double* cen, const double* wgt, int N, double c_ref, double* P0, double* P1, double* P2) {
+// inclusive->exclusive prefix sums of W, W c', W c'^2 over N bins by one wave; P*[0..N].  Returns jl1, the end of the last lane
+// chunk that holds a non-zero weight (see epan_prefix_eval).  Below the first weight every prefix is an exact zero.
+DEVFN int wave_prefix3(const double* cen, const double* wgt, int N, double c_ref, double* P0, double* P1, double* P2) {
   const int lane = threadIdx.x & 63;
   const int per = (N + 63) / 64;
   const int j0 = lane * per, j1 = min(j0 + per, N);
@@ -613,6 +626,9 @@ DEVFN void wave_prefix3(const double* cen, const double* wgt, int N, double c_re
     r0 += W; r1 += W * cc; r2 += W * cc * cc;
     P0[j + 1] = r0; P1[j + 1] = r1; P2[j + 1] = r2;
   }
+  const unsigned long long nz = __ballot(s0 != 0.);          // NaN counts as weight
+  const int last = 63 - __clzll(nz);                          // -1: no weight at all
+  return min((last + 1) * per, N);
 }
 
 // Per-(draw, event) statistics for the marginalized kernels: the chunk partials of k_samples combined once for all the event's
@@ -836,9 +852,9 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
     const double dbin = (hi - lo) / (double)B;
     const bool fast = L.binning && dbin > 0. && bw > 0. && bw < 1e300 && tot == tot && (tot > 0. || tot < 0.);
     if (fast) {
-      wave_prefix3(data, wgt, N, lo, P0, P1, P2);
+      const int jl1 = wave_prefix3(data, wgt, N, lo, P0, P1, P2);
       __syncthreads();
-      for (int i = lane; i < G; i += 64) dens[i] = epan_prefix_eval(eff[i], data, P0, P1, P2, N, lo, 1. / dbin, bw, inv_bw, lo);
+      for (int i = lane; i < G; i += 64) dens[i] = epan_prefix_eval(eff[i], data, P0, P1, P2, N, lo, 1. / dbin, bw, inv_bw, lo, jl1);
     } else {
       for (int i = lane; i < G; i += 64) dens[i] = kde_dense_eval(eff[i], data, wgt, N, true, bw, inv_bw);
     }
@@ -1036,6 +1052,17 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   const double x0 = sg_scan_add<SW>(s0w), x1 = sg_scan_add<SW>(s1w), x2 = sg_scan_add<SW>(s2w);
   const double tot = sg_last<SW>(x0, sub);
   const double sum2 = sg_last<SW>(sg_scan_add<SW>(sq), sub);
+  // End of the last lane chunk of bins that holds any weight.  The prefix values of the lanes after it come out of different
+  // summation trees and agree only to an ulp: a node that sees nothing but the empty bins above the data would get 1e-16 of the
+  // peak where the dense sum (math.py:80) has an exact zero -- which decides log L_i when the catalogue term is only non-zero out
+  // there.  The bin ranges are clipped to it (below the first weight every prefix is an exact zero already).
+  double fjl1;
+  {
+    const unsigned long long nz = __ballot(s0w != 0.);      // NaN counts as weight
+    const unsigned long long mine = SW == 64 ? nz : ((nz >> (sub * (SW & 63))) & ((1ull << (SW & 63)) - 1ull));
+    const int last = 63 - __clzll(mine);                    // -1: no weight at all (degenerate pixel, NaN below)
+    fjl1 = (double)min((last + 1) * per, B);
+  }
   {
     double r0 = x0 - s0w, r1 = x1 - s1w, r2 = x2 - s2w;
     constexpr int MAXPER = 16;
@@ -1091,8 +1118,8 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   const double zlo = degenerate ? lb : __builtin_fmax(lb, lo - bw - de), zhi = degenerate ? ub : __builtin_fmin(ub, hi + bw + de);
   // density (without the common factor `scale`) at the node with g' = g - lo and bin position t
   auto node = [&](double gp, double t) {
-    double fa = __builtin_fmin(__builtin_fmax(ceil(t - hb), 0.), dB);
-    double fb = __builtin_fmin(__builtin_fmax(floor(t + hb) + 1., fa), dB);
+    double fa = __builtin_fmin(__builtin_fmax(ceil(t - hb), 0.), fjl1);
+    double fb = __builtin_fmin(__builtin_fmax(floor(t + hb) + 1., fa), fjl1);
     const int ia = 3 * (int)fa, ib = 3 * (int)fb;
     double S0 = Q[ib] - Q[ia], S1 = Q[ib + 1] - Q[ia + 1], S2 = Q[ib + 2] - Q[ia + 2];
     double qq = fma(gp, fma(gp, S0, -2. * S1), S2);         // sum W (g' - c')^2 over the support
@@ -1147,6 +1174,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
 __global__ void __launch_bounds__(256) k_kde1d(LikeDev L, const DevParams* params) {
   extern __shared__ double lds[];
   __shared__ double red[16];
+  __shared__ int s_jl1;
   const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wid = t >> 6;
   const int e = L.e_off + blockIdx.x, b = blockIdx.y;
   const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
@@ -1208,9 +1236,10 @@ __global__ void __launch_bounds__(256) k_kde1d(LikeDev L, const DevParams* param
   const bool fast = epan && L.binning && dbin > 0. && bw > 0. && bw < 1e300 && tot == tot && (tot > 0. || tot < 0.);
   if (fast) {
     double* P0 = hw; double* P1 = hw + (N + 1); double* P2 = hw + 2 * (N + 1);
-    if (wid == 0) wave_prefix3(data, wgt, N, lo, P0, P1, P2);
+    if (wid == 0) { int j = wave_prefix3(data, wgt, N, lo, P0, P1, P2); if (lane == 0) s_jl1 = j; }
     __syncthreads();
-    for (int i = t; i < G; i += nt) dens[i] = epan_prefix_eval(eff[i], data, P0, P1, P2, N, lo, 1. / dbin, bw, inv_bw, lo) * st.norm;
+    const int jl1 = s_jl1;
+    for (int i = t; i < G; i += nt) dens[i] = epan_prefix_eval(eff[i], data, P0, P1, P2, N, lo, 1. / dbin, bw, inv_bw, lo, jl1) * st.norm;
   } else {
     for (int i = t; i < G; i += nt) dens[i] = kde_dense_eval(eff[i], data, wgt, N, epan, bw, inv_bw) * st.norm;
   }
@@ -1808,7 +1837,7 @@ __global__ void __launch_bounds__(256) k_model_eval(const DevParams* params, Tab
       case 6: r = dVcdz_from_dCt(P, bb ? dL2dCt(P, bb[i], x) : dCt_at_z(P, x, g.zt, g.It), x); break;
       case 7: r = Vc_from_dCt(P, bb ? dL2dCt(P, bb[i], x) : dCt_at_z(P, x, g.zt, g.It)); break;
       case 8: r = Xi_at_z(P, x); break;
-      case 9: r = jnp_interp(x, g.dLt, g.zt, P.Tc, false, 0., 0.); break;
+      case 9: r = jnp_interp(x, g.dLt, g.zt, P.Tc, false, 0., 0., P.dl_sorted == 0.); break;     // z_from_dGW: jax's scan search on an unsorted table
       case 10: r = merger_rate(P, x); break;
       case 11: r = p_m1m2(P, x, bb[i], g.mg, g.cdf); break;
       case 12: r = primary_notnorm(P, x); break;

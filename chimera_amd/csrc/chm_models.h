@@ -73,10 +73,27 @@ DEVFN int searchsorted_right(Acc xp, int n, double x) {
   return lo;
 }
 
+// jnp.searchsorted(xp, x, side='right') exactly as jax's default method does it ('scan': jax/_src/numpy/lax_numpy.py,
+// _searchsorted_via_scan): ceil(log2(n+1)) steps of  mid = (low+high)/2; go_left = x < xp[mid] (NaN sorts last); high = mid or
+// low = mid; result high.  Same answer as searchsorted_right on a sorted table; on a NON-monotonic one (the dL table of an
+// unphysical draw) the probe sequence decides, and this is the reference's.
+template <class Acc>
+DEVFN int searchsorted_right_scan(Acc xp, int n, double x) {
+  int lo = 0, hi = n, levels = 0;
+  while ((1LL << levels) < (long long)n + 1) levels++;
+  for (int l = 0; l < levels; l++) {
+    int mid = (lo + hi) >> 1;
+    double v = xp[mid];
+    bool go_left = (x < v) || ((v != v) && (x == x));
+    if (go_left) hi = mid; else lo = mid;
+  }
+  return hi;
+}
+
 // jnp.interp(x, xp, fp, left, right); has_lr == false -> clamp to fp[0] / fp[n-1].
 template <class AccX, class AccF>
-DEVFN double jnp_interp(double x, AccX xp, AccF fp, int n, bool has_lr, double left, double right) {
-  int i = searchsorted_right(xp, n, x);
+DEVFN double jnp_interp(double x, AccX xp, AccF fp, int n, bool has_lr, double left, double right, bool scan = false) {
+  int i = scan ? searchsorted_right_scan(xp, n, x) : searchsorted_right(xp, n, x);
   i = i < 1 ? 1 : (i > n - 1 ? n - 1 : i);
   double x0 = xp[i - 1], x1 = xp[i];
   double f0 = fp[i - 1], f1 = fp[i];
@@ -152,13 +169,13 @@ DEVFN void jnp_interp_x2_range(double xa, double xb, AccX xp, AccF fp, int n, in
 
 // z = z_from_dGW(dL) (cosmo.py:260-264) for two samples.  jnp_interp_x2's halving search returns searchsorted's answer on a sorted
 // table; on a NON-monotonic dL table (modified propagation with Xi(z) falling fast, or a closed universe past the antipode) the
-// result of a binary search depends on its probe sequence, so the reference's own bisection (jnp.searchsorted, method 'scan')
-// is followed step by step there -- flagged per draw by k_tables, never taken for sensible parameters.
+// result of a binary search depends on its probe sequence, so the reference's own search (jnp.searchsorted, method 'scan':
+// searchsorted_right_scan) is followed step by step there -- flagged per draw by k_tables, never taken for sensible parameters.
 template <class AccX, class AccF>
 DEVFN void z_from_dGW_x2(const DevParams& p, double xa, double xb, AccX dLt, AccF zt, double& za, double& zb) {
   if (p.dl_sorted != 0.) { jnp_interp_x2(xa, xb, dLt, zt, p.Tc, za, zb); return; }
-  za = jnp_interp(xa, dLt, zt, p.Tc, false, 0., 0.);
-  zb = jnp_interp(xb, dLt, zt, p.Tc, false, 0., 0.);
+  za = jnp_interp(xa, dLt, zt, p.Tc, false, 0., 0., true);
+  zb = jnp_interp(xb, dLt, zt, p.Tc, false, 0., 0., true);
 }
 
 // An unphysical draw (E(z)^2 < 0 somewhere, e.g. a strongly closed universe) leaves NaNs in the cumulative table of 1/E from

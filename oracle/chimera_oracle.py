@@ -42,9 +42,32 @@ def jnp_logspace(a, b, num):
   return np.power(10., jnp_linspace(a, b, num))
 
 
+def jnp_searchsorted_right(xp, x):
+  """jnp.searchsorted(xp, x, side='right') (default method 'scan').  On a sorted, NaN-free table this is np.searchsorted.  On a
+  NON-monotonic one (the dL table of an unphysical cosmology) the answer of a binary search depends on its probe sequence, so
+  jax's own is followed: ceil(log2(n+1)) steps of ``mid = (low+high)//2; go_left = x < xp[mid] (NaN sorts last);
+  high = mid if go_left else low = mid``, result ``high`` (jax/_src/numpy/lax_numpy.py:_searchsorted_via_scan).  np.searchsorted
+  itself is not usable there: it narrows the window from the previous key when the keys are increasing."""
+  xp = np.asarray(xp, dtype=np.float64)
+  x = np.asarray(x, dtype=np.float64)
+  with np.errstate(all='ignore'):
+    if not (np.any(np.isnan(xp)) or np.any(np.diff(xp) < 0)):
+      return np.searchsorted(xp, x, side='right')
+    n = len(xp)
+    lo = np.zeros(x.shape, dtype=np.int64)
+    hi = np.full(x.shape, n, dtype=np.int64)
+    for _ in range(int(np.ceil(np.log2(n + 1)))):
+      mid = (lo + hi) // 2
+      v = xp[mid]
+      go_left = (x < v) | (np.isnan(v) & ~np.isnan(x))
+      hi = np.where(go_left, mid, hi)
+      lo = np.where(go_left, lo, mid)
+    return hi
+
+
 def jnp_interp(x, xp, fp, left=None, right=None):
   x = np.asarray(x, dtype=np.float64)
-  i = np.clip(np.searchsorted(xp, x, side='right'), 1, len(xp) - 1)
+  i = np.clip(jnp_searchsorted_right(xp, x), 1, len(xp) - 1)
   df = fp[i] - fp[i - 1]
   dx = xp[i] - xp[i - 1]
   delta = x - xp[i - 1]

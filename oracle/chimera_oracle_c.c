@@ -49,9 +49,23 @@ static int ss_right(const double* xp, int n, double x) {
   return lo;
 }
 
-/* jnp.interp(x, xp, fp, left, right); has_lr == 0 -> clamp */
-static double interp1(double x, const double* xp, const double* fp, int n, int has_lr, double left, double right) {
-  int i = ss_right(xp, n, x);
+/* jnp.searchsorted(..., side='right', method='scan') step by step (jax/_src/numpy/lax_numpy.py:_searchsorted_via_scan): the same
+ * answer as ss_right on a sorted table; on a non-monotonic one (dL table of an unphysical cosmology) the probe sequence matters */
+static int ss_right_scan(const double* xp, int n, double x) {
+  int lo = 0, hi = n, levels = 0;
+  while ((1LL << levels) < (long long)n + 1) levels++;
+  for (int l = 0; l < levels; l++) {
+    int mid = (lo + hi) / 2;
+    double v = xp[mid];
+    int go_left = (x < v) || ((v != v) && (x == x));      /* NaN sorts last */
+    if (go_left) hi = mid; else lo = mid;
+  }
+  return hi;
+}
+
+/* jnp.interp(x, xp, fp, left, right); has_lr == 0 -> clamp; scan != 0: the table may be non-monotonic */
+static double interp1s(double x, const double* xp, const double* fp, int n, int has_lr, double left, double right, int scan) {
+  int i = scan ? ss_right_scan(xp, n, x) : ss_right(xp, n, x);
   if (i < 1) i = 1;
   if (i > n - 1) i = n - 1;
   double df = fp[i] - fp[i - 1], dx = xp[i] - xp[i - 1], delta = x - xp[i - 1];
@@ -59,6 +73,9 @@ static double interp1(double x, const double* xp, const double* fp, int n, int h
   if (x < xp[0]) f = has_lr ? left : fp[0];
   if (x > xp[n - 1]) f = has_lr ? right : fp[n - 1];
   return f;
+}
+static double interp1(double x, const double* xp, const double* fp, int n, int has_lr, double left, double right) {
+  return interp1s(x, xp, fp, n, has_lr, left, right, 0);
 }
 
 /* ------------------------------------------------------------------------------------------------------
@@ -70,6 +87,7 @@ typedef struct {
   double *zt, *It, *dLt, *mg, *cdf;
   double H0, Om0, Ok0, Or0, w0, wa, Xi0, n_mg, Ode0, dH;
   double norm_p_m1, fR;
+  int dl_unsorted;                 /* the dL table is non-monotonic or holds NaNs: z_from_dGW follows jax's scan search */
 } orc_model;
 
 /* cosmo.py:122-130 */
@@ -231,6 +249,7 @@ static int model_init(orc_model* m, const chm_params* p) {
   }
   cumtrapz(tmp, m->zt, m->It, Tc);
   for (int i = 0; i < Tc; i++) m->dLt[i] = dL_at_z(m, m->zt[i]);
+  for (int i = 0; i < Tc; i++) if (m->dLt[i] != m->dLt[i] || (i > 0 && m->dLt[i] < m->dLt[i - 1])) m->dl_unsorted = 1;
   double l0 = log10(p->mass[0]), l1 = log10(p->mass[1]);
   for (int i = 0; i < Tm; i++) { m->mg[i] = pow(10., lin_at(l0, l1, Tm, i)); tmp[i] = secondary_notnorm(p, m->mg[i], p->mass[1]); }
   cumtrapz(tmp, m->mg, m->cdf, Tm);
@@ -316,7 +335,7 @@ static double event_numlike(const orc_model* m, const orc_like* L, int ev, doubl
   /* get_theta_src_and_weights, pop_wrapper.py:67-80 */
   double sw = 0., sw2 = 0.;
   for (int s = 0; s < S; s++) {
-    double zz = interp1(L->dL[eo + s], m->dLt, m->zt, m->Tc, 0, 0., 0.);           /* z_from_dGW, cosmo.py:260-264 */
+    double zz = interp1s(L->dL[eo + s], m->dLt, m->zt, m->Tc, 0, 0., 0., m->dl_unsorted);           /* z_from_dGW, cosmo.py:260-264 */
     double m1 = L->m1det[eo + s] / (1. + zz), m2 = L->m2det[eo + s] / (1. + zz);
     z[s] = zz;
     w[s] = p_m1m2(m, m1, m2) / L->pe_prior[eo + s];
@@ -432,7 +451,7 @@ static double event_numlike_1d(const orc_model* m, const orc_like* L, int gauss,
   const size_t eo = (size_t)ev * S;
   double sw = 0., sw2 = 0.;
   for (int s = 0; s < S; s++) {                                                     /* pop_wrapper.py:67-80 */
-    double zz = interp1(L->dL[eo + s], m->dLt, m->zt, m->Tc, 0, 0., 0.);
+    double zz = interp1s(L->dL[eo + s], m->dLt, m->zt, m->Tc, 0, 0., 0., m->dl_unsorted);
     z[s] = zz;
     w[s] = p_m1m2(m, L->m1det[eo + s] / (1. + zz), L->m2det[eo + s] / (1. + zz)) / L->pe_prior[eo + s];
     sw += w[s]; sw2 += w[s] * w[s];
@@ -544,7 +563,7 @@ int orc_nexp(const chm_params* p, long long I, const double* dL, const double* m
 #endif
 #pragma omp parallel for reduction(+ : s1, s2) schedule(static)
   for (long long i = 0; i < I; i++) {
-    double z = interp1(dL[i], m.dLt, m.zt, m.Tc, 0, 0., 0.);
+    double z = interp1s(dL[i], m.dLt, m.zt, m.Tc, 0, 0., 0., m.dl_unsorted);
     double m1 = m1det[i] / (1. + z), m2 = m2det[i] / (1. + z);
     double dCt = dL2dCt(&m, dL[i], z);                               /* original distances */
     double p_z = dVcdz(&m, dCt, z);                                  /* gal_cat.p_bkg       pop_wrapper.py:106 */

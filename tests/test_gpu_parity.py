@@ -8,6 +8,7 @@ import pytest
 
 from tests import helpers as H
 from oracle import chimera_oracle as O
+import chimera_amd as CH
 
 pytestmark = pytest.mark.gpu
 
@@ -538,6 +539,54 @@ def test_unphysical_cosmology_behaves_like_the_reference(kind):
   H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
   np.testing.assert_array_equal(np.isneginf(rp[0]), np.isneginf(ro[0]))
   np.testing.assert_allclose(rp[2], ro[2], rtol=1e-10)
+
+
+@pytest.mark.parametrize('case', [
+  ('approximate', {}, 909250, 'tpl', 'flrw',
+   {'H0': 26.518558671537647, 'Om0': 0.871725516050871, 'gamma': 6.4229324865850135, 'kappa': 3.427411651741881, 'zp': 4.856931881940628,
+    'm_low': 8.351102188184093, 'm_high': 51.295931649573774, 'beta': 0.6654668225932907, 'Ok0': -0.03427301592113163, 'alpha': 8.560190290864174}),
+  ('marginalized', {'cut_grid': None, 'num_bins': 31}, 605202, 'plp', 'mg_flrw',
+   {'H0': 173.0737421847404, 'Om0': 0.27016236329203797, 'gamma': 1.9623967506108637, 'kappa': 6.005486513875636, 'zp': 1.1259641290540021,
+    'm_low': 3.1865187151476166, 'm_high': 69.80316153457956, 'beta': -0.7449746903909409, 'w0': -1.904242589617507, 'wa': 0.19610915312668364,
+    'Xi0': 5.642797377880129, 'n': 3.192431016954092, 'alpha': 8.38535074257262, 'lambda_peak': 0.8860688900006598, 'mu_g': 13.037789838841249,
+    'sigma_g': 11.113989312380001, 'delta_m': 2.1056043915480016})])
+def test_kde_is_an_exact_zero_above_the_last_weighted_bin(case):
+  """A handful of samples carry all the weight, the catalogue term is sizeable only far above them: the dense kernel sum is an exact
+  zero there, and a prefix-sum difference that is off by one ulp of the total (1e-16 of the peak) would decide log L_i (it came
+  out at -48 / -53 against the reference's -112 / -722).  The bin ranges are clipped to the last lane chunk that holds weight.
+  (Found by tests/tools/fuzz_extreme_modes.py.)"""
+  kind, like_kw, seed, mass, cosmo, lam = case
+  cfg, ev, inj = H.small_config(E=6, S=300, P=3, Z=50, I=3000, seed=seed, ragged=True)
+  models = dict(mass=mass, cosmo=cosmo)
+  like_p, _, _ = H.build_product(ev, inj, kind=kind, like_kw=like_kw, models=models)
+  like_o, _, _ = H.build_oracle(ev, inj, kind=kind, like_kw=like_kw, models=models)
+  with np.errstate(all='ignore'):
+    ro, rp = like_o.compute_all(**lam), like_p.compute_all(**lam)
+  assert np.nanmin(ro[0][ro[0] > -1e300]) < -100.                             # the event in question is there
+  H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
+
+
+def test_nan_tail_of_the_distance_table_and_the_scan_search():
+  """An unphysical closed universe whose 1/E turns NaN inside the table: jnp.cumsum carries the NaN only from the first NaN term
+  on, jnp.interp at its own nodes turns dL NaN one node earlier (0/dx * NaN), and searchsorted (method 'scan') on the NaN-tailed
+  table follows its own probe sequence -- N_exp and every event must still agree.  (Found by tests/tools/fuzz_extreme_modes.py.)"""
+  lam = {'H0': 172.90880151995614, 'Om0': 0.03371921860963653, 'gamma': -1.06608079317212, 'kappa': 3.136588508730526, 'zp': 2.6460173899198813,
+         'm_low': 5.780300710566562, 'm_high': 114.15291593846199, 'beta': 5.123153973860013, 'Ok0': -0.2685268289581615, 'alpha': 1.6484774521175334}
+  like_kw = dict(cut_grid=None, num_bins=31)
+  cfg, ev, inj = H.small_config(E=6, S=300, P=3, Z=50, I=3000, seed=231555, ragged=True)
+  models = dict(mass='tpl', cosmo='flrw')
+  like_p, pop_p, sel_p = H.build_product(ev, inj, like_kw=like_kw, models=models)
+  like_o, pop_o, sel_o = H.build_oracle(ev, inj, like_kw=like_kw, models=models)
+  with np.errstate(all='ignore'):
+    ro, rp = like_o.compute_all(**lam), like_p.compute_all(**lam)
+    co = pop_o.update(**lam).cosmo
+    assert np.isnan(co.integral_invE_interp).any()
+    zo = O.z_from_dGW(co, inj['dL'])
+    zp = CH.cosmo.z_from_dGW(pop_p.update(**lam).cosmo, inj['dL'])
+  np.testing.assert_allclose(zp, zo, rtol=1e-12, atol=0, equal_nan=True)
+  np.testing.assert_allclose(rp[2], ro[2], rtol=1e-10)
+  H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
+  np.testing.assert_array_equal(np.isneginf(rp[0]), np.isneginf(ro[0]))
 
 
 def test_vectorised_call_and_sampler_glue(cfg_pix):
