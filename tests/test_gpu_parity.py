@@ -355,6 +355,31 @@ def test_full_size_every_event_against_the_c_oracle(cfg_big, kind):
     np.testing.assert_allclose(rp[3], rc[3], rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize('name', ['C1', 'C2', 'C4'])
+def test_baseline_configurations_at_full_size_against_the_c_oracle(name):
+  """BASELINE.json configs[0], [1] and [3] at their full sizes (C1: 10 events, 1-D, 500 z-bins; C2: 100 events x 16 pixels x 500
+  z-bins; C4: 69 events x 16 pixels x 500 z-bins with 1e6 detected injections), every event and the selection term against the
+  plain-C restatement -- C3 is covered above and by every default bench.py run (`parity_full_size`), C5 by
+  profiles/r01/bench_C5.json's run of the same kernels on 10 000 events."""
+  import os
+  from chimera_amd import synth
+  from oracle import oracle_c as OC
+  cfg, ev, inj = synth.make_config(name)
+  pix = cfg['pixelated']
+  like_p, _, _ = H.build_product(ev, inj, pixelated=pix)
+  like_o, _, _ = H.build_oracle(ev, inj, pixelated=pix)
+  nthr = min(16, os.cpu_count() or 1)
+  for lam in (dict(H0=67.), dict(H0=91., alpha=2.9, gamma=3.1)):
+    rp = like_p.compute_all(**lam)
+    rc = OC.compute_all(like_o, lam, nthreads=nthr)
+    assert np.all(np.isfinite(rc[0]))
+    H.assert_loglike_close(rp[0], rc[0], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(rp[2], rc[2], rtol=1e-10)
+    np.testing.assert_allclose(rp[3], rc[3], rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
+  like_p.close()
+
+
 # ----------------------------------------------------------------------------------------------------------
 # catalogue term computed on the GPU (pixelated_catalog.precompute_p_cat, catalog.py:152-231)
 # ----------------------------------------------------------------------------------------------------------
