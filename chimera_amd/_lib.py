@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libchimera_hip.so')
+# CHIMERA_LIB: another build of the same library (A/B of kernel variants, scripts/abl.sh); never a fallback
+LIB_PATH = os.environ.get('CHIMERA_LIB') or os.path.join(_HERE, 'lib', 'libchimera_hip.so')
 
 CHM_OK, CHM_E_ARG, CHM_E_HIP, CHM_E_NOMEM, CHM_E_RCCL = 0, -1, -2, -3, -4
 MODE = {'1d': 0, 'approximate': 1, 'marginalized': 2, 'full': 3}

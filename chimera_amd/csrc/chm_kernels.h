@@ -1018,7 +1018,10 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   const double* ww = L.ws_w + so;
   const int s0 = L.seg_off[(size_t)e * (L.P + 1) + pp], s1 = live ? L.seg_off[(size_t)e * (L.P + 1) + pp + 1] : s0;
   const double lo = zmin;
-  constexpr int NR = 256 / SW;                              // samples per lane kept in registers (covers 256 per pixel)
+#ifndef CHM_NRS
+#define CHM_NRS 256
+#endif
+  constexpr int NR = CHM_NRS / SW;                          // samples per lane kept in registers (covers 256 per pixel)
   double zr[NR], wr[NR];
 #pragma unroll
   for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; zr[i] = s < s1 ? wz[s] : lo; wr[i] = s < s1 ? ww[s] : 0.; }
@@ -1047,8 +1050,21 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins
   const int per = (B + SW - 1) / SW;
   const int j0 = sl * per < B ? sl * per : B, j1 = min(j0 + per, B);
+#ifndef CHM_MAXPER
+#define CHM_MAXPER 8
+#endif
+  constexpr int MAXPER = CHM_MAXPER;                        // bins per lane held in registers (8: up to 256 bins at 32 lanes per pixel)
+  const bool small = per <= MAXPER;
+  double wv[MAXPER];
   double s0w = 0., s1w = 0., s2w = 0., sq = 0.;
-  for (int j = j0; j < j1; j++) { double w = Q[3 * j], cc = ((double)j + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
+  if (small) {                                              // the lane's bin counts: all loads in flight at once, summed in bin order
+#pragma unroll
+    for (int i = 0; i < MAXPER; i++) wv[i] = (j0 + i < j1) ? Q[3 * (j0 + i)] : 0.;
+#pragma unroll
+    for (int i = 0; i < MAXPER; i++) { double w = wv[i], cc = ((double)(j0 + i) + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
+  } else {
+    for (int j = j0; j < j1; j++) { double w = Q[3 * j], cc = ((double)j + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
+  }
   const double x0 = sg_scan_add<SW>(s0w), x1 = sg_scan_add<SW>(s1w), x2 = sg_scan_add<SW>(s2w);
   const double tot = sg_last<SW>(x0, sub);
   const double sum2 = sg_last<SW>(sg_scan_add<SW>(sq), sub);
@@ -1065,13 +1081,6 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   }
   {
     double r0 = x0 - s0w, r1 = x1 - s1w, r2 = x2 - s2w;
-    constexpr int MAXPER = 16;
-    double wv[MAXPER];
-    const bool small = per <= MAXPER;
-    if (small) {
-#pragma unroll
-      for (int i = 0; i < MAXPER; i++) wv[i] = (j0 + i < j1) ? Q[3 * (j0 + i)] : 0.;
-    }
     wave_sync();
     if (small) {
 #pragma unroll

@@ -7,8 +7,9 @@ from tests import helpers as H
 from oracle import chimera_oracle as O
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-targets = [float(x) for x in os.environ['DIAG_H0'].split(',')]
-rng = np.random.default_rng(4242)
+targets = [float(x) for x in os.environ["DIAG_H0"].split(",")]
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 4242
+rng = np.random.default_rng(SEED)
 found = []
 for kind, like_kw in [(None, {}), (None, dict(kernel='gauss', binning=False)), ('approximate', {}), ('approximate', dict(kernel='gauss', cut_grid=None)),
                       ('full', {}), ('marginalized', dict(binning=False)), ('marginalized', dict(cut_grid=None, num_bins=31))]:

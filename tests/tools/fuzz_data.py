@@ -6,7 +6,7 @@ import numpy as np
 from tests import helpers as H
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-rng = np.random.default_rng(31337)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31337)
 bad = 0
 for it in range(n):
   pixelated = rng.random() < 0.8

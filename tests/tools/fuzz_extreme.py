@@ -6,7 +6,7 @@ from tests import helpers as H
 from oracle import oracle_c as OC
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-rng = np.random.default_rng(2025)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2025)
 cfg, ev, inj = H.small_config(E=16, S=512, P=5, Z=120, I=8000, seed=77, ragged=True)
 bad = 0
 nfinite = 0

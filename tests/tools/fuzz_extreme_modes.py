@@ -5,7 +5,7 @@ import numpy as np
 from tests import helpers as H
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(4242)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 4242)
 bad = tot = 0
 for kind, like_kw in [(None, {}), (None, dict(kernel='gauss', binning=False)), ('approximate', {}), ('approximate', dict(kernel='gauss', cut_grid=None)),
                       ('full', {}), ('marginalized', dict(binning=False)), ('marginalized', dict(cut_grid=None, num_bins=31))]:
