@@ -18,7 +18,7 @@ NCOSMO, NMASS, NRATE = 8, 8, 4
 
 # function ids of chm_model_eval
 (F_E, F_INT_INVE, F_DCR, F_DCT, F_DL, F_DDLDZ, F_DVCDZ, F_VC, F_XI, F_Z_FROM_DGW, F_RATE, F_PM1M2, F_PRIMARY,
- F_SECONDARY, F_SMOOTHING, F_PM1M2_FUSED) = range(16)
+ F_SECONDARY, F_SMOOTHING, F_PM1M2_FUSED, F_TPL_CDF, F_GAUSSIAN, F_TRUNC_GAUSSIAN) = range(19)
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)
@@ -69,7 +69,8 @@ class chm_tab(C.Structure):
 SYMBOLS = ['chm_version', 'chm_device_count', 'chm_last_error', 'chm_like_create', 'chm_like_destroy',
            'chm_sel_create', 'chm_sel_destroy', 'chm_eval', 'chm_eval_tabulated', 'chm_model_eval', 'chm_model_tables',
            'chm_comm_unique_id', 'chm_comm_init_rank', 'chm_comm_destroy', 'chm_comm_allreduce_sum',
-           'chm_last_timing', 'chm_pcat_compute', 'chm_kde2d_pixels']
+           'chm_last_timing', 'chm_pcat_compute', 'chm_kde2d_pixels',
+           'chm_kde1d', 'chm_binning1d', 'chm_gkde_nd', 'chm_trapz', 'chm_cumtrapz']
 
 _lib = None
 
@@ -102,6 +103,12 @@ def lib():
   L.chm_last_timing.argtypes = [vp, vp, c_dp]
   L.chm_pcat_compute.argtypes = [C.POINTER(chm_params), C.POINTER(chm_pcat_desc), c_dp]
   L.chm_kde2d_pixels.argtypes = [C.c_int32, C.c_int32, C.c_int32, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, C.c_int32]
+  i32, i64, f64 = C.c_int32, C.c_int64, C.c_double
+  L.chm_kde1d.argtypes = [c_dp, c_dp, i64, c_dp, i64, i32, i32, f64, c_dp, i32]
+  L.chm_binning1d.argtypes = [c_dp, c_dp, i64, i32, c_dp, c_dp, i32]
+  L.chm_gkde_nd.argtypes = [c_dp, c_dp, i32, i64, c_dp, i64, i32, f64, c_dp, i32]
+  L.chm_trapz.argtypes = [c_dp, c_dp, i64, i32, i32, c_dp, i32]
+  L.chm_cumtrapz.argtypes = [c_dp, c_dp, i32, c_dp, i32]
   for name in SYMBOLS:
     if name not in ('chm_version', 'chm_last_error'):
       getattr(L, name).restype = C.c_int

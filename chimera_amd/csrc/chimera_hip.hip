@@ -719,7 +719,7 @@ static int with_tables(const chm_params* p, int device, Ctx& c) {
 extern "C" int chm_model_eval(const chm_params* p, int32_t func, const double* a, const double* b, int64_t n,
                               double* out, int32_t device) {
   if (!a || !out || n < 0) return fail(CHM_E_ARG, "chm_model_eval: null argument");
-  if (func < 0 || func > CHM_F_PM1M2_FUSED) return fail(CHM_E_ARG, "chm_model_eval: unknown function id");
+  if (func < 0 || func > CHM_F_TRUNC_GAUSSIAN) return fail(CHM_E_ARG, "chm_model_eval: unknown function id");
   if ((func == CHM_F_PM1M2 || func == CHM_F_SECONDARY || func == CHM_F_PM1M2_FUSED) && !b) return fail(CHM_E_ARG, "chm_model_eval: function needs two inputs");
   if (n == 0) return CHM_OK;
   Ctx c;
@@ -809,6 +809,103 @@ extern "C" int chm_pcat_compute(const chm_params* cosmo, const chm_pcat_desc* d,
   if (he != hipSuccess) return fail(CHM_E_HIP, std::string("chm_pcat_compute: ") + hipGetErrorString(he));
   return CHM_OK;
 }
+
+// ---- stand-alone forms of CHIMERA/utils/math.py (host arrays in, host arrays out; one call = one array) ----
+namespace {
+struct DevScope {                                             // device buffers of one call, freed when it returns
+  std::vector<void*> owned;
+  ~DevScope() { for (void* q : owned) (void)hipFree(q); }
+  template <class T> int up(const T* host, size_t n, const T** dev) { return upload(owned, host, n, dev, (hipStream_t)0); }
+  int alloc(double** dev, size_t n) {
+    *dev = nullptr;
+    HIPCHK(hipMalloc(dev, sizeof(double) * (n ? n : 1)));
+    owned.push_back(*dev);
+    return CHM_OK;
+  }
+};
+int math_device(const char* who, int32_t device) {
+  int ndev = chm_device_count();
+  if (device < 0 || device >= ndev) return fail(CHM_E_HIP, std::string(who) + ": no such HIP device (is a GPU visible?)");
+  HIPCHK(hipSetDevice(device));
+  return CHM_OK;
+}
+}  // namespace
+#define MCK(x) do { int _r = (x); if (_r) return _r; } while (0)
+
+extern "C" int chm_kde1d(const double* dataset, const double* weights, int64_t N, const double* grid, int64_t G, int32_t kernel,
+                         int32_t bw_method, double bw_scalar, double* out, int32_t device) {
+  if (!dataset || !grid || !out || N <= 0 || G <= 0 || kernel < 0 || kernel > 1 || bw_method < 0 || bw_method > 2)
+    return fail(CHM_E_ARG, "chm_kde1d: need dataset (N > 0), grid (G > 0), out, kernel in {0,1}, bw_method in {0,1,2}");
+  MCK(math_device("chm_kde1d", device));
+  DevScope sc;
+  const double *d_x = nullptr, *d_w = nullptr, *d_g = nullptr; double *d_st = nullptr, *d_o = nullptr;
+  MCK(sc.up(dataset, (size_t)N, &d_x)); MCK(sc.up(weights, weights ? (size_t)N : 0, &d_w)); MCK(sc.up(grid, (size_t)G, &d_g));
+  MCK(sc.alloc(&d_st, 2)); MCK(sc.alloc(&d_o, (size_t)G));
+  hipLaunchKernelGGL(k_math_kde1d_setup, dim3(1), dim3(1024), 0, (hipStream_t)0, d_x, d_w, (long long)N, bw_method, bw_scalar, d_st);
+  hipLaunchKernelGGL(k_math_kde1d_eval, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, (hipStream_t)0, d_x, d_w, (long long)N, d_g, (long long)G,
+                     kernel == 0 ? 1 : 0, (const double*)d_st, d_o);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, d_o, sizeof(double) * (size_t)G, hipMemcpyDeviceToHost));
+  return CHM_OK;
+}
+
+extern "C" int chm_binning1d(const double* dataset, const double* weights, int64_t N, int32_t num_bins, double* centers, double* counts,
+                             int32_t device) {
+  if (!dataset || !weights || !centers || !counts || N <= 0 || num_bins <= 0)
+    return fail(CHM_E_ARG, "chm_binning1d: need dataset, weights (N > 0), num_bins > 0, centers, counts");
+  MCK(math_device("chm_binning1d", device));
+  DevScope sc;
+  const double *d_x = nullptr, *d_w = nullptr; double *d_c = nullptr, *d_n = nullptr;
+  MCK(sc.up(dataset, (size_t)N, &d_x)); MCK(sc.up(weights, (size_t)N, &d_w));
+  MCK(sc.alloc(&d_c, (size_t)num_bins)); MCK(sc.alloc(&d_n, (size_t)num_bins));
+  hipLaunchKernelGGL(k_math_binning1d, dim3(1), dim3(64), 0, (hipStream_t)0, d_x, d_w, (long long)N, (int)num_bins, d_c, d_n);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(centers, d_c, sizeof(double) * (size_t)num_bins, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(counts, d_n, sizeof(double) * (size_t)num_bins, hipMemcpyDeviceToHost));
+  return CHM_OK;
+}
+
+extern "C" int chm_gkde_nd(const double* dataset, const double* weights, int32_t d, int64_t N, const double* points, int64_t M,
+                           int32_t bw_method, double bw_scalar, double* out, int32_t device) {
+  if (!dataset || !points || !out || d <= 0 || d > CHM_GKDE_MAXD || N <= 1 || M <= 0 || bw_method < 0 || bw_method > 2)
+    return fail(CHM_E_ARG, "chm_gkde_nd: need dataset (d in 1..4, N > 1), points (M > 0), out, bw_method in {0,1,2}");
+  MCK(math_device("chm_gkde_nd", device));
+  DevScope sc;
+  const double *d_x = nullptr, *d_w = nullptr, *d_p = nullptr; double *d_st = nullptr, *d_o = nullptr;
+  MCK(sc.up(dataset, (size_t)d * N, &d_x)); MCK(sc.up(weights, weights ? (size_t)N : 0, &d_w)); MCK(sc.up(points, (size_t)d * M, &d_p));
+  MCK(sc.alloc(&d_st, 2 + CHM_GKDE_MAXD * CHM_GKDE_MAXD)); MCK(sc.alloc(&d_o, (size_t)M));
+  hipLaunchKernelGGL(k_math_gkde_setup, dim3(1), dim3(1024), 0, (hipStream_t)0, d_x, d_w, (int)d, (long long)N, bw_method, bw_scalar, d_st);
+  hipLaunchKernelGGL(k_math_gkde_eval, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)0, d_x, d_w, (int)d, (long long)N, d_p,
+                     (long long)M, (const double*)d_st, d_o);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, d_o, sizeof(double) * (size_t)M, hipMemcpyDeviceToHost));
+  return CHM_OK;
+}
+
+extern "C" int chm_trapz(const double* y, const double* x, int64_t rows, int32_t n, int32_t x_per_row, double* out, int32_t device) {
+  if (!y || !x || !out || rows <= 0 || n <= 0) return fail(CHM_E_ARG, "chm_trapz: need y (rows x n), x, out, rows > 0, n > 0");
+  MCK(math_device("chm_trapz", device));
+  DevScope sc;
+  const double *d_y = nullptr, *d_x = nullptr; double* d_o = nullptr;
+  MCK(sc.up(y, (size_t)rows * n, &d_y)); MCK(sc.up(x, x_per_row ? (size_t)rows * n : (size_t)n, &d_x)); MCK(sc.alloc(&d_o, (size_t)rows));
+  hipLaunchKernelGGL(k_math_trapz, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)0, d_y, d_x, (long long)rows, (int)n, (int)x_per_row, d_o);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, d_o, sizeof(double) * (size_t)rows, hipMemcpyDeviceToHost));
+  return CHM_OK;
+}
+
+extern "C" int chm_cumtrapz(const double* y, const double* x, int32_t n, double* out, int32_t device) {
+  if (!y || !x || !out || n <= 0) return fail(CHM_E_ARG, "chm_cumtrapz: need y, x, out, n > 0");
+  MCK(math_device("chm_cumtrapz", device));
+  DevScope sc;
+  const double *d_y = nullptr, *d_x = nullptr; double* d_o = nullptr;
+  MCK(sc.up(y, (size_t)n, &d_y)); MCK(sc.up(x, (size_t)n, &d_x)); MCK(sc.alloc(&d_o, (size_t)n));
+  hipLaunchKernelGGL(k_math_cumtrapz, dim3(1), dim3(1024), 0, (hipStream_t)0, d_y, d_x, (int)n, d_o);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(out, d_o, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+  return CHM_OK;
+}
+#undef MCK
 
 extern "C" int chm_kde2d_pixels(int32_t E, int32_t S, int32_t P, const double* ra, const double* dec, const double* ra_pix,
                                 const double* dec_pix, const int32_t* npix, double* out, int32_t device) {

@@ -1853,7 +1853,196 @@ __global__ void __launch_bounds__(256) k_model_eval(const DevParams* params, Tab
       case 13: r = secondary_notnorm(P, x, bb[i]); break;
       case 14: r = smoothing(x, mass_delta_m(P), P.m[0]); break;
       case 15: r = p_m1m2_fused(P, x, bb[i], chm_log(x), chm_log(bb[i]), g.mg, g.cdf); break;   // the hot loops' form of case 11
+      case 16: r = tpl_cdf(-P.m[2], P.m[0], x); break;                                          // tpl_cdf(alpha, m_low, m): a tpl struct carries (-alpha, m_low)
+      case 17: { double mu = P.m[6], sg = P.m[7];                                                 // gaussian(x, mu, sigma): a plp struct carries (mu_g, sigma_g)   mass.py:267-269
+                 r = exp((-0.5 * log(2. * CHM_PI) - log(sg)) - (x - mu) * (x - mu) / (2. * sg * sg)); } break;
+      case 18: { double mu = P.m[6], sg = P.m[7], x_min = P.m[0], x_max = P.m[1];                 // truncated_gaussian(x, mu, sigma, x_min = m_low, x_max = m_high)   mass.py:271-279
+                 double norm = 0.5 * erf((x_max - mu) / (sg * sqrt(2.))) - 0.5 * erf((x_min - mu) / (sg * sqrt(2.)));
+                 double G = exp((-0.5 * log(2. * CHM_PI) - log(sg)) - (x - mu) * (x - mu) / (2. * sg * sg));
+                 r = (x_min <= x && x <= x_max) ? G / norm : 0.; } break;
     }
     out[i] = r;
   }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Stand-alone forms of CHIMERA/utils/math.py (the building blocks the kernels above fuse), one call = one array:
+// chm_kde1d, chm_binning1d, chm_gkde_nd, chm_trapz, chm_cumtrapz.  Dense sums in the reference's order of operations.
+// ------------------------------------------------------------------------------------------------------
+// kde1d set-up (math.py:58-73), one block: st[0] = sum(w) (1 when weights are absent: W = 1/N), st[1] = bandwidth
+__global__ void __launch_bounds__(1024) k_math_kde1d_setup(const double* data, const double* wgt, long long N, int bw_method, double bw_scalar,
+                                                            double* st) {
+  __shared__ double red[16];
+  const int t = threadIdx.x, nt = blockDim.x;
+  double a = 0.;
+  for (long long j = t; j < N; j += nt) a += wgt ? wgt[j] : 1.;
+  const double tot = wgt ? block_reduce<RED_SUM>(a, red) : (double)N;            // weights / sum(weights)  |  ones / size
+  a = 0.;
+  double c = 0.;
+  for (long long j = t; j < N; j += nt) { double W = (wgt ? wgt[j] : 1.) / tot; a += W * W; c += data[j]; }
+  const double neff = 1.0 / block_reduce<RED_SUM>(a, red);
+  const double mean = block_reduce<RED_SUM>(c, red) / (double)N;
+  a = 0.;
+  for (long long j = t; j < N; j += nt) { double d = data[j] - mean; a += d * d; }
+  const double sd = sqrt(block_reduce<RED_SUM>(a, red) / (double)N);            // jnp.std: two-pass, ddof = 0
+  if (t == 0) { st[0] = tot; st[1] = kde_bandwidth_factor(bw_method, bw_scalar, neff, 1) * sd; }
+}
+
+// density[i] = sum_j W_j K((grid_i - x_j)/h) / h (math.py:77-81); one thread per grid point, the dataset through LDS tiles
+__global__ void __launch_bounds__(256) k_math_kde1d_eval(const double* data, const double* wgt, long long N, const double* grid, long long G,
+                                                          int epan, const double* st, double* out) {
+  __shared__ double xs[512], ws[512];
+  const int t = threadIdx.x;
+  const long long i = (long long)blockIdx.x * blockDim.x + t;
+  const double tot = st[0], bw = st[1];
+  const double g = i < G ? grid[i] : 0.;
+  const double isq = 1. / sqrt(2. * CHM_PI);
+  double acc = 0.;
+  for (long long j0 = 0; j0 < N; j0 += 512) {
+    const int m = (int)((N - j0) < 512 ? (N - j0) : 512);
+    __syncthreads();
+    for (int j = t; j < m; j += blockDim.x) { xs[j] = data[j0 + j]; ws[j] = (wgt ? wgt[j0 + j] : 1.) / tot; }
+    __syncthreads();
+    for (int j = 0; j < m; j++) {
+      double u = (g - xs[j]) / bw;
+      double kv = epan ? (fabs(u) <= 1. ? 0.75 * (1. - u * u) : 0.) : exp(-0.5 * (u * u)) * isq;      // math.py:83-89
+      acc += ws[j] * kv;
+    }
+  }
+  if (i < G) out[i] = acc / bw;
+}
+
+// binning1d (math.py:32-46), ONE wave (deterministic accumulation order): centres[B], counts[B]; the histogram lives in `counts`
+__global__ void __launch_bounds__(64) k_math_binning1d(const double* data, const double* wgt, long long N, int B, double* centres, double* counts) {
+  const int lane = threadIdx.x;
+  double mn = __builtin_inf(), mx = -__builtin_inf();
+  bool sawnan = false;
+  for (long long j = lane; j < N; j += 64) { double v = data[j]; mn = __builtin_fmin(mn, v); mx = __builtin_fmax(mx, v); sawnan = sawnan || (v != v); }
+  mn = wave_min_dpp(mn); mx = wave_max_dpp(mx);
+  if (__ballot(sawnan)) { mn = __builtin_nan(""); mx = mn; }                                            // jnp.min / jnp.max propagate NaN
+  for (int j = lane; j < B; j += 64) {
+    double e0 = jnp_linspace_at(mn, mx, B + 1, j), e1 = jnp_linspace_at(mn, mx, B + 1, j + 1);
+    centres[j] = (e0 + e1) / 2.;
+    counts[j] = 0.;
+  }
+  __threadfence_block();
+  __builtin_amdgcn_wave_barrier();
+  // lanes take turns on colliding bins in lane order: one sample per lane per pass, lane by lane within a pass
+  for (long long j0 = 0; j0 < N; j0 += 64) {
+    const long long j = j0 + lane;
+    const int idx = j < N ? bin_index(data[j], mn, mx, B) : -1;
+    const double w = j < N ? wgt[j] : 0.;
+    for (int l = 0; l < 64; l++) {
+      if (l == lane && idx >= 0) counts[idx] += w;
+      __threadfence_block();
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// gkde_nd set-up (math.py:111-135), one block, d <= CHM_GKDE_MAXD: st = [sum w, log_norm, L (d x d, row-major lower Cholesky factor of inv_cov)]
+#define CHM_GKDE_MAXD 4
+__global__ void __launch_bounds__(1024) k_math_gkde_setup(const double* data /* (d,N) */, const double* wgt, int d, long long N, int bw_method,
+                                                           double bw_scalar, double* st) {
+  __shared__ double red[16];
+  __shared__ double mean[CHM_GKDE_MAXD];
+  __shared__ double cov[CHM_GKDE_MAXD * CHM_GKDE_MAXD];
+  const int t = threadIdx.x, nt = blockDim.x;
+  double a = 0.;
+  for (long long j = t; j < N; j += nt) a += wgt ? wgt[j] : 1.;
+  const double tot = wgt ? block_reduce<RED_SUM>(a, red) : (double)N;
+  a = 0.;
+  for (long long j = t; j < N; j += nt) { double W = (wgt ? wgt[j] : 1.) / tot; a += W * W; }
+  const double sw2 = block_reduce<RED_SUM>(a, red);
+  for (int k = 0; k < d; k++) {
+    a = 0.;
+    for (long long j = t; j < N; j += nt) a += ((wgt ? wgt[j] : 1.) / tot) * data[(size_t)k * N + j];
+    a = block_reduce<RED_SUM>(a, red);
+    if (t == 0) mean[k] = a;
+  }
+  __syncthreads();
+  for (int k = 0; k < d; k++) for (int l = 0; l <= k; l++) {
+    a = 0.;
+    for (long long j = t; j < N; j += nt) {
+      double W = (wgt ? wgt[j] : 1.) / tot;
+      a += ((data[(size_t)k * N + j] - mean[k]) * W) * (data[(size_t)l * N + j] - mean[l]);
+    }
+    a = block_reduce<RED_SUM>(a, red);
+    if (t == 0) { cov[k * d + l] = a / (1. - sw2); cov[l * d + k] = cov[k * d + l]; }                // math.py:127-128
+  }
+  __syncthreads();
+  if (t == 0) {
+    const double neff = 1. / sw2;
+    const double factor = kde_bandwidth_factor(bw_method, bw_scalar, neff, d);                         // math.py:116-123
+    // inverse by Gauss-Jordan with partial pivoting (np.linalg.inv), then inv_cov = inv / factor^2
+    double A[CHM_GKDE_MAXD][2 * CHM_GKDE_MAXD];
+    for (int r = 0; r < d; r++) for (int c2 = 0; c2 < d; c2++) { A[r][c2] = cov[r * d + c2]; A[r][d + c2] = r == c2 ? 1. : 0.; }
+    for (int c2 = 0; c2 < d; c2++) {
+      int piv = c2;
+      for (int r = c2 + 1; r < d; r++) if (fabs(A[r][c2]) > fabs(A[piv][c2])) piv = r;
+      if (piv != c2) for (int k = 0; k < 2 * d; k++) { double tmp = A[c2][k]; A[c2][k] = A[piv][k]; A[piv][k] = tmp; }
+      const double pv = A[c2][c2];
+      for (int k = 0; k < 2 * d; k++) A[c2][k] /= pv;
+      for (int r = 0; r < d; r++) if (r != c2) { const double f = A[r][c2]; for (int k = 0; k < 2 * d; k++) A[r][k] -= f * A[c2][k]; }
+    }
+    double ic[CHM_GKDE_MAXD][CHM_GKDE_MAXD], Lm[CHM_GKDE_MAXD][CHM_GKDE_MAXD];
+    for (int r = 0; r < d; r++) for (int c2 = 0; c2 < d; c2++) { ic[r][c2] = A[r][d + c2] / (factor * factor); Lm[r][c2] = 0.; }
+    for (int r = 0; r < d; r++) for (int c2 = 0; c2 <= r; c2++) {                                       // lower Cholesky factor (math.py:132)
+      double s = ic[r][c2];
+      for (int k = 0; k < c2; k++) s -= Lm[r][k] * Lm[c2][k];
+      Lm[r][c2] = r == c2 ? sqrt(s) : s / Lm[c2][c2];
+    }
+    double ln = 0.;
+    for (int r = 0; r < d; r++) ln += log(Lm[r][r]);
+    st[0] = tot; st[1] = ln - 0.5 * (double)d * log(2. * CHM_PI);                                     // math.py:135
+    for (int r = 0; r < d; r++) for (int c2 = 0; c2 < d; c2++) st[2 + r * d + c2] = Lm[r][c2];
+  }
+}
+
+// out[i] = sum_j W_j exp(log_norm - 1/2 |x_j L - p_i L|^2) (math.py:133-147); one thread per point, the dataset through LDS tiles
+__global__ void __launch_bounds__(256) k_math_gkde_eval(const double* data, const double* wgt, int d, long long N, const double* pts /* (d,M) */,
+                                                         long long M, const double* st, double* out) {
+  __shared__ double xs[CHM_GKDE_MAXD][256], ws[256];
+  __shared__ double Ls[CHM_GKDE_MAXD * CHM_GKDE_MAXD];
+  const int t = threadIdx.x;
+  if (t < d * d) Ls[t] = st[2 + t];
+  __syncthreads();
+  const long long i = (long long)blockIdx.x * blockDim.x + t;
+  const double tot = st[0], log_norm = st[1];
+  double q[CHM_GKDE_MAXD];
+  for (int c = 0; c < d; c++) { double s = 0.; for (int k = 0; k < d; k++) s += (i < M ? pts[(size_t)k * M + i] : 0.) * Ls[k * d + c]; q[c] = s; }      // points.T @ L
+  double acc = 0.;
+  for (long long j0 = 0; j0 < N; j0 += 256) {
+    const int m = (int)((N - j0) < 256 ? (N - j0) : 256);
+    __syncthreads();
+    if (t < m) {
+      for (int c = 0; c < d; c++) { double s = 0.; for (int k = 0; k < d; k++) s += data[(size_t)k * N + j0 + t] * Ls[k * d + c]; xs[c][t] = s; }     // dataset.T @ L
+      ws[t] = (wgt ? wgt[j0 + t] : 1.) / tot;
+    }
+    __syncthreads();
+    for (int j = 0; j < m; j++) {
+      double r2 = 0.;
+      for (int c = 0; c < d; c++) { double dd = xs[c][j] - q[c]; r2 += dd * dd; }
+      acc += ws[j] * exp(log_norm - 0.5 * r2);
+    }
+  }
+  if (i < M) out[i] = acc;
+}
+
+// jnp.trapezoid(y, x, axis=-1) of `rows` rows of n points (x: one shared row or one per row), a wave per row; cumtrapz (math.py:22-26) of
+// one row by one block
+__global__ void __launch_bounds__(256) k_math_trapz(const double* y, const double* x, long long rows, int n, int x_per_row, double* out) {
+  const int lane = threadIdx.x & 63;
+  const long long r = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const double* yy = y + (size_t)r * n;
+  const double* xx = x + (x_per_row ? (size_t)r * n : 0);
+  double acc = 0.;
+  for (int k = lane; k < n - 1; k += 64) acc += (xx[k + 1] - xx[k]) * (yy[k + 1] + yy[k]);
+  acc = wave_sum(acc);
+  if (lane == 0) out[r] = 0.5 * acc;
+}
+__global__ void __launch_bounds__(1024) k_math_cumtrapz(const double* y, const double* x, int n, double* out) {
+  __shared__ double sh[32];
+  block_cumtrapz(y, x, out, n, sh);
 }

@@ -71,6 +71,26 @@ def secondary_mass_conditioned_pdf_notnorm(mass, m2, m1):
   return model_eval(make_params(mass=mass), _lib.F_SECONDARY, m2, m1)
 
 
+def tpl_notnorm(m, alpha, m_low, m_high):
+  """mass.py:240-245: m**alpha inside [m_low, m_high], 0 outside."""
+  return model_eval(make_params(mass=tpl(alpha=-alpha, m_low=m_low, m_high=m_high)), _lib.F_PRIMARY, m)
+
+
+def tpl_cdf(alpha, m_low, m):
+  """mass.py:247-252."""
+  return model_eval(make_params(mass=tpl(alpha=-alpha, m_low=m_low, m_high=max(2. * m_low, m_low + 1.))), _lib.F_TPL_CDF, m)
+
+
+def gaussian(x, mu, sigma):
+  """mass.py:267-269."""
+  return model_eval(make_params(mass=plp(mu_g=mu, sigma_g=sigma)), _lib.F_GAUSSIAN, x)
+
+
+def truncated_gaussian(x, mu, sigma, x_min, x_max):
+  """mass.py:271-279."""
+  return model_eval(make_params(mass=plp(mu_g=mu, sigma_g=sigma, m_low=x_min, m_high=x_max)), _lib.F_TRUNC_GAUSSIAN, x)
+
+
 def smoothing(m, delta_m, m_low):
   """mass.py:255-264."""
   return model_eval(make_params(mass=plp(delta_m=delta_m, m_low=m_low)), _lib.F_SMOOTHING, m)

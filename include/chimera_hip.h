@@ -174,7 +174,11 @@ int chm_eval_tabulated(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_p
  * used by the Python free functions and by compute_z_grids (pop_wrapper.py:133-208).                  */
 enum { CHM_F_E = 0, CHM_F_INT_INVE, CHM_F_DCR, CHM_F_DCT, CHM_F_DL, CHM_F_DDLDZ, CHM_F_DVCDZ, CHM_F_VC,
        CHM_F_XI, CHM_F_Z_FROM_DGW, CHM_F_RATE, CHM_F_PM1M2, CHM_F_PRIMARY, CHM_F_SECONDARY, CHM_F_SMOOTHING,
-       CHM_F_PM1M2_FUSED /* the reduced-operation form of PM1M2 used inside the per-sample kernels (for tests) */ };
+       CHM_F_PM1M2_FUSED /* the reduced-operation form of PM1M2 used inside the per-sample kernels (for tests) */,
+       /* generic helpers of mass.py, parameters carried by a mass struct: tpl_cdf(alpha, m_low, m) with tpl(alpha = -alpha, m_low)
+        * (mass.py:247-252); gaussian(x, mu, sigma) with plp(mu_g, sigma_g) (:267-269); truncated_gaussian(x, mu, sigma, x_min,
+        * x_max) with plp(mu_g, sigma_g, m_low = x_min, m_high = x_max) (:271-279) */
+       CHM_F_TPL_CDF, CHM_F_GAUSSIAN, CHM_F_TRUNC_GAUSSIAN };
 /* out[i] = f(a[i] [, b[i]]):  cosmology functions take a = z and optional b = original distances
  * (cosmo.py:155-221; b may be NULL); Z_FROM_DGW takes a = dGW; RATE takes a = z; PM1M2 / SECONDARY take
  * a = m1, b = m2 (SECONDARY: a = m2, b = m1); PRIMARY / SMOOTHING take a = m.                           */
@@ -205,6 +209,24 @@ int chm_pcat_compute(const chm_params* cosmo, const chm_pcat_desc* desc, double*
  * ra, dec: (E,S); ra_pix, dec_pix: (E,P) with npix[e] valid entries per event; out: (E,P), entries >= npix[e] untouched.   */
 int chm_kde2d_pixels(int32_t E, int32_t S, int32_t P, const double* ra, const double* dec, const double* ra_pix,
                      const double* dec_pix, const int32_t* npix, double* out, int32_t device);
+
+/* Stand-alone forms of CHIMERA/utils/math.py -- the building blocks chm_eval fuses, for callers that use them directly
+ * (host arrays in, host arrays out, dense sums in the reference's order of operations):
+ *   chm_kde1d      kde1d(dataset, grid, weights, kernel, bw_method)            math.py:52-89   kernel 0 = 'epan', 1 = 'gauss';
+ *                  bw_method 0 = 'scott' / None, 1 = 'silverman', 2 = scalar (bw_scalar);  weights NULL = None
+ *   chm_binning1d  binning1d(dataset, weights, num_bins) -> centres, counts     math.py:32-46
+ *   chm_gkde_nd    jax_gkde_nd / numba_gkde_nd(dataset (d,N), points (d,M), weights, bw_method), in_log=False, d <= 4
+ *                                                                                math.py:95-148, 154-229
+ *   chm_trapz      trapz(y, x, axis=-1) of `rows` rows of n points; x one row (x_per_row = 0) or one per row   math.py:10-16
+ *   chm_cumtrapz   cumtrapz(y, x) of one row                                     math.py:22-26                                  */
+int chm_kde1d(const double* dataset, const double* weights, int64_t N, const double* grid, int64_t G, int32_t kernel,
+              int32_t bw_method, double bw_scalar, double* out, int32_t device);
+int chm_binning1d(const double* dataset, const double* weights, int64_t N, int32_t num_bins, double* centers, double* counts,
+                  int32_t device);
+int chm_gkde_nd(const double* dataset, const double* weights, int32_t d, int64_t N, const double* points, int64_t M,
+                int32_t bw_method, double bw_scalar, double* out, int32_t device);
+int chm_trapz(const double* y, const double* x, int64_t rows, int32_t n, int32_t x_per_row, double* out, int32_t device);
+int chm_cumtrapz(const double* y, const double* x, int32_t n, double* out, int32_t device);
 
 /* Event/injection sharding across GPUs: one process per GPU, RCCL over xGMI.
  * Replaces the MPI layer CHIMERA/parallel.py:94-99,68-73,366-376 (dead code in v2.0.0).               */

@@ -83,6 +83,19 @@ def test_argument_errors_and_missing_gpu(lib):
       like(H0=70.)
     with pytest.raises(RuntimeError):
       sel.N_exp(pop)
+    from chimera_amd.utils import math as M
+    x = np.linspace(0., 1., 50)
+    for call in (lambda: M.kde1d(x, x), lambda: M.binning1d(x, x, 10), lambda: M.gkde_nd(np.vstack([x, x**2]), np.zeros((2, 3))),
+                 lambda: M.trapz(x, x), lambda: M.cumtrapz(x, x), lambda: CH.mass.tpl_cdf(-2., 5., x)):
+      with pytest.raises(RuntimeError):
+        call()
+  from chimera_amd.utils import math as M
+  with pytest.raises(ValueError):
+    M.kde1d(np.ones(4), np.ones(3), bw_method='nope')
+  with pytest.raises(ValueError):
+    M.gkde_nd(np.ones((2, 5)), np.ones((3, 4)))
+  with pytest.raises(ValueError):
+    M.gkde_nd(np.ones((5, 9)), np.ones((5, 4)))                  # d > 4: CHM_E_ARG from the library
 
 
 def test_missing_library_fails_loudly(lib, monkeypatch):
