@@ -614,6 +614,30 @@ def test_nan_tail_of_the_distance_table_and_the_scan_search():
   np.testing.assert_array_equal(np.isneginf(rp[0]), np.isneginf(ro[0]))
 
 
+def test_events_dropping_out_one_by_one_give_the_reference_value_classes():
+  """H0 scanned beyond the range the z grids were built for: events lose their likelihood one by one, and log_num / log_hyper go
+  ordinary -> exactly -1.79769313e+308 (one such event) -> -inf (two or more), the three classes of the reference notebook's
+  `res_H0` (tests/golden/ref_notebook_res_H0.json, tests/test_oracle_pins.py)."""
+  cfg, ev, inj = H.small_config(E=5, S=200, P=3, Z=60, I=3000, seed=21, ragged=True)
+  like_o, _, _ = H.build_oracle(ev, inj)
+  like_p, _, _ = H.build_product(ev, inj)
+  big = -np.finfo(np.float64).max
+  seen = set()
+  for h in np.concatenate([np.linspace(2., 20., 19), np.linspace(200., 900., 15), [70.]]):
+    with np.errstate(all='ignore'):
+      ro, rp = like_o.compute_all(H0=float(h)), like_p.compute_all(H0=float(h))
+    H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
+    np.testing.assert_array_equal(rp[0] == big, ro[0] == big)
+    n_dead = int(np.sum(ro[0] == big))
+    if n_dead == 0:
+      np.testing.assert_allclose(rp[3], ro[3], rtol=0, atol=1e-7 * np.sqrt(cfg['E'])); seen.add('ordinary')
+    elif n_dead == 1:
+      assert rp[1] == big and rp[3] == big and ro[3] == big; seen.add('sentinel')
+    else:
+      assert np.isneginf(rp[1]) and np.isneginf(rp[3]) and np.isneginf(ro[3]); seen.add('-inf')
+  assert seen == {'ordinary', 'sentinel', '-inf'}
+
+
 def test_vectorised_call_and_sampler_glue(cfg_pix):
   from chimera_amd.utils.emcee_utils import generate_dict, make_log_prob
   cfg, ev, inj = cfg_pix

@@ -256,3 +256,42 @@ def test_h0_scan_recovers_the_injected_value():
   H0 = np.linspace(40., 110., 15)
   lp = np.array([like(H0=h) for h in H0])
   assert abs(H0[np.nanargmax(lp)] - 70.) <= 10.
+
+
+def test_value_classes_of_the_reference_notebook_scan():
+  """The one output array of this path the reference ships: `res_H0` of examples/test1dgalaxies.ipynb (cell 14), kept as data in
+  tests/golden/ref_notebook_res_H0.json (its inputs are not in the repository, so the numbers themselves cannot be re-derived).
+  What it pins: a log-hyperlikelihood is either an ordinary finite number, EXACTLY -1.79769313e+308 (one event with L_i = 0:
+  nan_to_num(-inf) absorbed every other term, likelihood.py:296-297) or -inf (two or more such events: the sum overflows) --
+  and the posterior of the scan peaks at the grid point next to the injected H0 = 70.  The oracle must produce the same three
+  classes by the same rule."""
+  import json
+  import os
+  with open(os.path.join(os.path.dirname(__file__), 'golden', 'ref_notebook_res_H0.json')) as f:
+    ref = json.load(f)
+  v = np.array([-np.inf if x == '-inf' else x for x in ref['res_H0']])
+  assert v.size == ref['H0']['num'] == 100
+  big = -np.finfo(np.float64).max
+  with np.errstate(all='ignore'):
+    sentinel, neginf = np.abs(v / big - 1.) < 1e-8, np.isneginf(v)       # printed with 9 digits: -1.79769313e+308
+  ordinary = ~sentinel & ~neginf
+  assert sentinel.sum() == 44 and neginf.sum() == 14 and ordinary.sum() == 42
+  assert np.all(np.abs(v[ordinary]) < 2e3)                                    # nothing in between the classes
+  H0 = np.linspace(ref['H0']['start'], ref['H0']['stop'], ref['H0']['num'])
+  assert abs(H0[np.argmax(np.where(ordinary, v, -np.inf))] - 70.) < 1.         # 70.9
+  # the oracle on mock data, scanned beyond the H0 range its z grids were built for, so that events drop out one by one
+  cfg, ev, inj = H.small_config(E=5, S=200, P=3, Z=60, I=3000, seed=21, ragged=True)
+  like, _, _ = H.build_oracle(ev, inj)
+  seen = set()
+  for h in np.concatenate([np.linspace(2., 20., 19), np.linspace(200., 900., 15), [70.]]):
+    with np.errstate(all='ignore'):
+      ll, log_num, _, log_hyper = like.compute_all(H0=float(h))
+    n_dead = int(np.sum(ll == big))
+    assert np.all((ll == big) | (np.isfinite(ll) & (np.abs(ll) < 1e4)))
+    if n_dead == 0:
+      assert np.isfinite(log_num) and abs(log_num) < 1e5; seen.add('ordinary')
+    elif n_dead == 1:
+      assert log_num == big and log_hyper == big; seen.add('sentinel')
+    else:
+      assert np.isneginf(log_num) and np.isneginf(log_hyper); seen.add('-inf')
+  assert seen == {'ordinary', 'sentinel', '-inf'}
