@@ -147,3 +147,24 @@ def angular_separation_from_LOS(ra, dec, ra_los, dec_los):
   """angles.py:144-160."""
   cos_angle = np.sin(dec) * np.sin(dec_los) + np.cos(dec) * np.cos(dec_los) * np.cos(ra - ra_los)
   return np.arccos(cos_angle)
+
+
+def gal_to_eq(l, b):
+  """angles.py:93-110: equatorial (RA, dec) [rad] from galactic (l, b) [rad], the reference's arctan form."""
+  l, b = np.asarray(l, dtype=np.float64), np.asarray(b, dtype=np.float64)
+  l_NCP, del_NGP, alpha_NGP = np.radians(122.93192), np.radians(27.128336), np.radians(192.859508)
+  RA = np.arctan((np.cos(b) * np.sin(l_NCP - l)) / (np.cos(del_NGP) * np.sin(b) - np.sin(del_NGP) * np.cos(b) * np.cos(l_NCP - l))) + alpha_NGP
+  dec = np.arcsin(np.sin(del_NGP) * np.sin(b) + np.cos(del_NGP) * np.cos(b) * np.cos(l_NCP - l))
+  return RA, dec
+
+
+def convert_pixelization(pixels, nside_in, nside_out, nest_in=False, nest_out=False):
+  """angles.py:163-190: pixel centres of ``pixels`` (rows with their own ``nside_in``) re-indexed at ``nside_out`` (RING only)."""
+  pixels = np.atleast_2d(pixels)
+  nside_in = np.atleast_1d(nside_in)
+  assert pixels.shape[0] == nside_in.shape[0], f"nside_in shape {nside_in.shape} does not match first dimension of pixels {pixels.shape}"
+  results = []
+  for i in range(pixels.shape[0]):
+    theta, phi = pix2ang(int(nside_in[i]), pixels[i], nest=nest_in)
+    results.append(ang2pix(nside_out, theta, phi, nest=nest_out))
+  return np.stack(results)

@@ -65,6 +65,19 @@ def test_angle_helpers():
   assert A.angular_separation_from_LOS(0., 0., np.pi / 2, 0.) == pytest.approx(np.pi / 2)
   groups = A.healpixelize(4, np.array([0.1, 0.1001, 3.0]), np.array([0.2, 0.2001, -1.0]))
   assert sorted(len(v) for v in groups.values()) == [1, 2]
+  # galactic -> equatorial (angles.py:93-110): the north galactic pole, and a point on the galactic equator
+  ra_p, dec_p = A.gal_to_eq(np.radians(122.93192), np.radians(90.))
+  assert np.degrees(ra_p) == pytest.approx(192.859508) and np.degrees(dec_p) == pytest.approx(27.128336)
+  _, dec_e = A.gal_to_eq(np.radians(122.93192), 0.)
+  assert np.degrees(dec_e) == pytest.approx(90. - 27.128336)
+  # re-indexing pixel centres at another resolution (angles.py:163-190): refine then coarsen is the identity, rows keep their nside
+  pix = np.vstack([np.arange(48), np.arange(100, 148)])
+  fine = A.convert_pixelization(pix, [2, 8], 64)
+  assert fine.shape == pix.shape
+  np.testing.assert_array_equal(A.convert_pixelization(fine[:1], [64], 2), pix[:1])
+  np.testing.assert_array_equal(A.convert_pixelization(fine[1:], [64], 8), pix[1:])
+  with pytest.raises(AssertionError):
+    A.convert_pixelization(pix, [2], 64)
 
 
 # ----------------------------------------------------------------------------------------------------------
