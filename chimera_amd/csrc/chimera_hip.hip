@@ -603,7 +603,11 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         if (zf_ranged) { launch_zfactors(); HIPCHK(hipGetLastError()); }
         if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         const bool fast = marg_std;
-        if (fast) hipLaunchKernelGGL(k_kde_marg_sub<32>, dim3(L.E_cnt * ((Pd + 1) / 2) * nb, 1), dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
+        if (fast) {
+          const int PG2 = (Pd + 1) / 2;
+          const dim3 kgrid = (L.E_cnt <= 65535 && PG2 <= 65535) ? dim3(nb, PG2, L.E_cnt) : dim3((unsigned)((size_t)L.E_cnt * PG2 * nb), 1, 1);
+          hipLaunchKernelGGL(k_kde_marg_sub<32>, kgrid, dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
+        }
         else { allow_lds(k_kde_marg, lds_kde); hipLaunchKernelGGL(k_kde_marg, dim3(L.E_cnt * Pd, nb), dim3(64), lds_kde, sg, L, dp); }
       } else {
         if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
@@ -809,6 +813,18 @@ extern "C" int chm_pcat_compute(const chm_params* cosmo, const chm_pcat_desc* d,
   if (he != hipSuccess) return fail(CHM_E_HIP, std::string("chm_pcat_compute: ") + hipGetErrorString(he));
   return CHM_OK;
 }
+
+#ifdef CHM_PHASE_PROF
+// diagnostic builds only: read (and clear) the phase-cycle sums of k_kde_marg_sub
+extern "C" int chm_debug_phase(double out[8]) {
+  unsigned long long h[8];
+  HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase), sizeof(h)));
+  for (int i = 0; i < 8; i++) out[i] = (double)h[i];
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)));
+  return CHM_OK;
+}
+#endif
 
 // ---- stand-alone forms of CHIMERA/utils/math.py (host arrays in, host arrays out; one call = one array) ----
 namespace {

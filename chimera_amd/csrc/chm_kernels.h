@@ -964,16 +964,31 @@ template <int SW> DEVFN double sg_max(double v) {
   return v;
 }
 
+// CHM_PHASE_PROF (diagnostic builds only, scripts/phase_prof.py): shader-clock cycles between phase marks of k_kde_marg_sub, summed over
+// every 64th wave into g_phase[] (g_phase[7] counts the waves)
+#ifdef CHM_PHASE_PROF
+__device__ unsigned long long g_phase[8];
+#define PH_INIT unsigned long long ph_prev = clock64(); const bool ph_on = threadIdx.x == 0 && (blockIdx.x & 63) == 0; if (ph_on) atomicAdd(&g_phase[7], 1ull)
+#define PH(i) do { __builtin_amdgcn_s_waitcnt(0); unsigned long long ph_t = clock64(); if (ph_on) atomicAdd(&g_phase[i], ph_t - ph_prev); ph_prev = clock64(); } while (0)
+#else
+#define PH_INIT
+#define PH(i)
+#endif
+
 template <int SW>
 __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevParams* params) {
 #pragma clang fp contract(fast)                  // a*b+c may fuse in this body; the bin index lives in bin_index_r() (contract off)
   extern __shared__ double lds_all[];
+  PH_INIT;
   constexpr int NPW = 64 / SW;                              // pixels per wave
   constexpr int PF = 4;                                     // p_cat prefetch passes: PF * SW * 2 grid points per pixel
   const int lane = threadIdx.x, sub = lane / SW, sl = lane % SW;
-  const int PG = (L.P + NPW - 1) / NPW;
-  const int b = blockIdx.x % L.nb, bx = blockIdx.x / L.nb;
-  const int p = (bx % PG) * NPW + sub, e = L.e_off + bx / PG;
+  // grid (draws, pixel groups, events) -- draw fastest in dispatch order -- so that a wave does not start with four integer divisions
+  // (no hardware divider: ~40 instructions each); a 1-D grid (more than 65535 events in a group) is decoded the long way
+  int b, pg, ei;
+  if (gridDim.y > 1 || gridDim.z > 1) { b = blockIdx.x; pg = blockIdx.y; ei = blockIdx.z; }
+  else { const int PG = (L.P + NPW - 1) / NPW; const int bx = blockIdx.x / L.nb; b = blockIdx.x % L.nb; pg = bx % PG; ei = bx / PG; }
+  const int p = pg * NPW + sub, e = L.e_off + ei;
   const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
   // LDS slice of this pixel: Q[3 j + c], j = 0..B, c = 0,1,2: prefix sums of (w, w c', w c'^2) interleaved, so that one
   // address serves the three reads of a bin boundary; the bin counts live in the c = 0 slots until the prefix pass
@@ -981,8 +996,11 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
   const double zmin = es[0], norm = es[3], n_eff = es[4], lb = es[6], ub = es[7];
   const bool ok = n_eff >= L.pe_neff;                       // likelihood.py:199 (same for every pixel of the event)
+  // The pixel's sample segment is requested together with the event statistics (one memory round trip before the samples can be
+  // addressed, not two): idle lane groups (odd P, padded pixels) shadow a valid pixel for addressing and never store.
+  const int pp = p < L.P ? p : L.P - 1;
+  const int sq0 = L.seg_off[(size_t)e * (L.P + 1) + pp], sq1 = L.seg_off[(size_t)e * (L.P + 1) + pp + 1];
   const bool live = p < L.P && p < L.neff_pixels[e];        // this lane group has a real pixel
-  const int pp = live ? p : 0;                              // idle groups shadow pixel 0 for addressing, never store
   double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
   double* dump = (L.p_gw_dump && p < L.P) ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
   const double* zg = L.z_grids + (size_t)e * Z;
@@ -991,6 +1009,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
     if (p < L.P) { if (sl == 0) *out_like = (live && poisoned) ? __builtin_nan("") : 0.; if (dump) for (int k = sl; k < Z; k += SW) dump[k] = 0.; }
     if (!ok) return;                                        // uniform over the wave
   }
+  PH(0);                                                    // evstat arrived, guard passed
   const double* pc = L.p_cat + ((size_t)e * L.P + pp) * Z;
   const size_t zo = ((size_t)b * L.E + e) * Z;
   const double* bkgA = L.bkgA + zo;
@@ -1016,7 +1035,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   const size_t so = ((size_t)b * L.E + e) * S;
   const double* wz = L.ws_z + so;
   const double* ww = L.ws_w + so;
-  const int s0 = L.seg_off[(size_t)e * (L.P + 1) + pp], s1 = live ? L.seg_off[(size_t)e * (L.P + 1) + pp + 1] : s0;
+  const int s0 = sq0, s1 = live ? sq1 : sq0;
   const double lo = zmin;
 #ifndef CHM_NRS
 #define CHM_NRS 256
@@ -1038,6 +1057,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
     const unsigned long long mine = SW == 64 ? ~0ull : (((1ull << (SW & 63)) - 1ull) << (sub * SW));
     if (votes & mine) hi = __builtin_nan("");
   }
+  PH(1);                                                    // samples arrived, max z of the pixel known
   for (int j = sl; j < B; j += SW) Q[3 * j] = 0.;
   const double dB = (double)B;
   const double dhl = hi - lo, rhl = 1. / dhl;
@@ -1047,6 +1067,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q[3 * bin_index_r(zr[i], lo, dhl, rhl, dB)], wr[i]); }
   for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q[3 * bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
   wave_sync();
+  PH(2);                                                    // histogram filled
   // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins
   const int per = (B + SW - 1) / SW;
   const int j0 = sl * per < B ? sl * per : B, j1 = min(j0 + per, B);
@@ -1101,6 +1122,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
     if (sl == 0) Q[0] = 0.;
     wave_sync();
   }
+  PH(3);                                                    // prefix sums written
   const double neff_k = (tot * tot) / sum2;
   const double stdc = dhl * L.std_unit;
   const double bw = kde_bandwidth_factor_fast(L.bw_method, L.bw_scalar, neff_k) * stdc;
@@ -1134,6 +1156,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
     double qq = fma(gp, fma(gp, S0, -2. * S1), S2);         // sum W (g' - c')^2 over the support
     return __builtin_fmax(S0 - qq * inv_bw2, 0.);           // a sum of non-negative kernel values (rounding may leave -1e-14 of the peak)
   };
+  PH(4);                                                    // per-pixel constants
   double acc = 0.;
   if (dump && live) { for (int k = sl; k < Z; k += SW) if (k < k_lo || k > k_hi) dump[k] = 0.; }
 #pragma unroll 1
@@ -1172,6 +1195,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
     zc0 = zn0; zc1 = zn1; bc0 = bn0; bc1 = bn1; ac0 = an0; ac1 = an1;
     if (it + 1 >= PF) { pf0[0] = pn0; pf1[0] = pn1; }
   }
+  PH(5);                                                    // grid loop
   acc = sg_scan_add<SW>(acc);                               // the group's last lane holds the pixel's integral
   if (sl == SW - 1 && live) *out_like = poisoned ? nan : acc;
 }
