@@ -251,7 +251,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
   L.mode = d->mode; L.kernel = d->kernel; L.bw_method = d->bw_method; L.binning = d->binning ? 1 : 0; L.num_bins = d->num_bins;
   L.has_cut = std::isnan(d->cut_grid) ? 0 : 1;
   L.G = L.has_cut ? d->Z / 2 : d->Z;                         // likelihood.py:121,188
-  L.NC = (int)((S + SAMPLE_CHUNK - 1) / SAMPLE_CHUNK);
+  L.NC = (int)((S + SAMPLE_CHUNK - 1) / SAMPLE_CHUNK) * SAMPLE_WPB;       // partial records per event: one per chunk and wave of k_samples
   L.bw_scalar = d->bw_scalar; L.cut_grid = d->cut_grid; L.pe_neff = d->pe_neff;
   { const double B = (double)(d->num_bins > 0 ? d->num_bins : 1); L.inv_B = 1. / B; L.std_unit = sqrt((B * B - 1.) / 12.) / B; }   // math.py:67 on uniform centres
   if (L.mode != CHM_MODE_FULL && L.G < 2) { chm_like_destroy(h); return fail(CHM_E_ARG, "chm_like_create: Z//2 must be >= 2 when cut_grid is set"); }
@@ -566,7 +566,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       }
       // sample stage
       if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g], sg));
-      const int nchunk = L.E_cnt * L.NC;
+      const int nchunk = L.E_cnt * (L.NC / SAMPLE_WPB);
       // blocks stage the draw's tables in LDS (40 KB) once and walk over their chunks of SAMPLE_CHUNK = 4096 samples (one set
       // of block-reduced statistics per chunk: 1024-sample chunks cost 3.68 ms at C3 / 64 draws, 2048: 3.33 ms, 4096: 2.98 ms);
       // two chunks per block amortise the staging while leaving enough blocks for dynamic balance (1 / 2 / 4 / 8 chunks per
@@ -822,6 +822,14 @@ extern "C" int chm_debug_phase(double out[8]) {
   for (int i = 0; i < 8; i++) out[i] = (double)h[i];
   unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)));
+  return CHM_OK;
+}
+extern "C" int chm_debug_phase_samples(double out[8]) {
+  unsigned long long h[8];
+  HIPCHK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_phase_s), sizeof(h)));
+  for (int i = 0; i < 8; i++) out[i] = (double)h[i];
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_s), z, sizeof(z)));
   return CHM_OK;
 }
 #endif

@@ -22,6 +22,7 @@
 // per-(draw,event,chunk) partial statistics written by k_samples; d = z - z_ref (z_ref = z of the event's first sample)
 enum { PT_SW = 0, PT_SW2, PT_SD1, PT_SD2, PT_ZMIN, PT_ZMAX, PT_WD0, PT_WD1, PT_WD2, PT_W00, PT_W01, PT_W02, PT_W11, PT_W12, PT_W22, PT_ZREF };
 #define SAMPLE_CHUNK 4096
+#define SAMPLE_WPB 4                   // waves per block of k_samples: one partial record per wave and chunk
 #define NEVSTAT 12           // doubles per (draw, event) written by k_event_prep
 
 struct LikeDev {                  // device-resident shard of events (see chm_like_desc)
@@ -43,7 +44,7 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   const double *fracB, *fracG;    // i/num_bins (num_bins+1), i/(G-1) (G): the step fractions of jnp.linspace
   // workspaces (nb-major)
   double *ws_z, *ws_w;            // (nb,E,S)
-  double *part;                   // (nb,E,NC,NPART)
+  double *part;                   // (nb,E,NC,NPART), NC = chunks per event x SAMPLE_WPB
   double *jac, *prate, *bkgA;     // (nb,E,Z)
   double *Aw;                     // (nb,E,Z)  prate/jac * trapezoid weight (marginalized)
   double *evstat;                 // (nb,E,8)  per-event statistics (k_event_prep)
@@ -312,6 +313,21 @@ DEVFN void block_reduce_stats(double* v, double* scratch /* 4 x (NS+2) */) {
   v[NS] = mn; v[NS + 1] = mx;
 }
 
+// CHM_PHASE_PROF (diagnostic builds only, scripts/phase_prof.py): shader-clock cycles between phase marks of k_kde_marg_sub (g_phase) and
+// k_samples (g_phase_s), summed over every 64th block's first wave ([7] counts them)
+#ifdef CHM_PHASE_PROF
+__device__ unsigned long long g_phase[8], g_phase_s[8];
+#define PH_INIT unsigned long long ph_prev = clock64(); const bool ph_on = threadIdx.x == 0 && (blockIdx.x & 63) == 0; if (ph_on) atomicAdd(&g_phase[7], 1ull)
+#define PHS_INIT unsigned long long ph_prev = clock64(); const bool ph_on = threadIdx.x == 0 && (blockIdx.x & 63) == 0; if (ph_on) atomicAdd(&g_phase_s[7], 1ull)
+#define PHS(i) do { __builtin_amdgcn_s_waitcnt(0); unsigned long long ph_t = clock64(); if (ph_on) atomicAdd(&g_phase_s[i], ph_t - ph_prev); ph_prev = clock64(); } while (0)
+#define PH(i) do { __builtin_amdgcn_s_waitcnt(0); unsigned long long ph_t = clock64(); if (ph_on) atomicAdd(&g_phase[i], ph_t - ph_prev); ph_prev = clock64(); } while (0)
+#else
+#define PH_INIT
+#define PH(i)
+#define PHS_INIT
+#define PHS(i)
+#endif
+
 template <bool LDS_TAB, bool FULL>
 __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
                                                   const double* dLt_all, const double* mg_all, const double* cdf_all,
@@ -324,12 +340,15 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
   const DevParams P = params[b];      // by value: uniform loads at kernel start -> scalar registers, nothing re-read in the loops
   TablePtrs g = { zt_all + (size_t)b * TcMax, It_all + (size_t)b * TcMax, dLt_all + (size_t)b * TcMax,
                   mg_all + (size_t)b * TmMax, cdf_all + (size_t)b * TmMax };
+  PHS_INIT;
   TabView T = stage_tables(P, g, LDS_TAB, lds, false);
+  PHS(0);                                                   // tables staged
   const int S = L.S;
-  const int nchunk = L.E_cnt * L.NC;
+  const int NCH = L.NC / SAMPLE_WPB;                        // chunks per event (L.NC counts the partial records: one per wave and chunk)
+  const int nchunk = L.E_cnt * NCH;
   const bool vec2 = ((S & 1) == 0);
   for (int ch = bx; ch < nchunk; ch += nbx) {
-    const int e = L.e_off + ch / L.NC, c = ch % L.NC;
+    const int e = L.e_off + ch / NCH, c = ch % NCH;
     const size_t so = ((size_t)b * L.E + e) * S;
     const size_t eo = (size_t)e * S;
     double* wz = L.ws_z + so;
@@ -353,6 +372,7 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
       c_lo = ired[0] + ired[2] + ired[4] + ired[6]; c_hi = ired[1] + ired[3] + ired[5] + ired[7];
       if (xlo == xlo && xhi == xhi && c_hi >= c_lo) { s_base = c_lo; s_len = c_hi - c_lo; }
     }
+    PHS(1);                                                 // reference point, bracket of the event on the table
     const double ra_ref = FULL ? L.ra[eo] : 0., dec_ref = FULL ? L.dec[eo] : 0.;
     double v[6] = { 0., 0., 0., 0., __builtin_inf(), -__builtin_inf() };     // sw, sw2, sd1, sd2, zmin, zmax
     double m[9] = { 0., 0., 0., 0., 0., 0., 0., 0., 0. };
@@ -414,18 +434,21 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
         if (s + 1 < s_end) { wz[s + 1] = zz[1]; ww[s + 1] = wv[1]; }
       }
     }
-    double* q = L.part + (((size_t)b * L.E + e) * L.NC + c) * NPART;
-    block_reduce_stats<4>(v, red);
-    if (v[2] != v[2]) { v[4] = v[2]; v[5] = v[2]; }         // jnp.min / jnp.max propagate NaN (any NaN z makes sum(d) NaN)
-    if (t == 0) { q[PT_SW] = v[0]; q[PT_SW2] = v[1]; q[PT_SD1] = v[2]; q[PT_SD2] = v[3]; q[PT_ZMIN] = v[4]; q[PT_ZMAX] = v[5]; q[PT_ZREF] = z_ref; }
-    if (FULL) {
-      double mm[11];
+    PHS(2);                                                 // sample loop
+    // One partial record per WAVE and chunk (no block barrier: the waves of a block finish their samples at different times and would
+    // wait for the slowest twice); combine_stats adds them up.  Every lane is active here (the loop bounds are uniform per wave pair).
+    double* q = L.part + (((size_t)b * L.E + e) * L.NC + (size_t)c * SAMPLE_WPB + (t >> 6)) * NPART;
 #pragma unroll
-      for (int i = 0; i < 9; i++) mm[i] = m[i];
-      mm[9] = 0.; mm[10] = 0.;
-      block_reduce_stats<9>(mm, red);
-      if (t == 0) { q[PT_WD0] = mm[0]; q[PT_WD1] = mm[1]; q[PT_WD2] = mm[2]; q[PT_W00] = mm[3]; q[PT_W01] = mm[4]; q[PT_W02] = mm[5];
-                    q[PT_W11] = mm[6]; q[PT_W12] = mm[7]; q[PT_W22] = mm[8]; }
+    for (int i = 0; i < 4; i++) v[i] = wave_sum_dpp(v[i]);
+    v[4] = wave_min_dpp(v[4]); v[5] = wave_max_dpp(v[5]);     // NaN-ignoring; NaN restored from the sums:
+    if (v[2] != v[2]) { v[4] = v[2]; v[5] = v[2]; }         // jnp.min / jnp.max propagate NaN (any NaN z makes sum(d) NaN)
+    if ((t & 63) == 0) { q[PT_SW] = v[0]; q[PT_SW2] = v[1]; q[PT_SD1] = v[2]; q[PT_SD2] = v[3]; q[PT_ZMIN] = v[4]; q[PT_ZMAX] = v[5]; q[PT_ZREF] = z_ref; }
+    PHS(3);                                                 // wave reductions
+    if (FULL) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) m[i] = wave_sum_dpp(m[i]);
+      if ((t & 63) == 0) { q[PT_WD0] = m[0]; q[PT_WD1] = m[1]; q[PT_WD2] = m[2]; q[PT_W00] = m[3]; q[PT_W01] = m[4]; q[PT_W02] = m[5];
+                           q[PT_W11] = m[6]; q[PT_W12] = m[7]; q[PT_W22] = m[8]; }
     }
   }
 }
@@ -964,16 +987,6 @@ template <int SW> DEVFN double sg_max(double v) {
   return v;
 }
 
-// CHM_PHASE_PROF (diagnostic builds only, scripts/phase_prof.py): shader-clock cycles between phase marks of k_kde_marg_sub, summed over
-// every 64th wave into g_phase[] (g_phase[7] counts the waves)
-#ifdef CHM_PHASE_PROF
-__device__ unsigned long long g_phase[8];
-#define PH_INIT unsigned long long ph_prev = clock64(); const bool ph_on = threadIdx.x == 0 && (blockIdx.x & 63) == 0; if (ph_on) atomicAdd(&g_phase[7], 1ull)
-#define PH(i) do { __builtin_amdgcn_s_waitcnt(0); unsigned long long ph_t = clock64(); if (ph_on) atomicAdd(&g_phase[i], ph_t - ph_prev); ph_prev = clock64(); } while (0)
-#else
-#define PH_INIT
-#define PH(i)
-#endif
 
 template <int SW>
 __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevParams* params) {

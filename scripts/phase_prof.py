@@ -18,7 +18,7 @@ lam = lambda s: [dict(H0=float(H0s[(s * nb + j) % len(H0s)])) for j in range(nb)
 L = _lib.lib()
 out = (C.c_double * 8)()
 for w in range(3): like.batch(lam(w))
-L.chm_debug_phase(out)
+L.chm_debug_phase(out); L.chm_debug_phase_samples(out)
 n = 10
 for k in range(n): like.batch(lam(3 + k))
 L.chm_debug_phase(out)
@@ -29,3 +29,10 @@ print('sampled waves', int(waves), ' cycles per wave: total %.0f' % (tot / waves
 for i, nm in enumerate(names):
   print('  %-18s %8.0f cycles  %5.1f %%' % (nm, v[i] / waves, 100 * v[i] / tot))
 print('GW kernel ms (HIP events, last call):', like.last_timing()[3])
+L.chm_debug_phase_samples(out)
+v = np.array(out[:]); blocks = v[7]
+names = ['0 table staging', '1 z_ref + bracket', '2 sample loop', '3 block reduction']
+tot = v[:4].sum()
+print('k_samples: sampled blocks', int(blocks), ' cycles per block (two chunks): total %.0f' % (tot / blocks))
+for i, nm in enumerate(names):
+  print('  %-18s %8.0f cycles  %5.1f %%' % (nm, v[i] / blocks, 100 * v[i] / tot))
