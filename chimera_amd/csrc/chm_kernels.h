@@ -353,25 +353,19 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
     const size_t eo = (size_t)e * S;
     double* wz = L.ws_z + so;
     double* ww = L.ws_w + so;
-    // reference point of the shifted sums: the event's first sample
-    const double z_ref = jnp_interp(L.dL[eo], T.dLt, T.zt, P.Tc, false, 0., 0.);
-    // Bracket of the event's distances on the (sorted) dL table, counted by the whole block: every sample's  #entries <= dL  lies
-    // in [c_lo, c_hi], so its halving search runs over c_hi - c_lo entries (~7 steps) instead of the table (11 steps).
+    // Bracket of the event's distances on the (sorted) dL table: every sample's  #entries <= dL  lies in [c_lo, c_hi], so its halving
+    // search runs over c_hi - c_lo entries (~7 steps) instead of the table (11 steps).  Each wave finds the two ends by its own
+    // (uniform) binary searches -- no block barrier anywhere in the chunk loop, the waves of a block drift freely.
+    // Reference point of the shifted sums: the table node at the lower end of the bracket (any value near the event's z serves; it
+    // travels with the partial records); without a bracket, the event's first sample.
     int s_base = 0, s_len = P.Tc;
+    double z_ref;
     if (P.dl_sorted != 0. && L.dl_lo) {
       const double xlo = L.dl_lo[e], xhi = L.dl_hi[e];
-      int c_lo = 0, c_hi = 0;
-      for (int j0 = 0; j0 < P.Tc; j0 += 256) {
-        const int j = j0 + t;
-        const double v = j < P.Tc ? T.dLt[j] : __builtin_inf();
-        c_lo += __popcll(__ballot(v <= xlo)); c_hi += __popcll(__ballot(v <= xhi));        // per wave, uniform
-      }
-      __syncthreads();
-      if ((t & 63) == 0) { ired[(t >> 6) * 2] = c_lo; ired[(t >> 6) * 2 + 1] = c_hi; }
-      __syncthreads();
-      c_lo = ired[0] + ired[2] + ired[4] + ired[6]; c_hi = ired[1] + ired[3] + ired[5] + ired[7];
+      const int c_lo = searchsorted_right(T.dLt, P.Tc, xlo), c_hi = searchsorted_right(T.dLt, P.Tc, xhi);
       if (xlo == xlo && xhi == xhi && c_hi >= c_lo) { s_base = c_lo; s_len = c_hi - c_lo; }
-    }
+      z_ref = T.zt[c_lo < P.Tc ? c_lo : P.Tc - 1];
+    } else z_ref = jnp_interp(L.dL[eo], T.dLt, T.zt, P.Tc, false, 0., 0.);
     PHS(1);                                                 // reference point, bracket of the event on the table
     const double ra_ref = FULL ? L.ra[eo] : 0., dec_ref = FULL ? L.dec[eo] : 0.;
     double v[6] = { 0., 0., 0., 0., __builtin_inf(), -__builtin_inf() };     // sw, sw2, sd1, sd2, zmin, zmax
