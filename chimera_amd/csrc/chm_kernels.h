@@ -62,10 +62,19 @@ struct EvStats { double zmin, zmax, sd, norm, n_eff, sumw; };
 DEVFN EvStats combine_stats(const double* part, int NC, int S) {
   double sw = 0., sw2 = 0., sd1 = 0., sd2 = 0.;
   double zmn = part[PT_ZMIN], zmx = part[PT_ZMAX];
-  for (int c = 0; c < NC; c++) {
-    const double* q = part + (size_t)c * NPART;
-    sw += q[PT_SW]; sw2 += q[PT_SW2]; sd1 += q[PT_SD1]; sd2 += q[PT_SD2];
-    zmn = nanmin2(zmn, q[PT_ZMIN]); zmx = nanmax2(zmx, q[PT_ZMAX]);
+  // four records (the waves of one k_samples block) per round: their loads are issued together, the sums run in record order
+  for (int c0 = 0; c0 < NC; c0 += 4) {
+    double f[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const double* q = part + (size_t)(c0 + i < NC ? c0 + i : NC - 1) * NPART;
+      f[i][0] = q[PT_SW]; f[i][1] = q[PT_SW2]; f[i][2] = q[PT_SD1]; f[i][3] = q[PT_SD2]; f[i][4] = q[PT_ZMIN]; f[i][5] = q[PT_ZMAX];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) if (c0 + i < NC) {
+      sw += f[i][0]; sw2 += f[i][1]; sd1 += f[i][2]; sd2 += f[i][3];
+      zmn = nanmin2(zmn, f[i][4]); zmx = nanmax2(zmx, f[i][5]);
+    }
   }
   EvStats s;
   double md = sd1 / (double)S;
