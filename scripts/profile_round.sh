@@ -16,7 +16,7 @@ cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 CHM_SERIAL=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_serial -- python3 bench.py --no-cpu-baseline > $OUT/bench_serial_under_rocprof.json 2> $OUT/trace_serial.err
 cp $OUT/trace_serial/*/*kernel_stats.csv $OUT/kernel_stats_serial.csv 2>/dev/null
 # 3. PMC passes (separate runs, counters only)
-for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES"; do
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS"; do
   tag=$(echo $c | tr ' ' '_' | cut -c1-24)
   timeout 900 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$tag -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_$tag.log 2>&1
 done
