@@ -355,6 +355,28 @@ def test_full_size_every_event_against_the_c_oracle(cfg_big, kind):
     np.testing.assert_allclose(rp[3], rc[3], rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
 
 
+def test_full_size_modified_propagation_against_the_c_oracle(cfg_big):
+  """BASELINE.json configs[4] (C5) physics at full per-event size: modified GW propagation (Xi0, n) varied per draw, 300 events x 32
+  pixels x 1000 z-bins x 4096 samples, every event and the selection term against the plain-C restatement."""
+  import os
+  from oracle import oracle_c as OC
+  cfg, ev, inj = cfg_big
+  models = dict(cosmo='mg_flrw', cosmo_kw=dict(Xi0=1.8, n=1.9))
+  like_p, _, _ = H.build_product(ev, inj, models=models)
+  like_o, _, _ = H.build_oracle(ev, inj, models=models)
+  nthr = min(16, os.cpu_count() or 1)
+  lams = [dict(H0=72., Xi0=2.4, n=1.5), dict(H0=61., Xi0=0.7, n=2.6)]
+  batch = like_p.batch(lams)
+  for i, lam in enumerate(lams):
+    rp = like_p.compute_all(**lam)
+    rc = OC.compute_all(like_o, lam, nthreads=nthr)
+    H.assert_loglike_close(rp[0], rc[0], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(rp[2], rc[2], rtol=1e-10)
+    np.testing.assert_allclose(rp[3], rc[3], rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
+    assert batch[i] == rp[3]
+  like_p.close()
+
+
 @pytest.mark.timeout(600)
 @pytest.mark.parametrize('name', ['C1', 'C2', 'C4'])
 def test_baseline_configurations_at_full_size_against_the_c_oracle(name):
