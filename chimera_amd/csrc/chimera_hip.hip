@@ -499,25 +499,12 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   rc = ctx_tables(c, params, nb, tab ? tab->fR : nullptr); if (rc) return rc;
   HIPCHK(hipEventRecord(c.ev[1], sA));
   HIPCHK(hipStreamWaitEvent(sB, c.ev[1], 0));               // fork: the other lanes start after the tables
-  HIPCHK(hipStreamWaitEvent(sC, c.ev[1], 0));
 
   const int Tc = c.TcMax, Tm = c.TmMax;
   const DevParams* dp = c.d_params;
   const size_t lds_samp = sizeof(double) * ((size_t)2 * Tc + (size_t)2 * Tm);      // zt, dLt, mg, cdf
   const size_t lds_zfac = sizeof(double) * (size_t)2 * Tc;                          // zt, It
   const bool tab_samp = lds_samp <= 64 * 1024, tab_zfac = lds_zfac <= 64 * 1024;
-
-  // ---- selection function on its own stream
-  if (sel) {
-    SelDev S = sel->S;
-    S.tab_pm = td.pm_i; S.tab_rate = td.rate_i; S.tab_bkg = td.bkg_i;
-    if (timing_all) HIPCHK(hipEventRecord(c.evb[1], sC));
-    if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
-      hipLaunchKernelGGL(k_selection<true>, dim3(S.nblocks, nb), dim3(256), lds_samp, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    } else hipLaunchKernelGGL(k_selection<false>, dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c.evb[2], sC));
-  }
 
   // ---- events: groups of events alternate between two streams, so that the (VALU-bound) sample stage of one group
   //      overlaps the (latency-bound) GW-kernel stage of the previous one
@@ -633,6 +620,20 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   } else {
     if (timing_all) HIPCHK(hipEventRecord(c.ev[3], sA));
   }
+  // ---- selection function on its own stream, forked after the tables.  Enqueued AFTER the event kernels: every API call between the
+  //      table kernel and the sample stage is stream time the GPU idles (k_tables is 19 us; the fork used to cost 23 us there)
+  if (sel) {
+    HIPCHK(hipStreamWaitEvent(sC, c.ev[1], 0));
+    SelDev S = sel->S;
+    S.tab_pm = td.pm_i; S.tab_rate = td.rate_i; S.tab_bkg = td.bkg_i;
+    if (timing_all) HIPCHK(hipEventRecord(c.evb[1], sC));
+    if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
+      hipLaunchKernelGGL(k_selection<true>, dim3(S.nblocks, nb), dim3(256), lds_samp, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    } else hipLaunchKernelGGL(k_selection<false>, dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c.evb[2], sC));
+  }
+
   double* d_lle = nullptr; double* d_nle = nullptr;
   const size_t El = like ? like->L.E : 0;
   if (like && out->log_like_evs) HIPCHK(hipMalloc(&d_lle, sizeof(double) * nb * El));
