@@ -543,7 +543,10 @@ DEVFN void eff_bounds(bool marg, double zmin, double zmax, double sd, double cut
 // jl1 (wave_prefix3): one past the last lane chunk of bins that holds any weight.  The prefix values after it stem from
 // different summation trees and agree only to an ulp, so a node whose support holds nothing but empty bins above the data would get
 // 1e-16 of the peak instead of the dense sum's exact zero; the range is clipped to jl1, where the values are consistent.
-DEVFN double epan_prefix_eval(double g, const double* cen, const double* P0, const double* P1, const double* P2, int N,
+// The prefix form carries an absolute error of ~1e-16 (R/h)^2 of the weight summed so far: where the bins in reach of a node hold
+// less than 1e-4 of what lies below them (the far upper tail; weights spanning many decades), the reference's dense sum over those
+// bins (math.py:77-81, `wgt` = the normalised bin weights) is evaluated instead -- exact, and rare.
+DEVFN double epan_prefix_eval(double g, const double* cen, const double* wgt, const double* P0, const double* P1, const double* P2, int N,
                               double lo, double inv_dbin, double bw, double inv_bw, double c_ref, int jl1) {
   double fa = ceil((g - bw - lo) * inv_dbin - 0.5), fb = floor((g + bw - lo) * inv_dbin - 0.5) + 1.;
   int ja = fa > 0. ? (fa < (double)N ? (int)fa : N) : 0;
@@ -557,6 +560,14 @@ DEVFN double epan_prefix_eval(double g, const double* cen, const double* P0, con
   if (jb > jl1) jb = jl1;
   if (ja > jl1) ja = jl1;
   double S0 = P0[jb] - P0[ja], S1 = P1[jb] - P1[ja], S2 = P2[jb] - P2[ja];
+  if (jb > ja && !(S0 >= 1e-4 * P0[jb])) {                       // also taken for NaN sums
+    double acc = 0.;
+    for (int j = ja; j < jb; j++) {
+      double u = (g - cen[j]) * inv_bw;
+      acc += wgt[j] * (fabs(u) <= 1. ? 0.75 * (1. - u * u) : 0.);
+    }
+    return acc / bw;
+  }
   double gp = g - c_ref;
   double qq = fma(gp, fma(gp, S0, -2. * S1), S2);                // sum W (g' - c')^2
   // a sum of non-negative kernel values: rounding of the prefix-sum form (~1e-14 of the peak) must not make it negative
@@ -898,7 +909,7 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
     if (fast) {
       const int jl1 = wave_prefix3(data, wgt, N, lo, P0, P1, P2);
       __syncthreads();
-      for (int i = lane; i < G; i += 64) dens[i] = epan_prefix_eval(eff[i], data, P0, P1, P2, N, lo, 1. / dbin, bw, inv_bw, lo, jl1);
+      for (int i = lane; i < G; i += 64) dens[i] = epan_prefix_eval(eff[i], data, wgt, P0, P1, P2, N, lo, 1. / dbin, bw, inv_bw, lo, jl1);
     } else {
       for (int i = lane; i < G; i += 64) dens[i] = kde_dense_eval(eff[i], data, wgt, N, true, bw, inv_bw);
     }
@@ -1306,7 +1317,7 @@ __global__ void __launch_bounds__(256) k_kde1d(LikeDev L, const DevParams* param
     if (wid == 0) { int j = wave_prefix3(data, wgt, N, lo, P0, P1, P2); if (lane == 0) s_jl1 = j; }
     __syncthreads();
     const int jl1 = s_jl1;
-    for (int i = t; i < G; i += nt) dens[i] = epan_prefix_eval(eff[i], data, P0, P1, P2, N, lo, 1. / dbin, bw, inv_bw, lo, jl1) * st.norm;
+    for (int i = t; i < G; i += nt) dens[i] = epan_prefix_eval(eff[i], data, wgt, P0, P1, P2, N, lo, 1. / dbin, bw, inv_bw, lo, jl1) * st.norm;
   } else {
     for (int i = t; i < G; i += nt) dens[i] = kde_dense_eval(eff[i], data, wgt, N, epan, bw, inv_bw) * st.norm;
   }

@@ -613,6 +613,25 @@ def test_kde_is_an_exact_zero_above_the_last_weighted_bin(case):
   H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
 
 
+def test_weights_spanning_many_decades_fall_back_to_the_dense_kernel_sum():
+  """Weights from 1e-271 to 1e-7 with n_eff = 4: the light bins above the bulk are below the rounding of the prefix sums (1e-16 of the
+  weight summed so far), yet they alone meet the catalogue term, so they decide log L_i (-44.128; the prefix form gave -44.134).
+  The general KDE evaluation switches to the reference's dense sum where the bins in reach hold < 1e-4 of the weight below them.
+  (Found by tests/tools/fuzz_extreme_modes.py.)"""
+  lam = {'H0': 109.89167374980342, 'Om0': 0.8346657563998994, 'gamma': 7.807241135391621, 'kappa': 3.30528277152718, 'zp': 4.6230440999507145,
+         'm_low': 8.989582612260971, 'm_high': 186.04784716991537, 'beta': 4.559581991531361, 'w0': -1.9249785711872833, 'wa': -0.9677983626855067,
+         'Xi0': 4.436192160268282, 'n': 3.364281867399951, 'alpha': 2.696354492046777, 'lambda_peak': 0.7837617293451652, 'mu_g': 57.98524711980541,
+         'sigma_g': 13.949408055627696, 'delta_m': 11.754930403127213}
+  cfg, ev, inj = H.small_config(E=6, S=300, P=3, Z=50, I=3000, seed=909250, ragged=True)
+  models = dict(mass='plp', cosmo='mg_flrw')
+  like_p, _, _ = H.build_product(ev, inj, kind='approximate', models=models)
+  like_o, _, _ = H.build_oracle(ev, inj, kind='approximate', models=models)
+  with np.errstate(all='ignore'):
+    ro, rp = like_o.compute_all(**lam), like_p.compute_all(**lam)
+  assert -45. < ro[0][1] < -44.
+  H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
+
+
 def test_nan_tail_of_the_distance_table_and_the_scan_search():
   """An unphysical closed universe whose 1/E turns NaN inside the table: jnp.cumsum carries the NaN only from the first NaN term
   on, jnp.interp at its own nodes turns dL NaN one node earlier (0/dx * NaN), and searchsorted (method 'scan') on the NaN-tailed
