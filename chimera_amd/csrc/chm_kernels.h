@@ -714,6 +714,19 @@ DEVFN void event_stats(const LikeDev& L, int b, int e, double* es) {
 
 // k_event_prep: one wave per (event, draw), four waves per block: event_stats -> evstat (nb,E,NEVSTAT) and, for the general kernel (k_kde_marg),
 // the effective grid effg (nb,E,G); the standard kernel (k_kde_marg_sub) forms its nodes arithmetically.
+// k_event_stats: the same statistics with a THREAD per (event, draw) -- the standard kernel needs no effective grid, and a wave per
+// event spent its 3 us of life on two dependent memory round trips with 63 lanes idle (107 us at C3 / 128 draws for 128 000 waves)
+__global__ void __launch_bounds__(256) k_event_stats(LikeDev L) {
+  const int ei = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (ei >= L.E_cnt) return;
+  const int e = L.e_off + ei;
+  double es[NEVSTAT];
+  event_stats(L, b, e, es);
+  double* o = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
+#pragma unroll
+  for (int i = 0; i < NEVSTAT; i++) o[i] = es[i];
+}
+
 __global__ void __launch_bounds__(256) k_event_prep(LikeDev L, int write_effg) {
   const int lane = threadIdx.x & 63, ei = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;     // four events (waves) per block
   if (ei >= L.E_cnt) return;
@@ -739,8 +752,11 @@ __global__ void __launch_bounds__(256) k_event_prep(LikeDev L, int write_effg) {
 //   jac = ddL/dz (1+z)^2 (likelihood.py:272);  prate = merger_rate/(1+z) (pop_wrapper.py:85);
 //   bkgA = (1 - P_compl) p_bkg (catalog.py:202)  or  p_bkg for the empty catalogue (catalog.py:43)
 // ------------------------------------------------------------------------------------------------------
+#ifndef CHM_ZF_WPE
+#define CHM_ZF_WPE 4                      // waves per SIMD the per-z-factor kernel is compiled for (128 VGPRs: 577 -> 536 us at C3 / 128 draws)
+#endif
 template <bool LDS_TAB>
-__global__ void __launch_bounds__(256) k_zfactors(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
+__global__ void __launch_bounds__(256, CHM_ZF_WPE) k_zfactors(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
                                                    int TcMax, int ranged) {
 #pragma clang fp contract(fast)                  // smooth per-z factors: a*b+c may fuse (jnp_interp keeps the default, off)
   extern __shared__ double lds[];
