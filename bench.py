@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np
 
-KERNEL_NAMES = {'marginalized': 'k_kde_marg_sub<32>', 'full': 'k_full_kde'}
+KERNEL_NAMES = {'marginalized': 'k_kde_marg_sub2<32, 4>', 'full': 'k_full_kde'}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
 
 

@@ -593,8 +593,18 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         const bool fast = marg_std;
         if (fast) {
           const int PG2 = (Pd + 1) / 2;
-          const dim3 kgrid = (L.E_cnt <= 65535 && PG2 <= 65535) ? dim3(nb, PG2, L.E_cnt) : dim3((unsigned)((size_t)L.E_cnt * PG2 * nb), 1, 1);
-          hipLaunchKernelGGL(k_kde_marg_sub<32>, kgrid, dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
+          static const bool one_item = getenv("CHM_KDE_ONE_ITEM") != nullptr;      // diagnostics: one pixel group per wave
+          if (!one_item && PG2 >= 2 && L.E_cnt <= 65535 && PG2 <= 65535) {
+            // several pixel groups of the same (event, draw) per wave, one after the other: event statistics and segment offsets once
+            // (four items per wave: 5.45 ms at C3 / 128 draws, two: 5.51, one: 5.66)
+            static const int ipw_env = getenv("CHM_KDE_IPW") ? atoi(getenv("CHM_KDE_IPW")) : 0;       // diagnostics: 2 or 4 items per wave
+            const int ipw = ipw_env == 2 || ipw_env == 4 ? ipw_env : (PG2 >= 4 ? 4 : 2);
+            if (ipw == 4) hipLaunchKernelGGL((k_kde_marg_sub2<32, 4>), dim3(nb, (PG2 + 3) / 4, L.E_cnt), dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
+            else hipLaunchKernelGGL((k_kde_marg_sub2<32, 2>), dim3(nb, (PG2 + 1) / 2, L.E_cnt), dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
+          } else {
+            const dim3 kgrid = (L.E_cnt <= 65535 && PG2 <= 65535) ? dim3(nb, PG2, L.E_cnt) : dim3((unsigned)((size_t)L.E_cnt * PG2 * nb), 1, 1);
+            hipLaunchKernelGGL(k_kde_marg_sub<32>, kgrid, dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
+          }
         }
         else { allow_lds(k_kde_marg, lds_kde); hipLaunchKernelGGL(k_kde_marg, dim3(L.E_cnt * Pd, nb), dim3(64), lds_kde, sg, L, dp); }
       } else {

@@ -1042,7 +1042,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   extern __shared__ double lds_all[];
   PH_INIT;
   constexpr int NPW = 64 / SW;                              // pixels per wave
-  constexpr int PF = 4;                                     // p_cat prefetch passes: PF * SW * 2 grid points per pixel
+  constexpr int PF = 1;                                     // p_cat passes requested before the histogram (1: 5.66 ms, 2: 5.75, 4: 5.84 at C3 / 128 draws)
   const int lane = threadIdx.x, sub = lane / SW, sl = lane % SW;
   // grid (draws, pixel groups, events) -- draw fastest in dispatch order -- so that a wave does not start with four integer divisions
   // (no hardware divider: ~40 instructions each); a 1-D grid (more than 65535 events in a group) is decoded the long way
@@ -1259,6 +1259,254 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
   PH(5);                                                    // grid loop
   acc = sg_scan_add<SW>(acc);                               // the group's last lane holds the pixel's integral
   if (sl == SW - 1 && live) *out_like = poisoned ? nan : acc;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_kde_marg_sub2<SW, IPW>: k_kde_marg_sub with IPW pixel groups of the same (event, draw) per wave, one after the other: the event
+// statistics, the sample segments of all the wave's items and the grid-row addresses are fetched once (the first of the two memory
+// round trips that make up 39 % of a wave's life in the one-item kernel -- phase timing, scripts/phase_prof.py).  Requesting the
+// next item's samples ahead was measured too: the registers it holds across the grid loop cost more than the latency it hides.
+// kde_sub_item is the one-item kernel's body from the p_cat prefetch on.
+// ------------------------------------------------------------------------------------------------------
+#ifndef CHM_NRS
+#define CHM_NRS 256
+#endif
+template <int SW, int NR>
+DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, const double* es, const int b, const int e, const int p,
+                        const int pp, const bool live, const bool poisoned, const int s0, const int s1, double (&zr)[NR], double (&wr)[NR]) {
+#pragma clang fp contract(fast)                  // as in k_kde_marg_sub
+  constexpr int PF = 1;                                     // as in k_kde_marg_sub
+  const int lane = threadIdx.x, sub = lane / SW, sl = lane % SW;
+  const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
+  const double zmin = es[0], norm = es[3], lb = es[6], ub = es[7];
+  double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
+  double* dump = (L.p_gw_dump && p < L.P) ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
+  const double* zg = L.z_grids + (size_t)e * Z;
+  if (!live && p < L.P) { if (sl == 0) *out_like = 0.; if (dump) for (int k = sl; k < Z; k += SW) dump[k] = 0.; }
+  const double* pc = L.p_cat + ((size_t)e * L.P + pp) * Z;
+  const size_t zo = ((size_t)b * L.E + e) * Z;
+  const double* bkgA = L.bkgA + zo;
+  const double* Aw = L.Aw + zo;
+  int k_lo = (int)es[8], k_hi = (int)es[9];
+  k_lo &= ~1;
+  const bool vec2 = (Z & 1) == 0;                           // then every pair (k, k+1), k even, is 16-byte aligned and in bounds
+  // two consecutive grid points of one array for this lane
+  auto load2 = [&](const double* a, int k, double& v0, double& v1) {
+    v0 = 0.; v1 = 0.;
+    if (live && k <= k_hi) {
+      if (vec2) { double2 v = *reinterpret_cast<const double2*>(a + k); v0 = v.x; v1 = v.y; }
+      else { v0 = a[k]; if (k + 1 <= k_hi) v1 = a[k + 1]; }
+    }
+  };
+  double pf0[PF], pf1[PF];
+#pragma unroll
+  for (int i = 0; i < PF; i++) load2(pc, k_lo + 2 * SW * i + 2 * sl, pf0[i], pf1[i]);
+  // grid, background and trapezoid factors of the first pass: in flight during the histogram phase
+  double zc0, zc1, bc0, bc1, ac0, ac1;
+  load2(zg, k_lo + 2 * sl, zc0, zc1); load2(bkgA, k_lo + 2 * sl, bc0, bc1); load2(Aw, k_lo + 2 * sl, ac0, ac1);
+  // histogram of the pixel's samples on [min z, max z in pixel] (math.py:32-46, likelihood.py:180-183)
+  const size_t so = ((size_t)b * L.E + e) * S;
+  const double* wz = L.ws_z + so;
+  const double* ww = L.ws_w + so;
+  const double lo = zmin;
+  // hi = max(where(mask, z, min z)) (likelihood.py:180, math.py:36), NaN-propagating like jnp.max: v_max_f64 over the
+  // samples plus a "saw a NaN" vote of the pixel's lanes
+  double hi = lo;
+  bool sawnan = lo != lo;
+#pragma unroll
+  for (int i = 0; i < NR; i++) { hi = __builtin_fmax(hi, zr[i]); sawnan = sawnan || (zr[i] != zr[i]); }
+  for (int s = s0 + sl + SW * NR; s < s1; s += SW) { double zz = wz[s]; hi = __builtin_fmax(hi, zz); sawnan = sawnan || (zz != zz); }
+  hi = sg_last<SW>(sg_scan_max<SW>(hi), sub);
+  {
+    const unsigned long long votes = __ballot(sawnan);
+    const unsigned long long mine = SW == 64 ? ~0ull : (((1ull << (SW & 63)) - 1ull) << (sub * SW));
+    if (votes & mine) hi = __builtin_nan("");
+  }
+  for (int j = sl; j < B; j += SW) Q[3 * j] = 0.;
+  const double dB = (double)B;
+  const double dhl = hi - lo, rhl = 1. / dhl;
+  const double dbin = dhl * L.inv_B;                        // c'_j = c_j - lo = (j + 1/2) dbin for the uniform edges of math.py:37-39
+  wave_sync();
+#pragma unroll
+  for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q[3 * bin_index_r(zr[i], lo, dhl, rhl, dB)], wr[i]); }
+  for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q[3 * bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
+  wave_sync();
+  // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins
+  const int per = (B + SW - 1) / SW;
+  const int j0 = sl * per < B ? sl * per : B, j1 = min(j0 + per, B);
+#ifndef CHM_MAXPER
+#define CHM_MAXPER 8
+#endif
+  constexpr int MAXPER = CHM_MAXPER;                        // bins per lane held in registers (8: up to 256 bins at 32 lanes per pixel)
+  const bool small = per <= MAXPER;
+  double wv[MAXPER];
+  double s0w = 0., s1w = 0., s2w = 0., sq = 0.;
+  if (small) {                                              // the lane's bin counts: all loads in flight at once, summed in bin order
+#pragma unroll
+    for (int i = 0; i < MAXPER; i++) wv[i] = (j0 + i < j1) ? Q[3 * (j0 + i)] : 0.;
+#pragma unroll
+    for (int i = 0; i < MAXPER; i++) { double w = wv[i], cc = ((double)(j0 + i) + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
+  } else {
+    for (int j = j0; j < j1; j++) { double w = Q[3 * j], cc = ((double)j + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
+  }
+  const double x0 = sg_scan_add<SW>(s0w), x1 = sg_scan_add<SW>(s1w), x2 = sg_scan_add<SW>(s2w);
+  const double tot = sg_last<SW>(x0, sub);
+  const double sum2 = sg_last<SW>(sg_scan_add<SW>(sq), sub);
+  // End of the last lane chunk of bins that holds any weight.  The prefix values of the lanes after it come out of different
+  // summation trees and agree only to an ulp: a node that sees nothing but the empty bins above the data would get 1e-16 of the
+  // peak where the dense sum (math.py:80) has an exact zero -- which decides log L_i when the catalogue term is only non-zero out
+  // there.  The bin ranges are clipped to it (below the first weight every prefix is an exact zero already).
+  double fjl1;
+  {
+    const unsigned long long nz = __ballot(s0w != 0.);      // NaN counts as weight
+    const unsigned long long mine = SW == 64 ? nz : ((nz >> (sub * (SW & 63))) & ((1ull << (SW & 63)) - 1ull));
+    const int last = 63 - __clzll(mine);                    // -1: no weight at all (degenerate pixel, NaN below)
+    fjl1 = (double)min((last + 1) * per, B);
+  }
+  {
+    double r0 = x0 - s0w, r1 = x1 - s1w, r2 = x2 - s2w;
+    wave_sync();
+    if (small) {
+#pragma unroll
+      for (int i = 0; i < MAXPER; i++) if (j0 + i < j1) {
+        double w = wv[i], cc = ((double)(j0 + i) + 0.5) * dbin;
+        r0 += w; r1 += w * cc; r2 += w * cc * cc;
+        double* q = Q + 3 * (j0 + i + 1);
+        q[0] = r0; q[1] = r1; q[2] = r2;
+      }
+    } else {                                                // many bins per lane: the count of bin j+1 shares the slot of P0[j+1]
+      double a0 = r0, a1 = r1, a2 = r2;
+      for (int j = j0; j < j1; j++) { double w = Q[3 * j], cc = ((double)j + 0.5) * dbin; a1 += w * cc; a2 += w * cc * cc; Q[3 * (j + 1) + 1] = a1; Q[3 * (j + 1) + 2] = a2; }
+      a0 = r0; for (int j = j0; j < j1; j++) a0 += Q[3 * j];
+      for (int j = j1 - 1; j >= j0; j--) { double w = Q[3 * j]; Q[3 * (j + 1)] = a0; a0 -= w; }
+    }
+    if (sl == 0) { Q[1] = 0.; Q[2] = 0.; }
+    wave_sync();
+    if (sl == 0) Q[0] = 0.;
+    wave_sync();
+  }
+  const double neff_k = (tot * tot) / sum2;
+  const double stdc = dhl * L.std_unit;
+  const double bw = kde_bandwidth_factor_fast(L.bw_method, L.bw_scalar, neff_k) * stdc;
+  const bool degenerate = !(dbin > 0.) || !(bw > 0.) || !(bw < 1e300) || !(tot > 0. || tot < 0.);
+  // Per-pixel constants of the node evaluation.  A node g of the effective grid sees the bins [ja, jb) with |g - c_j| <= h,
+  // c_j = lo + (j + 1/2) dbin:  ja = ceil(t - hb), jb = floor(t + hb) + 1 with t = (g - lo)/dbin - 1/2, hb = h/dbin; the next
+  // node is t + dd, dd = de/dbin.  A bin whose |u| is within rounding of 1 may land on either side (kernel value < 1e-12).
+  // one reciprocal serves 1/bw and the normalisation 3/4 / (bw sum w); 1/dbin = B / (hi - lo) re-uses the histogram's reciprocal
+  const double rbt = 1. / (bw * tot);
+  const double inv_dbin = dB * rhl, inv_bw = rbt * tot, inv_bw2 = inv_bw * inv_bw;
+  const double scale = 0.75 * rbt;
+  const double hb = bw * inv_dbin;
+  const double de = es[10], inv_de = es[11];                // spacing of jnp.linspace(lb, ub, G) and its inverse (k_event_prep)
+  const double dd = de * inv_dbin;
+  const double dG2 = (double)(G - 2);
+  const double lbl = lb - lo;
+  const double ng = norm * L.gw_pdf[(size_t)e * L.P + pp]; // kde_interp * norm * gw_pdf[i]    likelihood.py:194
+  const double fR = params[b].fR;
+  const double nan = __builtin_nan("");
+  // Support of THIS pixel's interpolated KDE on the event grid: the bin centres lie in [lo + dbin/2, hi - dbin/2], a node sees
+  // none of them beyond bw, and an event-grid point combines the two nodes within de of it -- so p_gw is an exact zero for
+  // z outside (lo - bw - de, hi + bw + de), typically a third of the event's range [lb, ub] (every pixel's histogram starts
+  // at the event's min z but ends at the pixel's own max z, likelihood.py:180).  Degenerate pixels keep [lb, ub] (NaN there).
+  const double zlo = degenerate ? lb : __builtin_fmax(lb, lo - bw - de), zhi = degenerate ? ub : __builtin_fmin(ub, hi + bw + de);
+  // density (without the common factor `scale`) at the node with g' = g - lo and bin position t
+  auto node = [&](double gp, double t) {
+    double fa = __builtin_fmin(__builtin_fmax(ceil(t - hb), 0.), fjl1);
+    double fb = __builtin_fmin(__builtin_fmax(floor(t + hb) + 1., fa), fjl1);
+    const int ia = 3 * (int)fa, ib = 3 * (int)fb;
+    double S0 = Q[ib] - Q[ia], S1 = Q[ib + 1] - Q[ia + 1], S2 = Q[ib + 2] - Q[ia + 2];
+    double qq = fma(gp, fma(gp, S0, -2. * S1), S2);         // sum W (g' - c')^2 over the support
+    return __builtin_fmax(S0 - qq * inv_bw2, 0.);           // a sum of non-negative kernel values (rounding may leave -1e-14 of the peak)
+  };
+  double acc = 0.;
+  if (dump && live) { for (int k = sl; k < Z; k += SW) if (k < k_lo || k > k_hi) dump[k] = 0.; }
+#pragma unroll 1
+  for (int it = 0; k_lo + 2 * SW * it <= k_hi; it++) {      // one pass = SW lanes x 2 consecutive grid points per pixel
+    const int k = k_lo + 2 * SW * it + 2 * sl;
+    // software pipeline: the loads of the next pass are issued before the arithmetic of this one
+    double zn0, zn1, bn0, bn1, an0, an1, pn0 = 0., pn1 = 0.;
+    const int kn = k + 2 * SW;
+    load2(zg, kn, zn0, zn1); load2(bkgA, kn, bn0, bn1); load2(Aw, kn, an0, an1);
+    if (it + 1 >= PF) load2(pc, kn, pn0, pn1);
+    double pc0 = pf0[0], pc1 = pf1[0];                      // this pass's p_cat: prefetched at kernel start or by the previous pass
+#pragma unroll
+    for (int i = 1; i < PF; i++) if (it == i) { pc0 = pf0[i]; pc1 = pf1[i]; }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int kk = k + h;
+      if (kk <= k_hi && live) {
+        const double zk = h == 0 ? zc0 : zc1;
+        double pgw = 0.;
+        if (zk >= zlo && zk <= zhi) {                       // inside: jnp.interp on the nodes; outside: 0 (left=0, right=0 or no bin in reach)
+          // bracket on the uniform effective grid: nodes x_i = lb + i de; a z within rounding of a node may pick either
+          // neighbouring segment -- the interpolant is continuous there
+          double tp = __builtin_fmin(floor((zk - lb) * inv_de), dG2);
+          double ga = fma(tp, de, lbl);                     // x_a - lo
+          double ta = fma(ga, inv_dbin, -0.5);
+          double da = node(ga, ta), db = node(ga + de, ta + dd);
+          double wgt = ((zk - lb) - tp * de) * inv_de;      // (z - x_a)/dx
+          double f = (da + wgt * (db - da)) * scale;
+          pgw = degenerate ? nan : f * ng;
+        } else if (zk != zk) pgw = nan;
+        if (dump) dump[kk] = pgw;
+        const double pcv = h == 0 ? pc0 : pc1;
+        if (pcv != -100.) acc += pgw * (fR * pcv + (h == 0 ? bc0 : bc1)) * (h == 0 ? ac0 : ac1);   // catalog.py:202, likelihood.py:275
+      }
+    }
+    zc0 = zn0; zc1 = zn1; bc0 = bn0; bc1 = bn1; ac0 = an0; ac1 = an1;
+    if (it + 1 >= PF) { pf0[0] = pn0; pf1[0] = pn1; }
+  }
+  acc = sg_scan_add<SW>(acc);                               // the group's last lane holds the pixel's integral
+  if (sl == SW - 1 && live) *out_like = poisoned ? nan : acc;
+}
+
+template <int SW, int IPW>
+__global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevParams* params) {
+  extern __shared__ double lds_all[];
+  constexpr int NPW = 64 / SW;
+  constexpr int NR = CHM_NRS / SW;
+  const int lane = threadIdx.x, sub = lane / SW, sl = lane % SW;
+  const int PG = (L.P + NPW - 1) / NPW, H = (PG + IPW - 1) / IPW;   // pixel groups of an event; the wave's items: blockIdx.y + i H
+  const int b = blockIdx.x, e = L.e_off + blockIdx.z;
+  const int Z = L.Z;
+  double* Q = lds_all + (size_t)sub * (3 * L.num_bins + 3);
+  const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
+  const bool ok = es[4] >= L.pe_neff;                       // likelihood.py:199 (same for every pixel of the event)
+  const int* so_ = L.seg_off + (size_t)e * (L.P + 1);
+  // every item's sample segment is requested up front, together with the event statistics (one memory round trip)
+  const int pA = blockIdx.y * NPW + sub, pB = (blockIdx.y + H) * NPW + sub;
+  const int pC = (blockIdx.y + 2 * H) * NPW + sub, pD = (blockIdx.y + 3 * H) * NPW + sub;
+  const int ppA = pA < L.P ? pA : L.P - 1, ppB = pB < L.P ? pB : L.P - 1, ppC = pC < L.P ? pC : L.P - 1, ppD = pD < L.P ? pD : L.P - 1;
+  const int a0 = so_[ppA], a1 = so_[ppA + 1], b0 = so_[ppB], b1 = so_[ppB + 1];
+  int c0 = 0, c1 = 0, d0 = 0, d1 = 0;
+  if (IPW > 2) { c0 = so_[ppC]; c1 = so_[ppC + 1]; d0 = so_[ppD]; d1 = so_[ppD + 1]; }
+  const int npx = L.neff_pixels[e];
+  const double* zg = L.z_grids + (size_t)e * Z;
+  const bool poisoned = grid_is_poisoned(params[b].z_bad, zg, Z);
+  const size_t so = ((size_t)b * L.E + e) * L.S;
+  const double* wz = L.ws_z + so;
+  const double* ww = L.ws_w + so;
+  const double lo = es[0];
+  auto run = [&](const int pgi, const int p, const int pp, const int q0, const int q1, const bool first) {
+    if (pgi >= PG) return;                                  // uniform
+    const bool live = p < L.P && p < npx;
+    if (!ok) {                                              // uniform: every pixel of the event is 0 (or 0 * NaN)
+      if (p < L.P) {
+        if (sl == 0) L.like_pix[((size_t)b * L.E + e) * L.P + p] = (live && poisoned) ? __builtin_nan("") : 0.;
+        if (L.p_gw_dump) { double* d = L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z; for (int k = sl; k < Z; k += SW) d[k] = 0.; }
+      }
+      return;
+    }
+    if (!first) wave_sync();                                // the next item reuses the wave's LDS slice
+    const int s0 = q0, s1 = live ? q1 : q0;
+    double zr[NR], wr[NR];
+#pragma unroll
+    for (int j = 0; j < NR; j++) { int s = s0 + sl + SW * j; zr[j] = s < s1 ? wz[s] : lo; wr[j] = s < s1 ? ww[s] : 0.; }
+    kde_sub_item<SW, NR>(L, params, Q, es, b, e, p, pp, live, poisoned, s0, s1, zr, wr);
+  };
+  run(blockIdx.y, pA, ppA, a0, a1, true);
+  run(blockIdx.y + H, pB, ppB, b0, b1, false);
+  if (IPW > 2) { run(blockIdx.y + 2 * H, pC, ppC, c0, c1, false); run(blockIdx.y + 3 * H, pD, ppD, d0, d1, false); }
 }
 
 // ------------------------------------------------------------------------------------------------------

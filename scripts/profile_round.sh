@@ -32,7 +32,7 @@ for f in glob.glob('$OUT/pmc_*/*/*counter_collection.csv'):
 json.dump(out, open('$OUT/pmc_per_launch.json', 'w'), indent=1, sort_keys=True)
 b = json.loads(open('$OUT/bench.json').read().strip().split('\n')[-1])
 nb = b['config']['nbatch']
-KN = 'k_kde_marg_sub<32>'
+KN = 'k_kde_marg_sub2<32, 4>'
 k = out.get(KN, {})
 if 'FETCH_SIZE' in k and 'WRITE_SIZE' in k:
     # gfx950: FETCH_SIZE counts 64 B per 128-B request of wide (16 B/lane) streaming reads -> doubled (MI355X_MICROARCH.md, HBM);
