@@ -1,6 +1,7 @@
 """Phase timing of k_kde_marg_sub on a CHM_PHASE_PROF build (scripts/build_variant.sh prof -DCHM_PHASE_PROF):
    CHIMERA_LIB=chimera_amd/lib/variants/libchimera_hip_prof.so python scripts/phase_prof.py"""
 import ctypes as C, os, sys
+os.environ.setdefault("CHM_KDE_ONE_ITEM", "1")       # the phase marks live in the one-item form of the GW kernel (k_kde_marg_sub)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import chimera_amd as CH
