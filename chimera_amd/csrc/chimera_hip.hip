@@ -554,15 +554,16 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       // sample stage
       if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g], sg));
       const int nchunk = L.E_cnt * (L.NC / SAMPLE_WPB);
-      // blocks stage the draw's tables in LDS (40 KB) once and walk over their chunks of SAMPLE_CHUNK = 4096 samples (one set
-      // of block-reduced statistics per chunk: 1024-sample chunks cost 3.68 ms at C3 / 64 draws, 2048: 3.33 ms, 4096: 2.98 ms);
-      // two chunks per block amortise the staging while leaving enough blocks for dynamic balance (1 / 2 / 4 / 8 chunks per
-      // block: 3.05 / 2.98 / 3.02 / 3.08 ms), one chunk per block when few draws leave fewer than ~2048 blocks
+      // blocks stage the draw's tables in LDS (40 KB) once and walk over their chunks of SAMPLE_CHUNK = 4096 samples (one record
+      // of statistics per wave and chunk; 1024-sample chunks cost 3.68 ms at C3 / 64 draws, 2048: 3.33 ms, 4096: 2.98 ms);
+      // four chunks per block amortise the staging while leaving enough blocks for dynamic balance (1 / 2 / 4 / 8 / 16 chunks per
+      // block at C3 / 128 draws, barrier-free chunk loop: 5.89 / 5.70 / 5.61 / 5.67 / 5.78 ms), fewer when few draws leave fewer
+      // than ~2048 blocks
       static const int cpb_env = getenv("CHM_SAMP_CPB") ? atoi(getenv("CHM_SAMP_CPB")) : 0;
-      int cpb = cpb_env > 0 ? cpb_env : 2;
+      int cpb = cpb_env > 0 ? cpb_env : 4;
       if (cpb_env <= 0) {
         long long want = (long long)nchunk * nb / 2048;
-        cpb = want < 1 ? 1 : (want > 2 ? 2 : (int)want);
+        cpb = want < 1 ? 1 : (want > 4 ? 4 : (int)want);
       }
       int samp_blocks = (nchunk + cpb - 1) / cpb;
       samp_blocks = samp_blocks < 1 ? 1 : (samp_blocks > 1024 ? 1024 : samp_blocks);
