@@ -262,3 +262,19 @@ def test_synthetic_inputs_are_seeded_and_well_formed():
     assert np.all(ev['pixels_opt_nsides'][e, n:] == -100) and np.all(ev['gw_loc2d_pdf'][e, n:] == -100.)
     assert np.all(np.diff(ev['z_grids'][e]) > 0)
   assert np.all(ev['m2det'] <= ev['m1det']) and np.all(ev['dL'] > 0) and np.all(inj['p_draw'] > 0) and inj['N_inj'] > 300
+
+
+def test_roofline_accounting_of_the_bench():
+  """The algorithmic byte counts bench.py prices the roofline with: C3 = 423.4 MB per evaluation for
+  the whole path, 370.7 MB per draw for the GW kernel; the kernel named in the bench line is the one the library launches."""
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('bench', os.path.join(ROOT, 'bench.py'))
+  bench = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(bench)
+  assert bench.algorithmic_bytes(1000, 4096, 32, 1000, 100000, 200) == 1000 * 4096 * 36 + 1000 * 32 * 1000 * 8 + 1000 * 1000 * 16 + 1000 * 32 * 24 + 100000 * 32 + 8000
+  assert abs(bench.algorithmic_bytes(1000, 4096, 32, 1000, 100000, 200) - 423.4e6) < 0.1e6
+  assert abs(bench.kde_kernel_bytes(1000, 4096, 32, 1000) - 370.7e6) < 0.1e6
+  assert bench.HBM_PEAK_GBS == 8000.0
+  src = open(os.path.join(ROOT, 'chimera_amd', 'csrc', 'chimera_hip.hip')).read()
+  name = bench.KERNEL_NAMES['marginalized']                       # e.g. k_kde_marg_sub2<32, 4>
+  assert name.split('<')[0] + '<' + name.split('<')[1].replace(' ', '') in src.replace(' ', '')
