@@ -7,15 +7,25 @@ function + reduce) over the C3 workload: 1000 events x 32 pixels x 1000 z-bins x
 injections, PowerLaw+Peak + Madau-Dickinson + flat-LCDM, kind_p_gw3d='marginalized', binning(200), cut_grid=2 --
 with the inputs already resident in HBM.  Every draw uses a different H0 (tables rebuilt for every draw, as in the
 reference's H0 scans, examples/test1dgalaxies.ipynb cell 11).  value = evaluations per second = steps * nbatch / time;
-the latency of a single-draw call (nbatch = 1, the reference's scalar call) is reported as ``single_call_ms``.
+the latency of the reference-shaped scalar call (one draw per call) is reported as ``single_call_ms``.
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 N > 1: events and injections are sharded across ranks (strong scaling: the total workload is fixed), one RCCL
-all-reduce of 3 * nbatch doubles per step inside chm_eval.  Rank 0 prints ONE JSON line.
+all-reduce of 3 * nbatch doubles per step inside chm_eval.  Rank 0 prints ONE JSON line.  No PyTorch anywhere: the
+launcher only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT; the ranks meet over chimera_amd.parallel.Rendezvous
+(a Unix-domain socket) for the RCCL unique id, the barriers and the max-over-ranks of the wall time.
+
+Roofline bookkeeping: the two kernels that make up ~90 % of a step -- the sample stage ``k_samples`` and
+the marginalized GW kernel ``k_kde_marg_sub2`` -- are fp64-VALU-issue bound, so each is reported against the fp64 vector peak
+(one wave64 fp64 instruction per SIMD per 4 cycles: 1024 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instructions/s = 78.6 TFLOP/s of
+FMAs) with its VALU wave-instruction count per launch taken from the committed PMC pass of the same command
+(profiles/rNN/pmc_per_launch*.json) and its duration measured live with HIP events; the HBM view (unique input/output bytes of
+the launch and the PMC-measured fabric traffic, both over the same live duration, against 8 TB/s) is printed next to it.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -26,21 +36,88 @@ sys.path.insert(0, ROOT)
 
 import numpy as np
 
-KERNEL_NAMES = {'marginalized': 'k_kde_marg_sub2<32, 4>', 'full': 'k_full_kde'}
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
+N_SIMD, CLK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; max shader clock (MI355X_MICROARCH.md, chip-level parameters)
+VALU_PEAK_GINST = N_SIMD * CLK_HZ / 4 / 1e9          # fp64: one wave64 instruction per SIMD per 4 cycles -> 614.4 G wave-inst/s
+FP64_PEAK_TFLOPS = VALU_PEAK_GINST * 64 * 2 / 1e3    # as FMAs: 78.6 TFLOP/s (the public fp64 vector figure)
+NPART, SAMPLE_WPB, SAMPLE_CHUNK, NEVSTAT = 16, 4, 4096, 12    # workspace record sizes of chm_kernels.h
 
 
 def algorithmic_bytes(E, S, P, Z, I, B, pixelated=True, full=False):
-  """every input read once, nothing materialised (fp64 values, int32 pixel index)."""
+  """every input of ONE evaluation read once, nothing materialised (fp64 values, int32 pixel index)."""
   b = E * S * (4 * 8 + (4 if pixelated else 0)) + (E * S * 16 if full else 0)
   b += (E * P * Z * 8 if pixelated else 0) + E * Z * 8 * 2 + E * P * 8 * 3 + I * 32 + E * 8
   return b
 
 
-def kde_kernel_bytes(E, S, P, Z):
-  """Algorithmic bytes of ONE launch of the dominant kernel (k_kde_integrate): z, w (fp64) and the pixel index
-  (int32) of every sample once, p_cat once, the event grid and the three per-z factors once, per-pixel scalars."""
-  return E * S * (8 + 8 + 4) + E * P * Z * 8 + E * Z * 8 * 4 + E * P * 8 * 3
+def gw_kernel_unique_bytes(E, S, P, Z, nb):
+  """Unique bytes of ONE launch of the marginalized GW kernel over nb draws: arrays shared by the draws (p_cat, the event grids,
+  segment offsets, sky densities) once; per-draw arrays (z and w of every sample, the two per-z factors on the grid, event
+  statistics, per-pixel results) nb times."""
+  shared = E * P * Z * 8 + E * Z * 8 + E * (P + 1) * 4 + E * P * 8 + E * 4
+  per_draw = E * S * 16 + E * Z * 16 + E * NEVSTAT * 8 + E * P * 8
+  return shared + nb * per_draw
+
+
+def sample_kernel_unique_bytes(E, S, nb, Tc=1500, Tm=1000):
+  """Unique bytes of ONE launch of the sample stage: the six per-sample inputs once (dL, m1det, m2det, 1/pe_prior, log m1det,
+  log m2det -- shared by the draws); per draw the tables (zt, dLt, m_grid, cdf_m2), the (z, w) output and the partial records."""
+  nc = -(-S // SAMPLE_CHUNK) * SAMPLE_WPB
+  return E * S * 48 + E * 16 + nb * ((2 * Tc + 2 * Tm) * 8 + E * S * 16 + E * nc * NPART * 8)
+
+
+def load_pmc(keys):
+  """Newest committed PMC summary (profiles/rNN/pmc_per_launch*.json, written by scripts/collect_pmc.py from separate
+  rocprofv3 --pmc passes of this very command) whose workload keys match; None otherwise."""
+  best = None
+  for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'pmc_per_launch*.json'))):
+    try:
+      with open(f) as fh:
+        j = json.load(fh)
+    except Exception:
+      continue
+    w = j.get('workload')
+    if isinstance(w, dict) and all(w.get(k) == v for k, v in keys.items()):
+      best = (os.path.relpath(f, ROOT), j)
+  return best
+
+
+def pmc_kernel(pmc, prefix):
+  if pmc is None:
+    return None
+  for name, c in pmc[1].get('kernels', {}).items():
+    if name.startswith(prefix):
+      return dict(c, name=name)
+  return None
+
+
+def quartiles(x):
+  x = np.sort(np.asarray(x, dtype=float))
+  return float(np.median(x)), float(np.percentile(x, 25)), float(np.percentile(x, 75))
+
+
+def kernel_roofline(label, prefix, ms, unique_bytes, pmc):
+  """One kernel against its two ceilings.  ms: live HIP-event duration of one launch."""
+  k = pmc_kernel(pmc, prefix)
+  sec = ms * 1e-3
+  out = {"kernel": k['name'] if k else prefix, "stage": label, "kernel_ms": ms, "bound": "fp64-valu",
+         "unique_bytes_per_launch": unique_bytes,
+         "hbm_unique_GBs": unique_bytes / sec / 1e9 if sec > 0 else None,
+         "hbm_unique_frac": unique_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else None}
+  if k and sec > 0:
+    insts = k.get('SQ_INSTS_VALU')
+    if insts:
+      out.update({"valu_inst_per_launch": insts, "valu_Ginst_s": insts / sec / 1e9, "valu_peak_Ginst_s": VALU_PEAK_GINST,
+                  "valu_frac": insts / sec / 1e9 / VALU_PEAK_GINST,
+                  "fp64_fma_equiv_TFLOPs": insts * 128 / sec / 1e12})
+    if k.get('FETCH_SIZE') is not None and k.get('WRITE_SIZE') is not None:
+      # gfx950: FETCH_SIZE tallies 64 B per 128-B request of wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM)
+      traffic = (2 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024
+      out.update({"traffic_bytes_per_launch": traffic, "hbm_traffic_GBs": traffic / sec / 1e9,
+                  "hbm_traffic_frac": traffic / sec / 1e9 / HBM_PEAK_GBS})
+    if k.get('GRBM_GUI_ACTIVE') and k.get('profiled_ms'):
+      out["clock_GHz_under_profile"] = k['GRBM_GUI_ACTIVE'] / 8 / (k['profiled_ms'] * 1e-3) / 1e9
+  return out
 
 
 def main():
@@ -54,14 +131,16 @@ def main():
   ap.add_argument('--events', type=int, default=None, help='shrink the number of events (debug)')
   ap.add_argument('--inj', type=int, default=None, help='shrink the number of injections (debug)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--single-call', action='store_true', help='also time the scalar one-draw call (extra launches after the timed region)')
-  ap.add_argument('--host-comm', action='store_true', help='reduce the partial sums through the host (gloo) instead of RCCL')
-  ap.add_argument('--force-comm', action='store_true', help='build the gloo group and the RCCL communicator even for one rank (rehearses the N > 1 path)')
-  ap.add_argument('--cpu-events', type=int, default=1000, help='events of the workload the CPU baseline evaluates (1000 = all of C3, ~15 s)')
+  ap.add_argument('--no-single-call', action='store_true', help='skip the scalar one-draw call timing (runs after the timed region)')
+  ap.add_argument('--single-calls', type=int, default=40, help='scalar calls timed for single_call_ms (median + IQR)')
+  ap.add_argument('--host-comm', action='store_true', help='reduce the partial sums through the host sockets instead of RCCL')
+  ap.add_argument('--force-comm', action='store_true', help='build the rendezvous and the RCCL communicator even for one rank (rehearses the N > 1 path)')
+  ap.add_argument('--cpu-events', type=int, default=1000, help='events of the workload the CPU baseline evaluates (1000 = all of C3)')
+  ap.add_argument('--cpu-evals', type=int, default=20, help='timed CPU evaluations (median + IQR)')
   args = ap.parse_args()
 
-  # stdout must carry ONE JSON line: gloo ("[Gloo] Rank 0 is connected ...") and RCCL (its version banner) print to fd 1 when
-  # they come up, so fd 1 points at stderr for the whole run and the JSON line goes to the saved descriptor
+  # stdout must carry ONE JSON line: RCCL prints its version banner to fd 1 when it comes up, so fd 1 points at stderr for the
+  # whole run and the JSON line goes to the saved descriptor
   sys.stdout.flush()
   real_stdout = os.dup(1)
   os.dup2(2, 1)
@@ -70,27 +149,21 @@ def main():
   local_rank = int(os.environ.get('LOCAL_RANK', 0))
   if world != args.gpus and world > 1:
     raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-  # one rank per GPU; on a box with fewer GPUs than ranks (a rehearsal with --host-comm) the ranks wrap around the devices
-  try:
-    import torch
-    ndev = torch.cuda.device_count()              # counting devices does not initialise the GPU
-  except ImportError:
-    ndev = 0
-  device = local_rank % ndev if ndev > 0 else local_rank
-  os.environ.setdefault('CHIMERA_DEVICE', str(device))
-
-  dist = None
-  if world > 1 or args.force_comm:
-    import torch
-    import torch.distributed as dist
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29533')
-    dist.init_process_group('gloo', rank=rank, world_size=world)      # control plane only (barrier, max-of-times, id exchange)
 
   import chimera_amd as CH
   from chimera_amd import synth, _lib
   from chimera_amd.catalog import dVdz_completeness, pixelated_catalog
-  from chimera_amd.parallel import Comm
+  from chimera_amd.parallel import Comm, HostComm, Rendezvous
+
+  L = _lib.lib()
+  ndev = L.chm_device_count()
+  if ndev < 1:
+    raise SystemExit("bench.py: no HIP device visible (the library has no CPU path)")
+  # one rank per GPU; on a box with fewer GPUs than ranks (a rehearsal with --host-comm) the ranks wrap around the devices
+  device = local_rank % ndev
+  os.environ['CHIMERA_DEVICE'] = str(device)
+
+  rdzv = Rendezvous(world, rank) if (world > 1 or args.force_comm) else None
 
   t0 = time.time()
   cfg, ev, inj = synth.make_config(args.config, E=args.events, I=args.inj)
@@ -99,24 +172,24 @@ def main():
   t_gen = time.time() - t0
 
   comm, comm_kind = None, None
-  if world > 1 or args.force_comm:
-    from chimera_amd.parallel import HostComm
+  if rdzv is not None:
     err = None
     try:
-      comm = None if args.host_comm else Comm(world, rank, device)          # one RCCL rank per GPU
+      comm = None if args.host_comm else Comm(world, rank, device, rendezvous=rdzv)    # one RCCL rank per GPU
     except Exception as e:                                                        # noqa: BLE001 -- any failure -> host fallback
       err = e
-    import torch
-    flag = torch.tensor([0 if comm is not None else 1], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.SUM)                                   # every rank must take the same branch
-    if int(flag[0]) > 0:
+    nfail = int(rdzv.allreduce_sum(np.array([0. if comm is not None else 1.]))[0])    # every rank must take the same branch
+    if nfail > 0:
       if comm is not None:
         comm.close()
       if err is not None:
-        print(f"[bench] rank {rank}: RCCL communicator failed ({err}); partial sums go through the host (gloo)", file=sys.stderr)
-      comm, comm_kind = HostComm(world, rank, device), "host (gloo) all-reduce of 3*nbatch doubles"
+        print(f"[bench] rank {rank}: RCCL communicator failed ({err}); partial sums go through the host sockets", file=sys.stderr)
+      comm = HostComm(world, rank, device, rendezvous=rdzv)
+      comm_kind = "HOST-socket all-reduce of 3*nbatch doubles (RCCL unavailable)" if not args.host_comm else "host-socket all-reduce (--host-comm)"
     else:
-      comm_kind = "RCCL all-reduce of 3*nbatch doubles inside chm_eval"
+      nr = L.chm_comm_nranks(comm.handle)
+      assert nr == world, (nr, world)
+      comm_kind = f"RCCL all-reduce of 3*nbatch doubles inside chm_eval, ncclCommCount={nr}"
   mg = args.config == 'C5'                      # BASELINE.json configs[4]: modified GW propagation (Xi0, n)
   cosmo = CH.cosmo.mg_flrw(H0=70., Om0=0.25, z_max=5., Xi0=1.8, n=1.9) if mg else CH.cosmo.flrw(H0=70., Om0=0.25, z_max=5.)
   mass = CH.mass.plp()
@@ -143,7 +216,6 @@ def main():
   t_upload = time.time() - t0
   nb = args.nbatch
   H0s = np.linspace(55., 95., 4099)          # a different H0 for every draw of every step
-
   Xi0s = np.linspace(0.6, 3.0, 4099)
 
   def lambdas(step):
@@ -152,14 +224,9 @@ def main():
     return [dict(H0=float(H0s[(step * nb + j) % len(H0s)])) for j in range(nb)]
 
   def sync():
-    try:
-      import torch
-      if torch.cuda.is_available():
-        torch.cuda.synchronize(device)
-    except ImportError:
-      pass
-    if dist is not None:
-      dist.barrier()
+    _lib.check(L.chm_device_synchronize(device))
+    if rdzv is not None:
+      rdzv.barrier()
 
   # the hyper-parameter draws of every step are the sampler's output, prepared before the timed region; packing them into
   # chm_params (hyperlikelihood._params_array) is part of the call and stays inside it
@@ -167,56 +234,72 @@ def main():
   vals = []
   for w in range(args.warmup):
     vals.append(like.batch(draws[w]))
-  # Python's cyclic collector off the clock: with torch imported (~170 000 tracked objects) its generational passes cost 0.4 ms
-  # per step on average (measured, scripts/host_overhead.py) -- nothing in a step creates reference cycles
   import gc
   gc.collect()
-  gc.freeze()
+  gc.freeze()                                   # nothing in a step creates reference cycles: keep the cyclic collector off the clock
   sync()
   kt = np.zeros(8)
+  step_s = []
   t1 = time.perf_counter()
   for k in range(args.steps):
+    ta = time.perf_counter()
     vals.append(like.batch(draws[args.warmup + k]))          # synchronous: returns after the HIP stream has drained
+    step_s.append(time.perf_counter() - ta)
     kt += like.last_timing()
   sync()
   dt = time.perf_counter() - t1
-  if dist is not None:
-    import torch
-    tt = torch.tensor([dt], dtype=torch.float64)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt[0])
+  if rdzv is not None:
+    dt = float(rdzv.allreduce_max(np.array([dt]))[0])        # max over ranks
   kt /= max(args.steps, 1)
-  single_ms = None
-  if args.single_call:      # latency of the reference-style scalar call (one draw per call), outside the timed region
-    for j in range(3):
+
+  single = None
+  if not args.no_single_call:      # latency of the reference-shaped scalar call (one draw per call), outside the timed region
+    for j in range(5):
       like(H0=float(H0s[-1 - j]))
     sync()
-    t2 = time.perf_counter()
-    nsingle = 10
-    for j in range(nsingle):
+    ts = []
+    for j in range(args.single_calls):
+      ta = time.perf_counter()
       like(H0=float(H0s[-10 - j]))
+      ts.append(1e3 * (time.perf_counter() - ta))
     sync()
-    single_ms = 1e3 * (time.perf_counter() - t2) / nsingle
-  traffic = None
-  tf = os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic.json')
-  if os.path.exists(tf):
-    try:
-      with open(tf) as f:
-        tj = json.load(f)
-      if (tj.get('E') == (like._e1 - like._e0) and tj.get('kernel') == KERNEL_NAMES.get(kind) and cfg['P'] == tj.get('P')
-          and cfg['Z'] == tj.get('Z') and tj.get('nbatch') == nb):      # measured on this workload, this many draws per call
-        traffic = tj['bytes_per_draw'] * nb
-    except Exception:
-      traffic = None
+    med, q1, q3 = quartiles(ts)
+    single = {"median_ms": med, "q25_ms": q1, "q75_ms": q3, "calls": len(ts), "evals_per_s": 1e3 / med}
 
   if rank == 0:
     evals = args.steps * nb
     value = evals / dt
     El = like._e1 - like._e0
-    kb = kde_kernel_bytes(El, S, P if pixelated else 1, Z) * nb
-    kde_ms = kt[3]
-    ach = kb / (kde_ms * 1e-3) / 1e9 if kde_ms > 0 else 0.
+    pmc = load_pmc(dict(config=args.config, E=El, P=P, Z=Z, S=S, nbatch=nb, mode=kind or '1d', n_gpus=1)) if world == 1 else None
+    kernels = []
+    if kind == 'marginalized':
+      kernels.append(kernel_roofline("marginalized GW kernel (histogram + KDE + interp + integrand + trapz)", "k_kde_marg_sub2", kt[3],
+                                     gw_kernel_unique_bytes(El, S, P, Z, nb), pmc))
+    if kind == 'full':
+      kernels.append(kernel_roofline("3-D Gaussian KDE + integrand", "k_full_kde", kt[3], El * S * 32 * nb + El * P * Z * 8, pmc))
+    kernels.append(kernel_roofline("sample stage (z(dL), source-frame masses, population weights, event statistics)", "k_samples", kt[2],
+                                   sample_kernel_unique_bytes(El, S, nb), pmc))
+    dom = kernels[0]
     path_bytes = algorithmic_bytes(E, S, P, Z, I, 200, pixelated, kind == 'full')
+    med, q1, q3 = quartiles(step_s) if step_s else (None, None, None)
+    roof = {"bound": "fp64-valu", "kernel": dom["kernel"],
+            "achieved": dom.get("fp64_fma_equiv_TFLOPs"), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom.get("valu_frac"),
+            "traffic": dom.get("traffic_bytes_per_launch"),
+            "traffic_source": (pmc[0] + " (separate rocprofv3 --pmc passes of this command)") if pmc else None,
+            "kernel_ms": dom["kernel_ms"],
+            "hbm": {"unique_bytes_per_launch": dom["unique_bytes_per_launch"], "achieved": dom["hbm_unique_GBs"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": dom["hbm_unique_frac"], "traffic_frac": dom.get("hbm_traffic_frac")},
+            "kernels": kernels,
+            "note": "both dominant kernels are fp64-VALU-issue bound: achieved = VALU wave-instructions of one launch (PMC SQ_INSTS_VALU, "
+                    "committed pass of this command) x 128 flop (a wave64 FMA) / the launch's LIVE HIP-event duration; peak = 1024 SIMDs x "
+                    "2.4 GHz / 4 cycles per fp64 wave-instruction x 128 = 78.6 TFLOP/s; frac is the share of fp64 issue slots used at the "
+                    "maximum clock (the chip holds less under load, see clock_GHz_under_profile).  hbm.* is the same launch against 8 TB/s: "
+                    "unique bytes (shared inputs once, per-draw arrays x nbatch) and PMC fabric traffic",
+            "path_bytes_per_eval": path_bytes,
+            "path_frac": path_bytes * nb / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[0] > 0 else None,
+            "stage_ms": {"eval": kt[0], "tables": kt[1], "samples": kt[2], "kde_integrate": kt[3],
+                         "selection": kt[4], "reduce": kt[5], "events_wall": kt[6], "event_groups": kt[7]}}
     out = {
       "metric": "log-likelihood evals/sec (full hyperposterior call), N_ev x N_pix x N_z",
       "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -227,27 +310,19 @@ def main():
                  "E": E, "P": P, "Z": Z, "S": S, "I": I, "kind_p_gw3d": kind, "nbatch": nb,
                  "parallelism": f"events+injections sharded over {world} GPU(s)" + (f"; {comm_kind}" if comm_kind else ""),
                  "cells_per_s": value * E * max(P, 1) * Z},
-      "single_call_ms": single_ms,
-      "roofline": {"bound": "hbm", "kernel": KERNEL_NAMES.get(kind, "k_kde1d+k_integrate_1d"),
-                   "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                   "traffic": traffic, "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)" if traffic else None,
-                   "bytes_per_launch": kb, "kernel_ms": kde_ms,
-                   "note": "achieved = ALGORITHMIC bytes of the launch (every input of the kernel once: 370.7 MB per draw at C3) / its "
-                           "HIP-event duration; the kernel moves far fewer bytes than that (see traffic): it reads only the part of "
-                           "each p_cat row inside the KDE's support, and the draws of a call share p_cat and samples through L2 / "
-                           "Infinity Cache -- so frac can approach or exceed 1 without the HBM being saturated; the kernel is "
-                           "fp64-VALU / latency bound (DESIGN.md section 4)",
-                   "path_bytes_per_eval": path_bytes,
-                   "path_frac": path_bytes * nb / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[0] > 0 else None,
-                   "stage_ms": {"eval": kt[0], "tables": kt[1], "samples": kt[2], "kde_integrate": kt[3],
-                                "selection": kt[4], "reduce": kt[5], "events_wall": kt[6], "event_groups": kt[7]}},
+      "step_ms": {"median": 1e3 * med, "q25": 1e3 * q1, "q75": 1e3 * q3, "n": len(step_s)} if step_s else None,
+      "single_call_ms": single["median_ms"] if single else None,
+      "single_call": single,
+      "roofline": roof,
       "setup_s": {"synthetic": t_gen, "upload_once": t_upload,
                   "note": "upload_once = chm_like_create + chm_sel_create (host pixel sort, log(m_det), H2D of the shard); every "
                           "evaluation afterwards moves ~350 B of parameters per draw host->device and 24 B back"},
       "last_log_hyper": float(np.asarray(vals[-1]).ravel()[-1]),
     }
     if world == 1 and not args.no_cpu_baseline:
-      out["cpu_baseline"] = cb = cpu_baseline(cfg, ev, inj, kind, args.cpu_events)
+      out["cpu_baseline"] = cb = cpu_baseline(cfg, ev, inj, kind, args.cpu_events, n_evals=args.cpu_evals)
+      if cb.get("value"):
+        out["vs_cpu_baseline"] = value / cb["value"]
       if cb.get("log_hyper_H0_67") is not None:      # full-size parity check of the timed path against the CPU port
         g = float(like(H0=67.))
         out["parity_full_size"] = {"H0": 67., "log_hyper_hip": g, "log_hyper_cpu_port": cb["log_hyper_H0_67"],
@@ -256,17 +331,19 @@ def main():
     os.write(real_stdout, (json.dumps(out) + '\n').encode())
   like.close()
   sel.close()
+  if rdzv is not None:
+    rdzv.barrier()
   if comm is not None:
     comm.close()
-  if dist is not None:
-    dist.barrier()
-    dist.destroy_process_group()
+  if rdzv is not None:
+    rdzv.close()
 
 
-def cpu_baseline(cfg, ev, inj, kind, n_ev, threads=None, numpy_events=48):
+def cpu_baseline(cfg, ev, inj, kind, n_ev, threads=None, numpy_events=48, n_evals=20):
   """CPU baselines on this host, same workload, same algorithm as the reference (dense G x B kernel sums):
   * value: the plain-C / OpenMP restatement (oracle/chimera_oracle_c.c) on `threads` cores (the GPU box's CPU share is 16),
-    n_ev events (default: the whole workload) + all injections, 2 evaluations with different H0 (tables rebuilt each time);
+    n_ev events (default: the whole workload) + all injections, `n_evals` evaluations with different H0 (tables rebuilt each
+    time), median and quartiles of the per-evaluation time;
   * numpy_1core: the NumPy restatement (oracle/chimera_oracle.py) on one core, on the first `numpy_events` events, scaled."""
   for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
     os.environ.setdefault(k, '1')
@@ -286,31 +363,35 @@ def cpu_baseline(cfg, ev, inj, kind, n_ev, threads=None, numpy_events=48):
 
   out = {}
   # NumPy, one core, bounded sample
-  n_np, like, pop, sel = build(numpy_events)
+  n_np, like, pop, sel = build(numpy_events if kind != 'full' else 2)
   popu = pop.update(H0=67.)
   t0 = time.perf_counter(); like.compute_log_likenum(popu); t_ev = time.perf_counter() - t0
   t0 = time.perf_counter(); sel.N_exp(popu); t_sel = time.perf_counter() - t0
   np1 = {"value": 1.0 / (t_ev * E / n_np + t_sel), "cores": 1,
          "sample": f"oracle/chimera_oracle.py, first {n_np} of {E} events ({t_ev:.2f} s) + all {cfg['I']} injections ({t_sel:.3f} s), "
                    f"1 evaluation, event time scaled x{E / n_np:.1f}"}
-  if kind != 'marginalized':
-    out = dict(np1, unit="evals/s", kind="port", host_cpus=os.cpu_count())
-    return out
-  # C / OpenMP, `threads` cores, the whole workload
+  # C / OpenMP, `threads` cores
   from oracle import oracle_c as OC
   threads = threads or min(16, os.cpu_count() or 1)
+  if kind == 'full':                               # ~1e8 exp per event: a bounded sample of the events, scaled
+    n_ev, n_evals = min(n_ev, 48), min(n_evals, 5)
   n_c, like, pop, sel = build(n_ev)
-  OC.numlike_marg(like, pop.update(H0=70.), nthreads=threads) if n_c <= 64 else None      # warm the library on small runs only
-  H0s = (67., 61., 73., 79.)                       # different H0 per evaluation: the tables are rebuilt each time
-  t0 = time.perf_counter()
-  vals = [OC.compute_all(like, dict(H0=h), nthreads=threads)[3] for h in H0s]
-  t_c = (time.perf_counter() - t0) / len(H0s)
-  val = vals[0]
-  t_full = t_c * (E / n_c) if n_c < E else t_c
-  out = {"value": 1.0 / t_full, "unit": "evals/s", "cores": threads, "kind": "port",
+  H0s = np.linspace(61., 79., max(n_evals, 1))      # different H0 per evaluation: the tables are rebuilt each time
+  H0s[0] = 67.
+  OC.compute_all(like, dict(H0=70.), nthreads=threads) if n_c <= 64 else None      # warm the library on small runs only
+  ts, vals = [], []
+  for h in H0s:
+    t0 = time.perf_counter()
+    vals.append(OC.compute_all(like, dict(H0=float(h)), nthreads=threads)[3])
+    ts.append(time.perf_counter() - t0)
+  scale = (E / n_c) if n_c < E else 1.
+  med, q1, q3 = quartiles(ts)
+  out = {"value": 1.0 / (med * scale), "unit": "evals/s", "cores": threads, "kind": "port",
+         "eval_s": {"median": med * scale, "q25": q1 * scale, "q75": q3 * scale, "n": len(ts)},
          "sample": f"oracle/chimera_oracle_c.c (C + OpenMP, {threads} threads), {n_c} of {E} events + all {cfg['I']} injections, "
-                   f"{len(H0s)} evaluations at different H0 ({t_c:.2f} s each; {len(H0s) * t_c * threads:.0f} core-seconds in all)",
-         "host_cpus": os.cpu_count(), "numpy_1core": np1, "log_hyper_H0_67": float(val) if n_c == E else None}
+                   f"{len(ts)} evaluations at different H0 (median {med:.3f} s each{'' if n_c == E else f', scaled x{scale:.1f}'}; "
+                   f"{sum(ts) * threads:.0f} core-seconds in all)",
+         "host_cpus": os.cpu_count(), "numpy_1core": np1, "log_hyper_H0_67": float(vals[0]) if n_c == E else None}
   return out
 
 

@@ -48,6 +48,9 @@ struct Ctx {
   hipStream_t stream2 = nullptr;        // second lane of the event-group pipeline
   hipStream_t stream3 = nullptr;        // selection function
   hipEvent_t evg[64] = {};              // per event-group timing: [4g+0..1] sample stage, [4g+2..3] GW kernel
+  hipEvent_t evf[16] = {};              // per event-group fork of the per-z-factor kernel onto the other lane
+  double *d_lle = nullptr, *d_nle = nullptr;   // (nb,E) per-event outputs (log L_i, L_i), grown on demand, kept across calls
+  size_t lle_cap = 0, nle_cap = 0;
   hipEvent_t ev[8] = {};                // timing on `stream`
   hipEvent_t evb[4] = {};               // fork/join + timing on `stream2`
   double ms[8] = {};
@@ -62,6 +65,7 @@ static int ctx_init(Ctx& c, int device) {
   HIPCHK(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&c.stream3, hipStreamNonBlocking));
   for (int i = 0; i < 64; i++) HIPCHK(hipEventCreate(&c.evg[i]));
+  for (int i = 0; i < 16; i++) HIPCHK(hipEventCreateWithFlags(&c.evf[i], hipEventDisableTiming));
   for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c.ev[i]));
   for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c.evb[i]));
   c.init = true;
@@ -85,6 +89,8 @@ static void ctx_destroy(Ctx& c) {
   for (int i = 0; i < 8; i++) if (c.ev[i]) (void)hipEventDestroy(c.ev[i]);
   for (int i = 0; i < 4; i++) if (c.evb[i]) (void)hipEventDestroy(c.evb[i]);
   for (int i = 0; i < 64; i++) if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
+  for (int i = 0; i < 16; i++) if (c.evf[i]) (void)hipEventDestroy(c.evf[i]);
+  (void)hipFree(c.d_lle); (void)hipFree(c.d_nle); c.d_lle = c.d_nle = nullptr; c.lle_cap = c.nle_cap = 0;
   if (c.stream3) (void)hipStreamDestroy(c.stream3);
   if (c.stream2) (void)hipStreamDestroy(c.stream2);
   if (c.stream) (void)hipStreamDestroy(c.stream);
@@ -549,7 +555,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       if (!zf_ranged) {
         launch_zfactors();
         HIPCHK(hipGetLastError());
-        if (sz != sg) HIPCHK(hipEventRecord(c.evg[32 + g], sz));
+        if (sz != sg) HIPCHK(hipEventRecord(c.evf[g], sz));
       }
       // sample stage
       if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g], sg));
@@ -581,7 +587,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       HIPCHK(hipGetLastError());
       if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g + 1], sg));
       // GW kernel + integrand (needs the per-z factors)
-      if (sz != sg) HIPCHK(hipStreamWaitEvent(sg, c.evg[32 + g], 0));
+      if (sz != sg) HIPCHK(hipStreamWaitEvent(sg, c.evf[g], 0));
       if (L.mode == CHM_MODE_FULL) {
         if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         hipLaunchKernelGGL(k_full_kde, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp);
@@ -648,8 +654,17 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
 
   double* d_lle = nullptr; double* d_nle = nullptr;
   const size_t El = like ? like->L.E : 0;
-  if (like && out->log_like_evs) HIPCHK(hipMalloc(&d_lle, sizeof(double) * nb * El));
-  if (like && out->numlike_evs) HIPCHK(hipMalloc(&d_nle, sizeof(double) * nb * El));
+  // per-event outputs: buffers of the context, grown on demand (no allocation in the steady state of a compute_all loop)
+  auto grow = [&](double*& buf, size_t& cap, size_t n) -> int {
+    if (n <= cap) return CHM_OK;
+    HIPCHK(hipStreamSynchronize(sA));
+    (void)hipFree(buf); buf = nullptr; cap = 0;
+    HIPCHK(hipMalloc(&buf, sizeof(double) * n));
+    cap = n;
+    return CHM_OK;
+  };
+  if (like && out->log_like_evs) { rc = grow(c.d_lle, c.lle_cap, (size_t)nb * El); if (rc) return rc; d_lle = c.d_lle; }
+  if (like && out->numlike_evs) { rc = grow(c.d_nle, c.nle_cap, (size_t)nb * El); if (rc) return rc; d_nle = c.d_nle; }
   const bool multi = comm != nullptr;       // with a communicator the partials always go through ncclAllReduce + k_combine (also for
                                             // one rank, so that a single GPU exercises the very path the multi-GPU run takes)
   double Etot = comm ? (double)E_total : (like ? (double)like->L.E : 0.);
@@ -688,8 +703,6 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     HIPCHK(hipMemcpyAsync(out->p_gw, src, sizeof(double) * nb * El * Pd * like->L.Z, hipMemcpyDeviceToHost, sA));
   }
   HIPCHK(hipStreamSynchronize(sA));
-  if (d_lle) (void)hipFree(d_lle);
-  if (d_nle) (void)hipFree(d_nle);
   for (int b = 0; b < nb; b++) {
     if (out->log_hyper) out->log_hyper[b] = c.h_out[b * 3];
     if (out->log_num) out->log_num[b] = c.h_out[b * 3 + 1];
@@ -1015,6 +1028,21 @@ extern "C" int chm_comm_destroy(chm_comm* c) {
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->comm) ncclCommDestroy(c->comm);
   delete c;
+  return CHM_OK;
+}
+
+extern "C" int chm_comm_nranks(chm_comm* c) {
+  if (!c || !c->comm) return 0;
+  int n = 0;
+  if (ncclCommCount(c->comm, &n) != ncclSuccess) return 0;     // what RCCL itself says, not what the caller passed
+  return n;
+}
+
+extern "C" int chm_device_synchronize(int32_t device) {
+  int ndev = chm_device_count();
+  if (device < 0 || device >= ndev) return fail(CHM_E_HIP, "chm_device_synchronize: no such HIP device");
+  HIPCHK(hipSetDevice(device));
+  HIPCHK(hipDeviceSynchronize());
   return CHM_OK;
 }
 

@@ -169,8 +169,10 @@ class hyperlikelihood(object):
       pass
 
   # -- one evaluation through the C ABI ----------------------------------------------------------------
-  def _eval(self, pops, want=(), mode=None, with_sel=True):
-    """Evaluate a list of population draws.  ``want`` subset of {'log_like_evs','numlike_evs','p_gw','partials'}."""
+  def _eval(self, pops, want=(), mode=None, with_sel=True, collective=True):
+    """Evaluate a list of population draws.  ``want`` subset of {'log_like_evs','numlike_evs','p_gw','partials'}.
+    ``collective=False``: this rank's shard only -- no communicator is passed, so the call runs no all-reduce and may be made
+    by one rank alone (the inspection calls p_gw*, compute_numlike_evs return per-event arrays of the rank's own events)."""
     nb = len(pops)
     tab, tab_keep = None, None
     if isinstance(pops, C.Array):
@@ -202,8 +204,9 @@ class hyperlikelihood(object):
     if 'partials' in want:
       res['partials'] = np.empty((nb, 3)); out.partials = _lib.dptr(res['partials'])
     sel = self.selection_function._handle() if (with_sel and self.selection_function is not None) else None
-    comm_h = getattr(self.comm, 'handle', None) if self.comm is not None else None       # RCCL all-reduce inside chm_eval
-    host_reduce = (self.comm is not None and comm_h is None and self.comm.nranks > 1 and hasattr(self.comm, 'allreduce_sum'))
+    comm = self.comm if collective else None
+    comm_h = getattr(comm, 'handle', None) if comm is not None else None                 # RCCL all-reduce inside chm_eval
+    host_reduce = (comm is not None and comm_h is None and comm.nranks > 1 and hasattr(comm, 'allreduce_sum'))
     if host_reduce and 'partials' not in res:               # HostComm: the partial sums are reduced and combined on the host
       res['partials'] = np.empty((nb, 3)); out.partials = _lib.dptr(res['partials'])
     if tab is not None:
@@ -231,27 +234,27 @@ class hyperlikelihood(object):
   # -- reference surface: GW kernels -------------------------------------------------------------------
   def p_gw1d(self, pop_lambdas):
     """likelihood.py:105-144 -> (Nevents, z_int_res)."""
-    return self._eval([pop_lambdas], want=('p_gw',), mode='1d', with_sel=False)['p_gw'][0]
+    return self._eval([pop_lambdas], want=('p_gw',), mode='1d', with_sel=False, collective=False)['p_gw'][0]
 
   def p_gw3dapprox(self, pop_lambdas):
     """likelihood.py:150-154 -> (Nevents, max_npixels, z_int_res)."""
-    return self._eval([pop_lambdas], want=('p_gw',), mode='approximate', with_sel=False)['p_gw'][0]
+    return self._eval([pop_lambdas], want=('p_gw',), mode='approximate', with_sel=False, collective=False)['p_gw'][0]
 
   def p_gw3dmarg(self, pop_lambdas):
     """likelihood.py:160-205."""
-    return self._eval([pop_lambdas], want=('p_gw',), mode='marginalized', with_sel=False)['p_gw'][0]
+    return self._eval([pop_lambdas], want=('p_gw',), mode='marginalized', with_sel=False, collective=False)['p_gw'][0]
 
   def p_gw3dfull(self, pop_lambdas):
     """likelihood.py:211-260."""
-    return self._eval([pop_lambdas], want=('p_gw',), mode='full', with_sel=False)['p_gw'][0]
+    return self._eval([pop_lambdas], want=('p_gw',), mode='full', with_sel=False, collective=False)['p_gw'][0]
 
   # -- reference surface: numerator --------------------------------------------------------------------
   def compute_numlike_evs(self, pop_lambdas):
     """likelihood.py:266-292 -> (Nevents,) [this rank's events when sharded]."""
-    return self._eval([pop_lambdas], want=('numlike_evs',), with_sel=False)['numlike_evs'][0]
+    return self._eval([pop_lambdas], want=('numlike_evs',), with_sel=False, collective=False)['numlike_evs'][0]
 
   def compute_log_likenum(self, pop_lambdas):
-    """likelihood.py:294-301."""
+    """likelihood.py:294-301.  Sharded: a collective call (every rank makes it; the sum runs over all events)."""
     return self._eval([pop_lambdas], with_sel=False)['log_num'][0]
 
   # -- reference surface: hyper-likelihood -------------------------------------------------------------

@@ -5,11 +5,16 @@ Replaces the design of the reference's (un-importable) MPI layer, CHIMERA/parall
 selection sums (:366-376, 406-407).  Here the payload is ``3 * nbatch`` doubles -- [sum_i log L_i, nansum dN, sum dN^2]
 per draw -- reduced by ``ncclAllReduce`` inside ``chm_eval`` on the evaluation stream.
 
-The RCCL unique id is exchanged out of band: through ``torch.distributed`` if a process group is up (plumbing only),
-else through a file (``CHIMERA_COMM_FILE``).
+Control plane (no PyTorch, no MPI): :class:`Rendezvous` is a small socket star over the ranks of one job -- rank 0 listens
+on a Unix-domain socket (one node; the path is derived from the launcher's MASTER_PORT and parent pid) or on TCP
+(``CHIMERA_COMM_ADDR=host:port``, several nodes) -- and carries only the 128-byte RCCL unique id, barriers and a few
+doubles (the max-over-ranks of a wall time).  :class:`HostComm` reduces the ``3 * nbatch`` partial sums over the same
+star for hosts on which RCCL cannot bring a communicator up; the data path of a healthy job never touches it.
 """
 import ctypes as C
 import os
+import socket
+import struct
 import time
 import numpy as np
 from . import _lib
@@ -23,23 +28,189 @@ def chunk_bounds(n, nranks, rank):
   return lo, lo + base + (1 if rank < extra else 0)
 
 
-class Comm(object):
-  """A rank of an RCCL communicator bound to one GPU."""
+# ----------------------------------------------------------------------------------------------------------
+# control plane
+# ----------------------------------------------------------------------------------------------------------
+_OP_SUM, _OP_MAX, _OP_BCAST = 1, 2, 3
 
-  def __init__(self, nranks, rank, device=None, unique_id=None):
+
+def _recv_exact(sock, n):
+  buf = bytearray()
+  while len(buf) < n:
+    chunk = sock.recv(n - len(buf))
+    if not chunk:
+      raise ConnectionError("chimera_amd.parallel: peer closed the rendezvous connection")
+    buf.extend(chunk)
+  return bytes(buf)
+
+
+def _send_msg(sock, op, payload):
+  sock.sendall(struct.pack('<BQ', op, len(payload)) + payload)
+
+
+def _recv_msg(sock):
+  op, n = struct.unpack('<BQ', _recv_exact(sock, 9))
+  return op, _recv_exact(sock, n)
+
+
+def default_address(world=None):
+  """Where the ranks of this job meet.  ``CHIMERA_COMM_ADDR=host:port`` -> TCP; otherwise a Unix-domain socket under
+  /tmp named after the launcher: MASTER_PORT (set by ``torch.distributed.run`` / any torchrun-style launcher) and the
+  parent pid shared by the ranks it started, so two jobs on one node -- or a stale path of an earlier job -- never meet."""
+  addr = os.environ.get('CHIMERA_COMM_ADDR')
+  if addr:
+    host, port = addr.rsplit(':', 1)
+    return (host, int(port))
+  tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+  return os.path.join(os.environ.get('CHIMERA_COMM_DIR', '/tmp'), f"chimera_rdzv_{tag}.sock")
+
+
+class Rendezvous(object):
+  """Socket star over the ranks of one job: rank 0 is the hub.  Every method is a collective (all ranks call it, in the
+  same order).  Reductions run in rank order on the hub, so every rank receives the same bits."""
+
+  def __init__(self, nranks, rank, address=None, timeout=300.):
+    self.nranks, self.rank = int(nranks), int(rank)
+    self.address = default_address() if address is None else address
+    self._peers, self._sock, self._listener = [], None, None
+    if self.nranks == 1:
+      return
+    unix = isinstance(self.address, str)
+    fam = socket.AF_UNIX if unix else socket.AF_INET
+    if self.rank == 0:
+      ls = socket.socket(fam, socket.SOCK_STREAM)
+      if unix:
+        try:
+          os.unlink(self.address)                               # a stale path of a dead job with the same launcher pid
+        except FileNotFoundError:
+          pass
+      else:
+        ls.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+      ls.bind(self.address)
+      ls.listen(self.nranks)
+      ls.settimeout(timeout)
+      self._listener = ls
+      peers = {}
+      while len(peers) < self.nranks - 1:
+        conn, _ = ls.accept()
+        conn.settimeout(timeout)
+        r, n = struct.unpack('<II', _recv_exact(conn, 8))
+        if n != self.nranks or r in peers or not (0 < r < self.nranks):
+          conn.close()
+          raise RuntimeError(f"chimera_amd.parallel: unexpected peer (rank {r} of {n}) at the rendezvous of a {self.nranks}-rank job")
+        peers[r] = conn
+      self._peers = [peers[r] for r in range(1, self.nranks)]
+    else:
+      t0 = time.time()
+      while True:
+        s = socket.socket(fam, socket.SOCK_STREAM)
+        try:
+          s.connect(self.address)
+          break
+        except (FileNotFoundError, ConnectionRefusedError, OSError):
+          s.close()
+          if time.time() - t0 > timeout:
+            raise RuntimeError(f"chimera_amd.parallel: rank {self.rank} could not reach rank 0 at {self.address}")
+          time.sleep(0.02)
+      s.settimeout(timeout)
+      s.sendall(struct.pack('<II', self.rank, self.nranks))
+      self._sock = s
+
+  # -- collectives ---------------------------------------------------------------------------------------
+  def _reduce(self, x, op):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if self.nranks == 1:
+      return x.copy()
+    if self.rank == 0:
+      acc = x.copy()
+      for p in self._peers:                                     # rank order: the same sum on every run
+        o, payload = _recv_msg(p)
+        if o != op or len(payload) != acc.nbytes:
+          raise RuntimeError("chimera_amd.parallel: ranks disagree on the collective being run")
+        y = np.frombuffer(payload, dtype=np.float64).reshape(acc.shape)
+        acc = acc + y if op == _OP_SUM else np.maximum(acc, y)
+      out = acc.tobytes()
+      for p in self._peers:
+        _send_msg(p, op, out)
+      return acc
+    _send_msg(self._sock, op, x.tobytes())
+    o, payload = _recv_msg(self._sock)
+    return np.frombuffer(payload, dtype=np.float64).reshape(x.shape).copy()
+
+  def allreduce_sum(self, x):
+    return self._reduce(x, _OP_SUM)
+
+  def allreduce_max(self, x):
+    return self._reduce(x, _OP_MAX)
+
+  def barrier(self):
+    self._reduce(np.zeros(1), _OP_SUM)
+
+  def broadcast_bytes(self, data=None):
+    """Rank 0's ``data`` on every rank."""
+    if self.nranks == 1:
+      return bytes(data)
+    if self.rank == 0:
+      for p in self._peers:
+        _send_msg(p, _OP_BCAST, bytes(data))
+      return bytes(data)
+    o, payload = _recv_msg(self._sock)
+    if o != _OP_BCAST:
+      raise RuntimeError("chimera_amd.parallel: ranks disagree on the collective being run")
+    return payload
+
+  def close(self):
+    for s in self._peers + [self._sock, self._listener]:
+      if s is not None:
+        try:
+          s.close()
+        except OSError:
+          pass
+    if self._listener is not None and isinstance(self.address, str):
+      try:
+        os.unlink(self.address)
+      except OSError:
+        pass
+    self._peers, self._sock, self._listener = [], None, None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+
+def env_ranks():
+  """(rank, world, local_rank) from the torchrun-style environment (RANK, WORLD_SIZE, LOCAL_RANK)."""
+  return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# data plane
+# ----------------------------------------------------------------------------------------------------------
+class Comm(object):
+  """A rank of an RCCL communicator bound to one GPU.  The 128-byte unique id comes from ``unique_id`` (every rank passes
+  the same bytes) or travels over ``rendezvous`` (rank 0 creates it)."""
+
+  def __init__(self, nranks, rank, device=None, unique_id=None, rendezvous=None):
     self.nranks, self.rank = int(nranks), int(rank)
     self.device = _lib.default_device() if device is None else int(device)
     self._h = C.c_void_p()
     if unique_id is None:
-      unique_id = exchange_unique_id(self.nranks, self.rank)
+      unique_id = exchange_unique_id(self.nranks, self.rank, rendezvous)
     buf = C.create_string_buffer(bytes(unique_id), 128)
     _lib.check(_lib.lib().chm_comm_init_rank(buf, self.nranks, self.rank, self.device, C.byref(self._h)))
+    got = _lib.lib().chm_comm_nranks(self._h)
+    if got != self.nranks:
+      self.close()
+      raise RuntimeError(f"RCCL communicator reports {got} ranks, expected {self.nranks}")
 
   @classmethod
-  def from_env(cls):
+  def from_env(cls, rendezvous=None):
     """Build from torchrun-style environment variables (RANK, WORLD_SIZE, LOCAL_RANK)."""
-    n, r = int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('RANK', 0))
-    return cls(n, r, int(os.environ.get('LOCAL_RANK', 0)))
+    r, n, lr = env_ranks()
+    ndev = _lib.lib().chm_device_count()
+    return cls(n, r, lr % ndev if ndev > 0 else lr, rendezvous=rendezvous)
 
   @property
   def handle(self):
@@ -63,28 +234,25 @@ class Comm(object):
 
 
 class HostComm(object):
-  """Fallback communicator for hosts where RCCL cannot bring up a communicator: the ``3 * nbatch`` partial sums travel through
-  ``torch.distributed`` (any initialised backend, e.g. gloo) on the host and the combination (likelihood.py:298-316,
-  selection_function.py:38-47) is formed by :func:`combine_partials` instead of ``k_combine``.  Same sharding, same sums; only the
-  transport differs (an extra D2H/H2D of 3 doubles per draw per call)."""
+  """Fallback communicator for hosts where RCCL cannot bring up a communicator: the ``3 * nbatch`` partial sums travel over the
+  :class:`Rendezvous` sockets on the host and the combination (likelihood.py:298-316, selection_function.py:38-47) is formed by
+  :func:`combine_partials` instead of ``k_combine``.  Same sharding, same sums; only the transport differs (an extra D2H of 3
+  doubles per draw per call).  ``handle`` is None: ``chm_eval`` then runs without a communicator and returns the shard's partials."""
   handle = None
 
-  def __init__(self, nranks, rank, device=None):
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-      raise RuntimeError("HostComm needs an initialised torch.distributed process group")
+  def __init__(self, nranks, rank, device=None, rendezvous=None):
     self.nranks, self.rank = int(nranks), int(rank)
     self.device = _lib.default_device() if device is None else int(device)
+    self._own = rendezvous is None
+    self.rendezvous = Rendezvous(self.nranks, self.rank) if rendezvous is None else rendezvous
 
   def allreduce_sum(self, x):
-    import torch
-    import torch.distributed as dist
-    t = torch.from_numpy(_lib.as_f64(x).copy())
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return t.numpy()
+    return self.rendezvous.allreduce_sum(_lib.as_f64(x))
 
   def close(self):
-    pass
+    if self._own and self.rendezvous is not None:
+      self.rendezvous.close()
+    self.rendezvous = None
 
 
 def combine_partials(partials, E_total, N_inj, N_eff, scale_free, R0, Tobs, has_like=True, has_sel=True):
@@ -117,32 +285,16 @@ def new_unique_id():
   return buf.raw
 
 
-def exchange_unique_id(nranks, rank):
-  """Rank 0 creates the RCCL unique id; the 128 bytes reach the other ranks through torch.distributed (if
-  initialised) or a rendezvous file."""
+def exchange_unique_id(nranks, rank, rendezvous=None):
+  """Rank 0 creates the RCCL unique id; the 128 bytes reach the other ranks over the rendezvous sockets (a temporary
+  :class:`Rendezvous` at the default address when none is passed)."""
   if nranks == 1:
     return new_unique_id()
+  own = rendezvous is None
+  rdzv = Rendezvous(nranks, rank) if own else rendezvous
   try:
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-      obj = [new_unique_id() if rank == 0 else None]
-      dist.broadcast_object_list(obj, src=0)
-      return obj[0]
-  except ImportError:
-    pass
-  path = os.environ.get('CHIMERA_COMM_FILE')
-  if not path:
-    raise RuntimeError("multi-rank Comm needs an initialised torch.distributed group or CHIMERA_COMM_FILE")
-  if rank == 0:
-    uid = new_unique_id()
-    with open(path + '.tmp', 'wb') as f:
-      f.write(uid)
-    os.replace(path + '.tmp', path)
-    return uid
-  t0 = time.time()
-  while not os.path.exists(path):
-    if time.time() - t0 > 120:
-      raise RuntimeError(f"timed out waiting for {path}")
-    time.sleep(0.05)
-  with open(path, 'rb') as f:
-    return f.read()
+    return rdzv.broadcast_bytes(new_unique_id() if rank == 0 else None)
+  finally:
+    if own:
+      rdzv.barrier()                                          # every rank holds the id before the hub goes away
+      rdzv.close()

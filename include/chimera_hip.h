@@ -235,6 +235,11 @@ int chm_comm_init_rank(const char id[128], int32_t nranks, int32_t rank, int32_t
 int chm_comm_destroy(chm_comm* c);
 /* sum a small fp64 vector over ranks in place (host pointer; staged through the device). */
 int chm_comm_allreduce_sum(chm_comm* c, double* buf, int32_t n);
+/* number of ranks RCCL reports for the communicator (ncclCommCount); 0 for a NULL / dead handle.  The sharded job checks it
+ * against the launcher's WORLD_SIZE (the partition of CHIMERA/parallel.py:68-73,94-99 assumes every rank is present).   */
+int chm_comm_nranks(chm_comm* c);
+/* hipDeviceSynchronize on `device`: the barrier bracket of a timed region (chm_eval itself returns after its stream drained). */
+int chm_device_synchronize(int32_t device);
 
 /* Timing of the last chm_eval on a handle, from HIP events recorded on the handle's own stream:
  * ms[0] = whole evaluation, ms[1] = tables, ms[2] = sample stage, ms[3] = KDE+integrand kernel,

@@ -14,7 +14,7 @@
  *
  * Scope: flrw / mg_flrw cosmology, tpl / bpl / plp mass models, the four rate models, the pixelated catalogue with
  * step completeness, kind_p_gw3d = 'marginalized' (likelihood.py:160-205, 266-281), the 1-D and 'approximate' modes
- * (likelihood.py:105-154, 283-292) and the injection selection
+ * (likelihood.py:105-154, 283-292), kind_p_gw3d = 'full' (likelihood.py:211-260 with utils/math.py:154-229) and the injection selection
  * function (selection_function.py:34-48, pop_wrapper.py:102-111).  Parameter block: `chm_params` of
  * include/chimera_hip.h (plain data; the same struct the product's C ABI takes).
  *
@@ -545,6 +545,170 @@ int orc_numlike_1d(const chm_params* p, int E, int S, int P, int Z, const double
     }
 #pragma omp for schedule(dynamic, 1)
     for (int ev = 0; ev < E; ev++) if (scratch) like_evs[ev] = event_numlike_1d(&m, &L, kernel, NULL, ev, scratch);
+    free(scratch);
+  }
+  model_free(&m);
+  return fail ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------------------------
+ * p_gw3dfull (likelihood.py:211-260) with numba_gkde_nd / numba_gaussian_kernel (utils/math.py:154-229, CPU branch,
+ * in_log=False) and the pixelated numerator (likelihood.py:266-281), one event.  The pair sum is the reference's
+ * plain double loop: one exp per (grid point, sample).
+ * ---------------------------------------------------------------------------------------------------- */
+/* np.linalg.inv of a 3x3 matrix: LU with partial pivoting (LAPACK getrf), then the columns of the identity are solved for (getri) */
+static void inv3_lu(const double A[3][3], double inv[3][3]) {
+  double lu[3][3];
+  int piv[3] = {0, 1, 2};
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) lu[r][c] = A[r][c];
+  for (int c = 0; c < 3; c++) {
+    int best = c;
+    for (int r = c + 1; r < 3; r++) if (fabs(lu[r][c]) > fabs(lu[best][c])) best = r;
+    if (best != c) {
+      for (int k = 0; k < 3; k++) { double t = lu[c][k]; lu[c][k] = lu[best][k]; lu[best][k] = t; }
+      int t = piv[c]; piv[c] = piv[best]; piv[best] = t;
+    }
+    for (int r = c + 1; r < 3; r++) {
+      lu[r][c] = lu[r][c] / lu[c][c];
+      for (int k = c + 1; k < 3; k++) lu[r][k] -= lu[r][c] * lu[c][k];
+    }
+  }
+  for (int col = 0; col < 3; col++) {
+    double b[3], y[3], x[3];
+    for (int r = 0; r < 3; r++) b[r] = piv[r] == col ? 1. : 0.;
+    for (int r = 0; r < 3; r++) { double s = b[r]; for (int k = 0; k < r; k++) s -= lu[r][k] * y[k]; y[r] = s; }
+    for (int r = 2; r >= 0; r--) { double s = y[r]; for (int k = r + 1; k < 3; k++) s -= lu[r][k] * x[k]; x[r] = s / lu[r][r]; }
+    for (int r = 0; r < 3; r++) inv[r][col] = x[r];
+  }
+}
+
+typedef struct {
+  const double *ra, *dec;            /* (E,S) */
+  const double *ra_pix, *dec_pix;    /* (E,P) */
+  const int32_t* neff_pixels;        /* (E,)  */
+} orc_full;
+
+static double event_numlike_full(const orc_model* m, const orc_like* L, const orc_full* F, int ev, double* scratch) {
+  const int S = L->S, P = L->P, Z = L->Z;
+  double* z = scratch;           double* w = z + S;          double* Wn = w + S;
+  double* dw = Wn + S;           /* (S,3) whitened dataset */
+  double* pz = dw + 3 * (size_t)S; double* jac = pz + Z;     double* bkg = jac + Z;     double* pg = bkg + Z;
+  double* msk = pg + Z;
+  const double* zg = L->z_grids + (size_t)ev * Z;
+  const size_t eo = (size_t)ev * S;
+  double sw = 0., sw2 = 0.;
+  for (int s = 0; s < S; s++) {                                                     /* pop_wrapper.py:67-80 */
+    double zz = interp1s(L->dL[eo + s], m->dLt, m->zt, m->Tc, 0, 0., 0., m->dl_unsorted);
+    z[s] = zz;
+    w[s] = p_m1m2(m, L->m1det[eo + s] / (1. + zz), L->m2det[eo + s] / (1. + zz)) / L->pe_prior[eo + s];
+    sw += w[s]; sw2 += w[s] * w[s];
+  }
+  const double norm = sw / (double)S, n_eff = (sw * sw) / sw2;                       /* likelihood.py:214-215 */
+  for (int k = 0; k < Z; k++) {                                                     /* p_cbc / jacobian on the event grid */
+    double dCt = dCt_at_z(m, zg[k]);
+    pz[k] = merger_rate(m->p, zg[k]) / (1. + zg[k]);
+    jac[k] = ddLdz(m, dCt, zg[k]) * ((1. + zg[k]) * (1. + zg[k]));
+    bkg[k] = dVcdz(m, dCt, zg[k]);
+  }
+  const int skip = n_eff < L->pe_neff;                                              /* `if n_effs[ev] < pe_neff: continue`  :234 */
+  int npix = F->neff_pixels[ev];
+  if (npix > P) npix = P;
+  double Lw[3][3] = {{0}}, log_norm = 0.;
+  int nmask = 0;
+  if (!skip) {
+    /* z mask                                                                        likelihood.py:222-225 */
+    double zmin = z[0], zmax = z[0];
+    for (int s = 1; s < S; s++) { if (z[s] < zmin || z[s] != z[s]) zmin = z[s]; if (z[s] > zmax || z[s] != z[s]) zmax = z[s]; }
+    const double sd = two_pass_std(z, S);
+    for (int k = 0; k < Z; k++) { msk[k] = (zg[k] <= zmax + L->cut_grid * sd) && (zg[k] >= zmin - L->cut_grid * sd) ? 1. : 0.; nmask += msk[k] != 0.; }
+    /* numba_gkde_nd set-up                                                          math.py:171-196 */
+    double s2 = 0.;
+    for (int s = 0; s < S; s++) { Wn[s] = w[s] / sw; s2 += Wn[s] * Wn[s]; }
+    const double neff = 1.0 / s2;
+    double factor;
+    if (L->bw_method == 0) factor = pow(neff, -1. / 7.);
+    else if (L->bw_method == 1) factor = pow(neff * 5. / 4.0, -1. / 7.);
+    else factor = L->bw_scalar;
+    const double* X[3] = { z, F->ra + eo, F->dec + eo };
+    double mean[3], cov[3][3], icov[3][3];
+    for (int c = 0; c < 3; c++) { double a = 0.; for (int s = 0; s < S; s++) a += Wn[s] * X[c][s]; mean[c] = a; }
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+      double acc = 0.;
+      for (int s = 0; s < S; s++) acc += ((X[a][s] - mean[a]) * Wn[s]) * (X[b][s] - mean[b]);
+      cov[a][b] = acc / (1. - s2);
+    }
+    inv3_lu(cov, icov);
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) icov[a][b] = icov[a][b] / (factor * factor);
+    for (int r = 0; r < 3; r++) for (int c = 0; c <= r; c++) {                      /* np.linalg.cholesky (lower) */
+      double s = icov[r][c];
+      for (int k = 0; k < c; k++) s -= Lw[r][k] * Lw[c][k];
+      Lw[r][c] = r == c ? sqrt(s) : s / Lw[c][c];
+    }
+    for (int s = 0; s < S; s++) for (int c = 0; c < 3; c++) {                       /* dataset.T @ whitening */
+      double a = 0.;
+      for (int k = 0; k < 3; k++) a += X[k][s] * Lw[k][c];
+      dw[3 * (size_t)s + c] = a;
+    }
+    log_norm = (log(Lw[0][0]) + log(Lw[1][1]) + log(Lw[2][2])) - 0.5 * 3. * log(2. * ORC_PI);     /* math.py:215 */
+  }
+  double Li = 0.;
+  for (int i = 0; i < P; i++) {
+    const double* pc = L->p_cat + ((size_t)ev * P + i) * Z;
+    for (int k = 0; k < Z; k++) pg[k] = 0.;                                         /* np.zeros result, kde_vals           :230,250 */
+    if (!skip && i < npix && nmask > 0) {
+      const double q[3] = { 0., F->ra_pix[(size_t)ev * P + i], F->dec_pix[(size_t)ev * P + i] };
+      for (int k = 0; k < Z; k++) {
+        if (msk[k] == 0.) continue;
+        double pw[3];
+        for (int c = 0; c < 3; c++) pw[c] = (zg[k] * Lw[0][c] + q[1] * Lw[1][c]) + q[2] * Lw[2][c];       /* points.T @ whitening */
+        double acc = 0.;
+        for (int s = 0; s < S; s++) {                                               /* numba_gaussian_kernel, math.py:217-227 */
+          double d0 = dw[3 * (size_t)s] - pw[0], d1 = dw[3 * (size_t)s + 1] - pw[1], d2 = dw[3 * (size_t)s + 2] - pw[2];
+          acc += Wn[s] * exp(log_norm - 0.5 * ((d0 * d0 + d1 * d1) + d2 * d2));
+        }
+        pg[k] = acc * norm;                                                         /* kde_vals ... * norm                 :252-253 */
+      }
+    }
+    double acc = 0., yprev = 0.;
+    for (int k = 0; k < Z; k++) {                                                   /* likelihood.py:270-278 */
+      double P_compl = (zg[k] > m->p->compl_z0 && zg[k] < m->p->compl_z1) ? 1. : 0.;
+      double p_gal = (pc[k] != -100.) ? m->fR * pc[k] + (1. - P_compl) * bkg[k] : -100.;
+      double p_z = (p_gal != -100.) ? p_gal * pz[k] : -100.;
+      double y = (p_z != -100.) ? pg[k] * p_z / jac[k] : 0.;
+      if (k > 0) acc += (zg[k] - zg[k - 1]) * (y + yprev);
+      yprev = y;
+    }
+    Li += 0.5 * acc;
+  }
+  return Li;
+}
+
+/* like_evs[ev] = L_i for kind_p_gw3d = 'full'; cut_grid must be set (the reference multiplies it into the mask) */
+int orc_numlike_full(const chm_params* p, int E, int S, int P, int Z, const double* dL, const double* m1det, const double* m2det,
+                     const double* pe_prior, const double* ra, const double* dec, const double* ra_pix, const double* dec_pix,
+                     const int32_t* neff_pixels, const double* z_grids, const double* p_cat, double cut_grid, double pe_neff,
+                     int bw_method, double bw_scalar, int nthreads, double* like_evs) {
+  orc_model m;
+  if (model_init(&m, p)) return -1;
+  orc_like L;
+  memset(&L, 0, sizeof(L));
+  L.E = E; L.S = S; L.P = P; L.Z = Z; L.has_cut = 1; L.bw_method = bw_method; L.cut_grid = cut_grid; L.pe_neff = pe_neff; L.bw_scalar = bw_scalar;
+  L.dL = dL; L.m1det = m1det; L.m2det = m2det; L.pe_prior = pe_prior; L.z_grids = z_grids; L.p_cat = p_cat;
+  orc_full F = { ra, dec, ra_pix, dec_pix, neff_pixels };
+  const size_t nscr = (size_t)6 * S + 5 * (size_t)Z;
+  int fail = 0;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+  {
+    double* scratch = malloc(sizeof(double) * nscr);
+    if (!scratch) {
+#pragma omp atomic write
+      fail = 1;
+    }
+#pragma omp for schedule(dynamic, 1)
+    for (int ev = 0; ev < E; ev++) if (scratch) like_evs[ev] = event_numlike_full(&m, &L, &F, ev, scratch);
     free(scratch);
   }
   model_free(&m);

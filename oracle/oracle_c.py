@@ -47,6 +47,9 @@ def lib():
     L.orc_numlike_1d.argtypes = [C.POINTER(chm_params), C.c_int, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp,
                                  C.c_double, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_int, C.c_int, c_dp]
     L.orc_numlike_1d.restype = C.c_int
+    L.orc_numlike_full.argtypes = [C.POINTER(chm_params), C.c_int, C.c_int, C.c_int, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp,
+                                   C.POINTER(C.c_int32), c_dp, c_dp, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int, c_dp]
+    L.orc_numlike_full.restype = C.c_int
     L.orc_nexp.argtypes = [C.POINTER(chm_params), C.c_longlong, c_dp, c_dp, c_dp, c_dp, C.c_double, C.c_double, C.c_int, c_dp]
     L.orc_nexp.restype = C.c_int
     L.orc_max_threads.restype = C.c_int
@@ -154,9 +157,33 @@ def numlike_1d(like, pop, nthreads=0):
   return out
 
 
+def numlike_full(like, pop, nthreads=0):
+  """L_i of every event for an oracle ``hyperlikelihood`` configured with kind_p_gw3d='full' (likelihood.py:211-260)."""
+  assert like.pixelated and like.kind_p_gw3d == 'full'
+  th = like.theta_gw_det
+  p = pack_params(pop)
+  dL, m1, m2, pr = _f64(th.dL), _f64(th.m1det), _f64(th.m2det), _f64(th.pe_prior)
+  ra, dec, rap, decp = _f64(th.ra), _f64(th.dec), _f64(th.ra_pix), _f64(th.dec_pix)
+  E, S = dL.shape
+  zg, pc = _f64(like.z_grids), _f64(pop.gal_cat.p_cat)
+  P, Z = pc.shape[1], zg.shape[1]
+  npx = np.ascontiguousarray(like.neff_pixels, dtype=np.int32)
+  bw = like.bw_method
+  bw_method, bw_scalar = (0, 0.) if bw in (None, 'scott') else ((1, 0.) if bw == 'silverman' else (2, float(bw)))
+  out = np.zeros(E)
+  rc = lib().orc_numlike_full(C.byref(p), E, S, P, Z, _dp(dL), _dp(m1), _dp(m2), _dp(pr), _dp(ra), _dp(dec), _dp(rap), _dp(decp),
+                              npx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(zg), _dp(pc), float(like.cut_grid), float(like.pe_neff),
+                              bw_method, bw_scalar, int(nthreads), _dp(out))
+  if rc:
+    raise MemoryError('orc_numlike_full')
+  return out
+
+
 def numlike(like, pop, nthreads=0):
   if like.pixelated and like.kind_p_gw3d == 'marginalized':
     return numlike_marg(like, pop, nthreads)
+  if like.pixelated and like.kind_p_gw3d == 'full':
+    return numlike_full(like, pop, nthreads)
   return numlike_1d(like, pop, nthreads)
 
 

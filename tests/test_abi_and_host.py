@@ -265,16 +265,43 @@ def test_synthetic_inputs_are_seeded_and_well_formed():
 
 
 def test_roofline_accounting_of_the_bench():
-  """The algorithmic byte counts bench.py prices the roofline with: C3 = 423.4 MB per evaluation for
-  the whole path, 370.7 MB per draw for the GW kernel; the kernel named in the bench line is the one the library launches."""
+  """The byte / instruction-slot accounting bench.py prices the roofline with: the whole path's
+  algorithmic bytes per evaluation; the UNIQUE bytes of one launch of each dominant kernel (arrays shared by the draws of a call
+  count once); the fp64 vector peak; every fraction the line prints is <= 1 by construction for physical durations."""
   import importlib.util
   spec = importlib.util.spec_from_file_location('bench', os.path.join(ROOT, 'bench.py'))
   bench = importlib.util.module_from_spec(spec)
   spec.loader.exec_module(bench)
   assert bench.algorithmic_bytes(1000, 4096, 32, 1000, 100000, 200) == 1000 * 4096 * 36 + 1000 * 32 * 1000 * 8 + 1000 * 1000 * 16 + 1000 * 32 * 24 + 100000 * 32 + 8000
   assert abs(bench.algorithmic_bytes(1000, 4096, 32, 1000, 100000, 200) - 423.4e6) < 0.1e6
-  assert abs(bench.kde_kernel_bytes(1000, 4096, 32, 1000) - 370.7e6) < 0.1e6
+  E, S, P, Z = 1000, 4096, 32, 1000
+  one = bench.gw_kernel_unique_bytes(E, S, P, Z, 1)
+  many = bench.gw_kernel_unique_bytes(E, S, P, Z, 128)
+  shared = E * P * Z * 8 + E * Z * 8 + E * (P + 1) * 4 + E * P * 8 + E * 4
+  assert one - shared == E * S * 16 + E * Z * 16 + E * 12 * 8 + E * P * 8
+  assert many == shared + 128 * (one - shared)                            # p_cat, grids, offsets: once per launch, not once per draw
+  assert 10.5e9 < many < 11.5e9
+  s1, s128 = bench.sample_kernel_unique_bytes(E, S, 1), bench.sample_kernel_unique_bytes(E, S, 128)
+  assert s128 - s1 == 127 * (s1 - E * S * 48 - E * 16)
   assert bench.HBM_PEAK_GBS == 8000.0
+  assert abs(bench.VALU_PEAK_GINST - 614.4) < 1e-9 and abs(bench.FP64_PEAK_TFLOPS - 78.6432) < 1e-3
+  # a kernel that issued one fp64 instruction per SIMD every 4 cycles for its whole life sits exactly at the peak
+  insts = bench.VALU_PEAK_GINST * 1e9 * 5e-3
+  r = bench.kernel_roofline('x', 'k_x', 5.0, 1e9, ('f.json', {'kernels': {'k_x<1>': {'SQ_INSTS_VALU': insts, 'FETCH_SIZE': 1e6, 'WRITE_SIZE': 1e6}}}))
+  assert abs(r['valu_frac'] - 1.0) < 1e-12 and abs(r['fp64_fma_equiv_TFLOPs'] - bench.FP64_PEAK_TFLOPS) < 1e-9
+  assert abs(r['traffic_bytes_per_launch'] - 3e6 * 1024) < 1 and r['hbm_unique_frac'] == 1e9 / 5e-3 / 1e9 / 8000.
   src = open(os.path.join(ROOT, 'chimera_amd', 'csrc', 'chimera_hip.hip')).read()
-  name = bench.KERNEL_NAMES['marginalized']                       # e.g. k_kde_marg_sub2<32, 4>
-  assert name.split('<')[0] + '<' + name.split('<')[1].replace(' ', '') in src.replace(' ', '')
+  assert 'k_kde_marg_sub2<' in src and 'k_samples<' in src             # the kernel-name prefixes the bench line matches
+
+
+def test_bench_and_product_are_torch_free():
+  """north_star: host code is Python calling HIP through ctypes -- no PyTorch, JAX or Triton in the product or in bench.py."""
+  import re
+  files = [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')]
+  for d, _, fs in os.walk(os.path.join(ROOT, 'chimera_amd')):
+    files += [os.path.join(d, f) for f in fs if f.endswith('.py')]
+  for f in files:
+    txt = open(f).read()
+    assert not re.search(r'^\s*(from|import)\s+(torch|jax|triton)\b', txt, flags=re.M), f
+  code = "import sys; import chimera_amd, chimera_amd.parallel; sys.exit(1 if any(m.split('.')[0] in ('torch', 'jax', 'triton') for m in sys.modules) else 0)"
+  assert subprocess.call([sys.executable, '-c', code], cwd=ROOT) == 0

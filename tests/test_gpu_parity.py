@@ -229,6 +229,8 @@ def test_rccl_single_rank_communicator(cfg_pix):
   from chimera_amd.parallel import Comm
   cfg, ev, inj = cfg_pix
   comm = Comm(1, 0, device=0)
+  from chimera_amd import _lib
+  assert _lib.lib().chm_comm_nranks(comm.handle) == 1
   x = np.array([1.5, -2.25, 1e300])
   np.testing.assert_array_equal(comm.allreduce_sum(x), x)
   like, _, _ = H.build_product(ev, inj, comm=comm)
@@ -237,17 +239,14 @@ def test_rccl_single_rank_communicator(cfg_pix):
   comm.close()
 
 
-def _hostcomm_worker(rank, world, port, outdir):
+def _hostcomm_worker(rank, world, addr, outdir):
   import os, sys
   sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-  import torch.distributed as dist
-  from chimera_amd.parallel import HostComm
+  from chimera_amd.parallel import HostComm, Rendezvous
   from tests import helpers as HH
-  os.environ['MASTER_ADDR'] = '127.0.0.1'
-  os.environ['MASTER_PORT'] = str(port)
-  dist.init_process_group('gloo', rank=rank, world_size=world)
+  rd = Rendezvous(world, rank, address=addr, timeout=120.)
   cfg, ev, inj = HH.small_config(E=9, S=300, P=4, Z=60, I=3001, seed=41, ragged=True)
-  comm = HostComm(world, rank, device=0)
+  comm = HostComm(world, rank, device=0, rendezvous=rd)
   out = []
   for pop_kw in ({}, dict(scale_free=False, R0=12., Tobs=1.5)):
     like, pop, sel = HH.build_product(ev, inj, comm=comm, pop_kw=pop_kw)
@@ -255,18 +254,26 @@ def _hostcomm_worker(rank, world, port, outdir):
     out.append(np.concatenate([like.batch(lams), [like(**lams[1]), sel.N_exp(pop.update(**lams[2]))]]))
     like.close(); sel.close()
   np.save(os.path.join(outdir, f'rank{rank}.npy'), np.array(out))
-  dist.barrier()
-  dist.destroy_process_group()
+  rd.barrier()
+  rd.close()
+
+
+def _spawn(target, world, args):
+  import multiprocessing as mp
+  ctx = mp.get_context('spawn')                              # fresh interpreters: the parent has initialised the GPU
+  procs = [ctx.Process(target=target, args=(r, world) + tuple(args)) for r in range(world)]
+  for p in procs:
+    p.start()
+  for p in procs:
+    p.join(280)
+    assert p.exitcode == 0, f"rank process exited with {p.exitcode}"
 
 
 @pytest.mark.timeout(300)
 def test_two_ranks_share_one_gpu_through_the_host_communicator(tmp_path):
   """The N > 1 path end to end on the device: two processes shard events and injections (both on GPU 0), reduce the three
-  partial sums per draw through the host communicator (gloo) and must each obtain the single-process result."""
-  import socket
-  import torch.multiprocessing as mp
-  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-  mp.spawn(_hostcomm_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+  partial sums per draw through the host communicator (Rendezvous sockets) and must each obtain the single-process result."""
+  _spawn(_hostcomm_worker, 2, (str(tmp_path / 'rdzv.sock'), str(tmp_path)))
   r0, r1 = np.load(tmp_path / 'rank0.npy'), np.load(tmp_path / 'rank1.npy')
   np.testing.assert_array_equal(r0, r1)
   cfg, ev, inj = H.small_config(E=9, S=300, P=4, Z=60, I=3001, seed=41, ragged=True)
@@ -275,6 +282,50 @@ def test_two_ranks_share_one_gpu_through_the_host_communicator(tmp_path):
     lams = [dict(H0=64.), dict(H0=70., alpha=3.0), dict(H0=81., gamma=2.0)]
     ref = np.concatenate([like.batch(lams), [like(**lams[1]), sel.N_exp(pop.update(**lams[2]))]])
     np.testing.assert_allclose(r0[k], ref, rtol=1e-12)
+
+
+def _rccl_worker(rank, world, addr, outdir):
+  import os, sys
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  from chimera_amd import _lib
+  from chimera_amd.parallel import Comm, Rendezvous
+  from tests import helpers as HH
+  rd = Rendezvous(world, rank, address=addr, timeout=120.)
+  comm = Comm(world, rank, device=rank, rendezvous=rd)        # one GPU per rank; the unique id travels over the sockets
+  assert _lib.lib().chm_comm_nranks(comm.handle) == world
+  np.testing.assert_array_equal(comm.allreduce_sum(np.array([rank + 1., 2.])), [world * (world + 1) / 2, 2. * world])
+  cfg, ev, inj = HH.small_config(E=9, S=300, P=4, Z=60, I=3001, seed=41, ragged=True)
+  out = []
+  for pop_kw in ({}, dict(scale_free=False, R0=12., Tobs=1.5)):
+    like, pop, sel = HH.build_product(ev, inj, comm=comm, pop_kw=pop_kw)
+    lams = [dict(H0=64.), dict(H0=70., alpha=3.0), dict(H0=81., gamma=2.0)]
+    out.append(np.concatenate([like.batch(lams), [like(**lams[1]), sel.N_exp(pop.update(**lams[2]))]]))
+    like.close(); sel.close()
+  np.save(os.path.join(outdir, f'rank{rank}.npy'), np.array(out))
+  rd.barrier()
+  comm.close()
+  rd.close()
+
+
+@pytest.mark.timeout(300)
+def test_real_multi_rank_rccl_communicator_when_several_gpus_are_visible(tmp_path):
+  """ncclAllReduce inside chm_eval with nranks > 1: one process per GPU, events and injections sharded, every rank must obtain the
+  single-process value.  Needs >= 2 visible GPUs (gpurun boxes expose one: skipped there; the driver's 8-GPU node runs it)."""
+  from chimera_amd import _lib
+  ndev = _lib.lib().chm_device_count()
+  if ndev < 2:
+    pytest.skip(f"{ndev} GPU visible: a multi-rank RCCL communicator needs one device per rank")
+  world = min(ndev, 4)
+  _spawn(_rccl_worker, world, (str(tmp_path / 'rdzv.sock'), str(tmp_path)))
+  rs = [np.load(tmp_path / f'rank{r}.npy') for r in range(world)]
+  for r in rs[1:]:
+    np.testing.assert_array_equal(r, rs[0])
+  cfg, ev, inj = H.small_config(E=9, S=300, P=4, Z=60, I=3001, seed=41, ragged=True)
+  for k, pop_kw in enumerate(({}, dict(scale_free=False, R0=12., Tobs=1.5))):
+    like, pop, sel = H.build_product(ev, inj, pop_kw=pop_kw)
+    lams = [dict(H0=64.), dict(H0=70., alpha=3.0), dict(H0=81., gamma=2.0)]
+    ref = np.concatenate([like.batch(lams), [like(**lams[1]), sel.N_exp(pop.update(**lams[2]))]])
+    np.testing.assert_allclose(rs[0][k], ref, rtol=1e-12)
 
 
 # ----------------------------------------------------------------------------------------------------------

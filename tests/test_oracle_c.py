@@ -82,3 +82,22 @@ def test_1d_and_approximate_modes_match_numpy_oracle(pixelated, like_kw, models,
   np.testing.assert_allclose(OC.numlike(like, popu, nthreads=1), like.compute_numlike_evs(popu), rtol=RT, atol=1e-300)
   if np.isfinite(ro[3]):
     np.testing.assert_allclose(rc[3], ro[3], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize('like_kw,models,lam', [
+  (dict(), dict(), dict(H0=68.)),
+  (dict(bw_method='silverman', cut_grid=1.5), dict(mass='tpl'), dict(H0=73., alpha=2.3)),
+  (dict(bw_method=0.4), dict(mass='bpl', cosmo='mg_flrw', cosmo_kw=dict(Xi0=1.5, n=1.8)), dict(H0=71.)),
+  (dict(pe_neff=1e9), dict(), dict(H0=70.)),               # every event skipped (`if n_effs[ev] < pe_neff: continue`) -> L_i = 0
+])
+def test_full_mode_matches_numpy_oracle(like_kw, models, lam):
+  """kind_p_gw3d='full': the C restatement of likelihood.py:211-260 + utils/math.py:154-229 against the NumPy one."""
+  cfg, ev, inj = H.small_config(E=4, S=160, P=3, Z=40, I=1200, seed=17, ragged=True)
+  like, pop, sel = H.build_oracle(ev, inj, kind='full', models=models, like_kw=like_kw)
+  ro = like.compute_all(**lam)
+  rc = OC.compute_all(like, lam, nthreads=2)
+  H.assert_loglike_close(rc[0], ro[0], rtol=RT, atol=1e-11)
+  popu = pop.update(**lam)
+  np.testing.assert_allclose(OC.numlike_full(like, popu, nthreads=1), like.compute_numlike_evs(popu), rtol=RT, atol=1e-300)
+  if np.isfinite(ro[3]):
+    np.testing.assert_allclose(rc[3], ro[3], rtol=0, atol=1e-9)

@@ -83,3 +83,80 @@ def test_host_combination_of_all_reduced_partials():
       np.testing.assert_allclose(got[0], want, rtol=1e-14)
     else:
       assert got[0] == want or (np.isnan(got[0]) and np.isnan(want))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# the product's own control plane (chimera_amd.parallel.Rendezvous / HostComm: sockets, no torch)
+# ----------------------------------------------------------------------------------------------------------
+def _rdzv_worker(rank, world, addr, outdir):
+  sys.path.insert(0, ROOT)
+  from chimera_amd.parallel import Rendezvous, HostComm, chunk_bounds, combine_partials
+  from tests import helpers as H
+  rd = Rendezvous(world, rank, address=addr, timeout=60.)
+  rec = {}
+  rec['bcast'] = rd.broadcast_bytes(bytes(range(128)) if rank == 0 else None)
+  x = np.array([rank + 1.0, -0.5 * rank, 1e300 if rank == 1 else 1.0])
+  rec['sum'] = rd.allreduce_sum(x)
+  rec['max'] = rd.allreduce_max(x)
+  rd.barrier()
+  # the sharded evaluation as bench.py / hyperlikelihood run it with a HostComm: partition, three partial sums per shard (the oracle is
+  # the per-shard evaluator here, the HIP library on the GPU), one SUM all-reduce over the sockets, the shared combination
+  comm = HostComm(world, rank, device=0, rendezvous=rd)
+  cfg, ev, inj = H.small_config(E=7, S=96, P=3, Z=32, I=501, seed=31, ragged=True)
+  like, pop0, sel = H.build_oracle(ev, inj, kind='marginalized')
+  res = []
+  for lam in (dict(H0=70.), dict(H0=61., alpha=3.0)):
+    e0, e1 = chunk_bounds(cfg['E'], world, rank)
+    i0, i1 = chunk_bounds(cfg['I'], world, rank)
+    tot = comm.allreduce_sum(H.shard_partials_oracle(like, lam, e0, e1, i0, i1))
+    pop = like.population.update(**lam)
+    got = combine_partials(tot, cfg['E'], inj['N_inj'], sel.N_eff, pop.scale_free, pop.R0, pop.Tobs)[0]
+    res.append((got, like(**lam)))
+  rec['res'] = np.array(res)
+  np.savez(os.path.join(outdir, f'rank{rank}.npz'), bcast=np.frombuffer(rec['bcast'], dtype=np.uint8), s=rec['sum'], m=rec['max'], res=rec['res'])
+  rd.barrier()
+  comm.close()
+  rd.close()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('world,tcp', [(2, False), (3, False), (2, True)])
+def test_rendezvous_star_and_host_comm_sharding(tmp_path, world, tcp):
+  """chimera_amd.parallel.Rendezvous over a Unix-domain socket (one node) or TCP: broadcast of the 128-byte id, SUM / MAX
+  all-reduce (same bits on every rank), barrier; and the HostComm-sharded evaluation equals the single-process one."""
+  import multiprocessing as mp
+  ctx = mp.get_context('spawn')
+  addr = ('127.0.0.1', _free_port()) if tcp else str(tmp_path / 'rdzv.sock')
+  procs = [ctx.Process(target=_rdzv_worker, args=(r, world, addr, str(tmp_path))) for r in range(world)]
+  for p in procs:
+    p.start()
+  for p in procs:
+    p.join(120)
+    assert p.exitcode == 0
+  recs = [np.load(tmp_path / f'rank{r}.npz') for r in range(world)]
+  want_sum = np.sum([[r + 1.0, -0.5 * r, 1e300 if r == 1 else 1.0] for r in range(world)], axis=0)
+  want_max = np.max([[r + 1.0, -0.5 * r, 1e300 if r == 1 else 1.0] for r in range(world)], axis=0)
+  for rec in recs:
+    assert bytes(rec['bcast']) == bytes(range(128))
+    np.testing.assert_array_equal(rec['s'], recs[0]['s'])
+    np.testing.assert_allclose(rec['s'], want_sum, rtol=1e-15)
+    np.testing.assert_array_equal(rec['m'], want_max)
+    np.testing.assert_array_equal(rec['res'], recs[0]['res'])
+    np.testing.assert_allclose(rec['res'][:, 0], rec['res'][:, 1], rtol=1e-13)
+  if not tcp:
+    assert not os.path.exists(addr)                          # the hub removes its socket path
+
+
+def test_default_rendezvous_address_is_per_launcher():
+  sys.path.insert(0, ROOT)
+  from chimera_amd import parallel
+  old = dict(os.environ)
+  try:
+    os.environ.pop('CHIMERA_COMM_ADDR', None)
+    os.environ['MASTER_PORT'] = '29999'
+    a = parallel.default_address()
+    assert isinstance(a, str) and '29999' in a and str(os.getppid()) in a
+    os.environ['CHIMERA_COMM_ADDR'] = 'node7:4242'
+    assert parallel.default_address() == ('node7', 4242)
+  finally:
+    os.environ.clear(); os.environ.update(old)
