@@ -40,6 +40,7 @@ struct Ctx {
   DevParams* d_params = nullptr;
   DevParams* h_params = nullptr;       // pinned
   double *zt = nullptr, *It = nullptr, *dLt = nullptr, *mg = nullptr, *cdf = nullptr, *tmp = nullptr;
+  double* rec = nullptr;               // (nb, TcMax, 4) node records of the fast sample stage (k_tables)
   double* d_evpart = nullptr;          // (nb, nblk_ev) block sums of log L_i
   int evpart_cap = 0;
   double* d_partials = nullptr;        // (nb,3)
@@ -74,7 +75,7 @@ static int ctx_init(Ctx& c, int device) {
 
 static void ctx_free_tables(Ctx& c) {
   (void)hipFree(c.d_params); (void)hipHostFree(c.h_params);
-  (void)hipFree(c.zt); (void)hipFree(c.It); (void)hipFree(c.dLt); (void)hipFree(c.mg); (void)hipFree(c.cdf); (void)hipFree(c.tmp);
+  (void)hipFree(c.zt); (void)hipFree(c.It); (void)hipFree(c.dLt); (void)hipFree(c.mg); (void)hipFree(c.cdf); (void)hipFree(c.tmp); (void)hipFree(c.rec); c.rec = nullptr;
   (void)hipFree(c.d_partials); (void)hipFree(c.d_out3); (void)hipHostFree(c.h_out); (void)hipFree(c.d_evpart);
   c.d_evpart = nullptr; c.evpart_cap = 0;
   c.d_params = nullptr; c.h_params = nullptr; c.zt = c.It = c.dLt = c.mg = c.cdf = c.tmp = nullptr;
@@ -111,6 +112,7 @@ static int ctx_ensure(Ctx& c, int nb, int Tc, int Tm) {
   HIPCHK(hipMalloc(&c.mg, sizeof(double) * nbn * Tmn));
   HIPCHK(hipMalloc(&c.cdf, sizeof(double) * nbn * Tmn));
   HIPCHK(hipMalloc(&c.tmp, sizeof(double) * nbn * ((size_t)Tcn + Tmn)));
+  HIPCHK(hipMalloc(&c.rec, sizeof(double) * nbn * (size_t)Tcn * 4));
   HIPCHK(hipMalloc(&c.d_partials, sizeof(double) * nbn * 3));
   HIPCHK(hipMalloc(&c.d_out3, sizeof(double) * nbn * 3));
   HIPCHK(hipHostMalloc(&c.h_out, sizeof(double) * nbn * 6));
@@ -147,7 +149,7 @@ static void fill_dev_params(const chm_params* p, DevParams* d) {
 }
 
 // upload nb draws and build their tables on c.stream
-static int ctx_tables(Ctx& c, const chm_params* params, int nb, const double* fR_given = nullptr) {
+static int ctx_tables(Ctx& c, const chm_params* params, int nb, const double* fR_given = nullptr, LutDesc lutA = LutDesc{}, LutDesc lutB = LutDesc{}) {
   int Tc = 0, Tm = 0;
   for (int b = 0; b < nb; b++) {
     int rc = check_params(&params[b]); if (rc) return rc;
@@ -163,9 +165,9 @@ static int ctx_tables(Ctx& c, const chm_params* params, int nb, const double* fR
   const size_t tl = sizeof(double) * 3 * (size_t)(Tc > Tm ? Tc : Tm);
   if (tl <= 120 * 1024) {
     if (tl > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_tables<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
-    hipLaunchKernelGGL(k_tables<true>, dim3(nb, 2), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax);
+    hipLaunchKernelGGL(k_tables<true>, dim3(nb, 2), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, lutA.nk > 0 ? c.rec : nullptr);
   } else {
-    hipLaunchKernelGGL(k_tables<false>, dim3(nb, 2), dim3(1024), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax);
+    hipLaunchKernelGGL(k_tables<false>, dim3(nb, 2), dim3(1024), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, lutA.nk > 0 ? c.rec : nullptr);
   }
   HIPCHK(hipGetLastError());
   return CHM_OK;
@@ -180,6 +182,11 @@ struct chm_like {
   std::vector<void*> owned;
   int nb_ws = 0;
   bool ws_dump = false;
+  // k_samples_fast: sample tiles (uploaded once), key range of the shard's distances, per-call direct-index tables
+  SampFast F = {};
+  bool fast_ok = false;
+  double dl_gmin = 0., dl_gmax = 0.;
+  unsigned short* d_lut = nullptr; int* d_lutinfo = nullptr;
 };
 struct chm_sel {
   Ctx ctx;
@@ -297,6 +304,28 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
     logs.assign(2, std::vector<double>(E * S));
     for (size_t k = 0; k < E * S; k++) { logs[0][k] = std::log(d->m1det[(size_t)e0 * S + k]); logs[1][k] = std::log(d->m2det[(size_t)e0 * S + k]); }
   }
+  // k_samples_fast reads the six per-sample inputs from ONE array of tiles (E, NT, 6, 128): dL, m1det, m2det, 1/pe_prior,
+  // log m1det, log m2det of 128 consecutive samples (the device order: pixel-sorted in marginalized mode); the last tile of an
+  // event is padded with harmless values
+  std::vector<double> tiles;
+  {
+    const size_t NT = (S + SF_TILE - 1) / SF_TILE;
+    tiles.assign(E * NT * 6 * SF_TILE, 1.0);
+    const bool mg = d->mode == CHM_MODE_MARG;
+    for (size_t e = 0; e < E; e++) {
+      const double* a[6];
+      if (mg) { a[0] = sorted[0].data() + e * S; a[1] = sorted[1].data() + e * S; a[2] = sorted[2].data() + e * S; a[3] = sorted[3].data() + e * S; }
+      else { a[0] = d->dL + (size_t)(e0 + e) * S; a[1] = d->m1det + (size_t)(e0 + e) * S; a[2] = d->m2det + (size_t)(e0 + e) * S; a[3] = tmp.data() + e * S; }
+      a[4] = logs[0].data() + e * S; a[5] = logs[1].data() + e * S;
+      for (size_t k = 0; k < S; k++) {
+        double* o = tiles.data() + ((e * NT + k / SF_TILE) * 6) * SF_TILE + k % SF_TILE;
+        for (int q = 0; q < 6; q++) o[q * SF_TILE] = a[q][k];
+      }
+      for (size_t k = S; k < NT * SF_TILE; k++) { double* o = tiles.data() + ((e * NT + k / SF_TILE) * 6) * SF_TILE + k % SF_TILE; o[4 * SF_TILE] = 0.; o[5 * SF_TILE] = 0.; }
+    }
+    rc = upload(h->owned, (const double*)tiles.data(), tiles.size(), &h->F.tiles, s); if (rc) { chm_like_destroy(h); return rc; }
+    h->F.NT = (int)NT;
+  }
   // smallest / largest finite distance of every event: the bracket of its table searches (k_samples)
   std::vector<double> dlo(E), dhi(E);
   for (size_t e = 0; e < E; e++) {
@@ -305,6 +334,21 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
     for (size_t k = 0; k < S; k++) if (std::isfinite(x[k])) { lo = x[k] < lo ? x[k] : lo; hi = x[k] > hi ? x[k] : hi; }
     if (!(lo <= hi)) { lo = NAN; hi = NAN; }                                     // no finite sample: the kernel searches the whole table
     dlo[e] = lo; dhi[e] = hi;
+  }
+  {                                                         // key range of the shard's positive finite distances (direct-index table)
+    double gmin = INFINITY, gmax = 0.;
+    for (size_t e = 0; e < E; e++) {
+      const double* x = d->dL + (size_t)(e0 + e) * S;
+      for (size_t k = 0; k < S; k++) if (std::isfinite(x[k]) && x[k] >= 2.2250738585072014e-308) { gmin = x[k] < gmin ? x[k] : gmin; gmax = x[k] > gmax ? x[k] : gmax; }
+    }
+    h->dl_gmin = gmin; h->dl_gmax = gmax;
+    h->fast_ok = gmin <= gmax;
+    if (h->fast_ok) {
+      int64_t hi0, hi1; memcpy(&hi0, &gmin, 8); memcpy(&hi1, &gmax, 8);
+      const int k0 = (int)(hi0 >> (32 + LUT_SHIFT)), k1 = (int)(hi1 >> (32 + LUT_SHIFT));
+      h->F.lut.key0 = k0; h->F.lut.nk = k1 - k0 + 1;
+      if (h->F.lut.nk > LUT_MAXKEYS) h->fast_ok = false;     // distances spanning > 64 octaves: the general kernel
+    }
   }
   rc = upload(h->owned, (const double*)dlo.data(), E, &L.dl_lo, s); if (rc) { chm_like_destroy(h); return rc; }
   rc = upload(h->owned, (const double*)dhi.data(), E, &L.dl_hi, s); if (rc) { chm_like_destroy(h); return rc; }
@@ -334,6 +378,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
 static void like_free_ws(chm_like* h) {
   LikeDev& L = h->L;
   (void)hipFree(L.ws_z); (void)hipFree(L.ws_w); (void)hipFree(L.part); (void)hipFree(L.jac); (void)hipFree(L.prate); (void)hipFree(L.bkgA);
+  (void)hipFree(h->d_lut); (void)hipFree(h->d_lutinfo); h->d_lut = nullptr; h->d_lutinfo = nullptr;
   (void)hipFree(L.pgw1d); (void)hipFree(L.like_pix); (void)hipFree(L.p_gw_dump); (void)hipFree(L.Aw); (void)hipFree(L.evstat); (void)hipFree(L.effg); (void)hipFree(L.krange); L.krange = nullptr;
   L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.pgw1d = L.like_pix = L.p_gw_dump = L.Aw = L.evstat = L.effg = nullptr;
   h->nb_ws = 0; h->ws_dump = false;
@@ -372,6 +417,7 @@ static int like_ensure_ws(chm_like* h, int nb, bool dump) {
   if (L.mode == CHM_MODE_MARG) { HIPCHK(hipMalloc(&L.Aw, sizeof(double) * n * E * Z)); HIPCHK(hipMalloc(&L.evstat, sizeof(double) * n * E * NEVSTAT));
                                  HIPCHK(hipMalloc(&L.effg, sizeof(double) * n * E * L.G)); }
   HIPCHK(hipMalloc(&L.like_pix, sizeof(double) * n * E * Pd));
+  if (h->fast_ok) { HIPCHK(hipMalloc(&h->d_lut, sizeof(unsigned short) * n * (h->F.lut.nk + 1))); HIPCHK(hipMalloc(&h->d_lutinfo, sizeof(int) * n * 4)); }
   if (dump && L.mode != CHM_MODE_1D) HIPCHK(hipMalloc(&L.p_gw_dump, sizeof(double) * n * E * Pd * Z));
   h->nb_ws = nb; h->ws_dump = dump;
   return CHM_OK;
@@ -502,7 +548,36 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   // costs ~3 us of stream time (measured: 35 us per call for the full set)
   const bool timing_all = timing && !comm;
   if (timing) HIPCHK(hipEventRecord(c.ev[0], sA));
-  rc = ctx_tables(c, params, nb, tab ? tab->fR : nullptr); if (rc) return rc;
+  // k_samples_fast (built-in mass model, the same for every draw of the call, tables of at most 65535 entries): the direct-index
+  // table of the dL table is built by k_tables for the key range of this shard's distances; LDS capacity of the table slice from the
+  // range (entries per octave of the reference's logspace z grid, cosmo.py:43-46, with a margin; a draw whose slice does not fit
+  // takes the general searches inside the same kernel)
+  LutDesc lutA = {};
+  bool use_fast = like && like->fast_ok && !td.pm_s && !getenv("CHM_SAMPLES_GENERIC");
+  size_t lds_fast = 0;
+  if (use_fast) {
+    int Tc_call = 0, Tm_call = 0;
+    double zmax_min = INFINITY;
+    for (int b = 0; b < nb; b++) {
+      if (params[b].mass_model != params[0].mass_model) use_fast = false;
+      Tc_call = params[b].z_grid_res > Tc_call ? params[b].z_grid_res : Tc_call;
+      Tm_call = params[b].mass_grid_res > Tm_call ? params[b].mass_grid_res : Tm_call;
+      zmax_min = params[b].z_max < zmax_min ? params[b].z_max : zmax_min;
+    }
+    if (Tc_call > 65535 || !(zmax_min > 0.)) use_fast = false;
+    if (use_fast) {
+      const double n_oct = std::log2(like->dl_gmax / like->dl_gmin) + 1.;
+      const double per_oct = (double)(Tc_call - 2) / (std::log2(zmax_min) + 33.22);
+      long long cap = (long long)(n_oct * per_oct * 1.3) + 64;
+      cap = cap > Tc_call ? Tc_call : cap;
+      cap = (cap + 7) / 8 * 8;
+      lutA = like->F.lut;
+      lutA.cap = (int)cap; lutA.lut = like->d_lut; lutA.info = like->d_lutinfo;
+      lds_fast = sizeof(double) * (4 * (size_t)cap + 2 * (size_t)Tm_call) + ((size_t)(lutA.nk + 1) * 2 + 15) / 16 * 16;
+      if (lds_fast > 96 * 1024) use_fast = false;
+    }
+  }
+  rc = ctx_tables(c, params, nb, tab ? tab->fR : nullptr, use_fast ? lutA : LutDesc{}); if (rc) return rc;
   HIPCHK(hipEventRecord(c.ev[1], sA));
   HIPCHK(hipStreamWaitEvent(sB, c.ev[1], 0));               // fork: the other lanes start after the tables
 
@@ -575,14 +650,22 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       samp_blocks = samp_blocks < 1 ? 1 : (samp_blocks > 1024 ? 1024 : samp_blocks);
       dim3 g1(samp_blocks * nb, 1);
       const bool fullm = L.mode == CHM_MODE_FULL;
-      if (tab_samp) {
+      if (use_fast) {
+        SampFast F = like->F; F.lut = lutA;
+#define LAUNCH_FAST(M, FU) do { allow_lds(k_samples_fast<M, FU>, lds_fast); \
+          hipLaunchKernelGGL((k_samples_fast<M, FU>), g1, dim3(64 * CHM_SF_WAVES), lds_fast, sg, L, F, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm); } while (0)
+        const int mm = params[0].mass_model;
+        if (fullm) { if (mm == 0) LAUNCH_FAST(0, true); else if (mm == 1) LAUNCH_FAST(1, true); else LAUNCH_FAST(2, true); }
+        else { if (mm == 0) LAUNCH_FAST(0, false); else if (mm == 1) LAUNCH_FAST(1, false); else LAUNCH_FAST(2, false); }
+#undef LAUNCH_FAST
+      } else if (tab_samp) {
         if (fullm) { allow_lds(k_samples<true, true>, lds_samp);
-          hipLaunchKernelGGL((k_samples<true, true>), g1, dim3(256), lds_samp, sg, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+          hipLaunchKernelGGL((k_samples<true, true>), g1, dim3(64 * SAMPLE_WPB), lds_samp, sg, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
         } else { allow_lds(k_samples<true, false>, lds_samp);
-          hipLaunchKernelGGL((k_samples<true, false>), g1, dim3(256), lds_samp, sg, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm); }
+          hipLaunchKernelGGL((k_samples<true, false>), g1, dim3(64 * SAMPLE_WPB), lds_samp, sg, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm); }
       } else {
-        if (fullm) hipLaunchKernelGGL((k_samples<false, true>), g1, dim3(256), 0, sg, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-        else hipLaunchKernelGGL((k_samples<false, false>), g1, dim3(256), 0, sg, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+        if (fullm) hipLaunchKernelGGL((k_samples<false, true>), g1, dim3(64 * SAMPLE_WPB), 0, sg, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+        else hipLaunchKernelGGL((k_samples<false, false>), g1, dim3(64 * SAMPLE_WPB), 0, sg, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
       }
       HIPCHK(hipGetLastError());
       if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g + 1], sg));

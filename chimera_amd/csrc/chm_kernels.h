@@ -16,13 +16,14 @@
 // BY PIXEL at upload time (stable, samples outside every pixel last) with seg_off[e][0..P] giving each pixel's
 // contiguous segment, so a (event,pixel) wave reads exactly its own samples; p_cat is (E,P,Z) and is streamed once.
 #pragma once
+#include <type_traits>
 #include "chm_models.h"
 
 #define NPART 16
 // per-(draw,event,chunk) partial statistics written by k_samples; d = z - z_ref (z_ref = z of the event's first sample)
 enum { PT_SW = 0, PT_SW2, PT_SD1, PT_SD2, PT_ZMIN, PT_ZMAX, PT_WD0, PT_WD1, PT_WD2, PT_W00, PT_W01, PT_W02, PT_W11, PT_W12, PT_W22, PT_ZREF };
 #define SAMPLE_CHUNK 4096
-#define SAMPLE_WPB 4                   // waves per block of k_samples: one partial record per wave and chunk
+#define SAMPLE_WPB 8                   // waves per block of k_samples (512 threads): one partial record per wave and chunk
 #define NEVSTAT 12           // doubles per (draw, event) written by k_event_prep
 
 struct LikeDev {                  // device-resident shard of events (see chm_like_desc)
@@ -150,9 +151,43 @@ DEVFN double block_interp(double x, const double* xp, const double* fp, int n, d
 // LDS_ARR) or, for very long tables, through global memory behind an agent-scope fence (gsync).
 DEVFN void gsync() { __threadfence(); __syncthreads(); }
 
+// Direct-index table for z_from_dGW (k_samples_fast, k_selection): the key of a distance is the top LUT_KEYBITS of its fp64 bit
+// pattern (sign, exponent, 7 mantissa bits: 128 keys per octave), monotone in the distance; lut[k] = #{table entries <= smallest
+// double with key key0 + k} (searchsorted side='right'), so a distance with key k has its searchsorted answer in [lut[k], lut[k+1]]
+// -- at most `lmax` entries to look at (1 for the reference's 1500-point table) instead of a 7-11 step binary search.
+// info[4] per draw: i_lo (first table entry a search or the interpolation can touch), ns (their number), lmax, fits (the draw's
+// table is sorted and its slice [i_lo, i_lo + ns) fits the LDS capacity the host reserved).
+#define LUT_SHIFT 13
+#define LUT_MAXKEYS 8192
+struct LutDesc { int key0, nk, cap, pad; unsigned short* lut; int* info; };
+DEVFN int lut_key(double x, int key0) { return (__double2hiint(x) >> LUT_SHIFT) - key0; }
+DEVFN double lut_key_floor(int key) { return __hiloint2double(key << LUT_SHIFT, 0); }
+
+// build one draw's LUT from its dL table (tab: LDS or global, Tc entries); every thread of the block calls it
+template <class Acc>
+DEVFN void build_lut(const LutDesc& D, int b, Acc tab, int Tc, bool sorted, double* sh) {
+  if (D.nk <= 0) return;
+  unsigned short* lut = D.lut + (size_t)b * (D.nk + 1);
+  int lm = 0;
+  for (int k = threadIdx.x; k <= D.nk; k += blockDim.x) {
+    const int c0 = searchsorted_right(tab, Tc, lut_key_floor(D.key0 + k));
+    lut[k] = (unsigned short)c0;
+    if (k < D.nk) { const int c1 = searchsorted_right(tab, Tc, lut_key_floor(D.key0 + k + 1)); lm = max(lm, c1 - c0); }
+  }
+  const double lmax = block_reduce<RED_MAX>((double)lm, sh);
+  if (threadIdx.x == 0) {
+    const int first = searchsorted_right(tab, Tc, lut_key_floor(D.key0)), last = searchsorted_right(tab, Tc, lut_key_floor(D.key0 + D.nk));
+    const int i_lo = first > 0 ? first - 1 : 0, i_hi = last + 1 < Tc ? last + 1 : Tc - 1;
+    int* info = D.info + (size_t)b * 4;
+    info[0] = i_lo; info[1] = i_hi - i_lo + 1; info[2] = (int)lmax;
+    info[3] = (sorted && i_hi - i_lo + 1 <= D.cap && Tc <= 65535) ? 1 : 0;
+  }
+}
+
 template <bool LDS_ARR>
 __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_all, double* It_all,
-                                                  double* dLt_all, double* mg_all, double* cdf_all, double* tmp_all, int TcMax, int TmMax) {
+                                                  double* dLt_all, double* mg_all, double* cdf_all, double* tmp_all, int TcMax, int TmMax,
+                                                  LutDesc lutA, LutDesc lutB, double* rec_all) {
   extern __shared__ double larr[];
   __shared__ double sh[32];
   __shared__ DevParams Ps;                          // block-local copy of the draw: constants derived here are shared through LDS
@@ -220,6 +255,19 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
         int j = (int)fmin(first, 1e9);
         Pg.z_bad = first < 1e299 ? zt[j > 0 ? j - 1 : 0] : __builtin_inf();
         Pg.dl_sorted = bad ? 0. : 1.;
+      }
+      // direct-index tables of the dL table (`tmp`) for the posterior samples (lutA) and the injections (lutB)
+      build_lut(lutA, b, (const double*)tmp, Tc, !bad, sh);
+      build_lut(lutB, b, (const double*)tmp, Tc, !bad, sh);
+      // node records of the fast sample stage: rec[i] = { dL_i, z_i, slope of z(dL) on [node i, node i+1], log(1 + z_i) }
+      if (rec_all) {
+        double* rec = rec_all + (size_t)b * TcMax * 4;
+        for (int i = t; i < Tc; i += nt) {
+          const double x0 = tmp[i], f0 = zt[i];
+          double sl = 0.;
+          if (i + 1 < Tc) { const double dx = tmp[i + 1] - x0; sl = (fabs(dx) <= 4.930380657631324e-32) ? 0. : (zt[i + 1] - f0) / dx; }
+          rec[4 * i] = x0; rec[4 * i + 1] = f0; rec[4 * i + 2] = sl; rec[4 * i + 3] = log1p(f0);
+        }
       }
     }
     // fR = Vc(z1) - Vc(z0)                                                       completeness.py:54-58
@@ -356,7 +404,7 @@ __device__ unsigned long long g_phase[8], g_phase_s[8];
 #endif
 
 template <bool LDS_TAB, bool FULL>
-__global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
+__global__ void __launch_bounds__(64 * SAMPLE_WPB) k_samples(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
                                                   const double* dLt_all, const double* mg_all, const double* cdf_all,
                                                   int TcMax, int TmMax) {
 #pragma clang fp contract(fast)                  // sums of products may fuse; z comes from jnp_interp_x2 (contract off) untouched
@@ -398,9 +446,9 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
     double v[6] = { 0., 0., 0., 0., __builtin_inf(), -__builtin_inf() };     // sw, sw2, sd1, sd2, zmin, zmax
     double m[9] = { 0., 0., 0., 0., 0., 0., 0., 0., 0. };
     const int s_end = min(S, (c + 1) * SAMPLE_CHUNK);
-    // 256 threads x 2 consecutive samples (16 B per lane per array) per pass
+    // 512 threads x 2 consecutive samples (16 B per lane per array) per pass
 #pragma unroll 1
-    for (int s = c * SAMPLE_CHUNK + 2 * t; s < s_end; s += 512) {
+    for (int s = c * SAMPLE_CHUNK + 2 * t; s < s_end; s += 128 * SAMPLE_WPB) {
       double dl[2], md1[2], md2[2], ipr[2], l1[2], l2[2];
       if (vec2) {                                 // s even, S even -> s + 1 < s_end and 16-byte aligned
         double2 a = *reinterpret_cast<const double2*>(L.dL + eo + s), bb = *reinterpret_cast<const double2*>(L.m1det + eo + s);
@@ -470,6 +518,224 @@ __global__ void __launch_bounds__(256) k_samples(LikeDev L, const DevParams* par
       for (int i = 0; i < 9; i++) m[i] = wave_sum_dpp(m[i]);
       if ((t & 63) == 0) { q[PT_WD0] = m[0]; q[PT_WD1] = m[1]; q[PT_WD2] = m[2]; q[PT_W00] = m[3]; q[PT_W01] = m[4]; q[PT_W02] = m[5];
                            q[PT_W11] = m[6]; q[PT_W12] = m[7]; q[PT_W22] = m[8]; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_samples_fast<MASS, FULL>: the sample stage for the built-in mass models with the per-draw tables in LDS -- same quantities,
+// same partial records as k_samples, fewer instructions per sample:
+//   * the mass model is a template parameter (one instantiation per model: no run-time model branches, the other models'
+//     parameters never reach the scalar registers);
+//   * z_from_dGW: the searchsorted answer comes from the draw's direct-index table (LutDesc: one LDS read + `lmax` probes, 1 for
+//     the reference's table) instead of a ~7-step binary search; the interpolation itself is jnp.interp's, bit for bit;
+//   * only the slice of the (dL, z) table the shard's distances can reach is staged in LDS (info[0..1]); a draw whose table is
+//     not sorted or whose slice does not fit takes the table searches of k_samples on the global tables (`slow`);
+//   * the six per-sample inputs come from one tile array (E, NT, 6, 128): one base address per pass, 16 B per lane per array.
+// ------------------------------------------------------------------------------------------------------
+#define SF_TILE 128
+struct SampFast {
+  const double* tiles;            // (E, NT, 6, SF_TILE): dL, m1det, m2det, 1/pe_prior, log m1det, log m2det of SF_TILE consecutive samples
+  int NT, pad;
+  LutDesc lut;
+};
+
+// log(1 + z) from the node record below z: 1 + z_0 = (1 + z)(1 - v), v = (z - z_0)/(1 + z) in [0, 0.017] for the reference's
+// logspace nodes, so log(1 + z) = log(1 + z_0) + v + v^2/2 + ... (8 terms: remainder < 1e-17 relative) -- 10 instructions, no log.
+// v > 0.02 (a coarser user table) or a lane without a record: chm_log_pos.
+DEVFN double log1pz_from_node(double z, double z0, double lz0, double r) {
+  const double v = (z - z0) * r;
+  double p = 0.125;
+  p = FM_FMA(p, v, 1. / 7.); p = FM_FMA(p, v, 1. / 6.); p = FM_FMA(p, v, 0.2); p = FM_FMA(p, v, 0.25);
+  p = FM_FMA(p, v, 1. / 3.); p = __builtin_fma(p, v, 0.5); p = __builtin_fma(p, v, 1.0);
+  return __builtin_fma(p, v, lz0);
+}
+
+// z = z_from_dGW(x) (cosmo.py:260-264) for two distances: searchsorted from the direct-index table (lut: one LDS read, then `lmax`
+// probes), then the interpolant of jnp.interp in slope form, z_0 + (x - x_0) s with s = dz/dx of the bracketing interval formed
+// once per draw (k_tables) -- the reference's z_0 + ((x - x_0)/dx) dz to <= 2e-18 relative (the increment is < 1.7 % of z).
+// rec: LDS slice [i_lo, i_lo + ns) of the node records.  Returns z and the record (z_0, log(1 + z_0)) used; lanes whose key is
+// outside the table (NaN, <= 0, inf) report bad.
+DEVFN void z_from_lut_x2(double xa, double xb, const double* rec, const unsigned short* luts, int key0, int nk,
+                         int i_lo, int ns, int lmax, int Tc, double x_last, double z_last,
+                         double& za, double& zb, double& z0a, double& z0b, double& lz0a, double& lz0b, bool& bad) {
+  const int ka = lut_key(xa, key0), kb = lut_key(xb, key0);
+  const bool oka = (unsigned)ka < (unsigned)nk, okb = (unsigned)kb < (unsigned)nk;
+  int pa = luts[oka ? ka : 0], pb = luts[okb ? kb : 0];
+  const int i_hi = i_lo + ns - 1;
+  // entries before lut[k] are <= x, entries from lut[k] + lmax on are > x: halving over [p, p + lmax), probes past the slice count as +inf
+  for (int l = lmax; l > 1;) {
+    const int half = l >> 1;
+    const int ia = pa + half - 1, ib = pb + half - 1;
+    const double va = rec[4 * ((ia < i_hi ? ia : i_hi) - i_lo)], vb = rec[4 * ((ib < i_hi ? ib : i_hi) - i_lo)];
+    pa += (ia <= i_hi && va <= xa) ? half : 0;
+    pb += (ib <= i_hi && vb <= xb) ? half : 0;
+    l -= half;
+  }
+  if (lmax > 0) {
+    const double va = rec[4 * ((pa < i_hi ? pa : i_hi) - i_lo)], vb = rec[4 * ((pb < i_hi ? pb : i_hi) - i_lo)];
+    pa += (pa <= i_hi && va <= xa) ? 1 : 0;
+    pb += (pb <= i_hi && vb <= xb) ? 1 : 0;
+  }
+  const int ja = (pa < 1 ? 1 : (pa > Tc - 1 ? Tc - 1 : pa)) - 1 - i_lo, jb = (pb < 1 ? 1 : (pb > Tc - 1 ? Tc - 1 : pb)) - 1 - i_lo;
+  const double4 ra = *reinterpret_cast<const double4*>(rec + 4 * ja), rb = *reinterpret_cast<const double4*>(rec + 4 * jb);
+  za = __builtin_fma(xa - ra.x, ra.z, ra.y);
+  zb = __builtin_fma(xb - rb.x, rb.z, rb.y);
+  if (xa > x_last) za = z_last;                           // jnp.interp clamps to fp[-1] (x < xp[0] = dL(z = 0) = 0 cannot occur for a valid key)
+  if (xb > x_last) zb = z_last;
+  z0a = ra.y; z0b = rb.y; lz0a = ra.w; lz0b = rb.w;
+  bad = !oka || !okb;
+}
+
+// build-time knobs of the fast sample stage (A/B through scripts/build_variant.sh): waves per block (each chunk always has SAMPLE_WPB
+// partial records: with fewer waves the surplus records are written neutral), waves per SIMD the register budget is cut for,
+// loads of the next tile issued before the arithmetic of the current one
+#ifndef CHM_SF_WAVES
+#define CHM_SF_WAVES 4
+#endif
+#ifndef CHM_SF_MINW
+#define CHM_SF_MINW 4
+#endif
+#ifndef CHM_SF_PREFETCH
+#define CHM_SF_PREFETCH 0
+#endif
+static_assert(SAMPLE_WPB % CHM_SF_WAVES == 0, "records per chunk must be a multiple of the waves per block");
+template <int MASS, bool FULL>
+__global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast(LikeDev L, SampFast F, const DevParams* params, const double* zt_all,
+                                                                    const double* dLt_all, const double* mg_all, const double* cdf_all,
+                                                                    const double* rec_all, int TcMax, int TmMax) {
+#pragma clang fp contract(fast)                  // sums of products may fuse; z comes from z_from_lut_x2 / jnp_interp (contract off) untouched
+  extern __shared__ double lds[];
+  constexpr int NT_ = 64 * CHM_SF_WAVES;
+  const int b = blockIdx.x % L.nb, bx = blockIdx.x / L.nb, nbx = gridDim.x / L.nb, t = threadIdx.x, lane = t & 63;
+  const DevParams P = params[b];      // by value: uniform loads at kernel start -> scalar registers, nothing re-read in the loops
+  const double* g_zt = zt_all + (size_t)b * TcMax;
+  const double* g_dLt = dLt_all + (size_t)b * TcMax;
+  const int Tc = P.Tc, Tm = P.Tm;
+  const int* info = F.lut.info + (size_t)b * 4;
+  const int i_lo = info[0], ns = info[1], lmax = info[2];
+  const bool fits = info[3] != 0;
+  const int key0 = F.lut.key0, nk = F.lut.nk, cap = F.lut.cap;
+  // LDS: node records of the table slice [cap x 4], m_grid [Tm], cdf_m2 [Tm], direct-index table [nk + 1] (u16)
+  double* rec = lds; double* mg = rec + 4 * (size_t)cap; double* cdf = mg + Tm;
+  unsigned short* luts = reinterpret_cast<unsigned short*>(cdf + Tm);
+  {
+    const double* gm = mg_all + (size_t)b * TmMax;
+    const double* gc = cdf_all + (size_t)b * TmMax;
+    const unsigned short* gl = F.lut.lut + (size_t)b * (nk + 1);
+    for (int i = t; i < Tm; i += NT_) { mg[i] = gm[i]; cdf[i] = gc[i]; }
+    if (fits) {
+      const double2* gr = reinterpret_cast<const double2*>(rec_all + ((size_t)b * TcMax + i_lo) * 4);
+      double2* lr = reinterpret_cast<double2*>(rec);
+      for (int i = t; i < 2 * ns; i += NT_) lr[i] = gr[i];
+      for (int i = t; i <= nk; i += NT_) luts[i] = gl[i];
+    }
+  }
+  const double x_last = g_dLt[Tc - 1], z_last = g_zt[Tc - 1];
+  __syncthreads();
+  const int S = L.S;
+  const int NCH = L.NC / SAMPLE_WPB;                        // chunks per event
+  const int nchunk = L.E_cnt * NCH;
+  for (int ch = bx; ch < nchunk; ch += nbx) {
+    const int e = L.e_off + ch / NCH, c = ch % NCH;
+    const size_t so = ((size_t)b * L.E + e) * S;
+    const size_t eo = (size_t)e * S;
+    double* wz = L.ws_z + so;
+    double* ww = L.ws_w + so;
+    // reference point of the shifted sums (any value near the event's z, the same for every chunk of the event): the table node
+    // next to the event's smallest distance
+    double z_ref;
+    {
+      const double xlo = L.dl_lo[e];
+      const int k = lut_key(xlo, key0);
+      if (fits) { const int q = ((unsigned)k < (unsigned)nk ? (int)luts[k] : i_lo) - i_lo; z_ref = rec[4 * (q < 0 ? 0 : (q > ns - 1 ? ns - 1 : q)) + 1]; }
+      else { const int c_lo = (P.dl_sorted != 0. && xlo == xlo) ? searchsorted_right(g_dLt, Tc, xlo) : 0; z_ref = g_zt[c_lo < Tc ? c_lo : Tc - 1]; }
+    }
+    const double ra_ref = FULL ? L.ra[eo] : 0., dec_ref = FULL ? L.dec[eo] : 0.;
+    double v[6] = { 0., 0., 0., 0., __builtin_inf(), -__builtin_inf() };     // sw, sw2, sd1, sd2, zmin, zmax
+    double m[9] = { 0., 0., 0., 0., 0., 0., 0., 0., 0. };
+    const int s_end = min(S, (c + 1) * SAMPLE_CHUNK);
+    const double2* tbase = reinterpret_cast<const double2*>(F.tiles + (size_t)e * F.NT * 6 * SF_TILE) + lane;
+    // the pass loop exists twice: the LUT form (the hot one) and the general searches (draws whose table slice is not in LDS)
+    auto passes = [&](auto fits_tag) {
+    constexpr bool FITS = decltype(fits_tag)::value;
+    double2 a, bb, cc, dd, ee, ff;
+    auto load_tile = [&](int s_, double2& a_, double2& b_, double2& c_, double2& d_, double2& e_, double2& f_) {
+      const double2* tp = tbase + (size_t)(s_ / SF_TILE) * (6 * SF_TILE / 2);
+      a_ = tp[0]; b_ = tp[SF_TILE / 2]; c_ = tp[2 * SF_TILE / 2]; d_ = tp[3 * SF_TILE / 2]; e_ = tp[4 * SF_TILE / 2]; f_ = tp[5 * SF_TILE / 2];
+    };
+    const int s_first = c * SAMPLE_CHUNK + 2 * t;
+    if (CHM_SF_PREFETCH && s_first < s_end) load_tile(s_first, a, bb, cc, dd, ee, ff);
+#pragma unroll 1
+    for (int s = s_first; s < s_end; s += 2 * NT_) {      // one tile of 128 samples per wave and pass
+      double2 na, nb_, nc, nd, ne, nf;
+      if (CHM_SF_PREFETCH) { if (s + 2 * NT_ < s_end) load_tile(s + 2 * NT_, na, nb_, nc, nd, ne, nf); }
+      else load_tile(s, a, bb, cc, dd, ee, ff);
+      const double dl[2] = { a.x, a.y }, md1[2] = { bb.x, bb.y }, md2[2] = { cc.x, cc.y }, ipr[2] = { dd.x, dd.y };
+      const double l1[2] = { ee.x, ee.y }, l2[2] = { ff.x, ff.y };
+      double zz[2], wv[2], z0[2] = { 0., 0. }, lz0[2] = { 0., 0. };
+      bool bad = true;
+      if (FITS) {                                     // z = z_from_dGW(dL) (cosmo.py:260-264)
+        z_from_lut_x2(dl[0], dl[1], rec, luts, key0, nk, i_lo, ns, lmax, Tc, x_last, z_last, zz[0], zz[1], z0[0], z0[1], lz0[0], lz0[1], bad);
+        if (__any(bad)) {                             // NaN / non-positive / infinite distances: the plain search on the global tables
+          if (bad) { zz[0] = jnp_interp(dl[0], g_dLt, g_zt, Tc, false, 0., 0.); zz[1] = jnp_interp(dl[1], g_dLt, g_zt, Tc, false, 0., 0.); }
+        }
+      } else z_from_dGW_x2(P, dl[0], dl[1], g_dLt, g_zt, zz[0], zz[1]);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        // m_src = m_det/(1+z) (pop_wrapper.py:70); w = p_m1m2 / pe_prior (pop_wrapper.py:79; the tile holds 1/pe_prior)
+        const double z = zz[h];
+        const double zp1 = 1. + z;
+        const double r = chm_div(1., zp1);
+        const double m1 = md1[h] * r, m2 = md2[h] * r;
+        // log(m_src) = log(m_det) - log(1+z): one log for both masses, from the node record when there is one
+        double lz;
+        if (FITS) {
+          lz = log1pz_from_node(z, z0[h], lz0[h], r);
+          if (__any(bad || !((z - z0[h]) * r <= 0.02))) { if (bad || !((z - z0[h]) * r <= 0.02)) lz = chm_log_pos(zp1); }
+        } else lz = chm_log_pos(zp1);
+        const double w = p_m1m2_fused<MASS>(P, m1, m2, l1[h] - lz, l2[h] - lz, mg, cdf) * ipr[h];
+        wv[h] = w;
+        if (s + h < s_end) {
+          const double d = z - z_ref;
+          v[0] += w; v[1] += w * w; v[2] += d; v[3] += d * d;
+          v[4] = __builtin_fmin(v[4], z); v[5] = __builtin_fmax(v[5], z);       // a NaN z is caught through sum(d) below
+          if (FULL) {                             // un-normalised weighted moments of (z, ra, dec) about the reference
+            const double d1 = L.ra[eo + s + h] - ra_ref, d2 = L.dec[eo + s + h] - dec_ref;
+            m[0] += w * d; m[1] += w * d1; m[2] += w * d2;
+            m[3] += w * d * d; m[4] += w * d * d1; m[5] += w * d * d2; m[6] += w * d1 * d1; m[7] += w * d1 * d2; m[8] += w * d2 * d2;
+          }
+        }
+      }
+      if ((S & 1) == 0) {                             // s even, S even: s + 1 < s_end, 16-byte aligned
+        *reinterpret_cast<double2*>(wz + s) = make_double2(zz[0], zz[1]);
+        *reinterpret_cast<double2*>(ww + s) = make_double2(wv[0], wv[1]);
+      } else {
+        wz[s] = zz[0]; ww[s] = wv[0];
+        if (s + 1 < s_end) { wz[s + 1] = zz[1]; ww[s + 1] = wv[1]; }
+      }
+      if (CHM_SF_PREFETCH) { a = na; bb = nb_; cc = nc; dd = nd; ee = ne; ff = nf; }
+    }
+    };
+    if (fits) passes(std::true_type{}); else passes(std::false_type{});
+    // one partial record per WAVE and chunk (as k_samples)
+    double* q = L.part + (((size_t)b * L.E + e) * L.NC + (size_t)c * SAMPLE_WPB + (t >> 6)) * NPART;
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = wave_sum_dpp(v[i]);
+    v[4] = wave_min_dpp(v[4]); v[5] = wave_max_dpp(v[5]);     // NaN-ignoring; NaN restored from the sums:
+    if (v[2] != v[2]) { v[4] = v[2]; v[5] = v[2]; }         // jnp.min / jnp.max propagate NaN (any NaN z makes sum(d) NaN)
+    if (lane == 0) { q[PT_SW] = v[0]; q[PT_SW2] = v[1]; q[PT_SD1] = v[2]; q[PT_SD2] = v[3]; q[PT_ZMIN] = v[4]; q[PT_ZMAX] = v[5]; q[PT_ZREF] = z_ref; }
+    if (FULL) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) m[i] = wave_sum_dpp(m[i]);
+      if (lane == 0) { q[PT_WD0] = m[0]; q[PT_WD1] = m[1]; q[PT_WD2] = m[2]; q[PT_W00] = m[3]; q[PT_W01] = m[4]; q[PT_W02] = m[5];
+                       q[PT_W11] = m[6]; q[PT_W12] = m[7]; q[PT_W22] = m[8]; }
+    }
+    if (CHM_SF_WAVES < SAMPLE_WPB && lane < NPART) {      // the chunk's surplus records: neutral for combine_stats (sums 0, min +inf, max -inf)
+      for (int r = (t >> 6) + CHM_SF_WAVES; r < SAMPLE_WPB; r += CHM_SF_WAVES) {
+        double* qn = L.part + (((size_t)b * L.E + e) * L.NC + (size_t)c * SAMPLE_WPB + r) * NPART;
+        qn[lane] = lane == PT_ZMIN ? __builtin_inf() : (lane == PT_ZMAX ? -__builtin_inf() : (lane == PT_ZREF ? z_ref : 0.));
+      }
     }
   }
 }

@@ -394,17 +394,20 @@ DEVFN double p_m1m2(const DevParams& p, double m1, double m2, A1 mg, A2 cdf) {
 //   final quotient need ONE division:  w = Pn norm^-1 dx / (D1 D2 (f0 dx + dm1 df)).
 // Relative difference to p_m1m2_l(): rounding only, <= ~(|beta lm2| + 8) ulp ~ 3e-15; the `p_m2m1 = NaN -> 0` rule
 // (mass.py:340) is applied to the same cases (0/0 at m1 = m2 = m_low).
-template <class A1, class A2>
+// MASS >= 0: the mass model is a compile-time constant (k_samples_fast / k_selection instantiate the hot loops per model, so the
+// other models' parameters never occupy scalar registers); MASS = -1: read from the draw (generic kernels).
+template <int MASS = -1, class A1, class A2>
 DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, double lm2, A1 mg, A2 cdf) {
 #pragma clang fp contract(fast)                  // smooth arithmetic only (no rounding-sensitive predicate): a*b+c may fuse
+  const int mass_model = MASS >= 0 ? MASS : p.mass_model;
   const double m_low = p.m[0], m_high = p.m[1];
   const bool in2 = (m_low <= m2 && m2 <= m1);               // tpl_notnorm(m2, beta, m_low, m1)   mass.py:240-245,322
-  const double e5 = in2 ? mass_beta(p) * lm2 : 0.;
+  const double e5 = in2 ? (mass_model == 0 ? p.m[3] : p.m[4]) * lm2 : 0.;
   // primary numerator (without smoothing), times m2^beta                                         mass.py:285-305
   double Pn;
-  if (p.mass_model == 0) {
+  if (mass_model == 0) {
     Pn = (m_low <= m1 && m1 <= m_high) ? chm_exp(-p.m[2] * lm1 + e5) : 0.;
-  } else if (p.mass_model == 1) {
+  } else if (mass_model == 1) {
     double a = (m_low <= m1 && m1 <= p.bpl_mbreak) ? chm_exp(-p.m[2] * lm1 + e5) : 0.;
     double b = (p.bpl_mbreak <= m1 && m1 <= m_high) ? chm_exp(-p.m[3] * lm1 + e5) : 0.;
     Pn = a + b * p.bpl_pl1 / p.bpl_pl2;
@@ -417,7 +420,7 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
   // smoothing denominators                                                                       mass.py:255-264
   double D1 = 1., D2 = 1.;
   bool zero = !in2;
-  if (p.mass_model != 0) {
+  if (mass_model != 0) {
     const double dm = p.m[5], eps = 1.e-99;
     const bool w1 = !(m1 < m_low) && !(m1 > m_low + dm), w2 = !(m2 < m_low) && !(m2 > m_low + dm);
     zero = zero || (m1 < m_low) || (m2 < m_low);

@@ -51,6 +51,7 @@ def main():
   if '--tag' in argv:
     tag = '_' + argv[argv.index('--tag') + 1]
   skip_trace = '--skip-trace' in argv
+  only = [int(x) for x in argv[argv.index('--passes') + 1].split(',')] if '--passes' in argv else None
   out = os.path.join(ROOT, 'gpurun_out', f'profiles_{rnd}')
   os.makedirs(out, exist_ok=True)
   os.environ['TMPDIR'] = '/tmp'
@@ -71,6 +72,8 @@ def main():
 
   kernels = collections.defaultdict(dict)
   for pi, counters in enumerate(PASSES):
+    if only is not None and pi not in only:
+      continue
     d = os.path.join(out, f'pmc{pi}')
     rc = run(['rocprofv3', '--kernel-trace', '--pmc'] + counters.split() + ['--output-format', 'csv', '-d', d, '--'] + quick +
              ['--steps', '3', '--warmup', '1'], os.path.join(out, f'pmc{pi}{tag}.log'))
