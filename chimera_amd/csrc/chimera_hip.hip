@@ -379,6 +379,7 @@ static void like_free_ws(chm_like* h) {
   LikeDev& L = h->L;
   (void)hipFree(L.ws_z); (void)hipFree(L.ws_w); (void)hipFree(L.part); (void)hipFree(L.jac); (void)hipFree(L.prate); (void)hipFree(L.bkgA);
   (void)hipFree(h->d_lut); (void)hipFree(h->d_lutinfo); h->d_lut = nullptr; h->d_lutinfo = nullptr;
+  (void)hipFree(L.err_pix); L.err_pix = nullptr;
   (void)hipFree(L.pgw1d); (void)hipFree(L.like_pix); (void)hipFree(L.p_gw_dump); (void)hipFree(L.Aw); (void)hipFree(L.evstat); (void)hipFree(L.effg); (void)hipFree(L.krange); L.krange = nullptr;
   L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.pgw1d = L.like_pix = L.p_gw_dump = L.Aw = L.evstat = L.effg = nullptr;
   h->nb_ws = 0; h->ws_dump = false;
@@ -414,7 +415,7 @@ static int like_ensure_ws(chm_like* h, int nb, bool dump) {
     HIPCHK(hipMalloc(&L.Aw, sizeof(double) * n * E * Z));
     HIPCHK(hipMalloc(&L.krange, sizeof(int) * n * E * 2));
   }
-  if (L.mode == CHM_MODE_MARG) { HIPCHK(hipMalloc(&L.Aw, sizeof(double) * n * E * Z)); HIPCHK(hipMalloc(&L.evstat, sizeof(double) * n * E * NEVSTAT));
+  if (L.mode == CHM_MODE_MARG) { HIPCHK(hipMalloc(&L.err_pix, sizeof(double) * n * E * Pd)); HIPCHK(hipMalloc(&L.Aw, sizeof(double) * n * E * Z)); HIPCHK(hipMalloc(&L.evstat, sizeof(double) * n * E * NEVSTAT));
                                  HIPCHK(hipMalloc(&L.effg, sizeof(double) * n * E * L.G)); }
   HIPCHK(hipMalloc(&L.like_pix, sizeof(double) * n * E * Pd));
   if (h->fast_ok) { HIPCHK(hipMalloc(&h->d_lut, sizeof(unsigned short) * n * (h->F.lut.nk + 1))); HIPCHK(hipMalloc(&h->d_lutinfo, sizeof(int) * n * 4)); }
@@ -602,11 +603,13 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     if (ngroups > 16) ngroups = 16;
     if (ngroups > L0.E) ngroups = L0.E;
     if (serial) ngroups = 1;
+    if ((L0.E + ngroups - 1) / ngroups > 65535) ngroups = (L0.E + 65534) / 65535;      // the GW kernel's grid carries the event in blockIdx.z
+    if (ngroups > 16) return fail(CHM_E_ARG, "chm_eval: more than 16 x 65535 events in one shard");
     for (int g = 0; g < ngroups; g++) {
       hipStream_t sg = (g & 1) ? sB : sA;
       LikeDev L = like->L;
       L.tab_pm = td.pm_s; L.tab_rate = td.rate_g; L.tab_bkg = td.bkg_g;
-      if (getenv("CHM_NO_BRACKET")) L.dl_lo = nullptr;       // diagnostics: table searches over the whole table
+      L.no_dense = getenv("CHM_NO_DENSE_NODE") ? 1 : 0;     // diagnostics: no dense-sum fallback in the standard GW kernel
       if (!want_dump) L.p_gw_dump = nullptr;
       const int eb = (int)((long long)L0.E * g / ngroups), ee = (int)((long long)L0.E * (g + 1) / ngroups);
       L.e_off = eb; L.E_cnt = ee - eb; L.nb = nb;
@@ -682,19 +685,18 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         const bool fast = marg_std;
         if (fast) {
+          // several pixel groups (pairs of pixels) of the same (event, draw) per wave, one after the other: event statistics and segment
+          // offsets once (four items per wave: 5.45 ms at C3 / 128 draws, two: 5.51, one: 5.66)
           const int PG2 = (Pd + 1) / 2;
-          static const bool one_item = getenv("CHM_KDE_ONE_ITEM") != nullptr;      // diagnostics: one pixel group per wave
-          if (!one_item && PG2 >= 2 && L.E_cnt <= 65535 && PG2 <= 65535) {
-            // several pixel groups of the same (event, draw) per wave, one after the other: event statistics and segment offsets once
-            // (four items per wave: 5.45 ms at C3 / 128 draws, two: 5.51, one: 5.66)
-            static const int ipw_env = getenv("CHM_KDE_IPW") ? atoi(getenv("CHM_KDE_IPW")) : 0;       // diagnostics: 2 or 4 items per wave
-            const int ipw = ipw_env == 2 || ipw_env == 4 ? ipw_env : (PG2 >= 4 ? 4 : 2);
-            if (ipw == 4) hipLaunchKernelGGL((k_kde_marg_sub2<32, 4>), dim3(nb, (PG2 + 3) / 4, L.E_cnt), dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
-            else hipLaunchKernelGGL((k_kde_marg_sub2<32, 2>), dim3(nb, (PG2 + 1) / 2, L.E_cnt), dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
-          } else {
-            const dim3 kgrid = (L.E_cnt <= 65535 && PG2 <= 65535) ? dim3(nb, PG2, L.E_cnt) : dim3((unsigned)((size_t)L.E_cnt * PG2 * nb), 1, 1);
-            hipLaunchKernelGGL(k_kde_marg_sub<32>, kgrid, dim3(64), sizeof(double) * (3 * N + 3) * 2, sg, L, dp);
-          }
+          static const int ipw_env = getenv("CHM_KDE_IPW") ? atoi(getenv("CHM_KDE_IPW")) : 0;       // diagnostics: 2 or 4 items per wave
+          const int ipw = ipw_env == 2 || ipw_env == 4 ? ipw_env : (PG2 >= 4 ? 4 : 2);
+          const size_t lds_sub = sizeof(double) * (3 * N + 3) * 2;
+#define LAUNCH_SUB2(I, BN) hipLaunchKernelGGL((k_kde_marg_sub2<32, I, BN>), dim3(nb, (PG2 + I - 1) / I, L.E_cnt), dim3(64), lds_sub, sg, L, dp)
+          if (L.num_bins == 200) { if (ipw == 4) LAUNCH_SUB2(4, 200); else LAUNCH_SUB2(2, 200); }      // the reference's default bin count (likelihood.py:59): compile-time
+          else { if (ipw == 4) LAUNCH_SUB2(4, 0); else LAUNCH_SUB2(2, 0); }
+#undef LAUNCH_SUB2
+          // pixels whose rounding bound matters against their event's L_i (tolerance 1e-10 per event) are redone with dense sums
+          if (!L.no_dense) { HIPCHK(hipGetLastError()); allow_lds(k_marg_fixup, lds_kde); hipLaunchKernelGGL(k_marg_fixup, dim3(L.E_cnt, nb), dim3(64), lds_kde, sg, L, dp, 1e-10); }
         }
         else { allow_lds(k_kde_marg, lds_kde); hipLaunchKernelGGL(k_kde_marg, dim3(L.E_cnt * Pd, nb), dim3(64), lds_kde, sg, L, dp); }
       } else {

@@ -25,12 +25,14 @@ enum { PT_SW = 0, PT_SW2, PT_SD1, PT_SD2, PT_ZMIN, PT_ZMAX, PT_WD0, PT_WD1, PT_W
 #define SAMPLE_CHUNK 4096
 #define SAMPLE_WPB 8                   // waves per block of k_samples (512 threads): one partial record per wave and chunk
 #define NEVSTAT 12           // doubles per (draw, event) written by k_event_prep
+#define KDE_STASH 4           // doubles behind a pixel's three sum arrays in LDS (kde_sub_item -> kde_sub_item_robust)
 
 struct LikeDev {                  // device-resident shard of events (see chm_like_desc)
   int E, S, Z, P;
   int mode, kernel, bw_method, binning, num_bins, G, has_cut, NC;
   int e_off, E_cnt;               // event group handled by this launch: events [e_off, e_off + E_cnt)
-  int nb, pad2;                   // draws in this call (hot kernels fold the draw into blockIdx.x, draw fastest, so that the
+  int nb, no_dense;               // draws in this call; no_dense (diagnostics, CHM_NO_DENSE_NODE=1): the standard GW kernel keeps the prefix differences everywhere
+                                  // (hot kernels fold the draw into blockIdx.x, draw fastest, so that the
                                   // blocks working on the same samples / p_cat rows for different draws run together and share L2)
   double bw_scalar, cut_grid, pe_neff;
   double inv_B, std_unit;         // 1/num_bins; std of num_bins uniform bin centres per unit range, sqrt((B^2-1)/12)/B (host, once)
@@ -53,6 +55,7 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   int *krange;                    // (nb,E,2)  first / last grid point with p_gw1d != 0 (k_kde1d; 1d / approximate)
   double *pgw1d;                  // (nb,E,Z)   1d / approximate
   double *like_pix;               // (nb,E,max(P,1))
+  double *err_pix;                // (nb,E,P)  marginalized, standard kernel: bound on what the prefix-sum form may have lost (k_marg_fixup)
   double *p_gw_dump;              // optional (nb,E,P,Z) or NULL
 };
 
@@ -1091,10 +1094,9 @@ __global__ void __launch_bounds__(256, CHM_ZF_WPE) k_zfactors(LikeDev L, const D
 // trapz(p_gw3d * p_z / jac) up to rounding (terms outside the range are exact zeros for finite inputs).
 // Dynamic LDS: cen[N], wgt[N], [P0,P1,P2 (N+1) when binning], eff[G], dens[G];  N = num_bins or S.
 #define MARG_PF 8            // prefetch depth: 8 x (64 lanes x 2 doubles) = 1024 grid points per pass
-__global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* params) {
-  extern __shared__ double lds[];
+// one (event, pixel, draw) by one wave (a block of 64 threads); own_eff: form the effective grid here instead of reading k_event_prep's
+DEVFN void kde_marg_general(const LikeDev& L, const DevParams* params, const int b, const int e, const int p, double* lds, const bool own_eff) {
   const int lane = threadIdx.x;
-  const int p = blockIdx.x % L.P, e = L.e_off + blockIdx.x / L.P, b = blockIdx.y;
   const DevParams& P = params[b];
   const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
   const int N = L.binning ? B : S;
@@ -1182,7 +1184,8 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
     const double stdc = sqrt(wave_sum(a) / (double)N);
     const double bw = kde_bandwidth_factor(L.bw_method, L.bw_scalar, neff_k, 1) * stdc;
     // effective grid (likelihood.py:185-190), built once per event by k_event_prep
-    { const double* eg = L.effg + ((size_t)b * L.E + e) * G; for (int i = lane; i < G; i += 64) eff[i] = eg[i]; }
+    if (own_eff) { for (int i = lane; i < G; i += 64) eff[i] = L.has_cut ? linspace_tab(lb, ub, G, i, L.fracG) : L.z_grids[(size_t)e * Z + i]; }       // likelihood.py:188,190
+    else { const double* eg = L.effg + ((size_t)b * L.E + e) * G; for (int i = lane; i < G; i += 64) eff[i] = eg[i]; }
     __syncthreads();
     // density on the effective grid: always Epanechnikov here (kde1d is called without kernel=, likelihood.py:192)
     const double inv_bw = 1. / bw;
@@ -1238,6 +1241,38 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
   if (lane == 0) *out_like = poisoned ? __builtin_nan("") : acc;     // NaN factors somewhere on the grid: 0 * NaN (see grid_is_poisoned)
 }
 
+__global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* params) {
+  extern __shared__ double lds[];
+  kde_marg_general(L, params, blockIdx.y, L.e_off + blockIdx.x / L.P, blockIdx.x % L.P, lds, false);
+}
+
+// k_marg_fixup: one wave per (event, draw) after the standard GW kernel (kde_sub_item).  Lane p holds pixel p's integral and the bound
+// on what the prefix-sum form may have lost in it (err_pix); a pixel whose bound exceeds its share tol / P of the event's L_i --
+// or any pixel with a non-zero bound when L_i is not positive -- is evaluated again by the general kernel's body (dense kernel sums
+// where the bins in reach are light, epan_prefix_eval), in pixel order.  No pixel qualifies for ordinary data: the wave reads 2 P
+// doubles and exits.  After it, every L_i agrees with the dense form to ~tol + the general kernel's own 1e-10.
+__global__ void __launch_bounds__(64) k_marg_fixup(LikeDev L, const DevParams* params, double tol) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x, e = L.e_off + blockIdx.x, b = blockIdx.y;
+  const size_t po = ((size_t)b * L.E + e) * L.P;
+  // L_i = sum over the pixels (all of them: P <= 1024)
+  double li = 0.;
+  for (int p = lane; p < L.P; p += 64) li += L.like_pix[po + p];
+  li = wave_sum(li);
+  const double share = tol * fabs(li) / (double)L.P;
+  for (int p0 = 0; p0 < L.P; p0 += 64) {
+    const int p = p0 + lane;
+    const double er = p < L.P ? L.err_pix[po + p] : 0.;
+    unsigned long long need = __ballot(er > share);     // false for NaN (li or er): a NaN event stays NaN
+    while (need) {
+      const int q = __ffsll((long long)need) - 1;
+      need &= need - 1ull;
+      __syncthreads();
+      kde_marg_general(L, params, b, e, p0 + q, lds, true);
+    }
+  }
+}
+
 // ordering point for LDS traffic inside ONE wave (its lanes exchange data through the wave's private LDS slice): LDS
 // instructions of a wave execute in issue order, so only the compiler has to be kept from moving accesses across it
 DEVFN void wave_sync() {
@@ -1247,9 +1282,11 @@ DEVFN void wave_sync() {
 }
 
 // ------------------------------------------------------------------------------------------------------
-// k_kde_marg_sub<SW>: the marginalized GW kernel for the standard configuration (binning=True, cut_grid set), SW lanes per
+// kde_sub_item<SW> / k_kde_marg_sub2: the marginalized GW kernel for the standard configuration (binning=True, cut_grid set), SW lanes per
 // pixel (64/SW pixels per wave; SW = 32 in production).  Same quantity as k_kde_marg, organised for latency and occupancy:
-//   * LDS holds only the three prefix-sum arrays, interleaved (9.6 KB per wave at 200 bins -> 16 waves per CU);
+//   * LDS holds only the three prefix-sum arrays P0 | P1 | P2 of (B + 1) doubles each (9.6 KB per wave at 200 bins -> 16 waves per CU);
+//   * a node whose bins in reach hold < 1e-4 of the weight below them (rounding of the prefix differences: far tails, weights spanning
+//     many decades) is evaluated by the reference's dense sum over the pixel's samples instead (dense_node), as k_kde_marg does;
 //   * the KDE is evaluated on demand at the two effective-grid nodes that bracket each event-grid point (the values
 //     jnp.interp combines, likelihood.py:193) instead of on the whole effective grid first;
 //   * weights stay un-normalised in the prefix sums, 1/sum(w) is applied at the end; std of the bin centres is the
@@ -1302,231 +1339,6 @@ template <int SW> DEVFN double sg_max(double v) {
 }
 
 
-template <int SW>
-__global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevParams* params) {
-#pragma clang fp contract(fast)                  // a*b+c may fuse in this body; the bin index lives in bin_index_r() (contract off)
-  extern __shared__ double lds_all[];
-  PH_INIT;
-  constexpr int NPW = 64 / SW;                              // pixels per wave
-  constexpr int PF = 1;                                     // p_cat passes requested before the histogram (1: 5.66 ms, 2: 5.75, 4: 5.84 at C3 / 128 draws)
-  const int lane = threadIdx.x, sub = lane / SW, sl = lane % SW;
-  // grid (draws, pixel groups, events) -- draw fastest in dispatch order -- so that a wave does not start with four integer divisions
-  // (no hardware divider: ~40 instructions each); a 1-D grid (more than 65535 events in a group) is decoded the long way
-  int b, pg, ei;
-  if (gridDim.y > 1 || gridDim.z > 1) { b = blockIdx.x; pg = blockIdx.y; ei = blockIdx.z; }
-  else { const int PG = (L.P + NPW - 1) / NPW; const int bx = blockIdx.x / L.nb; b = blockIdx.x % L.nb; pg = bx % PG; ei = bx / PG; }
-  const int p = pg * NPW + sub, e = L.e_off + ei;
-  const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
-  // LDS slice of this pixel: Q[3 j + c], j = 0..B, c = 0,1,2: prefix sums of (w, w c', w c'^2) interleaved, so that one
-  // address serves the three reads of a bin boundary; the bin counts live in the c = 0 slots until the prefix pass
-  double* Q = lds_all + (size_t)sub * (3 * B + 3);
-  const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
-  const double zmin = es[0], norm = es[3], n_eff = es[4], lb = es[6], ub = es[7];
-  const bool ok = n_eff >= L.pe_neff;                       // likelihood.py:199 (same for every pixel of the event)
-  // The pixel's sample segment is requested together with the event statistics (one memory round trip before the samples can be
-  // addressed, not two): idle lane groups (odd P, padded pixels) shadow a valid pixel for addressing and never store.
-  const int pp = p < L.P ? p : L.P - 1;
-  const int sq0 = L.seg_off[(size_t)e * (L.P + 1) + pp], sq1 = L.seg_off[(size_t)e * (L.P + 1) + pp + 1];
-  const bool live = p < L.P && p < L.neff_pixels[e];        // this lane group has a real pixel
-  double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
-  double* dump = (L.p_gw_dump && p < L.P) ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
-  const double* zg = L.z_grids + (size_t)e * Z;
-  const bool poisoned = grid_is_poisoned(params[b].z_bad, zg, Z);   // NaN factors somewhere on the grid: every live pixel is 0 * NaN
-  if (!ok || !live) {
-    if (p < L.P) { if (sl == 0) *out_like = (live && poisoned) ? __builtin_nan("") : 0.; if (dump) for (int k = sl; k < Z; k += SW) dump[k] = 0.; }
-    if (!ok) return;                                        // uniform over the wave
-  }
-  PH(0);                                                    // evstat arrived, guard passed
-  const double* pc = L.p_cat + ((size_t)e * L.P + pp) * Z;
-  const size_t zo = ((size_t)b * L.E + e) * Z;
-  const double* bkgA = L.bkgA + zo;
-  const double* Aw = L.Aw + zo;
-  int k_lo = (int)es[8], k_hi = (int)es[9];
-  k_lo &= ~1;
-  const bool vec2 = (Z & 1) == 0;                           // then every pair (k, k+1), k even, is 16-byte aligned and in bounds
-  // two consecutive grid points of one array for this lane
-  auto load2 = [&](const double* a, int k, double& v0, double& v1) {
-    v0 = 0.; v1 = 0.;
-    if (live && k <= k_hi) {
-      if (vec2) { double2 v = *reinterpret_cast<const double2*>(a + k); v0 = v.x; v1 = v.y; }
-      else { v0 = a[k]; if (k + 1 <= k_hi) v1 = a[k + 1]; }
-    }
-  };
-  double pf0[PF], pf1[PF];
-#pragma unroll
-  for (int i = 0; i < PF; i++) load2(pc, k_lo + 2 * SW * i + 2 * sl, pf0[i], pf1[i]);
-  // grid, background and trapezoid factors of the first pass: in flight during the histogram phase
-  double zc0, zc1, bc0, bc1, ac0, ac1;
-  load2(zg, k_lo + 2 * sl, zc0, zc1); load2(bkgA, k_lo + 2 * sl, bc0, bc1); load2(Aw, k_lo + 2 * sl, ac0, ac1);
-  // histogram of the pixel's samples on [min z, max z in pixel] (math.py:32-46, likelihood.py:180-183)
-  const size_t so = ((size_t)b * L.E + e) * S;
-  const double* wz = L.ws_z + so;
-  const double* ww = L.ws_w + so;
-  const int s0 = sq0, s1 = live ? sq1 : sq0;
-  const double lo = zmin;
-#ifndef CHM_NRS
-#define CHM_NRS 256
-#endif
-  constexpr int NR = CHM_NRS / SW;                          // samples per lane kept in registers (covers 256 per pixel)
-  double zr[NR], wr[NR];
-#pragma unroll
-  for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; zr[i] = s < s1 ? wz[s] : lo; wr[i] = s < s1 ? ww[s] : 0.; }
-  // hi = max(where(mask, z, min z)) (likelihood.py:180, math.py:36), NaN-propagating like jnp.max: v_max_f64 over the
-  // samples plus a "saw a NaN" vote of the pixel's lanes
-  double hi = lo;
-  bool sawnan = lo != lo;
-#pragma unroll
-  for (int i = 0; i < NR; i++) { hi = __builtin_fmax(hi, zr[i]); sawnan = sawnan || (zr[i] != zr[i]); }
-  for (int s = s0 + sl + SW * NR; s < s1; s += SW) { double zz = wz[s]; hi = __builtin_fmax(hi, zz); sawnan = sawnan || (zz != zz); }
-  hi = sg_last<SW>(sg_scan_max<SW>(hi), sub);
-  {
-    const unsigned long long votes = __ballot(sawnan);
-    const unsigned long long mine = SW == 64 ? ~0ull : (((1ull << (SW & 63)) - 1ull) << (sub * SW));
-    if (votes & mine) hi = __builtin_nan("");
-  }
-  PH(1);                                                    // samples arrived, max z of the pixel known
-  for (int j = sl; j < B; j += SW) Q[3 * j] = 0.;
-  const double dB = (double)B;
-  const double dhl = hi - lo, rhl = 1. / dhl;
-  const double dbin = dhl * L.inv_B;                        // c'_j = c_j - lo = (j + 1/2) dbin for the uniform edges of math.py:37-39
-  wave_sync();
-#pragma unroll
-  for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q[3 * bin_index_r(zr[i], lo, dhl, rhl, dB)], wr[i]); }
-  for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q[3 * bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
-  wave_sync();
-  PH(2);                                                    // histogram filled
-  // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins
-  const int per = (B + SW - 1) / SW;
-  const int j0 = sl * per < B ? sl * per : B, j1 = min(j0 + per, B);
-#ifndef CHM_MAXPER
-#define CHM_MAXPER 8
-#endif
-  constexpr int MAXPER = CHM_MAXPER;                        // bins per lane held in registers (8: up to 256 bins at 32 lanes per pixel)
-  const bool small = per <= MAXPER;
-  double wv[MAXPER];
-  double s0w = 0., s1w = 0., s2w = 0., sq = 0.;
-  if (small) {                                              // the lane's bin counts: all loads in flight at once, summed in bin order
-#pragma unroll
-    for (int i = 0; i < MAXPER; i++) wv[i] = (j0 + i < j1) ? Q[3 * (j0 + i)] : 0.;
-#pragma unroll
-    for (int i = 0; i < MAXPER; i++) { double w = wv[i], cc = ((double)(j0 + i) + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
-  } else {
-    for (int j = j0; j < j1; j++) { double w = Q[3 * j], cc = ((double)j + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
-  }
-  const double x0 = sg_scan_add<SW>(s0w), x1 = sg_scan_add<SW>(s1w), x2 = sg_scan_add<SW>(s2w);
-  const double tot = sg_last<SW>(x0, sub);
-  const double sum2 = sg_last<SW>(sg_scan_add<SW>(sq), sub);
-  // End of the last lane chunk of bins that holds any weight.  The prefix values of the lanes after it come out of different
-  // summation trees and agree only to an ulp: a node that sees nothing but the empty bins above the data would get 1e-16 of the
-  // peak where the dense sum (math.py:80) has an exact zero -- which decides log L_i when the catalogue term is only non-zero out
-  // there.  The bin ranges are clipped to it (below the first weight every prefix is an exact zero already).
-  double fjl1;
-  {
-    const unsigned long long nz = __ballot(s0w != 0.);      // NaN counts as weight
-    const unsigned long long mine = SW == 64 ? nz : ((nz >> (sub * (SW & 63))) & ((1ull << (SW & 63)) - 1ull));
-    const int last = 63 - __clzll(mine);                    // -1: no weight at all (degenerate pixel, NaN below)
-    fjl1 = (double)min((last + 1) * per, B);
-  }
-  {
-    double r0 = x0 - s0w, r1 = x1 - s1w, r2 = x2 - s2w;
-    wave_sync();
-    if (small) {
-#pragma unroll
-      for (int i = 0; i < MAXPER; i++) if (j0 + i < j1) {
-        double w = wv[i], cc = ((double)(j0 + i) + 0.5) * dbin;
-        r0 += w; r1 += w * cc; r2 += w * cc * cc;
-        double* q = Q + 3 * (j0 + i + 1);
-        q[0] = r0; q[1] = r1; q[2] = r2;
-      }
-    } else {                                                // many bins per lane: the count of bin j+1 shares the slot of P0[j+1]
-      double a0 = r0, a1 = r1, a2 = r2;
-      for (int j = j0; j < j1; j++) { double w = Q[3 * j], cc = ((double)j + 0.5) * dbin; a1 += w * cc; a2 += w * cc * cc; Q[3 * (j + 1) + 1] = a1; Q[3 * (j + 1) + 2] = a2; }
-      a0 = r0; for (int j = j0; j < j1; j++) a0 += Q[3 * j];
-      for (int j = j1 - 1; j >= j0; j--) { double w = Q[3 * j]; Q[3 * (j + 1)] = a0; a0 -= w; }
-    }
-    if (sl == 0) { Q[1] = 0.; Q[2] = 0.; }
-    wave_sync();
-    if (sl == 0) Q[0] = 0.;
-    wave_sync();
-  }
-  PH(3);                                                    // prefix sums written
-  const double neff_k = (tot * tot) / sum2;
-  const double stdc = dhl * L.std_unit;
-  const double bw = kde_bandwidth_factor_fast(L.bw_method, L.bw_scalar, neff_k) * stdc;
-  const bool degenerate = !(dbin > 0.) || !(bw > 0.) || !(bw < 1e300) || !(tot > 0. || tot < 0.);
-  // Per-pixel constants of the node evaluation.  A node g of the effective grid sees the bins [ja, jb) with |g - c_j| <= h,
-  // c_j = lo + (j + 1/2) dbin:  ja = ceil(t - hb), jb = floor(t + hb) + 1 with t = (g - lo)/dbin - 1/2, hb = h/dbin; the next
-  // node is t + dd, dd = de/dbin.  A bin whose |u| is within rounding of 1 may land on either side (kernel value < 1e-12).
-  // one reciprocal serves 1/bw and the normalisation 3/4 / (bw sum w); 1/dbin = B / (hi - lo) re-uses the histogram's reciprocal
-  const double rbt = 1. / (bw * tot);
-  const double inv_dbin = dB * rhl, inv_bw = rbt * tot, inv_bw2 = inv_bw * inv_bw;
-  const double scale = 0.75 * rbt;
-  const double hb = bw * inv_dbin;
-  const double de = es[10], inv_de = es[11];                // spacing of jnp.linspace(lb, ub, G) and its inverse (k_event_prep)
-  const double dd = de * inv_dbin;
-  const double dG2 = (double)(G - 2);
-  const double lbl = lb - lo;
-  const double ng = norm * L.gw_pdf[(size_t)e * L.P + pp]; // kde_interp * norm * gw_pdf[i]    likelihood.py:194
-  const double fR = params[b].fR;
-  const double nan = __builtin_nan("");
-  // Support of THIS pixel's interpolated KDE on the event grid: the bin centres lie in [lo + dbin/2, hi - dbin/2], a node sees
-  // none of them beyond bw, and an event-grid point combines the two nodes within de of it -- so p_gw is an exact zero for
-  // z outside (lo - bw - de, hi + bw + de), typically a third of the event's range [lb, ub] (every pixel's histogram starts
-  // at the event's min z but ends at the pixel's own max z, likelihood.py:180).  Degenerate pixels keep [lb, ub] (NaN there).
-  const double zlo = degenerate ? lb : __builtin_fmax(lb, lo - bw - de), zhi = degenerate ? ub : __builtin_fmin(ub, hi + bw + de);
-  // density (without the common factor `scale`) at the node with g' = g - lo and bin position t
-  auto node = [&](double gp, double t) {
-    double fa = __builtin_fmin(__builtin_fmax(ceil(t - hb), 0.), fjl1);
-    double fb = __builtin_fmin(__builtin_fmax(floor(t + hb) + 1., fa), fjl1);
-    const int ia = 3 * (int)fa, ib = 3 * (int)fb;
-    double S0 = Q[ib] - Q[ia], S1 = Q[ib + 1] - Q[ia + 1], S2 = Q[ib + 2] - Q[ia + 2];
-    double qq = fma(gp, fma(gp, S0, -2. * S1), S2);         // sum W (g' - c')^2 over the support
-    return __builtin_fmax(S0 - qq * inv_bw2, 0.);           // a sum of non-negative kernel values (rounding may leave -1e-14 of the peak)
-  };
-  PH(4);                                                    // per-pixel constants
-  double acc = 0.;
-  if (dump && live) { for (int k = sl; k < Z; k += SW) if (k < k_lo || k > k_hi) dump[k] = 0.; }
-#pragma unroll 1
-  for (int it = 0; k_lo + 2 * SW * it <= k_hi; it++) {      // one pass = SW lanes x 2 consecutive grid points per pixel
-    const int k = k_lo + 2 * SW * it + 2 * sl;
-    // software pipeline: the loads of the next pass are issued before the arithmetic of this one
-    double zn0, zn1, bn0, bn1, an0, an1, pn0 = 0., pn1 = 0.;
-    const int kn = k + 2 * SW;
-    load2(zg, kn, zn0, zn1); load2(bkgA, kn, bn0, bn1); load2(Aw, kn, an0, an1);
-    if (it + 1 >= PF) load2(pc, kn, pn0, pn1);
-    double pc0 = pf0[0], pc1 = pf1[0];                      // this pass's p_cat: prefetched at kernel start or by the previous pass
-#pragma unroll
-    for (int i = 1; i < PF; i++) if (it == i) { pc0 = pf0[i]; pc1 = pf1[i]; }
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int kk = k + h;
-      if (kk <= k_hi && live) {
-        const double zk = h == 0 ? zc0 : zc1;
-        double pgw = 0.;
-        if (zk >= zlo && zk <= zhi) {                       // inside: jnp.interp on the nodes; outside: 0 (left=0, right=0 or no bin in reach)
-          // bracket on the uniform effective grid: nodes x_i = lb + i de; a z within rounding of a node may pick either
-          // neighbouring segment -- the interpolant is continuous there
-          double tp = __builtin_fmin(floor((zk - lb) * inv_de), dG2);
-          double ga = fma(tp, de, lbl);                     // x_a - lo
-          double ta = fma(ga, inv_dbin, -0.5);
-          double da = node(ga, ta), db = node(ga + de, ta + dd);
-          double wgt = ((zk - lb) - tp * de) * inv_de;      // (z - x_a)/dx
-          double f = (da + wgt * (db - da)) * scale;
-          pgw = degenerate ? nan : f * ng;
-        } else if (zk != zk) pgw = nan;
-        if (dump) dump[kk] = pgw;
-        const double pcv = h == 0 ? pc0 : pc1;
-        if (pcv != -100.) acc += pgw * (fR * pcv + (h == 0 ? bc0 : bc1)) * (h == 0 ? ac0 : ac1);   // catalog.py:202, likelihood.py:275
-      }
-    }
-    zc0 = zn0; zc1 = zn1; bc0 = bn0; bc1 = bn1; ac0 = an0; ac1 = an1;
-    if (it + 1 >= PF) { pf0[0] = pn0; pf1[0] = pn1; }
-  }
-  PH(5);                                                    // grid loop
-  acc = sg_scan_add<SW>(acc);                               // the group's last lane holds the pixel's integral
-  if (sl == SW - 1 && live) *out_like = poisoned ? nan : acc;
-}
-
 // ------------------------------------------------------------------------------------------------------
 // k_kde_marg_sub2<SW, IPW>: k_kde_marg_sub with IPW pixel groups of the same (event, draw) per wave, one after the other: the event
 // statistics, the sample segments of all the wave's items and the grid-row addresses are fetched once (the first of the two memory
@@ -1537,18 +1349,18 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub(LikeDev L, const DevPara
 #ifndef CHM_NRS
 #define CHM_NRS 256
 #endif
-template <int SW, int NR>
+template <int SW, int NR, int BINS>
 DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, const double* es, const int b, const int e, const int p,
                         const int pp, const bool live, const bool poisoned, const int s0, const int s1, double (&zr)[NR], double (&wr)[NR]) {
-#pragma clang fp contract(fast)                  // as in k_kde_marg_sub
-  constexpr int PF = 1;                                     // as in k_kde_marg_sub
+#pragma clang fp contract(fast)                  // a*b+c may fuse in this body; the bin index lives in bin_index_r() (contract off)
+  constexpr int PF = 1;                                     // p_cat passes requested before the histogram (1: 5.66 ms, 2: 5.75, 4: 5.84 at C3 / 128 draws)
   const int lane = threadIdx.x, sub = lane / SW, sl = lane % SW;
-  const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
+  const int S = L.S, Z = L.Z, B = BINS > 0 ? BINS : L.num_bins, G = L.G;      // BINS > 0: the bin count is a compile-time constant (LDS offsets, loop bounds)
   const double zmin = es[0], norm = es[3], lb = es[6], ub = es[7];
   double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
   double* dump = (L.p_gw_dump && p < L.P) ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
   const double* zg = L.z_grids + (size_t)e * Z;
-  if (!live && p < L.P) { if (sl == 0) *out_like = 0.; if (dump) for (int k = sl; k < Z; k += SW) dump[k] = 0.; }
+  if (!live && p < L.P) { if (sl == 0) { *out_like = 0.; L.err_pix[((size_t)b * L.E + e) * L.P + p] = 0.; } if (dump) for (int k = sl; k < Z; k += SW) dump[k] = 0.; }
   const double* pc = L.p_cat + ((size_t)e * L.P + pp) * Z;
   const size_t zo = ((size_t)b * L.E + e) * Z;
   const double* bkgA = L.bkgA + zo;
@@ -1588,14 +1400,15 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
     const unsigned long long mine = SW == 64 ? ~0ull : (((1ull << (SW & 63)) - 1ull) << (sub * SW));
     if (votes & mine) hi = __builtin_nan("");
   }
-  for (int j = sl; j < B; j += SW) Q[3 * j] = 0.;
+  double* const Q0 = Q; double* const Q1 = Q + (B + 1); double* const Q2 = Q + 2 * (B + 1);      // P0 | P1 | P2, (B + 1) doubles each
+  for (int j = sl; j < B; j += SW) Q0[j] = 0.;
   const double dB = (double)B;
   const double dhl = hi - lo, rhl = 1. / dhl;
   const double dbin = dhl * L.inv_B;                        // c'_j = c_j - lo = (j + 1/2) dbin for the uniform edges of math.py:37-39
   wave_sync();
 #pragma unroll
-  for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q[3 * bin_index_r(zr[i], lo, dhl, rhl, dB)], wr[i]); }
-  for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q[3 * bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
+  for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q0[bin_index_r(zr[i], lo, dhl, rhl, dB)], wr[i]); }
+  for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q0[bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
   wave_sync();
   // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins
   const int per = (B + SW - 1) / SW;
@@ -1609,11 +1422,11 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   double s0w = 0., s1w = 0., s2w = 0., sq = 0.;
   if (small) {                                              // the lane's bin counts: all loads in flight at once, summed in bin order
 #pragma unroll
-    for (int i = 0; i < MAXPER; i++) wv[i] = (j0 + i < j1) ? Q[3 * (j0 + i)] : 0.;
+    for (int i = 0; i < MAXPER; i++) wv[i] = (j0 + i < j1) ? Q0[j0 + i] : 0.;
 #pragma unroll
     for (int i = 0; i < MAXPER; i++) { double w = wv[i], cc = ((double)(j0 + i) + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
   } else {
-    for (int j = j0; j < j1; j++) { double w = Q[3 * j], cc = ((double)j + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
+    for (int j = j0; j < j1; j++) { double w = Q0[j], cc = ((double)j + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
   }
   const double x0 = sg_scan_add<SW>(s0w), x1 = sg_scan_add<SW>(s1w), x2 = sg_scan_add<SW>(s2w);
   const double tot = sg_last<SW>(x0, sub);
@@ -1637,18 +1450,17 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
       for (int i = 0; i < MAXPER; i++) if (j0 + i < j1) {
         double w = wv[i], cc = ((double)(j0 + i) + 0.5) * dbin;
         r0 += w; r1 += w * cc; r2 += w * cc * cc;
-        double* q = Q + 3 * (j0 + i + 1);
-        q[0] = r0; q[1] = r1; q[2] = r2;
+        Q0[j0 + i + 1] = r0; Q1[j0 + i + 1] = r1; Q2[j0 + i + 1] = r2;
       }
     } else {                                                // many bins per lane: the count of bin j+1 shares the slot of P0[j+1]
       double a0 = r0, a1 = r1, a2 = r2;
-      for (int j = j0; j < j1; j++) { double w = Q[3 * j], cc = ((double)j + 0.5) * dbin; a1 += w * cc; a2 += w * cc * cc; Q[3 * (j + 1) + 1] = a1; Q[3 * (j + 1) + 2] = a2; }
-      a0 = r0; for (int j = j0; j < j1; j++) a0 += Q[3 * j];
-      for (int j = j1 - 1; j >= j0; j--) { double w = Q[3 * j]; Q[3 * (j + 1)] = a0; a0 -= w; }
+      for (int j = j0; j < j1; j++) { double w = Q0[j], cc = ((double)j + 0.5) * dbin; a1 += w * cc; a2 += w * cc * cc; Q1[j + 1] = a1; Q2[j + 1] = a2; }
+      a0 = r0; for (int j = j0; j < j1; j++) a0 += Q0[j];
+      for (int j = j1 - 1; j >= j0; j--) { double w = Q0[j]; Q0[j + 1] = a0; a0 -= w; }
     }
-    if (sl == 0) { Q[1] = 0.; Q[2] = 0.; }
+    if (sl == 0) { Q1[0] = 0.; Q2[0] = 0.; }
     wave_sync();
-    if (sl == 0) Q[0] = 0.;
+    if (sl == 0) Q0[0] = 0.;
     wave_sync();
   }
   const double neff_k = (tot * tot) / sum2;
@@ -1679,12 +1491,21 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   auto node = [&](double gp, double t) {
     double fa = __builtin_fmin(__builtin_fmax(ceil(t - hb), 0.), fjl1);
     double fb = __builtin_fmin(__builtin_fmax(floor(t + hb) + 1., fa), fjl1);
-    const int ia = 3 * (int)fa, ib = 3 * (int)fb;
-    double S0 = Q[ib] - Q[ia], S1 = Q[ib + 1] - Q[ia + 1], S2 = Q[ib + 2] - Q[ia + 2];
+    const int ia = (int)fa, ib = (int)fb;
+    double S0 = Q0[ib] - Q0[ia], S1 = Q1[ib] - Q1[ia], S2 = Q2[ib] - Q2[ia];
     double qq = fma(gp, fma(gp, S0, -2. * S1), S2);         // sum W (g' - c')^2 over the support
     return __builtin_fmax(S0 - qq * inv_bw2, 0.);           // a sum of non-negative kernel values (rounding may leave -1e-14 of the peak)
   };
-  double acc = 0.;
+  // A-posteriori bound on what the prefix-sum form can have lost.  Every prefix value carries <= 12 roundings (7 additions in the lane,
+  // 5 scan levels) relative to |P0| <= T, |P1| <= T R, |P2| <= T R^2 (T = sum w, R = hi - lo >= c'); a node's value
+  // S0 - (g'^2 S0 - 2 g' S1 + S2)/h^2 with |g'| <= R + h is therefore within  errD = 24 eps T (1 + (2 R/h + 1)^2)  of the dense sum
+  // (math.py:77-81), and so is the interpolant; the pixel's integral sum_k p_gw[k] C_k (C_k = (fR p_cat + bkgA) A_k) within
+  // errD sum_k |C_k| over the grid points inside the pixel's support (outside, p_gw is an exact zero in either form).  The bound goes
+  // to err_pix; k_marg_fixup compares it with the event's L_i and redoes the pixels that matter with the general kernel's dense sums
+  // (weights spanning many decades, a gap inside the data: the catalogue term sits where the KDE is far below its peak).
+  const double rh = dhl * inv_bw;
+  const double errD = (24. * 1.1102230246251565e-16) * fabs(tot) * (1. + (2. * rh + 1.) * (2. * rh + 1.));
+  double acc = 0., accC = 0.;
   if (dump && live) { for (int k = sl; k < Z; k += SW) if (k < k_lo || k > k_hi) dump[k] = 0.; }
 #pragma unroll 1
   for (int it = 0; k_lo + 2 * SW * it <= k_hi; it++) {      // one pass = SW lanes x 2 consecutive grid points per pixel
@@ -1703,7 +1524,8 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
       if (kk <= k_hi && live) {
         const double zk = h == 0 ? zc0 : zc1;
         double pgw = 0.;
-        if (zk >= zlo && zk <= zhi) {                       // inside: jnp.interp on the nodes; outside: 0 (left=0, right=0 or no bin in reach)
+        const bool ins = zk >= zlo && zk <= zhi;
+        if (ins) {                                          // inside: jnp.interp on the nodes; outside: 0 (left=0, right=0 or no bin in reach)
           // bracket on the uniform effective grid: nodes x_i = lb + i de; a z within rounding of a node may pick either
           // neighbouring segment -- the interpolant is continuous there
           double tp = __builtin_fmin(floor((zk - lb) * inv_de), dG2);
@@ -1716,17 +1538,21 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
         } else if (zk != zk) pgw = nan;
         if (dump) dump[kk] = pgw;
         const double pcv = h == 0 ? pc0 : pc1;
-        if (pcv != -100.) acc += pgw * (fR * pcv + (h == 0 ? bc0 : bc1)) * (h == 0 ? ac0 : ac1);   // catalog.py:202, likelihood.py:275
+        if (pcv != -100.) { const double cz = (fR * pcv + (h == 0 ? bc0 : bc1)) * (h == 0 ? ac0 : ac1); acc += pgw * cz; accC += ins ? fabs(cz) : 0.; }   // catalog.py:202, likelihood.py:275
       }
     }
     zc0 = zn0; zc1 = zn1; bc0 = bn0; bc1 = bn1; ac0 = an0; ac1 = an1;
     if (it + 1 >= PF) { pf0[0] = pn0; pf1[0] = pn1; }
   }
   acc = sg_scan_add<SW>(acc);                               // the group's last lane holds the pixel's integral
-  if (sl == SW - 1 && live) *out_like = poisoned ? nan : acc;
+  accC = sg_scan_add<SW>(accC);
+  if (sl == SW - 1 && live) {
+    *out_like = poisoned ? nan : acc;
+    L.err_pix[((size_t)b * L.E + e) * L.P + p] = (degenerate || poisoned) ? 0. : errD * accC * fabs(scale * ng);     // NaN results stay NaN: nothing to redo
+  }
 }
 
-template <int SW, int IPW>
+template <int SW, int IPW, int BINS>
 __global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevParams* params) {
   extern __shared__ double lds_all[];
   constexpr int NPW = 64 / SW;
@@ -1758,7 +1584,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevPar
     const bool live = p < L.P && p < npx;
     if (!ok) {                                              // uniform: every pixel of the event is 0 (or 0 * NaN)
       if (p < L.P) {
-        if (sl == 0) L.like_pix[((size_t)b * L.E + e) * L.P + p] = (live && poisoned) ? __builtin_nan("") : 0.;
+        if (sl == 0) { L.like_pix[((size_t)b * L.E + e) * L.P + p] = (live && poisoned) ? __builtin_nan("") : 0.; L.err_pix[((size_t)b * L.E + e) * L.P + p] = 0.; }
         if (L.p_gw_dump) { double* d = L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z; for (int k = sl; k < Z; k += SW) d[k] = 0.; }
       }
       return;
@@ -1768,7 +1594,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevPar
     double zr[NR], wr[NR];
 #pragma unroll
     for (int j = 0; j < NR; j++) { int s = s0 + sl + SW * j; zr[j] = s < s1 ? wz[s] : lo; wr[j] = s < s1 ? ww[s] : 0.; }
-    kde_sub_item<SW, NR>(L, params, Q, es, b, e, p, pp, live, poisoned, s0, s1, zr, wr);
+    kde_sub_item<SW, NR, BINS>(L, params, Q, es, b, e, p, pp, live, poisoned, s0, s1, zr, wr);
   };
   run(blockIdx.y, pA, ppA, a0, a1, true);
   run(blockIdx.y + H, pB, ppB, b0, b1, false);

@@ -683,6 +683,50 @@ def test_weights_spanning_many_decades_fall_back_to_the_dense_kernel_sum():
   H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
 
 
+def _decades_case():
+  """Mock events whose sample weights fall by 60 decades from the nearest to the farthest posterior sample (through pe_prior, which is
+  data) while the catalogue term lives only in the upper 40 % of each event's redshift range: the light bins far above the bulk --
+  1e-20 ... 1e-50 of the weight summed below them -- alone decide L_i."""
+  cfg, ev, inj = H.small_config(E=4, S=2000, P=3, Z=80, I=2000, seed=77, ragged=False)
+  ev = dict(ev)
+  dL = ev['dL']
+  rank = np.argsort(np.argsort(dL, axis=1), axis=1) / (dL.shape[1] - 1.)
+  ev['pe_prior'] = dL**2 * 10.**(60. * rank)
+  like_o, pop_o, _ = H.build_oracle(ev, inj)
+  z = O.get_theta_src_and_weights(pop_o.update(H0=70.), like_o.theta_gw_det)[0].z
+  pc = np.array(ev['p_cat'])
+  for e in range(cfg['E']):
+    m = ev['z_grids'][e] < np.quantile(z[e], 0.6)
+    pc[e][:, m] = np.where(pc[e][:, m] != -100., 0., -100.)
+  ev['p_cat'] = pc
+  return cfg, ev, inj
+
+
+def test_standard_marginalized_kernel_takes_the_dense_sum_where_the_prefix_differences_are_rounding():
+  """The production GW kernel (binning, cut_grid set, marginalized: kde_sub_item) on weights spanning 60 decades: nodes whose bins in
+  reach hold < 1e-4 of the weight below them take the reference's dense kernel sum (math.py:77-81) over the pixel's samples, so
+  log L_i (-41 ... -49 here) agrees with the oracle to the stated tolerance; with the fallback switched off (CHM_NO_DENSE_NODE=1,
+  diagnostics) the same events come out wrong, i.e. the case does exercise the limit of the prefix-sum form."""
+  import os
+  cfg, ev, inj = _decades_case()
+  like_o, _, _ = H.build_oracle(ev, inj)
+  with np.errstate(all='ignore'):
+    ro = like_o.compute_all(H0=70.)
+  assert np.sum(ro[0] < -35.) >= 2 and np.all(np.isfinite(ro[0]))
+  like_p, _, _ = H.build_product(ev, inj)
+  rp = like_p.compute_all(H0=70.)
+  H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
+  like_p.close()
+  os.environ['CHM_NO_DENSE_NODE'] = '1'
+  try:
+    like_q, _, _ = H.build_product(ev, inj)
+    rq = like_q.compute_all(H0=70.)
+    like_q.close()
+  finally:
+    del os.environ['CHM_NO_DENSE_NODE']
+  assert np.max(np.abs(rq[0] - ro[0])) > 1e-3                 # the prefix differences alone lose these events
+
+
 def test_nan_tail_of_the_distance_table_and_the_scan_search():
   """An unphysical closed universe whose 1/E turns NaN inside the table: jnp.cumsum carries the NaN only from the first NaN term
   on, jnp.interp at its own nodes turns dL NaN one node earlier (0/dx * NaN), and searchsorted (method 'scan') on the NaN-tailed
