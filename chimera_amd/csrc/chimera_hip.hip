@@ -56,6 +56,10 @@ struct Ctx {
   hipEvent_t evb[4] = {};               // fork/join + timing on `stream2`
   double ms[8] = {};
   int t_ngroups = 0; bool t_like = false, t_sel = false, t_valid = false, t_all = false;
+  // HIP graph of the few-draw call (the reference-shaped scalar call like(**lambda) is launch-bound: ~10 kernels on three streams):
+  // the launch sequence of one configuration is captured once and replayed; `gkey` = everything baked into the captured arguments
+  hipGraphExec_t gexec = nullptr;
+  std::vector<long long> gkey, gwarm;
   bool init = false;
 };
 
@@ -86,6 +90,7 @@ static void ctx_free_tables(Ctx& c) {
 static void ctx_destroy(Ctx& c) {
   if (!c.init) return;
   (void)hipSetDevice(c.device);
+  if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; }
   ctx_free_tables(c);
   for (int i = 0; i < 8; i++) if (c.ev[i]) (void)hipEventDestroy(c.ev[i]);
   for (int i = 0; i < 4; i++) if (c.evb[i]) (void)hipEventDestroy(c.evb[i]);
@@ -148,8 +153,8 @@ static void fill_dev_params(const chm_params* p, DevParams* d) {
   d->mg_first = pow(10., log10(p->mass[CHM_M_MLOW])); d->mg_last = pow(10., log10(p->mass[CHM_M_MHIGH]));
 }
 
-// upload nb draws and build their tables on c.stream
-static int ctx_tables(Ctx& c, const chm_params* params, int nb, const double* fR_given = nullptr, LutDesc lutA = LutDesc{}, LutDesc lutB = LutDesc{}) {
+// host part of the per-draw tables: parameter checks, buffers, the draws packed into the pinned staging block
+static int ctx_tables_host(Ctx& c, const chm_params* params, int nb, const double* fR_given, int* Tc_out, int* Tm_out) {
   int Tc = 0, Tm = 0;
   for (int b = 0; b < nb; b++) {
     int rc = check_params(&params[b]); if (rc) return rc;
@@ -161,6 +166,12 @@ static int ctx_tables(Ctx& c, const chm_params* params, int nb, const double* fR
     fill_dev_params(&params[b], &c.h_params[b]);
     if (fR_given) { c.h_params[b].fR = fR_given[b]; c.h_params[b].fR_given = 1.; }     // plug-in completeness (chm_tab.fR)
   }
+  *Tc_out = Tc; *Tm_out = Tm;
+  return CHM_OK;
+}
+
+// device part: upload nb draws and build their tables on c.stream
+static int ctx_tables_enqueue(Ctx& c, int nb, int Tc, int Tm, LutDesc lutA = LutDesc{}, LutDesc lutB = LutDesc{}) {
   HIPCHK(hipMemcpyAsync(c.d_params, c.h_params, sizeof(DevParams) * nb, hipMemcpyHostToDevice, c.stream));
   const size_t tl = sizeof(double) * 3 * (size_t)(Tc > Tm ? Tc : Tm);
   if (tl <= 120 * 1024) {
@@ -171,6 +182,12 @@ static int ctx_tables(Ctx& c, const chm_params* params, int nb, const double* fR
   }
   HIPCHK(hipGetLastError());
   return CHM_OK;
+}
+
+static int ctx_tables(Ctx& c, const chm_params* params, int nb, const double* fR_given = nullptr, LutDesc lutA = LutDesc{}, LutDesc lutB = LutDesc{}) {
+  int Tc = 0, Tm = 0;
+  int rc = ctx_tables_host(c, params, nb, fR_given, &Tc, &Tm); if (rc) return rc;
+  return ctx_tables_enqueue(c, nb, Tc, Tm, lutA, lutB);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -544,11 +561,20 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       rc = tab_upload(&td.bkg_i, tab->bkg_inj, NI, sA); if (rc) return rc;
     }
   }
-  static const bool timing = getenv("CHM_NO_TIMING") == nullptr;      // CHM_NO_TIMING=1: no timing events in the streams (chm_last_timing returns zeros)
-  // with a communicator (multi-GPU shards: short calls) only the whole evaluation and the GW kernel are timed: each event record
-  // costs ~3 us of stream time (measured: 35 us per call for the full set)
-  const bool timing_all = timing && !comm;
-  if (timing) HIPCHK(hipEventRecord(c.ev[0], sA));
+  static const bool timing_env = getenv("CHM_NO_TIMING") == nullptr;  // CHM_NO_TIMING=1: no timing events in the streams (chm_last_timing returns zeros)
+  // Few draws per call (the reference's scalar call): the launch sequence is replayed from a HIP graph -- no timing events, no
+  // per-event outputs, no communicator, no caller tables.  A configuration runs eagerly the first time it is seen (function
+  // attributes, workspaces), is captured the second time and replayed afterwards.
+  static const int graph_max_nb = getenv("CHM_GRAPH_MAX_NB") ? atoi(getenv("CHM_GRAPH_MAX_NB")) : 8;
+  const bool graph_ok = nb <= graph_max_nb && !comm && !tab && !want_dump && !out->log_like_evs && !out->numlike_evs;
+  int Tc_host = 0, Tm_host = 0;
+  rc = ctx_tables_host(c, params, nb, tab ? tab->fR : nullptr, &Tc_host, &Tm_host); if (rc) return rc;
+  if (like && (like->L.E + 255) / 256 * nb > c.evpart_cap) {       // block sums of log L_i for shards beyond 4096 events (k_reduce_events)
+    HIPCHK(hipStreamSynchronize(sA));
+    (void)hipFree(c.d_evpart); c.d_evpart = nullptr;
+    HIPCHK(hipMalloc(&c.d_evpart, sizeof(double) * nb * ((like->L.E + 255) / 256)));
+    c.evpart_cap = nb * ((like->L.E + 255) / 256);
+  }
   // k_samples_fast (built-in mass model, the same for every draw of the call, tables of at most 65535 entries): the direct-index
   // table of the dL table is built by k_tables for the key range of this shard's distances; LDS capacity of the table slice from the
   // range (entries per octave of the reference's logspace z grid, cosmo.py:43-46, with a margin; a draw whose slice does not fit
@@ -578,7 +604,39 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       if (lds_fast > 96 * 1024) use_fast = false;
     }
   }
-  rc = ctx_tables(c, params, nb, tab ? tab->fR : nullptr, use_fast ? lutA : LutDesc{}); if (rc) return rc;
+  // ---- graph bookkeeping: the key lists everything the captured launch arguments depend on
+  std::vector<long long> key;
+  bool capturing = false;
+  if (graph_ok) {
+    key = { (long long)(intptr_t)like, (long long)(intptr_t)sel, nb, (long long)E_total, like ? like->nb_ws : 0, sel ? sel->nb_ws : 0, c.nb_cap, c.TcMax, c.TmMax,
+            Tc_host, Tm_host, use_fast, lutA.key0, lutA.nk, lutA.cap, (long long)lds_fast, params[0].mass_model, out->partials != nullptr,
+            (long long)(intptr_t)c.d_evpart, (long long)(intptr_t)(like ? like->L.ws_z : nullptr), (long long)(intptr_t)(sel ? sel->S.partial : nullptr) };
+    if (c.gexec && key == c.gkey) {                           // replay
+      HIPCHK(hipGraphLaunch(c.gexec, sA));
+      HIPCHK(hipStreamSynchronize(sA));
+      for (int b = 0; b < nb; b++) {
+        if (out->log_hyper) out->log_hyper[b] = c.h_out[b * 3];
+        if (out->log_num) out->log_num[b] = c.h_out[b * 3 + 1];
+        if (out->N_exp) out->N_exp[b] = c.h_out[b * 3 + 2];
+        if (out->partials) for (int k = 0; k < 3; k++) out->partials[b * 3 + k] = c.h_out[3 * nb + b * 3 + k];
+      }
+      c.t_valid = false;
+      return CHM_OK;
+    }
+    if (key == c.gwarm) {                                     // second sight of this configuration: capture it
+      if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; c.gkey.clear(); }
+      HIPCHK(hipStreamBeginCapture(sA, hipStreamCaptureModeThreadLocal));
+      capturing = true;
+    } else c.gwarm = key;
+  }
+  const bool timing = timing_env && !capturing;
+  // with a communicator (multi-GPU shards: short calls) only the whole evaluation and the GW kernel are timed: each event record
+  // costs ~3 us of stream time (measured: 35 us per call for the full set)
+  const bool timing_all = timing && !comm;
+  // an error inside a capture must end it before returning
+  struct CaptureGuard { hipStream_t s; bool* on; ~CaptureGuard() { if (*on) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); } } } cguard{sA, &capturing};
+  if (timing) HIPCHK(hipEventRecord(c.ev[0], sA));
+  rc = ctx_tables_enqueue(c, nb, Tc_host, Tm_host, use_fast ? lutA : LutDesc{}); if (rc) return rc;
   HIPCHK(hipEventRecord(c.ev[1], sA));
   HIPCHK(hipStreamWaitEvent(sB, c.ev[1], 0));               // fork: the other lanes start after the tables
 
@@ -695,8 +753,8 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
           if (L.num_bins == 200) { if (ipw == 4) LAUNCH_SUB2(4, 200); else LAUNCH_SUB2(2, 200); }      // the reference's default bin count (likelihood.py:59): compile-time
           else { if (ipw == 4) LAUNCH_SUB2(4, 0); else LAUNCH_SUB2(2, 0); }
 #undef LAUNCH_SUB2
-          // pixels whose rounding bound matters against their event's L_i (tolerance 1e-10 per event) are redone with dense sums
-          if (!L.no_dense) { HIPCHK(hipGetLastError()); allow_lds(k_marg_fixup, lds_kde); hipLaunchKernelGGL(k_marg_fixup, dim3(L.E_cnt, nb), dim3(64), lds_kde, sg, L, dp, 1e-10); }
+          // events whose summed rounding bound matters against L_i (3e-10; the stated tolerance on L_i is 1e-9) get their heavy pixels redone with dense sums
+          if (!L.no_dense) { HIPCHK(hipGetLastError()); allow_lds(k_marg_fixup, lds_kde); hipLaunchKernelGGL(k_marg_fixup, dim3(L.E_cnt, nb), dim3(64), lds_kde, sg, L, dp, 3e-10); }
         }
         else { allow_lds(k_kde_marg, lds_kde); hipLaunchKernelGGL(k_kde_marg, dim3(L.E_cnt * Pd, nb), dim3(64), lds_kde, sg, L, dp); }
       } else {
@@ -714,12 +772,6 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     if (timing_all) HIPCHK(hipEventRecord(c.ev[3], sA));
     // per-event log-likelihoods and their block sums
     nblk_ev = (L0.E + 255) / 256;
-    if (nb * nblk_ev > c.evpart_cap) {
-      HIPCHK(hipStreamSynchronize(sA));
-      (void)hipFree(c.d_evpart); c.d_evpart = nullptr;
-      HIPCHK(hipMalloc(&c.d_evpart, sizeof(double) * nb * nblk_ev));
-      c.evpart_cap = nb * nblk_ev;
-    }
   } else {
     if (timing_all) HIPCHK(hipEventRecord(c.ev[3], sA));
   }
@@ -786,6 +838,16 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     size_t Pd = like->L.P > 0 ? like->L.P : 1;
     const double* src = like->L.mode == CHM_MODE_1D ? like->L.pgw1d : like->L.p_gw_dump;
     HIPCHK(hipMemcpyAsync(out->p_gw, src, sizeof(double) * nb * El * Pd * like->L.Z, hipMemcpyDeviceToHost, sA));
+  }
+  if (capturing) {
+    hipGraph_t graph = nullptr;
+    capturing = false;
+    HIPCHK(hipStreamEndCapture(sA, &graph));
+    hipError_t ge = hipGraphInstantiate(&c.gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ge != hipSuccess) { c.gexec = nullptr; return fail(CHM_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ge)); }
+    c.gkey = key;
+    HIPCHK(hipGraphLaunch(c.gexec, sA));
   }
   HIPCHK(hipStreamSynchronize(sA));
   for (int b = 0; b < nb; b++) {

@@ -1246,20 +1246,22 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
   kde_marg_general(L, params, blockIdx.y, L.e_off + blockIdx.x / L.P, blockIdx.x % L.P, lds, false);
 }
 
-// k_marg_fixup: one wave per (event, draw) after the standard GW kernel (kde_sub_item).  Lane p holds pixel p's integral and the bound
-// on what the prefix-sum form may have lost in it (err_pix); a pixel whose bound exceeds its share tol / P of the event's L_i --
-// or any pixel with a non-zero bound when L_i is not positive -- is evaluated again by the general kernel's body (dense kernel sums
-// where the bins in reach are light, epan_prefix_eval), in pixel order.  No pixel qualifies for ordinary data: the wave reads 2 P
-// doubles and exits.  After it, every L_i agrees with the dense form to ~tol + the general kernel's own 1e-10.
+// k_marg_fixup: one wave per (event, draw) after the standard GW kernel (kde_sub_item): sums the event's pixel integrals (L_i) and the
+// bounds on what the prefix-sum form may have lost in them (err_pix).  If the summed bound exceeds tol L_i, every pixel whose bound
+// exceeds its equal share tol L_i / P -- any pixel with a non-zero bound when L_i is not positive -- is evaluated again by the general
+// kernel's body (dense kernel sums where the bins in reach are light, epan_prefix_eval), in pixel order.  For ordinary data the bound
+// is ~1e-11 L_i: the wave reads 2 P doubles and exits.  After it, every L_i agrees with the dense form to ~tol + the general kernel's
+// own 1e-10.
 __global__ void __launch_bounds__(64) k_marg_fixup(LikeDev L, const DevParams* params, double tol) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x, e = L.e_off + blockIdx.x, b = blockIdx.y;
   const size_t po = ((size_t)b * L.E + e) * L.P;
-  // L_i = sum over the pixels (all of them: P <= 1024)
-  double li = 0.;
-  for (int p = lane; p < L.P; p += 64) li += L.like_pix[po + p];
-  li = wave_sum(li);
-  const double share = tol * fabs(li) / (double)L.P;
+  // L_i and the summed bound over the event's pixels (P <= 1024)
+  double li = 0., es = 0.;
+  for (int p = lane; p < L.P; p += 64) { li += L.like_pix[po + p]; es += L.err_pix[po + p]; }
+  li = wave_sum(li); es = wave_sum(es);
+  if (!(es > tol * fabs(li))) return;                   // the event is within the tolerance as it stands (also: NaN anywhere -> stays NaN)
+  const double share = tol * fabs(li) / (double)L.P;    // redo the pixels above their equal share: what is left sums to <= tol L_i
   for (int p0 = 0; p0 < L.P; p0 += 64) {
     const int p = p0 + lane;
     const double er = p < L.P ? L.err_pix[po + p] : 0.;
