@@ -7,10 +7,12 @@ Runtime part of the plugin: ``p_gal(cosmo, z) = fR * p_cat + (1 - P_compl) * p_b
 """
 import ctypes as C
 import numpy as np
+from ..utils.io import load_set, save_set
 from .. import _lib
 from ..utils.config import logger
 from ..population.cosmo import dVcdz_at_z
 from ..data import theta_src
+from .completeness import dVdz_completeness
 
 
 class empty_catalog(object):
@@ -57,12 +59,7 @@ class pixelated_catalog(object):
     self.data_gal_cat = ['p_cat', 'N_gal', 'P_compl']
     if gal_cat_file is not None:
       logger.info(f"Loading gal_cat object from {gal_cat_file}")
-      with np.load(gal_cat_file) as d:
-        self.p_cat = np.ascontiguousarray(d['p_cat'], dtype=np.float64)
-        self.N_gal = d['N_gal']
-        self.P_compl = np.ascontiguousarray(d['P_compl'], dtype=np.float64)
-        self.neff_pixels = np.asarray(d['neff_pixels'])
-        self.max_npixels = int(d['max_npixels'])
+      self._load(gal_cat_file)
     elif p_cat is not None:
       if z_grids is None:
         raise ValueError("pixelated_catalog: `z_grids` is needed with `p_cat`")
@@ -85,6 +82,10 @@ class pixelated_catalog(object):
         raise ValueError("pixelated_catalog: `cosmo`, `z_grids` and `data_gw_pixelated` are needed to compute p_cat")
       if sumgauss not in ("dVdz", "pbkg"):
         raise ValueError("sumgauss must be 'dVdz' or 'pbkg'")
+      if sumgauss == "pbkg" and not isinstance(completeness, dVdz_completeness):
+        # _sum_gaussians_pbkg (catalog.py:223-231) weights the Gaussians by the completeness' own p_bkg; the device kernel weights by
+        # dVc/dz, which is the same thing only for the built-in dVdz completeness
+        raise NotImplementedError("pixelated_catalog(sumgauss='pbkg') with a plug-in completeness: k_pcat weights by dVc/dz only")
       self.cosmo, self.z_grids, self.data_gw_pixelated = cosmo, np.ascontiguousarray(z_grids, dtype=np.float64), data_gw_pixelated
       self.z_err, self.sumgauss = z_err, sumgauss
       if data_gal is None:
@@ -165,8 +166,26 @@ class pixelated_catalog(object):
     self.P_compl = self.completeness.P_compl(zgrids)[:, np.newaxis, :]   # catalog.py:195
 
   def save(self, fname):
-    np.savez(fname, p_cat=self.p_cat, N_gal=self.N_gal, P_compl=self.P_compl, neff_pixels=self.neff_pixels,
-             max_npixels=self.max_npixels)
+    """The reference's cache layout (catalog.py:96-103 with io.save_set): ``max_npixels`` / ``neff_pixels`` as attributes, ``p_cat``,
+    ``N_gal``, ``P_compl`` as datasets -- HDF5 for ``.h5`` / ``.hdf5`` (interchangeable with the reference's and the Zenodo caches;
+    needs h5py), ``.npz`` otherwise."""
+    save_set(self, fname, self.attr_gal_cat, self.data_gal_cat)
+
+  def _load(self, fname):
+    if not str(fname).endswith(('.h5', '.hdf5')):
+      with np.load(fname) as d:
+        flat = 'attr/max_npixels' not in d.files and 'max_npixels' in d.files     # caches written before the attribute / dataset split
+        if flat:
+          for k in self.attr_gal_cat + self.data_gal_cat:
+            setattr(self, k, d[k])
+    else:
+      flat = False
+    if not flat:
+      load_set(self, fname, self.attr_gal_cat, self.data_gal_cat)
+    self.p_cat = np.ascontiguousarray(self.p_cat, dtype=np.float64)
+    self.P_compl = np.ascontiguousarray(self.P_compl, dtype=np.float64)
+    self.neff_pixels = np.asarray(self.neff_pixels)
+    self.max_npixels = int(self.max_npixels)
 
   def p_gal(self, cosmo_lambdas, z):
     """catalog.py:197-203."""

@@ -206,7 +206,8 @@ def pixelize_gw_catalog(theta_gw, nside_list, mean_npixels_event, sky_conf, nest
   opt_nsides = np.array(nside_list)[best]
   event_pixels = [compute_sky_conf_event(pixels_pe_all_nsides[f"nside_{opt_nsides[e]}"][e], sky_conf, opt_nsides[e])
                   for e in range(num_events)]
-  pixel_ra, pixel_dec = zip(*[angles.find_ra_dec(event_pixels[e], nside=opt_nsides[e]) for e in range(num_events)])
+  # (the reference calls find_ra_dec without `nest`, data.py:311 -- RING centres for NESTED indices; here the ordering is passed on)
+  pixel_ra, pixel_dec = zip(*[angles.find_ra_dec(event_pixels[e], nside=opt_nsides[e], nest=nest) for e in range(num_events)])
   pe_samples_pixels = np.zeros(ra.shape, dtype=np.int64)
   for e in range(num_events):
     sample_pix = pixels_pe_all_nsides[f"nside_{opt_nsides[e]}"][e]
@@ -223,7 +224,10 @@ def pixelize_gw_catalog(theta_gw, nside_list, mean_npixels_event, sky_conf, nest
                                        gw_loc2d_pdf=padded_pixel_probs, pixels_pe_opt_nside=pe_samples_pixels)
   if prefix is not None:
     print_list = "-".join(map(str, nside_list))
-    fname = prefix + f"_pixelated_nsidelist{print_list}_meanpixels{mean_npixels_event}_skyconf{sky_conf}_nest{nest}.npz"
+    # the reference writes HDF5 (data.py:368); without h5py the same sets go to .npz
+    from .utils import io as _io
+    ext = ".h5" if _io.h5py is not None else ".npz"
+    fname = prefix + f"_pixelated_nsidelist{print_list}_meanpixels{mean_npixels_event}_skyconf{sky_conf}_nest{nest}{ext}"
     save_set(theta_gw_pixelated, fname, datasets=[d for d in theta_pe_pixelated_datasets if getattr(theta_gw_pixelated, d) is not None],
              groups=theta_pe_pixelated_groups)
   return theta_gw_pixelated
@@ -231,11 +235,15 @@ def pixelize_gw_catalog(theta_gw, nside_list, mean_npixels_event, sky_conf, nest
 
 def load_pixelated_gw_catalog(fname):
   """data.py:395-404."""
-  avail = None
-  if not str(fname).endswith(('.h5', '.hdf5')):
+  if str(fname).endswith(('.h5', '.hdf5')):
+    from .utils import io as _io
+    _io._need_h5py(fname)
+    with _io.h5py.File(fname, 'r') as f:
+      avail = set(f.keys())
+  else:
     with np.load(fname) as f:
       avail = set(f.files)
-  datasets = [d for d in theta_pe_pixelated_datasets if avail is None or d in avail]
+  datasets = [d for d in theta_pe_pixelated_datasets if d in avail]
   return load_set(theta_pe_det(), fname, attrs=[], datasets=datasets, groups=theta_pe_pixelated_groups)
 
 

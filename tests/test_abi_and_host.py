@@ -188,6 +188,22 @@ def test_catalog_and_completeness_plugins(tmp_path):
   f = str(tmp_path / 'gc.npz'); gc.save(f)
   gc2 = pixelated_catalog(comp, gal_cat_file=f)
   np.testing.assert_array_equal(gc2.p_cat, p_cat); assert gc2.max_npixels == 2
+  with np.load(f) as d:                                      # the reference's split (catalog.py:96-103): two attributes, three datasets
+    assert sorted(d.files) == ['N_gal', 'P_compl', 'attr/max_npixels', 'attr/neff_pixels', 'p_cat']
+  f_old = str(tmp_path / 'gc_flat.npz')                      # caches written before the split keep loading
+  np.savez(f_old, p_cat=p_cat, N_gal=gc.N_gal, P_compl=gc.P_compl, neff_pixels=gc.neff_pixels, max_npixels=2)
+  gc3 = pixelated_catalog(comp, gal_cat_file=f_old)
+  np.testing.assert_array_equal(gc3.p_cat, p_cat); assert gc3.max_npixels == 2 and list(gc3.neff_pixels) == [1]
+
+  class other_completeness(dVdz_completeness):               # a plug-in completeness is not the built-in one, even when derived from it?
+    pass
+  class foreign(object):
+    z_range = (0.1, 1.0)
+    def P_compl(self, z): return np.ones_like(z)
+    def fR(self, c): return 1.
+    def p_bkg(self, c, z, distances=None): return np.ones_like(z)
+  with pytest.raises(NotImplementedError):                   # _sum_gaussians_pbkg with a foreign p_bkg is not what k_pcat computes
+    pixelated_catalog(foreign(), cosmo=object(), z_grids=zg, data_gw_pixelated=object(), data_gal={'z': np.array([0.5])}, sumgauss='pbkg')
   with pytest.raises(ValueError):
     pixelated_catalog(comp)
   assert empty_catalog().max_npixels is None

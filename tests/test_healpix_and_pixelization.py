@@ -1,4 +1,4 @@
-"""HEALPix RING indexing (own implementation; healpy is absent), file loaders and the GW-catalogue pixelisation
+"""HEALPix RING / NESTED indexing (own implementation; healpy is absent), file loaders and the GW-catalogue pixelisation
 (reference: CHIMERA/utils/angles.py, CHIMERA/utils/io.py, CHIMERA/data.py:107-404)."""
 import numpy as np
 import pytest
@@ -50,8 +50,45 @@ def test_healpix_known_values_and_equal_area():
   tc, pc = A.pix2ang(16, pp)
   sep = A.angular_separation_from_LOS(phi[:5000], np.pi / 2 - np.arccos(z[:5000]), pc, np.pi / 2 - tc)
   assert sep.max() < 1.1 * np.sqrt(4 * np.pi / A.nside2npix(16))
-  with pytest.raises(NotImplementedError):
-    A.ang2pix(4, 1., 1., nest=True)
+  with pytest.raises(ValueError):
+    A.ang2pix(6, 1., 1., nest=True)                        # NESTED needs nside = 2^k
+
+
+# RING -> NESTED at nside = 2, the table of the HEALPix scheme (what healpy.ring2nest(2, arange(48)) returns)
+RING2NEST_NSIDE2 = [3, 7, 11, 15, 2, 1, 6, 5, 10, 9, 14, 13, 19, 0, 23, 4, 27, 8, 31, 12, 17, 22, 21, 26, 25, 30, 29, 18, 16, 35, 20, 39, 24, 43,
+                    28, 47, 34, 33, 38, 37, 42, 41, 46, 45, 32, 36, 40, 44]
+
+
+def test_healpix_nested_ordering():
+  """NESTED indexing (CHIMERA/data.py:266,288,325 and utils/angles.py:32-85 take ``nest``): the published nside = 2 table, bijection
+  with RING, base pixels (nside = 1: NESTED = RING = face number), and the hierarchy that defines the scheme -- the children of
+  pixel p at 2 nside are 4p .. 4p + 3 and their centres lie inside p."""
+  np.testing.assert_array_equal(A.ring2nest(2, np.arange(48)), RING2NEST_NSIDE2)
+  np.testing.assert_array_equal(A.nest2ring(2, RING2NEST_NSIDE2), np.arange(48))
+  np.testing.assert_array_equal(A.ring2nest(1, np.arange(12)), np.arange(12))
+  for nside in (1, 2, 4, 16, 64, 512):
+    npix = A.nside2npix(nside)
+    r = np.arange(npix) if nside <= 64 else np.random.default_rng(1).integers(0, npix, 200_000)
+    n = A.ring2nest(nside, r)
+    np.testing.assert_array_equal(A.nest2ring(nside, n), r)
+    if nside <= 64:
+      assert np.array_equal(np.sort(n), np.arange(npix))
+    th, ph = A.pix2ang(nside, n, nest=True)
+    thr, phr = A.pix2ang(nside, r)
+    np.testing.assert_array_equal(th, thr); np.testing.assert_array_equal(ph, phr)
+    np.testing.assert_array_equal(A.ang2pix(nside, th, ph, nest=True), n)
+  for nside in (1, 2, 8, 32):
+    ch = np.arange(A.nside2npix(2 * nside))
+    th, ph = A.pix2ang(2 * nside, ch, nest=True)
+    np.testing.assert_array_equal(A.ang2pix(nside, th, ph, nest=True), ch // 4)
+  # the reference's helpers pass `nest` through
+  ra, dec = np.array([0.3, 2.0, 5.1]), np.array([-0.4, 0.9, 0.1])
+  pn = A.find_pix_RAdec(ra, dec, 16, nest=True)
+  np.testing.assert_array_equal(pn, A.ring2nest(16, A.find_pix_RAdec(ra, dec, 16)))
+  r2, d2 = A.find_ra_dec(pn, 16, nest=True)
+  r3, d3 = A.find_ra_dec(A.find_pix_RAdec(ra, dec, 16), 16)
+  np.testing.assert_array_equal(r2, r3); np.testing.assert_array_equal(d2, d3)
+  np.testing.assert_array_equal(A.convert_pixelization(np.array([pn]), [16], 4, nest_in=True, nest_out=True)[0], pn // 16)
 
 
 def test_angle_helpers():
