@@ -63,7 +63,7 @@ class chm_out(C.Structure):
 class chm_tab(C.Structure):
   """Caller-evaluated plug-in models of one call (include/chimera_hip.h: struct chm_tab)."""
   _fields_ = [('pm_samples', c_dp), ('pm_inj', c_dp), ('rate_grid', c_dp), ('rate_inj', c_dp), ('bkg_grid', c_dp),
-              ('bkg_inj', c_dp), ('fR', c_dp)]
+              ('bkg_inj', c_dp), ('fR', c_dp), ('z_table', c_dp), ('dL_table', c_dp), ('jac_grid', c_dp), ('jac_inj', c_dp)]
 
 
 SYMBOLS = ['chm_version', 'chm_device_count', 'chm_last_error', 'chm_like_create', 'chm_like_destroy',

@@ -171,14 +171,15 @@ static int ctx_tables_host(Ctx& c, const chm_params* params, int nb, const doubl
 }
 
 // device part: upload nb draws and build their tables on c.stream
-static int ctx_tables_enqueue(Ctx& c, int nb, int Tc, int Tm, LutDesc lutA = LutDesc{}, LutDesc lutB = LutDesc{}) {
+static int ctx_tables_enqueue(Ctx& c, int nb, int Tc, int Tm, LutDesc lutA = LutDesc{}, LutDesc lutB = LutDesc{},
+                              const double* tab_zt = nullptr, const double* tab_dLt = nullptr) {
   HIPCHK(hipMemcpyAsync(c.d_params, c.h_params, sizeof(DevParams) * nb, hipMemcpyHostToDevice, c.stream));
   const size_t tl = sizeof(double) * 3 * (size_t)(Tc > Tm ? Tc : Tm);
   if (tl <= 120 * 1024) {
     if (tl > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_tables<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
-    hipLaunchKernelGGL(k_tables<true>, dim3(nb, 2), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, lutA.nk > 0 ? c.rec : nullptr);
+    hipLaunchKernelGGL(k_tables<true>, dim3(nb, 2), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, lutA.nk > 0 ? c.rec : nullptr, tab_zt, tab_dLt);
   } else {
-    hipLaunchKernelGGL(k_tables<false>, dim3(nb, 2), dim3(1024), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, lutA.nk > 0 ? c.rec : nullptr);
+    hipLaunchKernelGGL(k_tables<false>, dim3(nb, 2), dim3(1024), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, lutA.nk > 0 ? c.rec : nullptr, tab_zt, tab_dLt);
   }
   HIPCHK(hipGetLastError());
   return CHM_OK;
@@ -510,7 +511,9 @@ static void allow_lds(K kernel, size_t bytes) {
 // device copies of the caller's tables for one call (plug-in models, chm_tab); freed when the call returns
 struct TabDev {
   double *pm_s = nullptr, *pm_i = nullptr, *rate_g = nullptr, *rate_i = nullptr, *bkg_g = nullptr, *bkg_i = nullptr;
-  ~TabDev() { (void)hipFree(pm_s); (void)hipFree(pm_i); (void)hipFree(rate_g); (void)hipFree(rate_i); (void)hipFree(bkg_g); (void)hipFree(bkg_i); }
+  double *zt = nullptr, *dLt = nullptr, *jac_g = nullptr, *jac_i = nullptr;      // plug-in cosmology
+  ~TabDev() { (void)hipFree(pm_s); (void)hipFree(pm_i); (void)hipFree(rate_g); (void)hipFree(rate_i); (void)hipFree(bkg_g); (void)hipFree(bkg_i);
+              (void)hipFree(zt); (void)hipFree(dLt); (void)hipFree(jac_g); (void)hipFree(jac_i); }
 };
 static int tab_upload(double** dst, const double* src, size_t n, hipStream_t s) {
   if (!src || n == 0) return CHM_OK;
@@ -548,17 +551,29 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
 
   TabDev td;
   if (tab) {                                                  // plug-in models: the caller's tables of this call, host -> device
+    if ((tab->z_table != nullptr) != (tab->dL_table != nullptr)) return fail(CHM_E_ARG, "chm_eval_tabulated: z_table and dL_table go together");
+    if (tab->z_table) {                                       // plug-in cosmology: everything cosmological must come from the caller
+      for (int b = 1; b < nb; b++) if (params[b].z_grid_res != params[0].z_grid_res) return fail(CHM_E_ARG, "chm_eval_tabulated: a plug-in cosmology needs the same z_grid_res for every draw");
+      if (like && (!tab->jac_grid || !tab->bkg_grid)) return fail(CHM_E_ARG, "chm_eval_tabulated: a plug-in cosmology needs jac_grid and bkg_grid");
+      if (like && params[0].has_catalog && !tab->fR) return fail(CHM_E_ARG, "chm_eval_tabulated: a plug-in cosmology with a catalogue needs fR");
+      if (sel && (!tab->jac_inj || !tab->bkg_inj)) return fail(CHM_E_ARG, "chm_eval_tabulated: a plug-in cosmology needs jac_inj and bkg_inj");
+      const size_t NT = (size_t)nb * params[0].z_grid_res;
+      rc = tab_upload(&td.zt, tab->z_table, NT, sA); if (rc) return rc;
+      rc = tab_upload(&td.dLt, tab->dL_table, NT, sA); if (rc) return rc;
+    }
     if (like) {
       const size_t ES = (size_t)nb * like->L.E * like->L.S, EZ = (size_t)nb * like->L.E * like->L.Z;
       rc = tab_upload(&td.pm_s, tab->pm_samples, ES, sA); if (rc) return rc;
       rc = tab_upload(&td.rate_g, tab->rate_grid, EZ, sA); if (rc) return rc;
       rc = tab_upload(&td.bkg_g, tab->bkg_grid, EZ, sA); if (rc) return rc;
+      rc = tab_upload(&td.jac_g, tab->jac_grid, EZ, sA); if (rc) return rc;
     }
     if (sel) {
       const size_t NI = (size_t)nb * (size_t)sel->S.I;
       rc = tab_upload(&td.pm_i, tab->pm_inj, NI, sA); if (rc) return rc;
       rc = tab_upload(&td.rate_i, tab->rate_inj, NI, sA); if (rc) return rc;
       rc = tab_upload(&td.bkg_i, tab->bkg_inj, NI, sA); if (rc) return rc;
+      rc = tab_upload(&td.jac_i, tab->jac_inj, NI, sA); if (rc) return rc;
     }
   }
   static const bool timing_env = getenv("CHM_NO_TIMING") == nullptr;  // CHM_NO_TIMING=1: no timing events in the streams (chm_last_timing returns zeros)
@@ -636,7 +651,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   // an error inside a capture must end it before returning
   struct CaptureGuard { hipStream_t s; bool* on; ~CaptureGuard() { if (*on) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); } } } cguard{sA, &capturing};
   if (timing) HIPCHK(hipEventRecord(c.ev[0], sA));
-  rc = ctx_tables_enqueue(c, nb, Tc_host, Tm_host, use_fast ? lutA : LutDesc{}); if (rc) return rc;
+  rc = ctx_tables_enqueue(c, nb, Tc_host, Tm_host, use_fast ? lutA : LutDesc{}, LutDesc{}, td.zt, td.dLt); if (rc) return rc;
   HIPCHK(hipEventRecord(c.ev[1], sA));
   HIPCHK(hipStreamWaitEvent(sB, c.ev[1], 0));               // fork: the other lanes start after the tables
 
@@ -666,7 +681,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     for (int g = 0; g < ngroups; g++) {
       hipStream_t sg = (g & 1) ? sB : sA;
       LikeDev L = like->L;
-      L.tab_pm = td.pm_s; L.tab_rate = td.rate_g; L.tab_bkg = td.bkg_g;
+      L.tab_pm = td.pm_s; L.tab_rate = td.rate_g; L.tab_bkg = td.bkg_g; L.tab_jac = td.jac_g;
       L.no_dense = getenv("CHM_NO_DENSE_NODE") ? 1 : 0;     // diagnostics: no dense-sum fallback in the standard GW kernel
       if (!want_dump) L.p_gw_dump = nullptr;
       const int eb = (int)((long long)L0.E * g / ngroups), ee = (int)((long long)L0.E * (g + 1) / ngroups);
@@ -780,7 +795,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   if (sel) {
     HIPCHK(hipStreamWaitEvent(sC, c.ev[1], 0));
     SelDev S = sel->S;
-    S.tab_pm = td.pm_i; S.tab_rate = td.rate_i; S.tab_bkg = td.bkg_i;
+    S.tab_pm = td.pm_i; S.tab_rate = td.rate_i; S.tab_bkg = td.bkg_i; S.tab_jac = td.jac_i;
     if (timing_all) HIPCHK(hipEventRecord(c.evb[1], sC));
     if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
       hipLaunchKernelGGL(k_selection<true>, dim3(S.nblocks, nb), dim3(256), lds_samp, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);

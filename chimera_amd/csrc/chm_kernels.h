@@ -44,6 +44,7 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   const double *dl_lo, *dl_hi;    // (E,) smallest / largest finite dL of each event (set at upload): brackets its table searches
   const int* perm;                // (E,S) marginalized: original index of the pixel-sorted sample (for caller-tabulated values)
   const double *tab_pm, *tab_rate, *tab_bkg;   // plug-in models evaluated by the caller (chm_tab), device copies; NULL = built-in
+  const double *tab_jac;          // (nb,E,Z) plug-in cosmology: ddL/dz (1+z)^2 on the event grids
   const double *fracB, *fracG;    // i/num_bins (num_bins+1), i/(G-1) (G): the step fractions of jnp.linspace
   // workspaces (nb-major)
   double *ws_z, *ws_w;            // (nb,E,S)
@@ -190,7 +191,7 @@ DEVFN void build_lut(const LutDesc& D, int b, Acc tab, int Tc, bool sorted, doub
 template <bool LDS_ARR>
 __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_all, double* It_all,
                                                   double* dLt_all, double* mg_all, double* cdf_all, double* tmp_all, int TcMax, int TmMax,
-                                                  LutDesc lutA, LutDesc lutB, double* rec_all) {
+                                                  LutDesc lutA, LutDesc lutB, double* rec_all, const double* tab_zt, const double* tab_dLt) {
   extern __shared__ double larr[];
   __shared__ double sh[32];
   __shared__ DevParams Ps;                          // block-local copy of the draw: constants derived here are shared through LDS
@@ -220,9 +221,10 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
     // zt = [0] U logspace(-10, log10 z_max, Tc-1); It = cumtrapz(1/E, zt)     cosmo.py:43-46
     const double lzmax = log10(P.z_max);
     for (int i = t; i < Tc; i += nt) {
-      double z = i == 0 ? 0. : pow(10., jnp_linspace_at(-10., lzmax, Tc - 1, i - 1));
+      // plug-in cosmology (chm_tab): the caller's z_grid_interp; 1/E is not needed (the Jacobian and p_bkg come tabulated too)
+      double z = tab_zt ? tab_zt[(size_t)b * Tc + i] : (i == 0 ? 0. : pow(10., jnp_linspace_at(-10., lzmax, Tc - 1, i - 1)));
       zt[i] = z;
-      tmp[i] = 1. / E_at_z(P, z);
+      tmp[i] = tab_zt ? 0. : 1. / E_at_z(P, z);
     }
     if (LDS_ARR) __syncthreads(); else gsync();
     block_cumtrapz(tmp, zt, It, Tc, sh);
@@ -237,7 +239,7 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
       double ii;
       if (i == Tc - 1) { double dx = zt[i] - zt[i - 1]; ii = It[i - 1] + (dx / dx) * (It[i] - It[i - 1]); }
       else ii = It[i] + (0. / (zt[i + 1] - zt[i])) * (It[i + 1] - It[i]);
-      double dl = dL_from_dCt(P, dCt_from_dCr(P, P.dH * ii), z);
+      double dl = tab_dLt ? tab_dLt[(size_t)b * Tc + i] : dL_from_dCt(P, dCt_from_dCr(P, P.dH * ii), z);
       dLt[i] = dl;
       tmp[i] = dl;
       if (LDS_ARR) { g_zt[i] = z; g_It[i] = It[i]; }
@@ -1062,11 +1064,12 @@ __global__ void __launch_bounds__(256, CHM_ZF_WPE) k_zfactors(LikeDev L, const D
     }
     for (int k = k_first + lane0; k <= k_last; k += stride) {
       double z = zg[k];
-      double dCt = dCt_at_z(P, z, zt, It);
+      const bool own_cosmo = !(L.tab_jac && L.tab_bkg);          // plug-in cosmology: Jacobian and p_bkg both come from the caller
+      double dCt = own_cosmo ? dCt_at_z(P, z, zt, It) : 0.;
       double zp1 = 1. + z;
       double lzp1 = chm_log_pos(zp1);
-      double Ez = E_at_z_l(P, z, lzp1);
-      double jac = ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1) * (zp1 * zp1);
+      double Ez = own_cosmo ? E_at_z_l(P, z, lzp1) : 1.;
+      double jac = L.tab_jac ? L.tab_jac[zo + k] : ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1) * (zp1 * zp1);
       double prate = (L.tab_rate ? L.tab_rate[zo + k] : merger_rate_l(P, z, lzp1)) / (1. + z);      // plug-in rate model: tabulated
       if (!ranged) { L.jac[zo + k] = jac; L.prate[zo + k] = prate; }
       double p_bkg = L.tab_bkg ? L.tab_bkg[zo + k] : dVcdz_from_dCt_E(P, dCt, Ez);                   // plug-in completeness: tabulated
@@ -1952,6 +1955,7 @@ struct SelDev {
   const double *dL, *m1det, *m2det, *p_draw;
   const double *lm1det, *lm2det;  // log(m1det), log(m2det), formed once at upload (as for the posterior samples)
   const double *tab_pm, *tab_rate, *tab_bkg;   // (nb,I) plug-in models evaluated by the caller (chm_tab); NULL = built-in
+  const double *tab_jac;          // (nb,I) plug-in cosmology: |ddL/dz| (1+z)^2 per injection
   double N_inj, N_eff; int has_neff, pad;
   double* partial;                // (nb, nblocks, 2)
   int nblocks;
@@ -1960,18 +1964,19 @@ struct SelDev {
 // one injection: dN/dtheta_det / p_draw                                     pop_wrapper.py:102-111, selection_function.py:38
 template <class A1, class A2>
 DEVFN double sel_term(const DevParams& P, double dl, double m1d, double m2d, double l1d, double l2d, double ipd, double z,
-                      A1 mg, A2 cdf, const double* tpm, const double* trate, const double* tbkg) {
+                      A1 mg, A2 cdf, const double* tpm, const double* trate, const double* tbkg, const double* tjac) {
 #pragma clang fp contract(fast)                  // smooth arithmetic only: a*b+c may fuse (the translation unit default is off)
   double zp1 = 1. + z;
   double rz = 1. / zp1;
   double m1 = m1d * rz, m2 = m2d * rz;
   double lzp1 = chm_log_pos(zp1);
-  double Ez = E_at_z_l(P, z, lzp1);
-  double dCt = dL2dCt_l(P, dl, z, lzp1);                           // original distances: cosmo.py:191-192,215-216
+  const bool own_cosmo = !(tjac && tbkg);                          // plug-in cosmology (chm_tab): both cosmological factors tabulated
+  double Ez = own_cosmo ? E_at_z_l(P, z, lzp1) : 1.;
+  double dCt = own_cosmo ? dL2dCt_l(P, dl, z, lzp1) : 0.;          // original distances: cosmo.py:191-192,215-216
   double p_z = tbkg ? *tbkg : dVcdz_from_dCt_E(P, dCt, Ez);        // gal_cat.p_bkg              pop_wrapper.py:106
   p_z = p_z * ((trate ? *trate : merger_rate_l(P, z, lzp1)) / (1. + z));              //         pop_wrapper.py:107
   double dN = P.R0 * (tpm ? *tpm : p_m1m2_fused(P, m1, m2, l1d - lzp1, l2d - lzp1, mg, cdf)) * p_z;   // pop_wrapper.py:108
-  double jacobian = fabs(ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1)) * (zp1 * zp1);      //           pop_wrapper.py:109
+  double jacobian = tjac ? *tjac : fabs(ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1)) * (zp1 * zp1);      //           pop_wrapper.py:109
   dN = dN / jacobian;
   return dN * ipd;                                                 // selection_function.py:38 (array holds 1/p_draw)
 }
@@ -2015,7 +2020,7 @@ __global__ void __launch_bounds__(256) k_selection(SelDev Sd, const DevParams* p
       for (int h = 0; h < 2; h++) {
         const size_t ti = (size_t)b * (size_t)I + (size_t)(i + (two ? h : 0));      // plug-in models: (nb,I) tables of the caller
         double dN = sel_term(P, dl[h], md1[h], md2[h], l1[h], l2[h], ipd[h], zz[h], T.mg, T.cdf, Sd.tab_pm ? Sd.tab_pm + ti : nullptr,
-                             Sd.tab_rate ? Sd.tab_rate + ti : nullptr, Sd.tab_bkg ? Sd.tab_bkg + ti : nullptr);
+                             Sd.tab_rate ? Sd.tab_rate + ti : nullptr, Sd.tab_bkg ? Sd.tab_bkg + ti : nullptr, Sd.tab_jac ? Sd.tab_jac + ti : nullptr);
         if (h == 0 || two) {
           if (dN == dN) s1 += dN;                                    // nansum                     selection_function.py:39
           s2 += dN * dN;                                             // plain sum     selection_function.py:44

@@ -40,7 +40,10 @@ def make_params(cosmo=None, mass=None, rate=None, R0=1., Tobs=1., scale_free=Tru
                 z_range=(0.073, 1.3)):
   """Fill one ``chm_params`` (include/chimera_hip.h) from model objects."""
   p = _lib.chm_params()
-  c = cosmo._pack() if cosmo is not None else _DEF_COSMO
+  if cosmo is not None and not hasattr(cosmo, '_pack'):                                    # plug-in cosmology: only the table size travels
+    c = dict(_DEF_COSMO, z_max=float(cosmo.z_max), z_grid_res=len(cosmo.z_grid_interp))
+  else:
+    c = cosmo._pack() if cosmo is not None else _DEF_COSMO
   m = mass._pack() if (mass is not None and hasattr(mass, '_pack')) else _DEF_MASS        # plug-in models (population/plugins.py):
   r = rate._pack() if (rate is not None and hasattr(rate, '_pack')) else _DEF_RATE        # their values come from the host
   p.cosmo_model, p.mass_model, p.rate_model = c['model'], m['model'], r['model']

@@ -57,6 +57,30 @@ class mg_flrw(flrw):
                 z_max=self.z_max, z_grid_res=self.z_grid_res)
 
 
+class plugin_cosmology(base_struct):
+  """Base of a user-written cosmology (the reference's open extension point: a new struct + plum overloads of the distance functions,
+  cosmo.py:122-264).  It has no ``_pack``: nothing of it runs inside a kernel; the host evaluates what the path needs of a cosmology
+  -- the (dL, z) table of ``z_from_dGW``, the Jacobian and ``p_bkg`` -- and hands the values over per draw (chm_tab, plugins.py).
+  A subclass lists its parameters in ``default`` (with ``z_max`` and ``z_grid_res``) and provides, in Gpc:
+
+    dL_at_z(z)                       GW luminosity distance                           (cosmo.py:205-210, 237-243)
+    ddLdz_at_z(z, distances=None)    its z-derivative; `distances`: original dL       (cosmo.py:212-221, 245-257)
+    dVcdz_at_z(z, distances=None)    differential comoving volume                     (cosmo.py:188-197)
+    Vc_at_z(z, distances=None)       comoving volume                                  (cosmo.py:166-186)
+  """
+  default = {'z_max': 10., 'z_grid_res': 1500}
+  name = 'plugin_cosmology'
+
+  @property
+  def z_grid_interp(self):
+    """cosmo.py:43-46: [0] U logspace(-10, log10 z_max, z_grid_res - 1)."""
+    return np.concatenate([[0.], np.logspace(-10., np.log10(self.z_max), int(self.z_grid_res) - 1)])
+
+
+def is_plugin(cosmo):
+  return cosmo is not None and not hasattr(cosmo, '_pack')
+
+
 def _zd(z, distances):
   """plum-dispatch overloads on theta_src (cosmo.py:269-279)."""
   if isinstance(z, theta_src):
@@ -106,23 +130,31 @@ def dA_at_z(cosmo, z, distances=None):
 def Vc_at_z(cosmo, z, distances=None):
   """cosmo.py:166-186, 273-275."""
   z, distances = _zd(z, distances)
+  if is_plugin(cosmo):
+    return np.asarray(cosmo.Vc_at_z(z, distances) if distances is not None else cosmo.Vc_at_z(z), dtype=np.float64)
   return _ev(cosmo, _lib.F_VC, z, distances)
 
 
 def dVcdz_at_z(cosmo, z, distances=None):
   """cosmo.py:188-197, 269-271."""
   z, distances = _zd(z, distances)
+  if is_plugin(cosmo):
+    return np.asarray(cosmo.dVcdz_at_z(z, distances) if distances is not None else cosmo.dVcdz_at_z(z), dtype=np.float64)
   return _ev(cosmo, _lib.F_DVCDZ, z, distances)
 
 
 def dL_at_z(cosmo, z):
   """cosmo.py:205-210, 237-243."""
+  if is_plugin(cosmo):
+    return np.asarray(cosmo.dL_at_z(np.asarray(z, dtype=np.float64)), dtype=np.float64)
   return _ev(cosmo, _lib.F_DL, z)
 
 
 def ddLdz_at_z(cosmo, z, distances=None):
   """cosmo.py:212-221, 245-257, 277-279."""
   z, distances = _zd(z, distances)
+  if is_plugin(cosmo):
+    return np.asarray(cosmo.ddLdz_at_z(z, distances) if distances is not None else cosmo.ddLdz_at_z(z), dtype=np.float64)
   return _ev(cosmo, _lib.F_DDLDZ, z, distances)
 
 
@@ -135,4 +167,7 @@ def Xi_at_z(cosmo, z):
 
 def z_from_dGW(cosmo, dGWs):
   """cosmo.py:260-264."""
+  if is_plugin(cosmo):                       # jnp.interp(dGWs, dL_at_z(z_grid_interp), z_grid_interp) on the host, slope form as the device's
+    zt = np.asarray(cosmo.z_grid_interp, dtype=np.float64)
+    return np.interp(np.asarray(dGWs, dtype=np.float64), dL_at_z(cosmo, zt), zt)
   return _ev(cosmo, _lib.F_Z_FROM_DGW, dGWs)

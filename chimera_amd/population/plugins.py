@@ -9,6 +9,9 @@ the function itself:
 * rate model           ``model.merger_rate(z) -> array``
 * completeness model   ``compl.P_compl(zgrids)``, ``compl.fR(cosmo)``, ``compl.p_bkg(cosmo, z_or_theta_src)``; anything that is not
                        ``dVdz_completeness`` (attribute ``builtin = True``) counts as a plug-in
+* cosmology            a subclass of ``cosmo.plugin_cosmology`` with ``dL_at_z``, ``ddLdz_at_z``, ``dVcdz_at_z``, ``Vc_at_z`` (Gpc): the host
+                       tabulates dL on ``z_grid_interp`` (the table of ``z_from_dGW``), the Jacobian on the event grids and per
+                       injection, and p_bkg / fR through the completeness model (cosmo.py:122-264)
 
 plus ``keys`` / ``as_dict`` / ``update(**lambdas)`` like every model (subclass ``base_struct``).  The host evaluates these on
 the source-frame quantities of every draw -- ``z = z_from_dGW(cosmo, dL)`` comes from the device, so it is the kernel's own
@@ -32,8 +35,10 @@ def is_plugin_completeness(gal_cat):
 
 
 def population_plugins(pop):
-  """(mass, rate, completeness) flags of a population."""
-  return is_plugin_model(pop.mass), is_plugin_model(pop.rate), is_plugin_completeness(pop.gal_cat)
+  """(mass, rate, completeness, cosmology) flags of a population.  A plug-in cosmology makes the background term a host quantity too
+  (p_bkg = dVc/dz of THAT cosmology), whatever the completeness model."""
+  cosmo = is_plugin_model(pop.cosmo)
+  return is_plugin_model(pop.mass), is_plugin_model(pop.rate), is_plugin_completeness(pop.gal_cat) or cosmo, cosmo
 
 
 def _bkg(gal_cat, cosmo, z):
@@ -49,8 +54,9 @@ def build_tab(pops, plugins, ev=None, inj=None):
   inj = dict(dL, m1det, m2det (I_loc,))                      of this shard, or None (no selection function in the call)
   Returns (chm_tab, keepalive): the arrays must outlive the call.
   """
-  from .cosmo import z_from_dGW
-  want_m, want_r, want_b = plugins
+  from .cosmo import z_from_dGW, dL_at_z, ddLdz_at_z
+  want_m, want_r, want_b = plugins[:3]
+  want_c = len(plugins) > 3 and plugins[3]
   nb = len(pops)
   tab, keep = _lib.chm_tab(), []
 
@@ -70,8 +76,13 @@ def build_tab(pops, plugins, ev=None, inj=None):
       put('rate_grid', [np.broadcast_to(np.asarray(p.rate.merger_rate(ev['z_grids']), dtype=np.float64), ev['z_grids'].shape) for p in pops])
     if want_b:
       put('bkg_grid', [np.broadcast_to(_bkg(p.gal_cat, p.cosmo, ev['z_grids']), ev['z_grids'].shape) for p in pops])
+    if want_c:                                      # likelihood.py:272: ddLdz_at_z(cosmo, z_grids) (1 + z_grids)^2
+      put('jac_grid', [np.asarray(ddLdz_at_z(p.cosmo, ev['z_grids']), dtype=np.float64) * (1. + ev['z_grids'])**2 for p in pops])
+  if want_c:                                        # the table of z_from_dGW (cosmo.py:260-264)
+    put('z_table', [np.asarray(p.cosmo.z_grid_interp, dtype=np.float64) for p in pops])
+    put('dL_table', [dL_at_z(p.cosmo, np.asarray(p.cosmo.z_grid_interp, dtype=np.float64)) for p in pops])
   if inj is not None and (want_m or want_r or want_b):
-    pm, rt, bk = [], [], []
+    pm, rt, bk, jc = [], [], [], []
     for p in pops:
       z = z_from_dGW(p.cosmo, inj['dL'])
       if want_m:
@@ -81,15 +92,19 @@ def build_tab(pops, plugins, ev=None, inj=None):
       if want_b:                                   # pop_wrapper.py:106: p_bkg(cosmo, theta_src) with the original distances
         src = theta_src(m1src=inj['m1det'] / (1. + z), m2src=inj['m2det'] / (1. + z), z=z, original_distances=inj['dL'])
         bk.append(_bkg(p.gal_cat, p.cosmo, src))
+        if want_c:                                 # pop_wrapper.py:109: |ddLdz_at_z(cosmo, theta_src)| (1 + z)^2
+          jc.append(np.abs(np.asarray(ddLdz_at_z(p.cosmo, src), dtype=np.float64)) * (1. + z)**2)
     if want_m:
       put('pm_inj', pm)
     if want_r:
       put('rate_inj', rt)
     if want_b:
       put('bkg_inj', bk)
+    if want_c:
+      put('jac_inj', jc)
   if want_b:
     compl = getattr(pops[0].gal_cat, 'completeness', None)
-    if compl is not None:
+    if compl is not None:                          # (a plug-in cosmology reaches fR through Vc_at_z's dispatch)
       fr = np.ascontiguousarray([float(np.asarray(p.gal_cat.completeness.fR(p.cosmo))) for p in pops], dtype=np.float64)
       keep.append(fr)
       tab.fR = _lib.dptr(fr)

@@ -115,9 +115,11 @@ def compute_z_grids(cosmo, theta_det, cosmo_prior=None, z_int_res=300, z_conf_ra
   if cosmo_prior is not None:
     cp.update(cosmo_prior)
   base = ['H0', 'Om0', 'Ok0', 'Or0', 'w0', 'wa']
+  if not hasattr(cosmo, '_pack'):              # plug-in cosmology: whatever parameters it has (the caller orders the prior low -> nearest)
+    base = [k for k in cosmo.keys if k not in ('z_max', 'z_grid_res')]
   lc_low = {k: cp[k][0] for k in base}
   lc_high = {k: cp[k][1] for k in base}
-  if cosmo.name != 'flrw':
+  if hasattr(cosmo, '_pack') and cosmo.name != 'flrw':
     lc_low.update(Xi0=cp['Xi0'][1], n=cp['n'][1])
     lc_high.update(Xi0=cp['Xi0'][0], n=cp['n'][1])
   cosmo1 = cosmo.update(**lc_low, z_grid_res=10_000)

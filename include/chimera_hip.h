@@ -139,6 +139,14 @@ typedef struct chm_tab {
   const double* bkg_grid;      /* (nb,E_loc,Z)  completeness.p_bkg(cosmo, z) on the event grids     catalog.py:200             */
   const double* bkg_inj;       /* (nb,I_loc)    p_bkg(cosmo, z_inj, original distances)             pop_wrapper.py:106         */
   const double* fR;            /* (nb,)         completeness.fR(cosmo)                              catalog.py:199             */
+  /* Plug-in COSMOLOGY (a user struct with its own plum overloads of the distance functions, cosmo.py:122-264): the path needs a
+   * cosmology only through the (dL, z) table of z_from_dGW, the Jacobian |ddL/dz| (1+z)^2 and p_bkg -- all four arrays below must be
+   * given together with bkg_grid / bkg_inj (and fR for a catalogue); z_grid_res must be the same for every draw of the call and
+   * chm_params.cosmo is then ignored.  NULL = the built-in flrw / mg_flrw of chm_params.                                        */
+  const double* z_table;       /* (nb,z_grid_res)  cosmo.z_grid_interp                              cosmo.py:43-46             */
+  const double* dL_table;      /* (nb,z_grid_res)  dL_at_z(cosmo, z_grid_interp): the table of z_from_dGW   cosmo.py:260-264     */
+  const double* jac_grid;      /* (nb,E_loc,Z)  ddLdz_at_z(cosmo, z_grids) (1 + z_grids)^2                  likelihood.py:272    */
+  const double* jac_inj;       /* (nb,I_loc)    |ddLdz_at_z(cosmo, z_inj, original distances)| (1 + z_inj)^2   pop_wrapper.py:109  */
 } chm_tab;
 
 typedef struct chm_like chm_like;
