@@ -1774,14 +1774,22 @@ __global__ void __launch_bounds__(256) k_integrate_1d(LikeDev L, const DevParams
 //   |x_j - q_k|^2 = (a_j - t_k)^2 + b_j,   a_j = (x_j L)_0,  t_k = z_k l00 + ra_p l10 + dec_p l20,  b_j = k-independent,
 // so  val_k = sum_j c_j g_jk,  c_j = W_j exp(log_norm - b_j/2)  (one exp per sample and pixel),  g_jk = exp(-(a_j - t_k)^2/2).
 // On a uniform stretch of the event grid (t_k = t_0 + k D) the Gaussian obeys g_{k+1} = g_k r_k, r_{k+1} = r_k rho,
-// r_k = exp((a - t_k) D - D^2/2), rho = exp(-D^2): a thread marches FULL_LK = 16 grid points per sample with two exps and
-// then 2 multiplies + 1 fma per pair (relative error <= ~16^2/2 eps ~ 3e-14, restarted from exact exps every chunk).
+// r_k = exp((a - t_k) D - D^2/2), rho = exp(-D^2): a thread marches FULL_LK = 32 grid points per sample with two exps (bounded
+// arguments: chm_exp_nb) and then 2 multiplies + 1 add per pair (relative error <= ~32^2/2 eps + 3e-14, restarted from exact exps every
+// chunk).  Tried: the march as one multiply + one fma against an LDS table of exp(-D^2 i (i-1)/2) -- the compiler hoists the table into
+// 64 registers and spills (175 vs 182 evaluations/s at C3); 16 points per pair of exps: 140/s; 48: register spills, 69/s.
 // A chunk whose grid is not uniform to 1e-11 falls back to one exp per pair.
 #define FULL_TILE 1024
-#define FULL_LK 16
-__global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* params) {
+#ifndef FULL_LK
+#define FULL_LK 32            // grid points a thread marches per sample from one pair of exps (16: the exps cost as much as the march)
+#endif
+#define FULL_RH 16            // grid points of a chunk reduced through LDS at a time
+#ifndef FULL_MINW
+#define FULL_MINW 3
+#endif
+__global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const DevParams* params) {
   __shared__ double sa[FULL_TILE], sc[FULL_TILE];
-  __shared__ double racc[256 * FULL_LK];                   // per-thread partial sums of a pass (blockDim.x = 256)
+  __shared__ double racc[256 * FULL_RH];                   // per-thread partial sums of a pass, FULL_RH grid points at a time (blockDim.x = 256)
   __shared__ double red[16];
   __shared__ double wh[12];
   const int t = threadIdx.x, nt = blockDim.x;
@@ -1873,7 +1881,7 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
         if (z <= zhi && z >= zlo) any = true;
       }
       t0 = z0 * l00 + t_base; D = dz * l00;
-      if (!(fabs(D) <= 1.)) uni = false;                  // grid coarser than the kernel width: one exp per pair (no recurrence)
+      if (!(fabs(D) * (double)(FULL_LK - 1) <= 15.)) uni = false;      // the chunk spans more than 15 kernel widths: one exp per pair (no recurrence)
     }
     const double rho = chm_exp(-(D * D)), hD2 = 0.5 * D * D;
     double acc[FULL_LK];
@@ -1895,52 +1903,60 @@ __global__ void __launch_bounds__(256) k_full_kde(LikeDev L, const DevParams* pa
             double d = sa[s] - t0;
             const double e1 = -0.5 * (d * d);
             // a sample more than 37 kernel widths from the chunk's first point is left out: exp(e1) underflows (and the step
-            // factor may overflow: 0 * inf); with |D| <= 1 it stays >= 22 widths from every point of the chunk, i.e. it would add
-            // < 1e-105 of its own weight
-            double g = e1 > -700. ? sc[s] * chm_exp(e1) : 0.;
-            double r = e1 > -700. ? chm_exp(d * D - hD2) : 0.;
+            // factor may overflow: 0 * inf); the chunk spans <= 15 widths, so it stays >= 22 widths from every point of the chunk,
+            // i.e. it would add < 1e-105 of its own weight
+            // (both arguments are bounded: -700 < e1 <= 0, |d D - D^2/2| <= 37.5 x 15/31 + 1: the exps need no range checks)
+            const bool in = e1 > -700.;
+            double g = in ? sc[s] * chm_exp_nb(e1) : 0.;
+            double r = in ? chm_exp_nb(d * D - hD2) : 0.;
 #pragma unroll
             for (int i = 0; i < FULL_LK; i++) { acc[i] += g; g *= r; r *= rho; }
           }
         } else {
-          for (int s = sl; s < ns; s += NS) {
-            double a0 = sa[s], cj = sc[s];
+          // one exp per pair (a chunk that is not uniform, or spans many kernel widths): the grid points one after the other -- a rolled
+          // loop, so that the 32 exps do not all live in registers at once; the sum of point i reaches acc[i] through a compile-time
+          // indexed select (acc[] must stay in registers)
+#pragma unroll 1
+          for (int i = 0; i < nk; i++) {
+            const double ti = zg[k0 + i] * l00 + t_base;
+            double a = 0.;
+            for (int s = sl; s < ns; s += NS) { const double d = sa[s] - ti; a += sc[s] * chm_exp(-0.5 * (d * d)); }
 #pragma unroll
-            for (int i = 0; i < FULL_LK; i++) {
-              double ti = (i < nk ? zg[k0 + i] : zg[k0]) * l00 + t_base;
-              double d = a0 - ti;
-              acc[i] += cj * chm_exp(-0.5 * (d * d));
-            }
+            for (int j = 0; j < FULL_LK; j++) acc[j] += (j == i) ? a : 0.;
           }
         }
       }
     }
-    // the NS partial sums of every grid point meet in LDS; then one thread per grid point forms p_gw and the integrand
-    __syncthreads();
+    // the NS partial sums of every grid point meet in LDS (FULL_RH points of each chunk at a time); then one thread per grid point
+    // forms p_gw and the integrand
 #pragma unroll
-    for (int i = 0; i < FULL_LK; i++) racc[t * FULL_LK + i] = acc[i];
-    __syncthreads();
-    const int npts = min(cpp, nch - cb) * FULL_LK;
-    for (int idx = t; idx < npts; idx += nt) {
-      const int cl = idx / FULL_LK, i = idx % FULL_LK;
-      const int k = k_first + (cb + cl) * FULL_LK + i;
-      if (k > k_last) continue;
-      double v = 0.;
-      for (int q = 0; q < NS; q++) v += racc[(cl * NS + q) * FULL_LK + i];
-      const double z = zg[k];
-      const bool inm = (z <= zhi) && (z >= zlo);
-      double pgw = inm ? v * st.norm : 0.;              // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
-      if (dump) dump[k] = pgw;
-      double pcv = pc[k];
-      double y = 0.;
-      if (pcv != -100.) {
-        double p_gal = P.fR * pcv + L.bkgA[zo + k];
-        double p_z = p_gal * L.prate[zo + k];
-        y = (p_z != -100.) ? pgw * p_z / L.jac[zo + k] : 0.;
+    for (int h0 = 0; h0 < FULL_LK; h0 += FULL_RH) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < FULL_RH; i++) racc[t * FULL_RH + i] = acc[h0 + i];
+      __syncthreads();
+      const int npts = min(cpp, nch - cb) * FULL_RH;
+      for (int idx = t; idx < npts; idx += nt) {
+        const int cl = idx / FULL_RH, i = idx % FULL_RH;
+        const int k = k_first + (cb + cl) * FULL_LK + h0 + i;
+        if (k > k_last) continue;
+        double v = 0.;
+        for (int q = 0; q < NS; q++) v += racc[(cl * NS + q) * FULL_RH + i];
+        const double z = zg[k];
+        const bool inm = (z <= zhi) && (z >= zlo);
+        double pgw = inm ? v * st.norm : 0.;              // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
+        if (dump) dump[k] = pgw;
+        double pcv = pc[k];
+        double y = 0.;
+        if (pcv != -100.) {
+          double p_gal = P.fR * pcv + L.bkgA[zo + k];
+          double p_z = p_gal * L.prate[zo + k];
+          y = (p_z != -100.) ? pgw * p_z / L.jac[zo + k] : 0.;
+        }
+        // trapezoid: y_k enters the two adjacent intervals
+        double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
+        accl += y * ((z - zl) + (zr - z));
       }
-      // trapezoid: y_k enters the two adjacent intervals
-      double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
-      accl += y * ((z - zl) + (zr - z));
     }
   }
   accl = block_reduce<RED_SUM>(accl, red);

@@ -62,6 +62,28 @@ DEVFN double chm_exp(double x) {
   return v;
 }
 
+// exp(x) for |x| <= 708 (no overflow / underflow handling; NaN propagates), Taylor degree 11 on |r| <= 0.347: relative error < 3e-14.
+// For arguments that are bounded by construction and feed a product recurrence whose own error is larger (k_full_kde).
+DEVFN double chm_exp_nb(double x) {
+  const double L2E = 1.44269504088896338700e+00, LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10;
+  double n = __builtin_rint(x * L2E);
+  double r = __builtin_fma(-n, LN2HI, x);
+  r = __builtin_fma(-n, LN2LO, r);
+  double p = 2.505210838544172e-08;                  // 1/11!
+  p = FM_FMA(p, r, 2.755731922398589e-07);    // 1/10!
+  p = FM_FMA(p, r, 2.7557319223985893e-06);   // 1/9!
+  p = FM_FMA(p, r, 2.48015873015873e-05);     // 1/8!
+  p = FM_FMA(p, r, 0.0001984126984126984);    // 1/7!
+  p = FM_FMA(p, r, 0.001388888888888889);     // 1/6!
+  p = FM_FMA(p, r, 0.008333333333333333);     // 1/5!
+  p = FM_FMA(p, r, 0.041666666666666664);     // 1/4!
+  p = FM_FMA(p, r, 0.16666666666666666);      // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)n);
+}
+
 // log(x) for finite x > 0 (NaN propagates); fdlibm e_log.c scheme, < 1 ulp
 DEVFN double chm_log_pos(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
