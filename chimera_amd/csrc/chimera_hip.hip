@@ -205,6 +205,9 @@ struct chm_like {
   bool fast_ok = false;
   double dl_gmin = 0., dl_gmax = 0.;
   unsigned short* d_lut = nullptr; int* d_lutinfo = nullptr;
+  // draw-independent part of the per-z factors (k_grid_prep), made for the (z_max, z_grid_res) below
+  int* d_zg_i = nullptr; double *d_zg_t = nullptr, *d_zg_lz = nullptr;
+  double zg_zmax = -1.; int zg_Tc = 0;
 };
 struct chm_sel {
   Ctx ctx;
@@ -374,6 +377,8 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
   rc = upload(h->owned, (const double*)logs[1].data(), E * S, &L.lm2det, s); if (rc) { chm_like_destroy(h); return rc; }
   if (d->mode == CHM_MODE_FULL) { UP(ra, d->ra, S); UP(dec, d->dec, S); }
   UP(z_grids, d->z_grids, Z);
+  { hipError_t e1 = hipMalloc(&h->d_zg_i, sizeof(int) * E * Z), e2 = hipMalloc(&h->d_zg_t, sizeof(double) * E * Z), e3 = hipMalloc(&h->d_zg_lz, sizeof(double) * E * Z);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { chm_like_destroy(h); return fail(CHM_E_NOMEM, "chm_like_create: grid bracket arrays"); } }
   // step fractions of jnp.linspace (i/div), shared by every event: bin edges (math.py:37) and effective grid (likelihood.py:188)
   std::vector<double> fracB(L.num_bins > 0 ? L.num_bins + 1 : 1), fracG(L.G > 0 ? L.G : 1);
   for (size_t i = 0; i < fracB.size(); i++) fracB[i] = (double)i / (double)(L.num_bins > 0 ? L.num_bins : 1);
@@ -410,6 +415,7 @@ extern "C" int chm_like_destroy(chm_like* h) {
   if (h->ctx.stream2) (void)hipStreamSynchronize(h->ctx.stream2);
   if (h->ctx.stream3) (void)hipStreamSynchronize(h->ctx.stream3);
   like_free_ws(h);
+  (void)hipFree(h->d_zg_i); (void)hipFree(h->d_zg_t); (void)hipFree(h->d_zg_lz);
   for (void* p : h->owned) (void)hipFree(p);
   ctx_destroy(h->ctx);
   delete h;
@@ -619,13 +625,22 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       if (lds_fast > 96 * 1024) use_fast = false;
     }
   }
+  // draw-independent brackets of the event grids on the z table: usable when every draw of the call has one (z_max, z_grid_res) and the
+  // cosmology is built in; (re)made by k_grid_prep after k_tables when that pair changes
+  bool zg_use = false, zg_make = false;
+  if (like && !td.zt && !getenv("CHM_NO_GRID_PREP")) {
+    zg_use = true;
+    for (int b = 1; b < nb; b++) if (params[b].z_max != params[0].z_max || params[b].z_grid_res != params[0].z_grid_res) zg_use = false;
+    if (zg_use && (like->zg_zmax != params[0].z_max || like->zg_Tc != params[0].z_grid_res)) zg_make = true;
+  }
   // ---- graph bookkeeping: the key lists everything the captured launch arguments depend on
   std::vector<long long> key;
   bool capturing = false;
   if (graph_ok) {
     key = { (long long)(intptr_t)like, (long long)(intptr_t)sel, nb, (long long)E_total, like ? like->nb_ws : 0, sel ? sel->nb_ws : 0, c.nb_cap, c.TcMax, c.TmMax,
             Tc_host, Tm_host, use_fast, lutA.key0, lutA.nk, lutA.cap, (long long)lds_fast, params[0].mass_model, out->partials != nullptr,
-            (long long)(intptr_t)c.d_evpart, (long long)(intptr_t)(like ? like->L.ws_z : nullptr), (long long)(intptr_t)(sel ? sel->S.partial : nullptr) };
+            (long long)(intptr_t)c.d_evpart, (long long)(intptr_t)(like ? like->L.ws_z : nullptr), (long long)(intptr_t)(sel ? sel->S.partial : nullptr),
+            zg_use, zg_make };
     if (c.gexec && key == c.gkey) {                           // replay
       HIPCHK(hipGraphLaunch(c.gexec, sA));
       HIPCHK(hipStreamSynchronize(sA));
@@ -652,6 +667,13 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   struct CaptureGuard { hipStream_t s; bool* on; ~CaptureGuard() { if (*on) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); } } } cguard{sA, &capturing};
   if (timing) HIPCHK(hipEventRecord(c.ev[0], sA));
   rc = ctx_tables_enqueue(c, nb, Tc_host, Tm_host, use_fast ? lutA : LutDesc{}, LutDesc{}, td.zt, td.dLt); if (rc) return rc;
+  if (zg_make) {                                            // the table of draw 0 stands for all of them
+    const size_t n = (size_t)like->L.E * like->L.Z;
+    hipLaunchKernelGGL(k_grid_prep, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, sA, like->L.E, like->L.Z, like->L.z_grids,
+                       (const double*)c.zt, params[0].z_grid_res, like->d_zg_i, like->d_zg_t, like->d_zg_lz);
+    HIPCHK(hipGetLastError());
+    like->zg_zmax = params[0].z_max; like->zg_Tc = params[0].z_grid_res;
+  }
   HIPCHK(hipEventRecord(c.ev[1], sA));
   HIPCHK(hipStreamWaitEvent(sB, c.ev[1], 0));               // fork: the other lanes start after the tables
 
@@ -682,6 +704,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       hipStream_t sg = (g & 1) ? sB : sA;
       LikeDev L = like->L;
       L.tab_pm = td.pm_s; L.tab_rate = td.rate_g; L.tab_bkg = td.bkg_g; L.tab_jac = td.jac_g;
+      if (zg_use) { L.zg_i = like->d_zg_i; L.zg_t = like->d_zg_t; L.zg_lz = like->d_zg_lz; }
       L.no_dense = getenv("CHM_NO_DENSE_NODE") ? 1 : 0;     // diagnostics: no dense-sum fallback in the standard GW kernel
       if (!want_dump) L.p_gw_dump = nullptr;
       const int eb = (int)((long long)L0.E * g / ngroups), ee = (int)((long long)L0.E * (g + 1) / ngroups);

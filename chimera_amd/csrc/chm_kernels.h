@@ -45,6 +45,10 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   const int* perm;                // (E,S) marginalized: original index of the pixel-sorted sample (for caller-tabulated values)
   const double *tab_pm, *tab_rate, *tab_bkg;   // plug-in models evaluated by the caller (chm_tab), device copies; NULL = built-in
   const double *tab_jac;          // (nb,E,Z) plug-in cosmology: ddL/dz (1+z)^2 on the event grids
+  // draw-independent part of the per-z factors (k_grid_prep; valid while every draw has the z_max / z_grid_res it was made for: the
+  // z table [0] U logspace(-10, log10 z_max, Tc - 1) depends on nothing else): bracket of each grid point on the table, its
+  // interpolation weight (z - zt[i-1])/(zt[i] - zt[i-1]) (codes < 0: see interp_pre) and log(1 + z)
+  const int* zg_i; const double* zg_t; const double* zg_lz;
   const double *fracB, *fracG;    // i/num_bins (num_bins+1), i/(G-1) (G): the step fractions of jnp.linspace
   // workspaces (nb-major)
   double *ws_z, *ws_w;            // (nb,E,S)
@@ -1026,6 +1030,36 @@ __global__ void __launch_bounds__(256) k_event_prep(LikeDev L, int write_effg) {
 #ifndef CHM_ZF_WPE
 #define CHM_ZF_WPE 4                      // waves per SIMD the per-z-factor kernel is compiled for (128 VGPRs: 577 -> 536 us at C3 / 128 draws)
 #endif
+// jnp.interp(z, zt, fp) from a prepared bracket: fp[i-1] + t (fp[i] - fp[i-1]) with t = delta/dx formed once (the same two roundings
+// as jnp_interp, in a body without fp contraction); t = -1: dx below jnp.interp's epsilon -> fp[i-1]; -2: z < zt[0] -> fp[0];
+// -3: z > zt[n-1] -> fp[n-1]; NaN stays NaN
+template <class A>
+DEVFN double interp_pre(A fp, int n, int i, double t) {
+  const double f0 = fp[i - 1], f1 = fp[i];
+  double f = f0 + t * (f1 - f0);
+  if (t == -1.) f = f0;
+  if (t == -2.) f = fp[0];
+  if (t == -3.) f = fp[n - 1];
+  return f;
+}
+
+// k_grid_prep: bracket, weight and log(1 + z) of every event-grid point on the z table of a draw (all draws of equal z_max / z_grid_res
+// share it bit for bit); a thread per grid point
+__global__ void __launch_bounds__(256) k_grid_prep(int E, int Z, const double* z_grids, const double* zt, int Tc, int* out_i, double* out_t, double* out_lz) {
+  const size_t n = (size_t)E * Z;
+  for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) {
+    const double z = z_grids[q];
+    int i = searchsorted_right(zt, Tc, z);
+    i = i < 1 ? 1 : (i > Tc - 1 ? Tc - 1 : i);
+    const double x0 = zt[i - 1], dx = zt[i] - x0;
+    double t = (z - x0) / dx;
+    if (fabs(dx) <= 4.930380657631324e-32) t = -1.;
+    if (z < zt[0]) t = -2.;
+    if (z > zt[Tc - 1]) t = -3.;
+    out_i[q] = i; out_t[q] = t; out_lz[q] = chm_log_pos(1. + z);
+  }
+}
+
 template <bool LDS_TAB>
 __global__ void __launch_bounds__(256, CHM_ZF_WPE) k_zfactors(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
                                                    int TcMax, int ranged) {
@@ -1065,9 +1099,16 @@ __global__ void __launch_bounds__(256, CHM_ZF_WPE) k_zfactors(LikeDev L, const D
     for (int k = k_first + lane0; k <= k_last; k += stride) {
       double z = zg[k];
       const bool own_cosmo = !(L.tab_jac && L.tab_bkg);          // plug-in cosmology: Jacobian and p_bkg both come from the caller
-      double dCt = own_cosmo ? dCt_at_z(P, z, zt, It) : 0.;
       double zp1 = 1. + z;
-      double lzp1 = chm_log_pos(zp1);
+      double dCt = 0., lzp1;
+      if (L.zg_i) {                                              // prepared bracket (k_grid_prep): no table search, no division, no log
+        const size_t q = (size_t)e * Z + k;
+        if (own_cosmo) dCt = dCt_from_dCr(P, P.dH * interp_pre(It, P.Tc, L.zg_i[q], L.zg_t[q]));      // cosmo.py:132-153
+        lzp1 = L.zg_lz[q];
+      } else {
+        if (own_cosmo) dCt = dCt_at_z(P, z, zt, It);
+        lzp1 = chm_log_pos(zp1);
+      }
       double Ez = own_cosmo ? E_at_z_l(P, z, lzp1) : 1.;
       double jac = L.tab_jac ? L.tab_jac[zo + k] : ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1) * (zp1 * zp1);
       double prate = (L.tab_rate ? L.tab_rate[zo + k] : merger_rate_l(P, z, lzp1)) / (1. + z);      // plug-in rate model: tabulated
