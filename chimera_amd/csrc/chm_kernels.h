@@ -1814,17 +1814,24 @@ __global__ void __launch_bounds__(256) k_integrate_1d(LikeDev L, const DevParams
 // and whitening with the lower Cholesky factor maps z to the FIRST whitened coordinate only:
 //   |x_j - q_k|^2 = (a_j - t_k)^2 + b_j,   a_j = (x_j L)_0,  t_k = z_k l00 + ra_p l10 + dec_p l20,  b_j = k-independent,
 // so  val_k = sum_j c_j g_jk,  c_j = W_j exp(log_norm - b_j/2)  (one exp per sample and pixel),  g_jk = exp(-(a_j - t_k)^2/2).
-// On a uniform stretch of the event grid (t_k = t_0 + k D) the Gaussian obeys g_{k+1} = g_k r_k, r_{k+1} = r_k rho,
-// r_k = exp((a - t_k) D - D^2/2), rho = exp(-D^2): a thread marches FULL_LK = 32 grid points per sample with two exps (bounded
-// arguments: chm_exp_nb) and then 2 multiplies + 1 add per pair (relative error <= ~32^2/2 eps + 3e-14, restarted from exact exps every
-// chunk).  Tried: the march as one multiply + one fma against an LDS table of exp(-D^2 i (i-1)/2) -- the compiler hoists the table into
-// 64 registers and spills (175 vs 182 evaluations/s at C3); 16 points per pair of exps: 140/s; 48: register spills, 69/s.
+// On a uniform stretch of the event grid (t_i = t_0 + i D, d = a - t_0) the Gaussian factorises,
+//   g_ji = exp(-d^2/2) u^i exp(-i^2 D^2/2),   u = exp(d D),
+// and the last factor is common to all samples: a thread accumulates the power sums sum_j c_j g_j0 u_j^i of FULL_LK = 32 grid points
+// (two exps with bounded arguments per sample and chunk: chm_exp_nb; then 4 fma + 1 multiply per 4 pairs against u, u^2, u^3, u^4) and
+// multiplies grid point i by exp(-i^2 D^2/2) once per chunk.  Relative error <= ~12 eps from the powers + 3e-14 from the exps; the
+// sums stay in range: |d D| <= 18 and i^2 D^2/2 <= 113 for a chunk that spans <= 15 kernel widths.
+// Round 2 before this form: the recurrence g <- g r, r <- r rho (3 instructions per pair, 192 evaluations/s at C3); an LDS table of
+// exp(-D^2 i (i-1)/2) is hoisted into 64 registers by the compiler and spills (175/s); 16 points per chunk 140/s; 48: spills, 69/s.
+// Staging U_j = exp((a_j - t_first) D) per sample so that u = U_j exp(-32 c D^2) needs no exp per chunk: 240 vs 247/s (8 spilled registers).
 // A chunk whose grid is not uniform to 1e-11 falls back to one exp per pair.
 #define FULL_TILE 1024
 #ifndef FULL_LK
 #define FULL_LK 32            // grid points a thread marches per sample from one pair of exps (16: the exps cost as much as the march)
 #endif
-#define FULL_RH 16            // grid points of a chunk reduced through LDS at a time
+#ifndef FULL_NSMAX
+#define FULL_NSMAX 128
+#endif
+#define FULL_RH 8             // grid points of a chunk reduced through LDS at a time
 #ifndef FULL_MINW
 #define FULL_MINW 3
 #endif
@@ -1900,10 +1907,11 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
   // chunks of FULL_LK grid points; NS threads share a chunk and split the samples (any NS: their partial sums meet in LDS)
   const int nch = k_last >= k_first ? (k_last - k_first + FULL_LK) / FULL_LK : 0;
   int NS = nch > 0 ? nt / nch : 1;
-  NS = NS < 1 ? 1 : (NS > 32 ? 32 : NS);
+  NS = NS < 1 ? 1 : (NS > FULL_NSMAX ? FULL_NSMAX : NS);
   const int cpp = nt / NS;                                // chunks per pass
   double accl = 0.;
   if (dump) for (int k = t; k < Z; k += nt) if (!ok || k < k_first || k > k_last) dump[k] = 0.;
+  const double inv_sumw = 1. / st.sumw;
   for (int cb = 0; cb < nch && ok; cb += cpp) {
     const int c = cb + t / NS, sl = t % NS;
     const bool has = c < nch && t < cpp * NS;
@@ -1924,7 +1932,7 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
       t0 = z0 * l00 + t_base; D = dz * l00;
       if (!(fabs(D) * (double)(FULL_LK - 1) <= 15.)) uni = false;      // the chunk spans more than 15 kernel widths: one exp per pair (no recurrence)
     }
-    const double rho = chm_exp(-(D * D)), hD2 = 0.5 * D * D;
+    const double hD2 = 0.5 * D * D;
     double acc[FULL_LK];
 #pragma unroll
     for (int i = 0; i < FULL_LK; i++) acc[i] = 0.;
@@ -1935,7 +1943,7 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
         double x0 = wz[s0 + s], x1 = L.ra[eo + s0 + s], x2 = L.dec[eo + s0 + s];
         double d1 = (x1 * l11 + x2 * l21) - q1, d2 = x2 * l22 - q2;
         sa[s] = x0 * l00 + x1 * l10 + x2 * l20;
-        sc[s] = (ww[s0 + s] / st.sumw) * chm_exp(log_norm - 0.5 * (d1 * d1 + d2 * d2));
+        sc[s] = (ww[s0 + s] * inv_sumw) * chm_exp(log_norm - 0.5 * (d1 * d1 + d2 * d2));
       }
       __syncthreads();
       if (has && any) {
@@ -1948,11 +1956,19 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
             // i.e. it would add < 1e-105 of its own weight
             // (both arguments are bounded: -700 < e1 <= 0, |d D - D^2/2| <= 37.5 x 15/31 + 1: the exps need no range checks)
             const bool in = e1 > -700.;
-            double g = in ? sc[s] * chm_exp_nb(e1) : 0.;
-            double r = in ? chm_exp_nb(d * D - hD2) : 0.;
+            double pw = in ? sc[s] * chm_exp_nb(e1) : 0.;
+            const double u = in ? chm_exp_nb(d * D) : 0.;
+            const double u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
 #pragma unroll
-            for (int i = 0; i < FULL_LK; i++) { acc[i] += g; g *= r; r *= rho; }
+            for (int i = 0; i < FULL_LK; i += 4) {
+              acc[i] += pw;
+              acc[i + 1] = __builtin_fma(pw, u, acc[i + 1]);
+              acc[i + 2] = __builtin_fma(pw, u2, acc[i + 2]);
+              acc[i + 3] = __builtin_fma(pw, u3, acc[i + 3]);
+              pw *= u4;
+            }
           }
+
         } else {
           // one exp per pair (a chunk that is not uniform, or spans many kernel widths): the grid points one after the other -- a rolled
           // loop, so that the 32 exps do not all live in registers at once; the sum of point i reaches acc[i] through a compile-time
@@ -1968,13 +1984,18 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
         }
       }
     }
+    // a marched chunk holds sum_j c_j g_j0 u_j^i in acc[i]: the common factor exp(-i^2 D^2 / 2) of grid point i completes the Gaussians
+    if (has && any && uni) {
+#pragma unroll
+      for (int i = 0; i < FULL_LK; i++) acc[i] *= chm_exp(-hD2 * (double)(i * i));
+    }
     // the NS partial sums of every grid point meet in LDS (FULL_RH points of each chunk at a time); then one thread per grid point
     // forms p_gw and the integrand
 #pragma unroll
     for (int h0 = 0; h0 < FULL_LK; h0 += FULL_RH) {
       __syncthreads();
 #pragma unroll
-      for (int i = 0; i < FULL_RH; i++) racc[t * FULL_RH + i] = acc[h0 + i];
+      for (int i = 0; i < FULL_RH; i++) racc[i * 256 + t] = acc[h0 + i];
       __syncthreads();
       const int npts = min(cpp, nch - cb) * FULL_RH;
       for (int idx = t; idx < npts; idx += nt) {
@@ -1982,7 +2003,7 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
         const int k = k_first + (cb + cl) * FULL_LK + h0 + i;
         if (k > k_last) continue;
         double v = 0.;
-        for (int q = 0; q < NS; q++) v += racc[(cl * NS + q) * FULL_RH + i];
+        for (int q = 0; q < NS; q++) v += racc[i * 256 + cl * NS + q];
         const double z = zg[k];
         const bool inm = (z <= zhi) && (z >= zlo);
         double pgw = inm ? v * st.norm : 0.;              // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
