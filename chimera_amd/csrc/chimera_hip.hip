@@ -177,9 +177,9 @@ static int ctx_tables_enqueue(Ctx& c, int nb, int Tc, int Tm, LutDesc lutA = Lut
   const size_t tl = sizeof(double) * 3 * (size_t)(Tc > Tm ? Tc : Tm);
   if (tl <= 120 * 1024) {
     if (tl > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_tables<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
-    hipLaunchKernelGGL(k_tables<true>, dim3(nb, 2), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, lutA.nk > 0 ? c.rec : nullptr, tab_zt, tab_dLt);
+    hipLaunchKernelGGL(k_tables<true>, dim3(nb, 2), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt);
   } else {
-    hipLaunchKernelGGL(k_tables<false>, dim3(nb, 2), dim3(1024), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, lutA.nk > 0 ? c.rec : nullptr, tab_zt, tab_dLt);
+    hipLaunchKernelGGL(k_tables<false>, dim3(nb, 2), dim3(1024), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt);
   }
   HIPCHK(hipGetLastError());
   return CHM_OK;
@@ -214,6 +214,11 @@ struct chm_sel {
   SelDev S;
   std::vector<void*> owned;
   int nb_ws = 0;
+  // k_selection_fast: key range of the shard's distances, per-call direct-index tables (as chm_like::F)
+  LutDesc lut = {};
+  bool fast_ok = false;
+  double dl_gmin = 0., dl_gmax = 0.;
+  unsigned short* d_lut = nullptr; int* d_lutinfo = nullptr;
 };
 struct chm_comm {
   ncclComm_t comm = nullptr;
@@ -478,6 +483,18 @@ extern "C" int chm_sel_create(const chm_sel_desc* d, chm_sel** out) {
   rc = upload(h->owned, (const double*)l2.data(), n, &S.lm2det, s); if (rc) { chm_sel_destroy(h); return rc; }
   long long nblk = (S.I + SEL_TILE - 1) / SEL_TILE;
   S.nblocks = (int)(nblk < 1 ? 1 : (nblk > 2048 ? 2048 : nblk));
+  {                                                         // key range of the shard's positive finite distances (direct-index table)
+    double gmin = INFINITY, gmax = 0.;
+    for (size_t k = 0; k < n; k++) { const double x = d->dL[i0 + k]; if (std::isfinite(x) && x >= 2.2250738585072014e-308) { gmin = x < gmin ? x : gmin; gmax = x > gmax ? x : gmax; } }
+    h->dl_gmin = gmin; h->dl_gmax = gmax;
+    h->fast_ok = gmin <= gmax;
+    if (h->fast_ok) {
+      int64_t hi0, hi1; memcpy(&hi0, &gmin, 8); memcpy(&hi1, &gmax, 8);
+      const int k0 = (int)(hi0 >> (32 + LUT_SHIFT)), k1 = (int)(hi1 >> (32 + LUT_SHIFT));
+      h->lut.key0 = k0; h->lut.nk = k1 - k0 + 1;
+      if (h->lut.nk > LUT_MAXKEYS) h->fast_ok = false;
+    }
+  }
   hipError_t he = hipStreamSynchronize(s);
   if (he != hipSuccess) { chm_sel_destroy(h); return fail(CHM_E_HIP, std::string("chm_sel_create: ") + hipGetErrorString(he)); }
   *out = h;
@@ -490,7 +507,7 @@ extern "C" int chm_sel_destroy(chm_sel* h) {
   if (h->ctx.stream) (void)hipStreamSynchronize(h->ctx.stream);
   if (h->ctx.stream2) (void)hipStreamSynchronize(h->ctx.stream2);
   if (h->ctx.stream3) (void)hipStreamSynchronize(h->ctx.stream3);
-  (void)hipFree(h->S.partial);
+  (void)hipFree(h->S.partial); (void)hipFree(h->d_lut); (void)hipFree(h->d_lutinfo);
   for (void* p : h->owned) (void)hipFree(p);
   ctx_destroy(h->ctx);
   delete h;
@@ -502,6 +519,8 @@ static int sel_ensure_ws(chm_sel* h, int nb) {
   HIPCHK(hipStreamSynchronize(h->ctx.stream));
   (void)hipFree(h->S.partial); h->S.partial = nullptr;
   HIPCHK(hipMalloc(&h->S.partial, sizeof(double) * (size_t)nb * h->S.nblocks * 2));
+  (void)hipFree(h->d_lut); (void)hipFree(h->d_lutinfo); h->d_lut = nullptr; h->d_lutinfo = nullptr;
+  if (h->fast_ok) { HIPCHK(hipMalloc(&h->d_lut, sizeof(unsigned short) * (size_t)nb * (h->lut.nk + 1))); HIPCHK(hipMalloc(&h->d_lutinfo, sizeof(int) * (size_t)nb * 4)); }
   h->nb_ws = nb;
   return CHM_OK;
 }
@@ -625,6 +644,32 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       if (lds_fast > 96 * 1024) use_fast = false;
     }
   }
+  // k_selection_fast: built-in models of an FLRW draw (cosmo_model 0), the same mass model for every draw; table slice capacity as above
+  LutDesc lutB = {};
+  bool sel_fast = sel && sel->fast_ok && !td.pm_i && !td.rate_i && !td.bkg_i && !td.jac_i && !td.zt && !getenv("CHM_SELECTION_GENERIC");
+  size_t lds_sel = 0;
+  if (sel_fast) {
+    int Tc_call = 0, Tm_call = 0;
+    double zmax_min = INFINITY;
+    for (int b = 0; b < nb; b++) {
+      if (params[b].mass_model != params[0].mass_model || params[b].cosmo_model != 0) sel_fast = false;
+      Tc_call = params[b].z_grid_res > Tc_call ? params[b].z_grid_res : Tc_call;
+      Tm_call = params[b].mass_grid_res > Tm_call ? params[b].mass_grid_res : Tm_call;
+      zmax_min = params[b].z_max < zmax_min ? params[b].z_max : zmax_min;
+    }
+    if (Tc_call > 65535 || !(zmax_min > 0.)) sel_fast = false;
+    if (sel_fast) {
+      const double n_oct = std::log2(sel->dl_gmax / sel->dl_gmin) + 1.;
+      const double per_oct = (double)(Tc_call - 2) / (std::log2(zmax_min) + 33.22);
+      long long cap = (long long)(n_oct * per_oct * 1.3) + 64;
+      cap = cap > Tc_call ? Tc_call : cap;
+      cap = (cap + 7) / 8 * 8;
+      lutB = sel->lut;
+      lutB.cap = (int)cap; lutB.lut = sel->d_lut; lutB.info = sel->d_lutinfo;
+      lds_sel = sizeof(double) * (4 * (size_t)cap + 2 * (size_t)Tm_call) + ((size_t)(lutB.nk + 1) * 2 + 15) / 16 * 16;
+      if (lds_sel > 64 * 1024) sel_fast = false;
+    }
+  }
   // draw-independent brackets of the event grids on the z table: usable when every draw of the call has one (z_max, z_grid_res) and the
   // cosmology is built in; (re)made by k_grid_prep after k_tables when that pair changes
   bool zg_use = false, zg_make = false;
@@ -639,6 +684,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   if (graph_ok) {
     key = { (long long)(intptr_t)like, (long long)(intptr_t)sel, nb, (long long)E_total, like ? like->nb_ws : 0, sel ? sel->nb_ws : 0, c.nb_cap, c.TcMax, c.TmMax,
             Tc_host, Tm_host, use_fast, lutA.key0, lutA.nk, lutA.cap, (long long)lds_fast, params[0].mass_model, out->partials != nullptr,
+            sel_fast, lutB.key0, lutB.nk, lutB.cap, (long long)lds_sel, (long long)(intptr_t)lutB.lut,
             (long long)(intptr_t)c.d_evpart, (long long)(intptr_t)(like ? like->L.ws_z : nullptr), (long long)(intptr_t)(sel ? sel->S.partial : nullptr),
             zg_use, zg_make };
     if (c.gexec && key == c.gkey) {                           // replay
@@ -666,7 +712,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   // an error inside a capture must end it before returning
   struct CaptureGuard { hipStream_t s; bool* on; ~CaptureGuard() { if (*on) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); } } } cguard{sA, &capturing};
   if (timing) HIPCHK(hipEventRecord(c.ev[0], sA));
-  rc = ctx_tables_enqueue(c, nb, Tc_host, Tm_host, use_fast ? lutA : LutDesc{}, LutDesc{}, td.zt, td.dLt); if (rc) return rc;
+  rc = ctx_tables_enqueue(c, nb, Tc_host, Tm_host, use_fast ? lutA : LutDesc{}, sel_fast ? lutB : LutDesc{}, td.zt, td.dLt); if (rc) return rc;
   if (zg_make) {                                            // the table of draw 0 stands for all of them
     const size_t n = (size_t)like->L.E * like->L.Z;
     hipLaunchKernelGGL(k_grid_prep, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, sA, like->L.E, like->L.Z, like->L.z_grids,
@@ -820,7 +866,17 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     SelDev S = sel->S;
     S.tab_pm = td.pm_i; S.tab_rate = td.rate_i; S.tab_bkg = td.bkg_i; S.tab_jac = td.jac_i;
     if (timing_all) HIPCHK(hipEventRecord(c.evb[1], sC));
-    if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
+    if (sel_fast) {
+#define LAUNCH_SELF(M) do { allow_lds(k_selection_fast<M>, lds_sel); \
+        hipLaunchKernelGGL((k_selection_fast<M>), dim3(gx, nb), dim3(256), lds_sel, sC, S, lutB, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm); } while (0)
+      // every block stages the draw's table slice (tens of KB): ~8192 blocks in all, each walking over several tiles of injections
+      static const int self_blocks = getenv("CHM_SELF_BLOCKS") ? atoi(getenv("CHM_SELF_BLOCKS")) : 8192;
+      int gx = self_blocks / nb;
+      gx = gx < 1 ? 1 : (gx > S.nblocks ? S.nblocks : gx);
+      const int mm = params[0].mass_model;
+      if (mm == 0) LAUNCH_SELF(0); else if (mm == 1) LAUNCH_SELF(1); else LAUNCH_SELF(2);
+#undef LAUNCH_SELF
+    } else if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
       hipLaunchKernelGGL(k_selection<true>, dim3(S.nblocks, nb), dim3(256), lds_samp, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
     } else hipLaunchKernelGGL(k_selection<false>, dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
     HIPCHK(hipGetLastError());

@@ -2114,6 +2114,116 @@ __global__ void __launch_bounds__(256) k_selection(SelDev Sd, const DevParams* p
   }
 }
 
+// k_selection_fast<MASS>: the selection sums for the built-in models of a flat-or-curved FLRW draw (cosmo_model 0) with the front
+// end of k_samples_fast -- z from the draw's direct-index table and node records (lutB of k_tables), log(1 + z) from the record,
+// the mass model a template parameter -- and ONE division per injection: with dCt = dL/(1+z), X = dCt E + dH (1+z),
+//   dN/p_draw = R0 p_m1m2 (4 pi dH dCt^2 / E) (rate/(1+z)) / (|dCt + dH (1+z)/E| (1+z)^2) / p_draw            pop_wrapper.py:102-111
+//             = R0 p_m1m2 4 pi dH dCt^2 rate_num / (rate_den |X| (1+z)^3) / p_draw                              (E(z) > 0 cancels)
+// (k_selection: 880 VALU instructions per injection, of which 6 IEEE divisions, a binary search and a log).
+#ifndef CHM_SELF_MINW
+#define CHM_SELF_MINW 3
+#endif
+template <int MASS>
+__global__ void __launch_bounds__(256, CHM_SELF_MINW) k_selection_fast(SelDev Sd, LutDesc lut, const DevParams* params, const double* zt_all,
+                                                             const double* dLt_all, const double* mg_all, const double* cdf_all,
+                                                             const double* rec_all, int TcMax, int TmMax) {
+#pragma clang fp contract(fast)
+  extern __shared__ double lds[];
+  __shared__ double red[16];
+  const int b = blockIdx.y, t = threadIdx.x;
+#ifdef CHM_SELF_PLDS
+  __shared__ DevParams Ps;
+  if (t == 0) Ps = params[b];
+  __syncthreads();
+  const DevParams& P = Ps;
+#else
+  const DevParams P = params[b];
+#endif
+  const double* g_zt = zt_all + (size_t)b * TcMax;
+  const double* g_dLt = dLt_all + (size_t)b * TcMax;
+  const int Tc = P.Tc, Tm = P.Tm;
+  const int* info = lut.info + (size_t)b * 4;
+  const int i_lo = info[0], ns = info[1], lmax = info[2];
+  const bool fits = info[3] != 0;
+  const int key0 = lut.key0, nk = lut.nk, cap = lut.cap;
+  double* rec = lds; double* mg = rec + 4 * (size_t)cap; double* cdf = mg + Tm;
+  unsigned short* luts = reinterpret_cast<unsigned short*>(cdf + Tm);
+  {
+    const double* gm = mg_all + (size_t)b * TmMax;
+    const double* gc = cdf_all + (size_t)b * TmMax;
+    const unsigned short* gl = lut.lut + (size_t)b * (nk + 1);
+    for (int i = t; i < Tm; i += 256) { mg[i] = gm[i]; cdf[i] = gc[i]; }
+    if (fits) {
+      const double2* gr = reinterpret_cast<const double2*>(rec_all + ((size_t)b * TcMax + i_lo) * 4);
+      double2* lr = reinterpret_cast<double2*>(rec);
+      for (int i = t; i < 2 * ns; i += 256) lr[i] = gr[i];
+      for (int i = t; i <= nk; i += 256) luts[i] = gl[i];
+    }
+  }
+  const double x_last = g_dLt[Tc - 1], z_last = g_zt[Tc - 1];
+  const double c0 = P.R0 * (4. * CHM_PI * P.dH);
+  __syncthreads();
+  double s1 = 0., s2 = 0.;
+  const long long I = Sd.I;
+  for (long long base = (long long)blockIdx.x * SEL_TILE; base < I; base += (long long)gridDim.x * SEL_TILE) {
+#pragma unroll 1
+    for (int off = 2 * t; off < SEL_TILE; off += 512) {
+      const long long i = base + off;
+      if (i >= I) break;
+      const bool two = i + 1 < I;
+      double dl[2], md1[2], md2[2], ipd[2], l1[2], l2[2];
+      if (two) {                                    // i even: 16-byte aligned pairs
+        double2 a = *reinterpret_cast<const double2*>(Sd.dL + i), bb = *reinterpret_cast<const double2*>(Sd.m1det + i);
+        double2 cc = *reinterpret_cast<const double2*>(Sd.m2det + i), dd = *reinterpret_cast<const double2*>(Sd.p_draw + i);
+        double2 ee = *reinterpret_cast<const double2*>(Sd.lm1det + i), ff = *reinterpret_cast<const double2*>(Sd.lm2det + i);
+        dl[0] = a.x; dl[1] = a.y; md1[0] = bb.x; md1[1] = bb.y; md2[0] = cc.x; md2[1] = cc.y; ipd[0] = dd.x; ipd[1] = dd.y;
+        l1[0] = ee.x; l1[1] = ee.y; l2[0] = ff.x; l2[1] = ff.y;
+      } else {
+        dl[0] = dl[1] = Sd.dL[i]; md1[0] = md1[1] = Sd.m1det[i]; md2[0] = md2[1] = Sd.m2det[i]; ipd[0] = ipd[1] = Sd.p_draw[i];
+        l1[0] = l1[1] = Sd.lm1det[i]; l2[0] = l2[1] = Sd.lm2det[i];
+      }
+      double zz[2], z0[2] = { 0., 0. }, lz0[2] = { 0., 0. };
+      bool bad = true;
+      if (fits) {                                   // z = z_from_dGW(dL)   cosmo.py:260-264
+        z_from_lut_x2(dl[0], dl[1], rec, luts, key0, nk, i_lo, ns, lmax, Tc, x_last, z_last, zz[0], zz[1], z0[0], z0[1], lz0[0], lz0[1], bad);
+        if (__any(bad)) {
+          if (bad) { zz[0] = jnp_interp(dl[0], g_dLt, g_zt, Tc, false, 0., 0.); zz[1] = jnp_interp(dl[1], g_dLt, g_zt, Tc, false, 0., 0.); }
+        }
+      } else z_from_dGW_x2(P, dl[0], dl[1], g_dLt, g_zt, zz[0], zz[1]);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const double z = zz[h];
+        const double zp1 = 1. + z;
+        const double r = chm_div(1., zp1);
+        const double m1 = md1[h] * r, m2 = md2[h] * r;
+        double lz = log1pz_from_node(z, z0[h], lz0[h], r);
+        const bool nolog = !fits || bad || !((z - z0[h]) * r <= 0.02);
+        if (__any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
+        const double pm = p_m1m2_fused<MASS>(P, m1, m2, l1[h] - lz, l2[h] - lz, mg, cdf);
+        const double Ez = E_at_z_lr(P, z, zp1, r, lz);
+        const double dCt = dl[h] * r;                                    // original distances: cosmo.py:191-192,215-216
+        const double X = __builtin_fma(dCt, Ez, P.dH * zp1);
+        double rnum, rden;
+        merger_rate_nd(P, z, lz, rnum, rden);
+        const double num = ((c0 * pm) * (dCt * dCt)) * (rnum * ipd[h]);
+        const double den = (rden * fabs(X)) * ((zp1 * zp1) * zp1);
+        const double dN = num / den;
+        if (h == 0 || two) {
+          if (dN == dN) s1 += dN;                                        // nansum                     selection_function.py:39
+          s2 += dN * dN;                                                 // plain sum     selection_function.py:44
+        }
+      }
+    }
+  }
+  s1 = block_reduce<RED_SUM>(s1, red);
+  s2 = block_reduce<RED_SUM>(s2, red);
+  if (threadIdx.x == 0) {                           // the grid may hold fewer blocks than the partial array has records: the rest are zeros
+    double* o = Sd.partial + (size_t)b * Sd.nblocks * 2;
+    o[2 * blockIdx.x] = s1; o[2 * blockIdx.x + 1] = s2;
+    for (int x = blockIdx.x + gridDim.x; x < Sd.nblocks; x += gridDim.x) { o[2 * x] = 0.; o[2 * x + 1] = 0.; }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------------------

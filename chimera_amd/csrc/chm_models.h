@@ -209,6 +209,16 @@ DEVFN double E_at_z_l(const DevParams& p, double z, double lzp1) {
   double de = ex == 0. ? 1. : pow_l(lzp1, ex);               // (1+z)^(3(1+w(z))); exponent 0 for a cosmological constant
   return sqrt(p.Om0 * z3 + p.Or0 * z4 + p.Ok0 * z2 + p.Ode0 * de);
 }
+// the same with 1 + z and its reciprocal given: z/(1+z) as a product (1 ulp of w(z))
+DEVFN double E_at_z_lr(const DevParams& p, double z, double zp1, double rzp1, double lzp1) {
+  const double z2 = zp1 * zp1, z3 = z2 * zp1, z4 = z2 * z2;
+  double de = 1.;
+  if (!(p.wa == 0. && p.w0 == -1.)) {
+    const double ex = 3. * (1. + (p.w0 + p.wa * (z * rzp1)));
+    de = ex == 0. ? 1. : pow_l(lzp1, ex);
+  }
+  return sqrt(p.Om0 * z3 + p.Or0 * z4 + p.Ok0 * z2 + p.Ode0 * de);
+}
 DEVFN bool de_needs_log(const DevParams& p) { return !(p.wa == 0. && p.w0 == -1.); }
 DEVFN double E_at_z(const DevParams& p, double z) {
   return E_at_z_l(p, z, de_needs_log(p) ? chm_log(1. + z) : 0.);
@@ -470,6 +480,17 @@ DEVFN double merger_rate_l(const DevParams& p, double z, double lzp1) {
   return z < p.r[3] ? p.md_norm * md : 0.;
 }
 DEVFN double merger_rate(const DevParams& p, double z) { return merger_rate_l(p, z, chm_log(1. + z)); }
+// merger_rate_l as a quotient num/den (k_selection_fast folds den into its one division); the same value classes: a cut model is
+// 0 / den above its z cut, (1 + ...) overflowing to inf gives 0 as the division does.
+DEVFN void merger_rate_nd(const DevParams& p, double z, double lzp1, double& num, double& den) {
+  const double g = p.r[0];
+  const double a = pow_l(lzp1, g);
+  if (p.rate_model == 0) { num = a; den = 1.; return; }
+  if (p.rate_model == 2) { num = z < p.r[3] ? a : 0.; den = p.tpl_rate_norm; return; }
+  den = 1. + pow_l(lzp1 - p.l1pzp, g + p.r[1]);
+  num = p.md_norm * a;
+  if (p.rate_model != 1 && !(z < p.r[3])) num = 0.;
+}
 
 // ------------------------------------------------------------------------------------------------------
 // wave / block reductions (wave = 64 lanes)
