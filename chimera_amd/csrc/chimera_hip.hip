@@ -175,7 +175,7 @@ static int ctx_tables_enqueue(Ctx& c, int nb, int Tc, int Tm, LutDesc lutA = Lut
                               const double* tab_zt = nullptr, const double* tab_dLt = nullptr) {
   HIPCHK(hipMemcpyAsync(c.d_params, c.h_params, sizeof(DevParams) * nb, hipMemcpyHostToDevice, c.stream));
   const size_t tl = sizeof(double) * 3 * (size_t)(Tc > Tm ? Tc : Tm);
-  if (tl <= 120 * 1024) {
+  if (tl <= 112 * 1024) {                                   // + 33 KB of static LDS (build_lut scratch, parameter block)
     if (tl > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_tables<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);
     hipLaunchKernelGGL(k_tables<true>, dim3(nb, 2), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt);
   } else {
@@ -550,6 +550,17 @@ static int tab_upload(double** dst, const double* src, size_t n, hipStream_t s) 
 static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_params* params, int32_t nb,
                      int64_t E_total, const chm_tab* tab, chm_out* out);
 
+// CHM_HOST_PROF=1 (diagnostics): host-side time of the graph-replayed scalar call, printed at exit -- before the launch (argument checks,
+// key, parameter packing), inside hipGraphLaunch, inside hipStreamSynchronize
+#include <chrono>
+#include <algorithm>
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static bool host_prof_on() { static const bool on = getenv("CHM_HOST_PROF") != nullptr; return on; }
+static struct HostProf { std::vector<double> pre, launch, sync;
+  static double med(std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
+  ~HostProf() { if (!pre.empty()) fprintf(stderr, "[chm host prof] %zu replayed calls: before launch %.1f us, hipGraphLaunch %.1f us, hipStreamSynchronize %.1f us (medians)\n",
+                                          pre.size(), med(pre), med(launch), med(sync)); } } g_hp;
+
 extern "C" int chm_eval(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_params* params, int32_t nb,
                         int64_t E_total, chm_out* out) {
   return eval_impl(like, sel, comm, params, nb, E_total, nullptr, out);
@@ -565,6 +576,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   if ((!like && !sel) || !params || !out || nb <= 0) return fail(CHM_E_ARG, "chm_eval: need a handle, params, out and nb > 0");
   if (like && sel && like->ctx.device != sel->ctx.device) return fail(CHM_E_ARG, "chm_eval: like and sel live on different devices");
   Ctx& c = like ? like->ctx : sel->ctx;
+  const double hp0 = host_prof_on() ? now_us() : 0.;
   if (comm && comm->device != c.device) return fail(CHM_E_ARG, "chm_eval: comm lives on a different device");
   HIPCHK(hipSetDevice(c.device));
   static const bool serial = getenv("CHM_SERIAL") != nullptr;     // diagnostics: everything on one stream
@@ -688,8 +700,11 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
             (long long)(intptr_t)c.d_evpart, (long long)(intptr_t)(like ? like->L.ws_z : nullptr), (long long)(intptr_t)(sel ? sel->S.partial : nullptr),
             zg_use, zg_make };
     if (c.gexec && key == c.gkey) {                           // replay
+      const double hp1 = host_prof_on() ? now_us() : 0.;
       HIPCHK(hipGraphLaunch(c.gexec, sA));
+      const double hp2 = host_prof_on() ? now_us() : 0.;
       HIPCHK(hipStreamSynchronize(sA));
+      if (host_prof_on()) { const double hp3 = now_us(); g_hp.pre.push_back(hp1 - hp0); g_hp.launch.push_back(hp2 - hp1); g_hp.sync.push_back(hp3 - hp2); }
       for (int b = 0; b < nb; b++) {
         if (out->log_hyper) out->log_hyper[b] = c.h_out[b * 3];
         if (out->log_num) out->log_num[b] = c.h_out[b * 3 + 1];

@@ -171,39 +171,55 @@ struct LutDesc { int key0, nk, cap, pad; unsigned short* lut; int* info; };
 DEVFN int lut_key(double x, int key0) { return (__double2hiint(x) >> LUT_SHIFT) - key0; }
 DEVFN double lut_key_floor(int key) { return __hiloint2double(key << LUT_SHIFT, 0); }
 
-// build one draw's LUT from its dL table (tab: LDS or global, Tc entries); every thread of the block calls it
+// build one draw's LUT from its dL table (tab: LDS or global, Tc entries); every thread of the block calls it.  ks: LDS scratch of
+// nk + 1 ints (one search per key; the neighbour's answer gives the number of entries a key spans)
 template <class Acc>
-DEVFN void build_lut(const LutDesc& D, int b, Acc tab, int Tc, bool sorted, double* sh) {
+DEVFN void build_lut(const LutDesc& D, int b, Acc tab, int Tc, bool sorted, double* sh, int* ks) {
   if (D.nk <= 0) return;
   unsigned short* lut = D.lut + (size_t)b * (D.nk + 1);
-  int lm = 0;
   for (int k = threadIdx.x; k <= D.nk; k += blockDim.x) {
     const int c0 = searchsorted_right(tab, Tc, lut_key_floor(D.key0 + k));
     lut[k] = (unsigned short)c0;
-    if (k < D.nk) { const int c1 = searchsorted_right(tab, Tc, lut_key_floor(D.key0 + k + 1)); lm = max(lm, c1 - c0); }
+    ks[k] = c0;
   }
+  __syncthreads();
+  int lm = 0;
+  for (int k = threadIdx.x; k < D.nk; k += blockDim.x) lm = max(lm, ks[k + 1] - ks[k]);
   const double lmax = block_reduce<RED_MAX>((double)lm, sh);
   if (threadIdx.x == 0) {
-    const int first = searchsorted_right(tab, Tc, lut_key_floor(D.key0)), last = searchsorted_right(tab, Tc, lut_key_floor(D.key0 + D.nk));
+    const int first = ks[0], last = ks[D.nk];
     const int i_lo = first > 0 ? first - 1 : 0, i_hi = last + 1 < Tc ? last + 1 : Tc - 1;
     int* info = D.info + (size_t)b * 4;
     info[0] = i_lo; info[1] = i_hi - i_lo + 1; info[2] = (int)lmax;
     info[3] = (sorted && i_hi - i_lo + 1 <= D.cap && Tc <= 65535) ? 1 : 0;
   }
+  __syncthreads();
 }
 
+#ifdef CHM_TABLES_PROF
+#define TS_INIT long long ts_[9]; int ts_n = 0
+#define TS(i) do { __syncthreads(); ts_[ts_n++] = wall_clock64(); } while (0)
+#define TS_PRINT do { if (t == 0 && b == 0) printf("[k_tables phases, x10 ns] params %lld | nodes+1/E %lld | cumtrapz %lld | dL %lld | flags %lld | luts %lld | records %lld | fR %lld\n", \
+  ts_[0] - ts_[0], ts_[1] - ts_[0], ts_[2] - ts_[1], ts_[3] - ts_[2], ts_[4] - ts_[3], ts_[5] - ts_[4], ts_[6] - ts_[5], ts_[7] - ts_[6]); } while (0)
+#else
+#define TS_INIT
+#define TS(i)
+#define TS_PRINT
+#endif
 template <bool LDS_ARR>
 __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_all, double* It_all,
                                                   double* dLt_all, double* mg_all, double* cdf_all, double* tmp_all, int TcMax, int TmMax,
                                                   LutDesc lutA, LutDesc lutB, double* rec_all, const double* tab_zt, const double* tab_dLt) {
   extern __shared__ double larr[];
   __shared__ double sh[32];
+  __shared__ int lut_ks[LUT_MAXKEYS + 1];           // build_lut: searchsorted answer of every key
   __shared__ DevParams Ps;                          // block-local copy of the draw: constants derived here are shared through LDS
   const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
   DevParams& Pg = params[b];
   if (t < (int)(sizeof(DevParams) / sizeof(double))) reinterpret_cast<double*>(&Ps)[t] = reinterpret_cast<const double*>(&Pg)[t];
   __syncthreads();
   const DevParams& P = Ps;
+  TS_INIT; TS(0);
   const int Tc = P.Tc, Tm = P.Tm;
   double* g_zt = zt_all + (size_t)b * TcMax;
   double* g_It = It_all + (size_t)b * TcMax;
@@ -226,13 +242,15 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
     const double lzmax = log10(P.z_max);
     for (int i = t; i < Tc; i += nt) {
       // plug-in cosmology (chm_tab): the caller's z_grid_interp; 1/E is not needed (the Jacobian and p_bkg come tabulated too)
-      double z = tab_zt ? tab_zt[(size_t)b * Tc + i] : (i == 0 ? 0. : pow(10., jnp_linspace_at(-10., lzmax, Tc - 1, i - 1)));
+      double z = tab_zt ? tab_zt[(size_t)b * Tc + i] : (i == 0 ? 0. : chm_pow10(jnp_linspace_at(-10., lzmax, Tc - 1, i - 1)));
       zt[i] = z;
       tmp[i] = tab_zt ? 0. : 1. / E_at_z(P, z);
     }
     if (LDS_ARR) __syncthreads(); else gsync();
+    TS(1);
     block_cumtrapz(tmp, zt, It, Tc, sh);
     if (!LDS_ARR) gsync();
+    TS(2);
     // dL table of z_from_dGW: dL_at_z(cosmo, z_grid_interp) (cosmo.py:263): jnp.interp evaluated AT its own nodes (below; the last
     // node is bracketed from the left: It[Tc-2] + (dx/dx) dI).  The values also go into `tmp` (free
     // after the cumulative integral) for the monotonicity check below.
@@ -249,6 +267,7 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
       if (LDS_ARR) { g_zt[i] = z; g_It[i] = It[i]; }
     }
     if (LDS_ARR) __syncthreads(); else gsync();
+    TS(3);
     // one pass over the table for two per-draw flags: z_bad, the last finite stretch of the cumulative integral (first non-finite
     // node -> grid_is_poisoned), and dl_sorted, whether the dL table is non-decreasing (-> z_from_dGW_x2)
     {
@@ -265,9 +284,11 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
         Pg.z_bad = first < 1e299 ? zt[j > 0 ? j - 1 : 0] : __builtin_inf();
         Pg.dl_sorted = bad ? 0. : 1.;
       }
+    TS(4);
       // direct-index tables of the dL table (`tmp`) for the posterior samples (lutA) and the injections (lutB)
-      build_lut(lutA, b, (const double*)tmp, Tc, !bad, sh);
-      build_lut(lutB, b, (const double*)tmp, Tc, !bad, sh);
+      build_lut(lutA, b, (const double*)tmp, Tc, !bad, sh, lut_ks);
+      build_lut(lutB, b, (const double*)tmp, Tc, !bad, sh, lut_ks);
+    TS(5);
       // node records of the fast sample stage: rec[i] = { dL_i, z_i, slope of z(dL) on [node i, node i+1], log(1 + z_i) }
       if (rec_all) {
         double* rec = rec_all + (size_t)b * TcMax * 4;
@@ -279,6 +300,7 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
         }
       }
     }
+    TS(6);
     // fR = Vc(z1) - Vc(z0)                                                       completeness.py:54-58
     double i0 = block_interp(P.zc0, zt, It, Tc, sh);
     double i1 = block_interp(P.zc1, zt, It, Tc, sh);
@@ -287,6 +309,7 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
       double v1 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * i1));
       Pg.fR = P.fR_given != 0. ? P.fR : v1 - v0;      // a plug-in completeness hands its own fR(cosmo) over (chm_tab.fR)
     }
+    TS(7); TS_PRINT;
   } else {
     double* mg = LDS_ARR ? larr : g_mg;
     double* tmp = LDS_ARR ? larr + Tm : g_tmp;
@@ -318,7 +341,7 @@ __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_a
     // m_grid = logspace(log10 m_low, log10 m_high, Tm); cdf = cumtrapz(secondary(m_grid; m_high))   mass.py:45-49
     const double l0 = log10(P.m[0]), l1 = log10(P.m[1]);
     for (int i = t; i < Tm; i += nt) {
-      double m = i == 0 ? P.mg_first : (i == Tm - 1 ? P.mg_last : pow(10., jnp_linspace_at(l0, l1, Tm, i)));   // end nodes: host libm (DevParams)
+      double m = i == 0 ? P.mg_first : (i == Tm - 1 ? P.mg_last : chm_pow10(jnp_linspace_at(l0, l1, Tm, i)));   // end nodes: host libm (DevParams)
       mg[i] = m;
       tmp[i] = secondary_notnorm(P, m, P.m[1]);
     }

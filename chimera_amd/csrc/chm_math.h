@@ -62,6 +62,18 @@ DEVFN double chm_exp(double x) {
   return v;
 }
 
+// 10^y as exp(y ln 10) with the product formed in two pieces (ln 10 = hi + lo, the rounding of y * hi recovered by an fma): the argument
+// of the exp carries < 1e-17 relative error, so the result is exp's own (0.63 ulp) -- ~35 instructions against ~300 of ocml's pow().
+// For the logspace nodes of the z and mass tables (cosmo.py:43-46, mass.py:45): k_tables runs two blocks per draw, and the two pow()
+// per thread were 5 us of its 30.
+DEVFN double chm_pow10(double y) {
+  const double LN10_HI = 2.302585092994046, LN10_LO = -2.1707562233822494e-16;
+  const double a = y * LN10_HI;
+  const double e = __builtin_fma(y, LN10_HI, -a) + y * LN10_LO;
+  const double v = chm_exp(a);
+  return __builtin_fma(v, e, v);
+}
+
 // exp(x) for |x| <= 708 (no overflow / underflow handling; NaN propagates), Taylor degree 11 on |r| <= 0.347: relative error < 3e-14.
 // For arguments that are bounded by construction and feed a product recurrence whose own error is larger (k_full_kde).
 DEVFN double chm_exp_nb(double x) {

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Timeline of the kernels of one scalar call (one draw per call, HIP-graph replay) from a rocprofv3 kernel trace:
+
+  python3 scripts/timeline_scalar.py [out.txt]          (on the GPU box; never touches the GPU itself)
+
+Runs `rocprofv3 --kernel-trace -- python3 bench.py --nbatch 1 ...`, takes the LAST complete call of the trace (k_tables ... k_combine /
+k_reduce_final) and prints start / end of every kernel relative to the call's first kernel, plus the idle gaps on the critical path.
+"""
+import csv, glob, os, shutil, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'gpurun_out', 'timeline_scalar.txt')
+d = os.path.join(ROOT, 'gpurun_out', 'tl_trace')
+shutil.rmtree(d, ignore_errors=True)
+os.environ['TMPDIR'] = '/tmp'
+cmd = ['rocprofv3', '--kernel-trace', '--output-format', 'csv', '-d', d, '--', 'python3', 'bench.py', '--nbatch', '1', '--steps', '200', '--warmup', '20',
+       '--no-cpu-baseline', '--no-single-call']
+subprocess.call(cmd, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+rows = []
+for f in glob.glob(os.path.join(d, '*', '*kernel_trace.csv')):
+  for r in csv.DictReader(open(f)):
+    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', '')))
+rows.sort()
+# calls start at k_tables
+starts = [i for i, r in enumerate(rows) if r[2].startswith('k_tables')]
+lines = []
+per_call = []
+for a, b in zip(starts[-60:-1], starts[-59:]):
+  call = rows[a:b]
+  per_call.append((call[-1][1] - call[0][0]) * 1e-3)
+a, b = starts[-2], starts[-1]
+call = rows[a:b]
+t0 = call[0][0]
+lines.append('one scalar call (last complete one of the trace); times in us relative to the start of k_tables')
+for s, e, n in call:
+  lines.append('%8.1f %8.1f  %6.1f us  %s' % ((s - t0) * 1e-3, (e - t0) * 1e-3, (e - s) * 1e-3, n))
+lines.append('first kernel start -> last kernel end: %.1f us; median over the last %d calls %.1f us' % ((call[-1][1] - t0) * 1e-3, len(per_call), sorted(per_call)[len(per_call) // 2]))
+lines.append('start-to-start of consecutive calls (median): %.1f us' % sorted((rows[y][0] - rows[x][0]) * 1e-3 for x, y in zip(starts[-60:-1], starts[-59:]))[29])
+open(out, 'w').write('\n'.join(lines) + '\n')
+print('\n'.join(lines))
+shutil.rmtree(d, ignore_errors=True)
