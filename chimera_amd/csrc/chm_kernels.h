@@ -209,14 +209,27 @@ DEVFN void build_lut(const LutDesc& D, int b, Acc tab, int Tc, bool sorted, doub
 template <bool LDS_ARR>
 __global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_all, double* It_all,
                                                   double* dLt_all, double* mg_all, double* cdf_all, double* tmp_all, int TcMax, int TmMax,
-                                                  LutDesc lutA, LutDesc lutB, double* rec_all, const double* tab_zt, const double* tab_dLt) {
+                                                  LutDesc lutA, LutDesc lutB, double* rec_all, const double* tab_zt, const double* tab_dLt, const DevParams* hsrc) {
   extern __shared__ double larr[];
   __shared__ double sh[32];
   __shared__ int lut_ks[LUT_MAXKEYS + 1];           // build_lut: searchsorted answer of every key
   __shared__ DevParams Ps;                          // block-local copy of the draw: constants derived here are shared through LDS
   const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
   DevParams& Pg = params[b];
-  if (t < (int)(sizeof(DevParams) / sizeof(double))) reinterpret_cast<double*>(&Ps)[t] = reinterpret_cast<const double*>(&Pg)[t];
+  if (t < (int)(sizeof(DevParams) / sizeof(double))) {
+    // hsrc: the draw comes straight from the pinned host copy (no copy node in front of this kernel); block y = 1 then fills the device
+    // copy the later kernels read -- every field except the ones block y = 0 derives below (disjoint stores, no ordering needed)
+    // (LDS_ARR only: the long-table variant runs at its register limit)
+    const bool from_host = LDS_ARR && hsrc != nullptr;
+    const double v = reinterpret_cast<const double*>(from_host ? &hsrc[b] : &Pg)[t];
+    reinterpret_cast<double*>(&Ps)[t] = v;
+    if (from_host && blockIdx.y == 1) {
+      const size_t o = (size_t)t * sizeof(double);
+      const bool y0 = o == offsetof(DevParams, md_norm) || o == offsetof(DevParams, tpl_rate_norm) || o == offsetof(DevParams, l1pzp) ||
+                      o == offsetof(DevParams, z_bad) || o == offsetof(DevParams, dl_sorted) || o == offsetof(DevParams, fR);
+      if (!y0) reinterpret_cast<double*>(&Pg)[t] = v;
+    }
+  }
   __syncthreads();
   const DevParams& P = Ps;
   TS_INIT; TS(0);

@@ -321,3 +321,22 @@ def test_bench_and_product_are_torch_free():
     assert not re.search(r'^\s*(from|import)\s+(torch|jax|triton)\b', txt, flags=re.M), f
   code = "import sys; import chimera_amd, chimera_amd.parallel; sys.exit(1 if any(m.split('.')[0] in ('torch', 'jax', 'triton') for m in sys.modules) else 0)"
   assert subprocess.call([sys.executable, '-c', code], cwd=ROOT) == 0
+
+
+def test_compiler_resource_report_of_the_kernels(lib):
+  """build() keeps the compiler's per-kernel resource report.  The hot kernels must be in it, every kernel must reach the occupancy its
+  launch bounds ask for, and k_tables -- 1024-thread blocks -- must not use scratch: with two spilled registers its long-table variant died
+  with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on the MI355X boxes (round 2; the same source without the spill runs)."""
+  import json
+  path = os.path.join(os.path.dirname(__file__), '..', 'chimera_amd', 'lib', 'kernel_resources.json')
+  if not os.path.exists(path):
+    import __graft_entry__ as g
+    g.build(force=True)
+  res = json.load(open(path))
+  for k in ('k_tables<true>', 'k_tables<false>', 'k_samples_fast<2, false>', 'k_kde_marg_sub2<32, 4, 200>', 'k_selection_fast<2>', 'k_full_kde',
+            'k_zfactors<true>', 'k_marg_fixup', 'k_reduce_final'):
+    assert k in res, (k, sorted(res))
+  for k in ('k_tables<true>', 'k_tables<false>'):
+    assert res[k]['scratch_bytes_per_lane'] == 0 and res[k]['vgpr_spills'] == 0, (k, res[k])
+  assert res['k_kde_marg_sub2<32, 4, 200>']['waves_per_simd'] >= 4 and res['k_samples_fast<2, false>']['waves_per_simd'] >= 4
+  assert res['k_full_kde']['waves_per_simd'] >= 3 and res['k_full_kde']['vgpr_spills'] == 0
