@@ -852,7 +852,8 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
           // offsets once (four items per wave: 5.45 ms at C3 / 128 draws, two: 5.51, one: 5.66)
           const int PG2 = (Pd + 1) / 2;
           static const int ipw_env = getenv("CHM_KDE_IPW") ? atoi(getenv("CHM_KDE_IPW")) : 0;       // diagnostics: 2 or 4 items per wave
-          const int ipw = ipw_env == 2 || ipw_env == 4 ? ipw_env : (PG2 >= 4 ? 4 : 2);
+          // (few draws per call: two items per wave -- twice the waves, half the serial chain of each: 0.238 -> 0.229 ms for the scalar call at C3)
+          const int ipw = ipw_env == 2 || ipw_env == 4 ? ipw_env : ((PG2 >= 4 && nb > 8) ? 4 : 2);
           const size_t lds_sub = sizeof(double) * (3 * N + 3) * 2;
 #define LAUNCH_SUB2(I, BN) hipLaunchKernelGGL((k_kde_marg_sub2<32, I, BN>), dim3(nb, (PG2 + I - 1) / I, L.E_cnt), dim3(64), lds_sub, sg, L, dp)
           if (L.num_bins == 200) { if (ipw == 4) LAUNCH_SUB2(4, 200); else LAUNCH_SUB2(2, 200); }      // the reference's default bin count (likelihood.py:59): compile-time
