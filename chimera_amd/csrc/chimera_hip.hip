@@ -788,8 +788,13 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       const int zf_target = 2048 / nb > 1 ? 2048 / nb : 1;
       const int zf_units = zf_mode ? (L.E_cnt + 3) / 4 : L.E_cnt;     // ranged: four events (waves) per block pass
       const int zf_blocks = zf_units < zf_target ? zf_units : zf_target;
+      // few draws per call, standard marginalized configuration: the per-z-factor kernel forms the event statistics itself
+      static const int few_nb = getenv("CHM_FEW_NB") ? atoi(getenv("CHM_FEW_NB")) : 8;
+      const bool zf_stats = zf_mode == 1 && marg_std && tab_zfac && nb <= few_nb;
       auto launch_zfactors = [&]() {
-        if (tab_zfac) { allow_lds(k_zfactors<true>, lds_zfac);
+        if (zf_stats) { allow_lds((k_zfactors<true, true>), lds_zfac);
+          hipLaunchKernelGGL((k_zfactors<true, true>), dim3(zf_blocks, nb), dim3(256), lds_zfac, sz, L, dp, c.zt, c.It, Tc, zf_mode);
+        } else if (tab_zfac) { allow_lds(k_zfactors<true>, lds_zfac);
           hipLaunchKernelGGL(k_zfactors<true>, dim3(zf_blocks, nb), dim3(256), lds_zfac, sz, L, dp, c.zt, c.It, Tc, zf_mode);
         } else hipLaunchKernelGGL(k_zfactors<false>, dim3(zf_blocks, nb), dim3(256), 0, sz, L, dp, c.zt, c.It, Tc, zf_mode);
       };
@@ -818,7 +823,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       const bool fullm = L.mode == CHM_MODE_FULL;
       if (use_fast) {
         SampFast F = like->F; F.lut = lutA;
-#define LAUNCH_FAST(M, FU) do { allow_lds(k_samples_fast<M, FU>, lds_fast); \
+#define LAUNCH_FAST(M, FU) do { allow_lds((k_samples_fast<M, FU>), lds_fast); \
           hipLaunchKernelGGL((k_samples_fast<M, FU>), g1, dim3(64 * CHM_SF_WAVES), lds_fast, sg, L, F, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm); } while (0)
         const int mm = params[0].mass_model;
         if (fullm) { if (mm == 0) LAUNCH_FAST(0, true); else if (mm == 1) LAUNCH_FAST(1, true); else LAUNCH_FAST(2, true); }
@@ -841,7 +846,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         hipLaunchKernelGGL(k_full_kde, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp);
       } else if (L.mode == CHM_MODE_MARG) {
-        if (marg_std) hipLaunchKernelGGL(k_event_stats, dim3((L.E_cnt + 255) / 256, nb), dim3(256), 0, sg, L);
+        if (marg_std) { if (!zf_stats) hipLaunchKernelGGL(k_event_stats, dim3((L.E_cnt + 255) / 256, nb), dim3(256), 0, sg, L); }
         else hipLaunchKernelGGL(k_event_prep, dim3((L.E_cnt + 3) / 4, nb), dim3(256), 0, sg, L, 1);
         HIPCHK(hipGetLastError());
         if (zf_ranged) { launch_zfactors(); HIPCHK(hipGetLastError()); }

@@ -645,8 +645,11 @@ DEVFN void z_from_lut_x2(double xa, double xb, const double* rec, const unsigned
 #define CHM_SF_PREFETCH 0
 #endif
 static_assert(SAMPLE_WPB % CHM_SF_WAVES == 0, "records per chunk must be a multiple of the waves per block");
-template <int MASS, bool FULL>
-__global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast(LikeDev L, SampFast F, const DevParams* params, const double* zt_all,
+// PF: the next tile's loads are issued before the arithmetic of the current one, compiled for 3 waves per SIMD so that the twelve extra
+// registers do not spill.  Measured for calls of one draw, where every block of the grid is resident at once: the scalar call takes
+// 0.242 instead of 0.232 ms -- the fourth wave per SIMD hides more latency than the prefetch (profiles/r02/ab_scalar_call_*.txt)
+template <int MASS, bool FULL, bool PF = (CHM_SF_PREFETCH != 0)>
+__global__ void __launch_bounds__(64 * CHM_SF_WAVES, PF ? (CHM_SF_MINW < 3 ? CHM_SF_MINW : 3) : CHM_SF_MINW) k_samples_fast(LikeDev L, SampFast F, const DevParams* params, const double* zt_all,
                                                                     const double* dLt_all, const double* mg_all, const double* cdf_all,
                                                                     const double* rec_all, int TcMax, int TmMax) {
 #pragma clang fp contract(fast)                  // sums of products may fuse; z comes from z_from_lut_x2 / jnp_interp (contract off) untouched
@@ -710,11 +713,11 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
       a_ = tp[0]; b_ = tp[SF_TILE / 2]; c_ = tp[2 * SF_TILE / 2]; d_ = tp[3 * SF_TILE / 2]; e_ = tp[4 * SF_TILE / 2]; f_ = tp[5 * SF_TILE / 2];
     };
     const int s_first = c * SAMPLE_CHUNK + 2 * t;
-    if (CHM_SF_PREFETCH && s_first < s_end) load_tile(s_first, a, bb, cc, dd, ee, ff);
+    if (PF && s_first < s_end) load_tile(s_first, a, bb, cc, dd, ee, ff);
 #pragma unroll 1
     for (int s = s_first; s < s_end; s += 2 * NT_) {      // one tile of 128 samples per wave and pass
       double2 na, nb_, nc, nd, ne, nf;
-      if (CHM_SF_PREFETCH) { if (s + 2 * NT_ < s_end) load_tile(s + 2 * NT_, na, nb_, nc, nd, ne, nf); }
+      if (PF) { if (s + 2 * NT_ < s_end) load_tile(s + 2 * NT_, na, nb_, nc, nd, ne, nf); }
       else load_tile(s, a, bb, cc, dd, ee, ff);
       const double dl[2] = { a.x, a.y }, md1[2] = { bb.x, bb.y }, md2[2] = { cc.x, cc.y }, ipr[2] = { dd.x, dd.y };
       const double l1[2] = { ee.x, ee.y }, l2[2] = { ff.x, ff.y };
@@ -759,7 +762,7 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
         wz[s] = zz[0]; ww[s] = wv[0];
         if (s + 1 < s_end) { wz[s + 1] = zz[1]; ww[s + 1] = wv[1]; }
       }
-      if (CHM_SF_PREFETCH) { a = na; bb = nb_; cc = nc; dd = nd; ee = ne; ff = nf; }
+      if (PF) { a = na; bb = nb_; cc = nc; dd = nd; ee = ne; ff = nf; }
     }
     };
     if (fits) passes(std::true_type{}); else passes(std::false_type{});
@@ -1096,7 +1099,9 @@ __global__ void __launch_bounds__(256) k_grid_prep(int E, int Z, const double* z
   }
 }
 
-template <bool LDS_TAB>
+// STATS (few draws per call, ranged == 1): the wave forms its event's statistics itself and writes them for the GW kernel -- no k_event_stats
+// launch in front of this kernel
+template <bool LDS_TAB, bool STATS = false>
 __global__ void __launch_bounds__(256, CHM_ZF_WPE) k_zfactors(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
                                                    int TcMax, int ranged) {
 #pragma clang fp contract(fast)                  // smooth per-z factors: a*b+c may fuse (jnp_interp keeps the default, off)
@@ -1124,7 +1129,17 @@ __global__ void __launch_bounds__(256, CHM_ZF_WPE) k_zfactors(LikeDev L, const D
     // the support of its KDE (NEVSTAT slots 8-9), nothing for an event that fails the n_eff guard (likelihood.py:199);
     // 2 (1d / approximate, after k_kde1d): the range where p_gw1d is non-zero
     int k_first = 0, k_last = Z - 1;
-    if (ranged == 1) {
+    if (STATS) {                                    // every lane forms the same numbers (uniform loads); lane 0 keeps them for the GW kernel
+      double es[NEVSTAT];
+      event_stats(L, b, e, es);
+      if (lane0 == 0) {
+        double* o = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
+#pragma unroll
+        for (int i = 0; i < NEVSTAT; i++) o[i] = es[i];
+      }
+      if (!(es[4] >= L.pe_neff)) continue;
+      k_first = ((int)es[8]) & ~1; k_last = (int)es[9];
+    } else if (ranged == 1) {
       const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
       if (!(es[4] >= L.pe_neff)) continue;
       k_first = ((int)es[8]) & ~1; k_last = (int)es[9];
