@@ -301,7 +301,26 @@ def main():
                  "peak_Gpairs_s": VALU_PEAK_GINST * 64 / 1.25, "pair_frac": full_pairs / sec / 1e9 / (VALU_PEAK_GINST * 64 / 1.25) if sec > 0 else None})
     kernels.append(kernel_roofline("sample stage (z(dL), source-frame masses, population weights, event statistics)", "k_samples", kt[2],
                                    sample_kernel_unique_bytes(El, S, nb), pmc))
-    dom = kernels[0]
+    # the selection kernel runs on its own stream beside the event kernels (its span there is not a kernel duration): timed standalone
+    # here, after the timed region, as the selection-only call chm_eval(NULL, sel, ...) of the same draws
+    sel_ms = None
+    if world == 1:
+      import ctypes as C
+      pa = like._params_array(draws[-1])
+      nexp = np.empty(nb)
+      o = _lib.chm_out(); o.N_exp = _lib.dptr(nexp)
+      ms = np.zeros(8)
+      acc = []
+      for j in range(6):
+        _lib.check(L.chm_eval(None, sel._handle(), None, pa, nb, 0, C.byref(o)))
+        _lib.check(L.chm_last_timing(None, sel._handle(), _lib.dptr(ms)))
+        if j >= 2 and ms[4] > 0:
+          acc.append(ms[4])
+      if acc:
+        sel_ms = float(np.median(acc))
+        kernels.append(kernel_roofline("selection function (dN/dtheta per injection, two sums); standalone selection-only call", "k_selection", sel_ms,
+                                       I * 48 + nb * (2 * 1500 + 2 * 1000) * 8, pmc))
+    dom = max(kernels, key=lambda k_: k_["kernel_ms"] or 0.) if kind != 'full' else kernels[0]
     path_bytes = algorithmic_bytes(E, S, P, Z, I, 200, pixelated, kind == 'full')
     med, q1, q3 = quartiles(step_s) if step_s else (None, None, None)
     roof = {"bound": "fp64-valu", "kernel": dom["kernel"],
@@ -322,7 +341,7 @@ def main():
             "path_bytes_per_eval": path_bytes,
             "path_frac": path_bytes * nb / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[0] > 0 else None,
             "stage_ms": {"eval": kt[0], "tables": kt[1], "samples": kt[2], "kde_integrate": kt[3],
-                         "selection": kt[4], "reduce": kt[5], "events_wall": kt[6], "event_groups": kt[7]}}
+                         "selection": kt[4], "selection_standalone": sel_ms, "reduce": kt[5], "events_wall": kt[6], "event_groups": kt[7]}}
     out = {
       "metric": "log-likelihood evals/sec (full hyperposterior call), N_ev x N_pix x N_z",
       "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
