@@ -206,8 +206,10 @@ DEVFN void build_lut(const LutDesc& D, int b, Acc tab, int Tc, bool sorted, doub
 #define TS(i)
 #define TS_PRINT
 #endif
+// (the long-table variant, LDS_ARR = false, runs 512-thread blocks: at 1024 threads it sits at the 128-register limit and any spill there
+//  has ended in a memory-aperture fault on the MI355X boxes, see tests/test_abi_and_host.py)
 template <bool LDS_ARR>
-__global__ void __launch_bounds__(1024) k_tables(DevParams* params, double* zt_all, double* It_all,
+__global__ void __launch_bounds__(LDS_ARR ? 1024 : 512) k_tables(DevParams* params, double* zt_all, double* It_all,
                                                   double* dLt_all, double* mg_all, double* cdf_all, double* tmp_all, int TcMax, int TmMax,
                                                   LutDesc lutA, LutDesc lutB, double* rec_all, const double* tab_zt, const double* tab_dLt, const DevParams* hsrc) {
   extern __shared__ double larr[];

@@ -2,7 +2,7 @@
 //
 // ocml's log() is a ~95-instruction double-double routine and exp() ~36 instructions; the hot kernels are fp64-VALU bound and
 // evaluate 1 log + 4-5 exp per posterior sample, so these are written out here at ~36 and ~24 instructions:
-//   chm_exp      n = rint(x log2 e), r = x - n ln2 (two-term), Taylor degree 13 on |r| <= 0.347, ldexp;  max error 0.63 ulp
+//   chm_exp      n = rint(x log2 e), r = x - n ln2 (two-term), 1 + r + r^2 q(r) with a degree-9 fit of q on |r| <= 0.347, ldexp;  max error 0.65 ulp
 //   chm_log_pos  fdlibm's scheme: x = 2^k m, m in [sqrt(1/2), sqrt 2), s = f/(2+f), degree-7 minimax in s^2;  max error 0.69 ulp
 //                for finite x > 0 (NaN propagates); chm_log adds log(0) = -inf, log(<0) = NaN, log(inf) = inf
 // (errors measured against long double on 2e7 random arguments, scripts/check_fastmath.cpp).  Subnormal results of exp and
@@ -41,18 +41,18 @@ DEVFN double chm_exp(double x) {
   double n = __builtin_rint(x * L2E);
   double r = __builtin_fma(-n, LN2HI, x);
   r = __builtin_fma(-n, LN2LO, r);
-  double p = 1.6059043836821613e-10;                 // 1/13!
-  p = FM_FMA(p, r, 2.08767569878681e-09);     // 1/12!
-  p = FM_FMA(p, r, 2.505210838544172e-08);    // 1/11!
-  p = FM_FMA(p, r, 2.755731922398589e-07);    // 1/10!
-  p = FM_FMA(p, r, 2.7557319223985893e-06);   // 1/9!
-  p = FM_FMA(p, r, 2.48015873015873e-05);     // 1/8!
-  p = FM_FMA(p, r, 0.0001984126984126984);    // 1/7!
-  p = FM_FMA(p, r, 0.001388888888888889);     // 1/6!
-  p = FM_FMA(p, r, 0.008333333333333333);     // 1/5!
-  p = FM_FMA(p, r, 0.041666666666666664);     // 1/4!
-  p = FM_FMA(p, r, 0.16666666666666666);      // 1/3!
-  p = __builtin_fma(p, r, 0.5);
+  // e^r = 1 + r + r^2 q(r): q = degree-9 Chebyshev fit of (e^r - 1 - r)/r^2 on |r| <= ln2/2 (mpmath.chebyfit; |error| < 2e-17 of e^r) -- two
+  // Horner steps fewer than the degree-13 Taylor sum at the same measured accuracy (0.65 against 0.63 ulp, scripts/check_fastmath.cpp)
+  double p = 2.510038549551032e-08;
+  p = FM_FMA(p, r, 2.7620088445409746e-07);
+  p = FM_FMA(p, r, 2.7557268459997064e-06);
+  p = FM_FMA(p, r, 2.4801521295954376e-05);
+  p = FM_FMA(p, r, 0.00019841269863053618);
+  p = FM_FMA(p, r, 0.0013888888917213717);
+  p = FM_FMA(p, r, 0.008333333333330062);
+  p = FM_FMA(p, r, 0.04166666666662413);
+  p = FM_FMA(p, r, 0.16666666666666669);
+  p = FM_FMA(p, r, 0.5000000000000001);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
   int k = (int)n;
@@ -74,23 +74,24 @@ DEVFN double chm_pow10(double y) {
   return __builtin_fma(v, e, v);
 }
 
-// exp(x) for |x| <= 708 (no overflow / underflow handling; NaN propagates), Taylor degree 11 on |r| <= 0.347: relative error < 3e-14.
-// For arguments that are bounded by construction and feed a product recurrence whose own error is larger (k_full_kde).
+// exp(x) for |x| <= 708: chm_exp without the overflow / underflow handling (NaN propagates), the same polynomial (its coefficients then
+// occupy one set of registers in a kernel that uses both: a shorter degree-9 fit spilled 9 registers in k_full_kde).  For arguments that
+// are bounded by construction (k_full_kde).
 DEVFN double chm_exp_nb(double x) {
   const double L2E = 1.44269504088896338700e+00, LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10;
   double n = __builtin_rint(x * L2E);
   double r = __builtin_fma(-n, LN2HI, x);
   r = __builtin_fma(-n, LN2LO, r);
-  double p = 2.505210838544172e-08;                  // 1/11!
-  p = FM_FMA(p, r, 2.755731922398589e-07);    // 1/10!
-  p = FM_FMA(p, r, 2.7557319223985893e-06);   // 1/9!
-  p = FM_FMA(p, r, 2.48015873015873e-05);     // 1/8!
-  p = FM_FMA(p, r, 0.0001984126984126984);    // 1/7!
-  p = FM_FMA(p, r, 0.001388888888888889);     // 1/6!
-  p = FM_FMA(p, r, 0.008333333333333333);     // 1/5!
-  p = FM_FMA(p, r, 0.041666666666666664);     // 1/4!
-  p = FM_FMA(p, r, 0.16666666666666666);      // 1/3!
-  p = __builtin_fma(p, r, 0.5);
+  double p = 2.510038549551032e-08;
+  p = FM_FMA(p, r, 2.7620088445409746e-07);
+  p = FM_FMA(p, r, 2.7557268459997064e-06);
+  p = FM_FMA(p, r, 2.4801521295954376e-05);
+  p = FM_FMA(p, r, 0.00019841269863053618);
+  p = FM_FMA(p, r, 0.0013888888917213717);
+  p = FM_FMA(p, r, 0.008333333333330062);
+  p = FM_FMA(p, r, 0.04166666666662413);
+  p = FM_FMA(p, r, 0.16666666666666669);
+  p = FM_FMA(p, r, 0.5000000000000001);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
   return __builtin_ldexp(p, (int)n);

@@ -32,6 +32,30 @@ DEVFN double chm_exp(double x) {
   return v;
 }
 
+// degree-11 form: exp(r) = 1 + r + r^2 q(r), q the degree-9 Chebyshev fit of (e^r - 1 - r)/r^2 on |r| <= ln2/2 (mpmath.chebyfit, error 1e-17)
+DEVFN double chm_exp11(double x) {
+  const double L2E = 1.44269504088896338700e+00, LN2HI = 6.93147180369123816490e-01, LN2LO = 1.90821492927058770002e-10;
+  double n = __builtin_rint(x * L2E);
+  double r = __builtin_fma(-n, LN2HI, x);
+  r = __builtin_fma(-n, LN2LO, r);
+  double p = 2.510038549551032e-08;
+  p = __builtin_fma(p, r, 2.7620088445409746e-07);
+  p = __builtin_fma(p, r, 2.7557268459997064e-06);
+  p = __builtin_fma(p, r, 2.4801521295954376e-05);
+  p = __builtin_fma(p, r, 0.00019841269863053618);
+  p = __builtin_fma(p, r, 0.0013888888917213717);
+  p = __builtin_fma(p, r, 0.008333333333330062);
+  p = __builtin_fma(p, r, 0.04166666666662413);
+  p = __builtin_fma(p, r, 0.16666666666666669);
+  p = __builtin_fma(p, r, 0.5000000000000001);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  int k = (int)n;
+  double v = __builtin_ldexp(p, k);
+  if (x > 709.782712893384) v = __builtin_inf();
+  if (x < -745.1332191019412) v = 0.;
+  return v;
+}
 // log(x) for finite x > 0 (NaN propagates); fdlibm e_log.c scheme, < 1 ulp
 DEVFN double chm_log_pos(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
@@ -69,13 +93,14 @@ DEVFN double chm_log(double x) {
 int main() {
   std::mt19937_64 g(1);
   std::uniform_real_distribution<double> ue(-745, 709), ul(-700, 700), us(-1, 1);
-  double maxe = 0, maxl = 0; double we=0, wl=0;
+  double maxe = 0, maxl = 0, maxe11 = 0; double we=0, wl=0;
   for (int i = 0; i < 20000000; i++) {
     double x = i % 3 == 0 ? ue(g) : (i % 3 == 1 ? us(g) * 40 : us(g));
     long double ref = expl((long double)x);
     double v = chm_exp(x);
     double err = fabs((double)(((long double)v - ref) / ref));
     if (x > -708 && err > maxe) { maxe = err; we = x; }
+    { double v2 = chm_exp11(x); double e2 = fabs((double)(((long double)v2 - ref) / ref)); if (x > -708 && e2 > maxe11) maxe11 = e2; }
     double y = i % 2 ? exp(ul(g)) : 1.0 + fabs(us(g)) * 6;
     long double rl = logl((long double)y);
     double vl = chm_log(y);
@@ -83,6 +108,7 @@ int main() {
     if (el > maxl) { maxl = el; wl = y; }
   }
   printf("exp max rel err %.3e (at %g) = %.2f ulp; log max rel err %.3e (at %g) = %.2f ulp\n", maxe, we, maxe / 1.11e-16, maxl, wl, maxl / 1.11e-16);
+  printf("degree-11 exp (chm_exp since round 2) max rel err %.3e = %.2f half-ulp\n", maxe11, maxe11 / 1.11e-16);
   printf("specials: exp(-inf)=%g exp(inf)=%g exp(nan)=%g exp(-746)=%g exp(-740)=%g (ref %g) exp(710)=%g log(0)=%g log(-1)=%g log(inf)=%g log(nan)=%g log(1)=%g log(5e-324)=%g (ref %g)\n",
     chm_exp(-INFINITY), chm_exp(INFINITY), chm_exp(NAN), chm_exp(-746), chm_exp(-740), exp(-740.), chm_exp(710), chm_log(0.), chm_log(-1.), chm_log(INFINITY), chm_log(NAN), chm_log(1.), chm_log(5e-324), log(5e-324));
   // near 1
