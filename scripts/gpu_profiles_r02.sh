@@ -8,7 +8,8 @@ O=gpurun_out/profiles_r02; mkdir -p $O
 python3 scripts/collect_profiles.py r02 > $O/collect_C3.log 2>&1; tail -12 $O/collect_C3.log
 python3 scripts/collect_profiles.py r02 --tag nbatch1 -- --nbatch 1 --no-graph --steps 200 --warmup 20 > $O/collect_nb1.log 2>&1; tail -8 $O/collect_nb1.log
 python3 scripts/collect_profiles.py r02 --tag full --passes 0,1,3 -- --mode full --nbatch 4 --steps 5 --warmup 2 > $O/collect_full.log 2>&1; tail -6 $O/collect_full.log
-for c in C1 C2 C4; do timeout -k 10 300 python3 bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err; done
+python3 scripts/collect_profiles.py r02 --tag C4 -- --config C4 > $O/collect_C4.log 2>&1; tail -4 $O/collect_C4.log
+for c in C1 C2; do timeout -k 10 300 python3 bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err; done
 timeout -k 10 600 python3 bench.py --config C5 --nbatch 16 --steps 10 --warmup 2 --cpu-evals 3 > $O/bench_C5.json 2> $O/bench_C5.err
 timeout -k 10 300 python3 bench.py --mode approximate > $O/bench_approximate.json 2> $O/bench_approximate.err
 for f in $O/bench_C1.json $O/bench_C2.json $O/bench_C4.json $O/bench_C5.json $O/bench_approximate.json; do python3 -c "
