@@ -1162,18 +1162,24 @@ __global__ void __launch_bounds__(256, CHM_ZF_WPE) k_zfactors(LikeDev L, const D
         if (own_cosmo) dCt = dCt_at_z(P, z, zt, It);
         lzp1 = chm_log_pos(zp1);
       }
-      double Ez = own_cosmo ? E_at_z_l(P, z, lzp1) : 1.;
-      double jac = L.tab_jac ? L.tab_jac[zo + k] : ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1) * (zp1 * zp1);
-      double prate = (L.tab_rate ? L.tab_rate[zo + k] : merger_rate_l(P, z, lzp1)) / (1. + z);      // plug-in rate model: tabulated
-      if (!ranged) { L.jac[zo + k] = jac; L.prate[zo + k] = prate; }
-      double p_bkg = L.tab_bkg ? L.tab_bkg[zo + k] : dVcdz_from_dCt_E(P, dCt, Ez);                   // plug-in completeness: tabulated
+      // One reciprocal of E(z) serves the Jacobian (dH/E) and dVc/dz (.../E); the rate stays a quotient num/den until it meets the
+      // Jacobian, so that A_k = prate/jac tw costs one division instead of three (five IEEE divisions per grid point before: 248 VALU
+      // instructions per point, 129 M per launch at C3 / 128 draws).  Differences to the separate quotients: rounding (<= 4 ulp).
+      const double Ez = own_cosmo ? E_at_z_l(P, z, lzp1) : 1.;
+      const double rEz = chm_div(1., Ez);
+      const double jac = L.tab_jac ? L.tab_jac[zo + k] : ddLdz_from_dCt_rE(P, dCt, zp1, rEz, lzp1) * (zp1 * zp1);
+      double rnum, rden = 1.;
+      if (L.tab_rate) rnum = L.tab_rate[zo + k];                                                       // plug-in rate model: tabulated
+      else merger_rate_nd(P, z, lzp1, rnum, rden);
+      if (!ranged) { L.jac[zo + k] = jac; L.prate[zo + k] = rnum / (rden * zp1); }
+      const double p_bkg = L.tab_bkg ? L.tab_bkg[zo + k] : (4. * CHM_PI * P.dH) * (dCt * dCt) * rEz;   // plug-in completeness: tabulated; cosmo.py:188-197
       // a 1-D handle built from a catalogue population (hyperlikelihood.p_gw1d on a pixelated object) carries no P_compl
       L.bkgA[zo + k] = (P.has_catalog && L.P_compl) ? (1. - L.P_compl[(size_t)e * Z + k]) * p_bkg : p_bkg;
       if (L.Aw) {
         // trapezoid weight of grid point k: y_k enters the two adjacent intervals (jnp.trapezoid, likelihood.py:278)
         double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
         double tw = 0.5 * ((z - zl) + (zr - z));
-        L.Aw[zo + k] = (prate / jac) * tw;
+        L.Aw[zo + k] = (rnum * tw) / ((rden * zp1) * jac);
       }
     }
   }

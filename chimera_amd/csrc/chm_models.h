@@ -272,6 +272,17 @@ DEVFN double ddLdz_from_dCt_E(const DevParams& p, double dCt, double z, double E
   }
   return ddLflrw;
 }
+// the same with 1/E(z) given and the modified-propagation factors from ONE exp: Xi = Xi0 + (1 - Xi0) q, q = (1+z)^-n, and
+// dL_flrw dXi/dz = dCt (1+z) n (Xi0 - 1) q / (1+z) = dCt n (Xi0 - 1) q  (no division; k_zfactors)
+DEVFN double ddLdz_from_dCt_rE(const DevParams& p, double dCt, double zp1, double rEz, double lzp1) {
+  const double ddLflrw = dCt + (p.dH * rEz) * zp1;
+  if (p.cosmo_model == 1) {
+    const double q = chm_exp(-p.n_mg * lzp1);
+    const double Xiz = p.Xi0 + (1. - p.Xi0) * q;
+    return ddLflrw * Xiz + dCt * (p.n_mg * (p.Xi0 - 1.) * q);
+  }
+  return ddLflrw;
+}
 DEVFN double ddLdz_from_dCt(const DevParams& p, double dCt, double z) {
   double l = (p.cosmo_model == 1 || de_needs_log(p)) ? chm_log(1. + z) : 0.;
   return ddLdz_from_dCt_E(p, dCt, z, E_at_z_l(p, z, l), l);
