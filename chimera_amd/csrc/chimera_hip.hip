@@ -585,7 +585,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   if (comm && comm->device != c.device) return fail(CHM_E_ARG, "chm_eval: comm lives on a different device");
   HIPCHK(hipSetDevice(c.device));
   static const bool serial = getenv("CHM_SERIAL") != nullptr;     // diagnostics: everything on one stream
-  hipStream_t sA = c.stream, sB = serial ? c.stream : c.stream2, sC = serial ? c.stream : c.stream3;
+  hipStream_t sA = c.stream, sB = serial ? c.stream : c.stream2, sC = serial ? c.stream : c.stream3;      // (all three = sA for fused few-draw calls, below)
   const bool want_dump = like && out->p_gw != nullptr;
   int rc;
   if (like) { rc = like_ensure_ws(like, nb, want_dump); if (rc) return rc; }
@@ -689,6 +689,17 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       if (lds_sel > 64 * 1024) sel_fast = false;
     }
   }
+  // Few draws per call (the scalar call), standard marginalized configuration, fast selection kernel: the per-z factors, the event
+  // statistics and the selection sums share ONE launch (k_zf_sel) and the whole call runs on one stream -- the captured graph is a plain
+  // chain (hipGraphLaunch 10 instead of 39 us) and the selection kernel hides behind the per-z factors.
+  static const int few_nb = getenv("CHM_FEW_NB") ? atoi(getenv("CHM_FEW_NB")) : 8;
+  static const bool fuse_env = getenv("CHM_NO_ZF_SEL") == nullptr;
+  const size_t lds_zfac_call = sizeof(double) * (size_t)2 * c.TcMax;
+  const bool fuse_sel = fuse_env && !serial && like && sel && sel_fast && nb <= few_nb && !comm && !td.rate_g && !td.bkg_g && !td.jac_g &&
+                        like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && !getenv("CHM_MARG_GENERIC") && !getenv("CHM_ZF_FULL") &&
+                        !getenv("CHM_GROUPS") && lds_zfac_call <= 64 * 1024 && like->L.E <= 65535;
+  const bool one_stream = serial || fuse_sel;
+  if (fuse_sel) { sB = sA; sC = sA; }
   // draw-independent brackets of the event grids on the z table: usable when every draw of the call has one (z_max, z_grid_res) and the
   // cosmology is built in; (re)made by k_grid_prep after k_tables when that pair changes
   bool zg_use = false, zg_make = false;
@@ -703,7 +714,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   if (graph_ok) {
     key = { (long long)(intptr_t)like, (long long)(intptr_t)sel, nb, (long long)E_total, like ? like->nb_ws : 0, sel ? sel->nb_ws : 0, c.nb_cap, c.TcMax, c.TmMax,
             Tc_host, Tm_host, use_fast, lutA.key0, lutA.nk, lutA.cap, (long long)lds_fast, params[0].mass_model, out->partials != nullptr,
-            sel_fast, lutB.key0, lutB.nk, lutB.cap, (long long)lds_sel, (long long)(intptr_t)lutB.lut,
+            sel_fast, lutB.key0, lutB.nk, lutB.cap, (long long)lds_sel, (long long)(intptr_t)lutB.lut, fuse_sel,
             (long long)(intptr_t)c.d_evpart, (long long)(intptr_t)(like ? like->L.ws_z : nullptr), (long long)(intptr_t)(sel ? sel->S.partial : nullptr),
             zg_use, zg_make };
     if (c.gexec && key == c.gkey) {                           // replay
@@ -743,7 +754,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     like->zg_zmax = params[0].z_max; like->zg_Tc = params[0].z_grid_res;
   }
   HIPCHK(hipEventRecord(c.ev[1], sA));
-  HIPCHK(hipStreamWaitEvent(sB, c.ev[1], 0));               // fork: the other lanes start after the tables
+  if (!one_stream) HIPCHK(hipStreamWaitEvent(sB, c.ev[1], 0));               // fork: the other lanes start after the tables
 
   const int Tc = c.TcMax, Tm = c.TmMax;
   const DevParams* dp = c.d_params;
@@ -765,7 +776,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     ngroups = env_groups > 0 ? env_groups : 1;      // >1: event groups alternate between two streams (measured: no net gain at C3)
     if (ngroups > 16) ngroups = 16;
     if (ngroups > L0.E) ngroups = L0.E;
-    if (serial) ngroups = 1;
+    if (one_stream) ngroups = 1;
     if ((L0.E + ngroups - 1) / ngroups > 65535) ngroups = (L0.E + 65534) / 65535;      // the GW kernel's grid carries the event in blockIdx.z
     if (ngroups > 16) return fail(CHM_E_ARG, "chm_eval: more than 16 x 65535 events in one shard");
     for (int g = 0; g < ngroups; g++) {
@@ -784,16 +795,24 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       // 30 % slower: 19 KB of LDS per wave halve the occupancy); anything else, or CHM_MARG_GENERIC=1, -> the general kernel
       const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC");
       const int zf_mode = !zf_ranged ? 0 : (L.mode == CHM_MODE_MARG ? 1 : 2);
-      hipStream_t sz = (serial || zf_ranged) ? sg : ((g & 1) ? sA : sB);
+      hipStream_t sz = (one_stream || zf_ranged) ? sg : ((g & 1) ? sA : sB);
       // ~2048 blocks in all: each stages the draw's (zt, It) tables in LDS once and walks over E_cnt / gridDim.x events
       const int zf_target = 2048 / nb > 1 ? 2048 / nb : 1;
       const int zf_units = zf_mode ? (L.E_cnt + 3) / 4 : L.E_cnt;     // ranged: four events (waves) per block pass
       const int zf_blocks = zf_units < zf_target ? zf_units : zf_target;
       // few draws per call, standard marginalized configuration: the per-z-factor kernel forms the event statistics itself
-      static const int few_nb = getenv("CHM_FEW_NB") ? atoi(getenv("CHM_FEW_NB")) : 8;
       const bool zf_stats = zf_mode == 1 && marg_std && tab_zfac && nb <= few_nb;
       auto launch_zfactors = [&]() {
-        if (zf_stats) { allow_lds((k_zfactors<true, true>), lds_zfac);
+        if (fuse_sel) {                                     // + the selection sums: blocks [zf_blocks, zf_blocks + gx)
+          SelDev S = sel->S;
+          int gx = 8192 / nb; gx = gx < 1 ? 1 : (gx > S.nblocks ? S.nblocks : gx);
+          const size_t lds_f = lds_zfac > lds_sel ? lds_zfac : lds_sel;
+#define LAUNCH_ZS(M) do { allow_lds(k_zf_sel<M>, lds_f); \
+            hipLaunchKernelGGL((k_zf_sel<M>), dim3(zf_blocks + gx, nb), dim3(256), lds_f, sz, L, S, lutB, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm, zf_blocks); } while (0)
+          const int mm = params[0].mass_model;
+          if (mm == 0) LAUNCH_ZS(0); else if (mm == 1) LAUNCH_ZS(1); else LAUNCH_ZS(2);
+#undef LAUNCH_ZS
+        } else if (zf_stats) { allow_lds((k_zfactors<true, true>), lds_zfac);
           hipLaunchKernelGGL((k_zfactors<true, true>), dim3(zf_blocks, nb), dim3(256), lds_zfac, sz, L, dp, c.zt, c.It, Tc, zf_mode);
         } else if (tab_zfac) { allow_lds(k_zfactors<true>, lds_zfac);
           hipLaunchKernelGGL(k_zfactors<true>, dim3(zf_blocks, nb), dim3(256), lds_zfac, sz, L, dp, c.zt, c.It, Tc, zf_mode);
@@ -847,7 +866,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         hipLaunchKernelGGL(k_full_kde, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp);
       } else if (L.mode == CHM_MODE_MARG) {
-        if (marg_std) { if (!zf_stats) hipLaunchKernelGGL(k_event_stats, dim3((L.E_cnt + 255) / 256, nb), dim3(256), 0, sg, L); }
+        if (marg_std) { if (!zf_stats && !fuse_sel) hipLaunchKernelGGL(k_event_stats, dim3((L.E_cnt + 255) / 256, nb), dim3(256), 0, sg, L); }
         else hipLaunchKernelGGL(k_event_prep, dim3((L.E_cnt + 3) / 4, nb), dim3(256), 0, sg, L, 1);
         HIPCHK(hipGetLastError());
         if (zf_ranged) { launch_zfactors(); HIPCHK(hipGetLastError()); }
@@ -880,7 +899,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       HIPCHK(hipGetLastError());
       if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 3], sg));
     }
-    if (!serial) { HIPCHK(hipEventRecord(c.evb[0], sB)); HIPCHK(hipStreamWaitEvent(sA, c.evb[0], 0)); }   // join the two lanes
+    if (!one_stream) { HIPCHK(hipEventRecord(c.evb[0], sB)); HIPCHK(hipStreamWaitEvent(sA, c.evb[0], 0)); }   // join the two lanes
     if (timing_all) HIPCHK(hipEventRecord(c.ev[3], sA));
     // per-event log-likelihoods and their block sums
     nblk_ev = (L0.E + 255) / 256;
@@ -889,7 +908,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   }
   // ---- selection function on its own stream, forked after the tables.  Enqueued AFTER the event kernels: every API call between the
   //      table kernel and the sample stage is stream time the GPU idles (k_tables is 19 us; the fork used to cost 23 us there)
-  if (sel) {
+  if (sel && !fuse_sel) {
     HIPCHK(hipStreamWaitEvent(sC, c.ev[1], 0));
     SelDev S = sel->S;
     S.tab_pm = td.pm_i; S.tab_rate = td.rate_i; S.tab_bkg = td.bkg_i; S.tab_jac = td.jac_i;
@@ -934,7 +953,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
                        (const double*)like->L.like_pix, c.d_evpart, d_lle, d_nle);
     HIPCHK(hipGetLastError());
   }
-  if (sel) HIPCHK(hipStreamWaitEvent(sA, c.evb[2], 0));     // join: selection sums
+  if (sel && !fuse_sel) HIPCHK(hipStreamWaitEvent(sA, c.evb[2], 0));     // join: selection sums
   if (one_kernel) {
     hipLaunchKernelGGL(k_reduce_final, dim3(nb), dim3(1024), 0, sA, like ? like->L.E : 0, like ? (like->L.P > 0 ? like->L.P : 1) : 1,
                        like ? (const double*)like->L.like_pix : nullptr, sel ? sel->S.nblocks : 0,
@@ -979,7 +998,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     if (out->N_exp) out->N_exp[b] = c.h_out[b * 3 + 2];
     if (out->partials) for (int k = 0; k < 3; k++) out->partials[b * 3 + k] = c.h_out[3 * nb + b * 3 + k];
   }
-  c.t_ngroups = ngroups; c.t_like = like != nullptr; c.t_sel = sel != nullptr; c.t_valid = timing; c.t_all = timing_all;
+  c.t_ngroups = ngroups; c.t_like = like != nullptr; c.t_sel = sel != nullptr && !fuse_sel;      // fused: the selection sums have no span of their own c.t_valid = timing; c.t_all = timing_all;
   return CHM_OK;
 }
 

@@ -1103,12 +1103,12 @@ __global__ void __launch_bounds__(256) k_grid_prep(int E, int Z, const double* z
 
 // STATS (few draws per call, ranged == 1): the wave forms its event's statistics itself and writes them for the GW kernel -- no k_event_stats
 // launch in front of this kernel
-template <bool LDS_TAB, bool STATS = false>
-__global__ void __launch_bounds__(256, CHM_ZF_WPE) k_zfactors(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
-                                                   int TcMax, int ranged) {
+// (body shared by k_zfactors and k_zf_sel: block bx of nbx, draw b)
+template <bool LDS_TAB, bool STATS>
+DEVFN void zfactors_body(const LikeDev& L, const DevParams* params, const double* zt_all, const double* It_all, int TcMax, int ranged,
+                         const int b, const int bx, const int nbx, double* lds) {
 #pragma clang fp contract(fast)                  // smooth per-z factors: a*b+c may fuse (jnp_interp keeps the default, off)
-  extern __shared__ double lds[];
-  const int b = blockIdx.y, t = threadIdx.x, nt = blockDim.x;
+  const int t = threadIdx.x, nt = blockDim.x;
   const DevParams P = params[b];      // by value: uniform loads at kernel start -> scalar registers, nothing re-read in the loops
   const double* zt = zt_all + (size_t)b * TcMax;
   const double* It = It_all + (size_t)b * TcMax;
@@ -1122,7 +1122,7 @@ __global__ void __launch_bounds__(256, CHM_ZF_WPE) k_zfactors(LikeDev L, const D
   // ranged: a WAVE per event (the support of an event's KDE is ~Z/3 points: 64-lane passes waste less than 256-thread ones);
   // whole grids: the block walks over the events
   const int lane0 = ranged ? (t & 63) : t, stride = ranged ? 64 : nt;
-  const int ev_first = ranged ? blockIdx.x * (nt >> 6) + (t >> 6) : blockIdx.x, ev_step = ranged ? gridDim.x * (nt >> 6) : gridDim.x;
+  const int ev_first = ranged ? bx * (nt >> 6) + (t >> 6) : bx, ev_step = ranged ? nbx * (nt >> 6) : nbx;
   for (int ei = ev_first; ei < L.E_cnt; ei += ev_step) {
     const int e = L.e_off + ei;
     const size_t zo = ((size_t)b * L.E + e) * Z;
@@ -1183,6 +1183,13 @@ __global__ void __launch_bounds__(256, CHM_ZF_WPE) k_zfactors(LikeDev L, const D
       }
     }
   }
+}
+
+template <bool LDS_TAB, bool STATS = false>
+__global__ void __launch_bounds__(256, CHM_ZF_WPE) k_zfactors(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
+                                                   int TcMax, int ranged) {
+  extern __shared__ double lds[];
+  zfactors_body<LDS_TAB, STATS>(L, params, zt_all, It_all, TcMax, ranged, blockIdx.y, blockIdx.x, gridDim.x, lds);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2182,14 +2189,13 @@ __global__ void __launch_bounds__(256) k_selection(SelDev Sd, const DevParams* p
 #ifndef CHM_SELF_MINW
 #define CHM_SELF_MINW 3
 #endif
+// (body shared by k_selection_fast and k_zf_sel: block bx of nbx, draw b; red: 16 doubles of LDS)
 template <int MASS>
-__global__ void __launch_bounds__(256, CHM_SELF_MINW) k_selection_fast(SelDev Sd, LutDesc lut, const DevParams* params, const double* zt_all,
-                                                             const double* dLt_all, const double* mg_all, const double* cdf_all,
-                                                             const double* rec_all, int TcMax, int TmMax) {
+DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevParams* params, const double* zt_all, const double* dLt_all,
+                               const double* mg_all, const double* cdf_all, const double* rec_all, int TcMax, int TmMax,
+                               const int b, const int bx, const int nbx, double* lds, double* red) {
 #pragma clang fp contract(fast)
-  extern __shared__ double lds[];
-  __shared__ double red[16];
-  const int b = blockIdx.y, t = threadIdx.x;
+  const int t = threadIdx.x;
 #ifdef CHM_SELF_PLDS
   __shared__ DevParams Ps;
   if (t == 0) Ps = params[b];
@@ -2224,7 +2230,7 @@ __global__ void __launch_bounds__(256, CHM_SELF_MINW) k_selection_fast(SelDev Sd
   __syncthreads();
   double s1 = 0., s2 = 0.;
   const long long I = Sd.I;
-  for (long long base = (long long)blockIdx.x * SEL_TILE; base < I; base += (long long)gridDim.x * SEL_TILE) {
+  for (long long base = (long long)bx * SEL_TILE; base < I; base += (long long)nbx * SEL_TILE) {
 #pragma unroll 1
     for (int off = 2 * t; off < SEL_TILE; off += 512) {
       const long long i = base + off;
@@ -2278,9 +2284,33 @@ __global__ void __launch_bounds__(256, CHM_SELF_MINW) k_selection_fast(SelDev Sd
   s2 = block_reduce<RED_SUM>(s2, red);
   if (threadIdx.x == 0) {                           // the grid may hold fewer blocks than the partial array has records: the rest are zeros
     double* o = Sd.partial + (size_t)b * Sd.nblocks * 2;
-    o[2 * blockIdx.x] = s1; o[2 * blockIdx.x + 1] = s2;
-    for (int x = blockIdx.x + gridDim.x; x < Sd.nblocks; x += gridDim.x) { o[2 * x] = 0.; o[2 * x + 1] = 0.; }
+    o[2 * bx] = s1; o[2 * bx + 1] = s2;
+    for (int x = bx + nbx; x < Sd.nblocks; x += nbx) { o[2 * x] = 0.; o[2 * x + 1] = 0.; }
   }
+}
+
+template <int MASS>
+__global__ void __launch_bounds__(256, CHM_SELF_MINW) k_selection_fast(SelDev Sd, LutDesc lut, const DevParams* params, const double* zt_all,
+                                                             const double* dLt_all, const double* mg_all, const double* cdf_all,
+                                                             const double* rec_all, int TcMax, int TmMax) {
+  extern __shared__ double lds[];
+  __shared__ double red[16];
+  selection_fast_body<MASS>(Sd, lut, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.y, blockIdx.x, gridDim.x, lds, red);
+}
+
+// k_zf_sel<MASS>: the per-z factors (with the event statistics: zfactors_body<true, true>) and the selection sums in ONE launch -- blocks
+// [0, zf_blocks) do the former, the rest the latter.  For calls of few draws (the scalar call): the selection function then needs no stream
+// of its own, the captured graph is a plain chain (hipGraphLaunch 10 instead of 39 us) and the selection kernel's 16 us hide behind the
+// per-z factors instead of competing with the sample stage.
+template <int MASS>
+__global__ void __launch_bounds__(256, CHM_SELF_MINW) k_zf_sel(LikeDev L, SelDev Sd, LutDesc lut, const DevParams* params, const double* zt_all,
+                                                     const double* It_all, const double* dLt_all, const double* mg_all, const double* cdf_all,
+                                                     const double* rec_all, int TcMax, int TmMax, int zf_blocks) {
+  extern __shared__ double lds[];
+  __shared__ double red[16];
+  if ((int)blockIdx.x < zf_blocks) zfactors_body<true, true>(L, params, zt_all, It_all, TcMax, 1, blockIdx.y, blockIdx.x, zf_blocks, lds);
+  else selection_fast_body<MASS>(Sd, lut, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.y, blockIdx.x - zf_blocks,
+                                 gridDim.x - zf_blocks, lds, red);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -21,21 +21,20 @@ for f in glob.glob(os.path.join(d, '*', '*kernel_trace.csv')):
   for r in csv.DictReader(open(f)):
     rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0].replace('void ', '')))
 rows.sort()
-# calls start at k_tables
-starts = [i for i, r in enumerate(rows) if r[2].startswith('k_tables')]
+# calls start at k_tables; only full evaluations count (bench.py ends with a few selection-only calls: chm_eval(NULL, sel, ...))
+st = [i for i, r in enumerate(rows) if r[2].startswith('k_tables')]
+calls = [rows[a:b] for a, b in zip(st, st[1:] + [len(rows)]) if any(r[2].startswith('k_kde_marg') for r in rows[a:b])]
+calls = calls[-61:-1]                                        # the last complete ones
 lines = []
-per_call = []
-for a, b in zip(starts[-60:-1], starts[-59:]):
-  call = rows[a:b]
-  per_call.append((call[-1][1] - call[0][0]) * 1e-3)
-a, b = starts[-2], starts[-1]
-call = rows[a:b]
+per_call = sorted((c[-1][1] - c[0][0]) * 1e-3 for c in calls)
+period = sorted((b[0][0] - a[0][0]) * 1e-3 for a, b in zip(calls[:-1], calls[1:]))
+call = calls[-1]
 t0 = call[0][0]
-lines.append('one scalar call (last complete one of the trace); times in us relative to the start of k_tables')
-for s, e, n in call:
-  lines.append('%8.1f %8.1f  %6.1f us  %s' % ((s - t0) * 1e-3, (e - t0) * 1e-3, (e - s) * 1e-3, n))
-lines.append('first kernel start -> last kernel end: %.1f us; median over the last %d calls %.1f us' % ((call[-1][1] - t0) * 1e-3, len(per_call), sorted(per_call)[len(per_call) // 2]))
-lines.append('start-to-start of consecutive calls (median): %.1f us' % sorted((rows[y][0] - rows[x][0]) * 1e-3 for x, y in zip(starts[-60:-1], starts[-59:]))[29])
+lines.append('one scalar call (a late one of the trace); times in us relative to the start of k_tables')
+for s_, e_, n_ in call:
+  lines.append('%8.1f %8.1f  %6.1f us  %s' % ((s_ - t0) * 1e-3, (e_ - t0) * 1e-3, (e_ - s_) * 1e-3, n_))
+lines.append('first kernel start -> last kernel end: %.1f us; median over %d calls %.1f us' % ((call[-1][1] - t0) * 1e-3, len(per_call), per_call[len(per_call) // 2]))
+lines.append('start-to-start of consecutive calls (median): %.1f us' % period[len(period) // 2])
 open(out, 'w').write('\n'.join(lines) + '\n')
 print('\n'.join(lines))
 shutil.rmtree(d, ignore_errors=True)
