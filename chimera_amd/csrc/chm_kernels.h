@@ -171,36 +171,11 @@ struct LutDesc { int key0, nk, cap, pad; unsigned short* lut; int* info; };
 DEVFN int lut_key(double x, int key0) { return (__double2hiint(x) >> LUT_SHIFT) - key0; }
 DEVFN double lut_key_floor(int key) { return __hiloint2double(key << LUT_SHIFT, 0); }
 
-// build one draw's LUT from its dL table (tab: LDS or global, Tc entries); every thread of the block calls it.  ks: LDS scratch of
-// nk + 1 ints (one search per key; the neighbour's answer gives the number of entries a key spans)
-template <class Acc>
-DEVFN void build_lut(const LutDesc& D, int b, Acc tab, int Tc, bool sorted, double* sh, int* ks) {
-  if (D.nk <= 0) return;
-  unsigned short* lut = D.lut + (size_t)b * (D.nk + 1);
-  for (int k = threadIdx.x; k <= D.nk; k += blockDim.x) {
-    const int c0 = searchsorted_right(tab, Tc, lut_key_floor(D.key0 + k));
-    lut[k] = (unsigned short)c0;
-    ks[k] = c0;
-  }
-  __syncthreads();
-  int lm = 0;
-  for (int k = threadIdx.x; k < D.nk; k += blockDim.x) lm = max(lm, ks[k + 1] - ks[k]);
-  const double lmax = block_reduce<RED_MAX>((double)lm, sh);
-  if (threadIdx.x == 0) {
-    const int first = ks[0], last = ks[D.nk];
-    const int i_lo = first > 0 ? first - 1 : 0, i_hi = last + 1 < Tc ? last + 1 : Tc - 1;
-    int* info = D.info + (size_t)b * 4;
-    info[0] = i_lo; info[1] = i_hi - i_lo + 1; info[2] = (int)lmax;
-    info[3] = (sorted && i_hi - i_lo + 1 <= D.cap && Tc <= 65535) ? 1 : 0;
-  }
-  __syncthreads();
-}
-
 #ifdef CHM_TABLES_PROF
 #define TS_INIT long long ts_[9]; int ts_n = 0
 #define TS(i) do { __syncthreads(); ts_[ts_n++] = wall_clock64(); } while (0)
-#define TS_PRINT do { if (t == 0 && b == 0) printf("[k_tables phases, x10 ns] params %lld | nodes+1/E %lld | cumtrapz %lld | dL %lld | flags %lld | luts %lld | records %lld | fR %lld\n", \
-  ts_[0] - ts_[0], ts_[1] - ts_[0], ts_[2] - ts_[1], ts_[3] - ts_[2], ts_[4] - ts_[3], ts_[5] - ts_[4], ts_[6] - ts_[5], ts_[7] - ts_[6]); } while (0)
+#define TS_PRINT do { if (t == 0 && b == 0) printf("[k_tables phases, x10 ns] nodes+1/E %lld | cumtrapz %lld | dL %lld | flags + index tables + records + fR %lld\n", \
+  ts_[1] - ts_[0], ts_[2] - ts_[1], ts_[3] - ts_[2], ts_[4] - ts_[3]); } while (0)
 #else
 #define TS_INIT
 #define TS(i)
@@ -214,10 +189,12 @@ __global__ void __launch_bounds__(LDS_ARR ? 1024 : 512) k_tables(DevParams* para
                                                   LutDesc lutA, LutDesc lutB, double* rec_all, const double* tab_zt, const double* tab_dLt, const DevParams* hsrc) {
   extern __shared__ double larr[];
   __shared__ double sh[32];
-  __shared__ int lut_ks[LUT_MAXKEYS + 1];           // build_lut: searchsorted answer of every key
+  __shared__ int lut_ks[LUT_MAXKEYS + 1];           // searchsorted answer of every key of the direct-index tables
+  __shared__ int s_int[8];                          // [0] first non-finite node of the integral, [1], [2] widest key of table A / B, [3], [4] brackets of the completeness limits
   __shared__ DevParams Ps;                          // block-local copy of the draw: constants derived here are shared through LDS
   const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
   DevParams& Pg = params[b];
+  if (t == 0) { s_int[0] = 0x7fffffff; s_int[1] = 0; s_int[2] = 0; s_int[3] = -1; s_int[4] = -1; }
   if (t < (int)(sizeof(DevParams) / sizeof(double))) {
     // hsrc: the draw comes straight from the pinned host copy (no copy node in front of this kernel); block y = 1 then fills the device
     // copy the later kernels read -- every field except the ones block y = 0 derives below (disjoint stores, no ordering needed)
@@ -283,28 +260,30 @@ __global__ void __launch_bounds__(LDS_ARR ? 1024 : 512) k_tables(DevParams* para
     }
     if (LDS_ARR) __syncthreads(); else gsync();
     TS(3);
-    // one pass over the table for two per-draw flags: z_bad, the last finite stretch of the cumulative integral (first non-finite
-    // node -> grid_is_poisoned), and dl_sorted, whether the dL table is non-decreasing (-> z_from_dGW_x2)
+    // Everything that only reads the finished tables runs between TWO barriers (each of the ~14 it took before costs ~0.4 us with 16 waves):
+    //   per-draw flags   z_bad, the last finite stretch of the cumulative integral (first non-finite node -> grid_is_poisoned), and
+    //                    dl_sorted, whether the dL table is non-decreasing (-> z_from_dGW_x2)
+    //   direct-index tables of the dL table (`tmp`) for the posterior samples (lutA) and the injections (lutB): one search per key
+    //   node records of the fast sample stage: rec[i] = { dL_i, z_i, slope of z(dL) on [node i, node i+1], log(1 + z_i) }
+    //   brackets of the completeness limits on the z table (fR = Vc(z1) - Vc(z0), completeness.py:54-58)
     {
-      double first = 1e300;
       int bad = 0;
       for (int i = t; i < Tc; i += nt) {
-        if (!(fabs(It[i]) <= 1.7976931348623157e308)) first = fmin(first, (double)i);
+        if (!(fabs(It[i]) <= 1.7976931348623157e308)) atomicMin(&s_int[0], i);
         if (i > 0) bad |= ((tmp[i] < tmp[i - 1]) || (tmp[i] != tmp[i])) ? 1 : 0;
       }
-      first = block_reduce<RED_MIN>(first, sh);
-      bad = __syncthreads_or(bad);
-      if (t == 0) {
-        int j = (int)fmin(first, 1e9);
-        Pg.z_bad = first < 1e299 ? zt[j > 0 ? j - 1 : 0] : __builtin_inf();
-        Pg.dl_sorted = bad ? 0. : 1.;
-      }
-    TS(4);
-      // direct-index tables of the dL table (`tmp`) for the posterior samples (lutA) and the injections (lutB)
-      build_lut(lutA, b, (const double*)tmp, Tc, !bad, sh, lut_ks);
-      build_lut(lutB, b, (const double*)tmp, Tc, !bad, sh, lut_ks);
-    TS(5);
-      // node records of the fast sample stage: rec[i] = { dL_i, z_i, slope of z(dL) on [node i, node i+1], log(1 + z_i) }
+      const int nkA = lutA.nk > 0 ? lutA.nk + 1 : 0, nkB = lutB.nk > 0 ? lutB.nk + 1 : 0;      // entries of each table (keys + 1)
+      int* ksA = lut_ks; int* ksB = lut_ks + nkA;
+      auto search = [&](const LutDesc& D, int* ks, int n) {
+        unsigned short* lut = D.lut + (size_t)b * n;
+        for (int q = t; q < n; q += nt) {
+          const int c0 = searchsorted_right((const double*)tmp, Tc, lut_key_floor(D.key0 + q));
+          lut[q] = (unsigned short)c0; ks[q] = c0;
+        }
+      };
+      const bool lut_both = nkA + nkB <= LUT_MAXKEYS + 1;         // both tables' answers fit the scratch (else B follows A, below)
+      if (nkA) search(lutA, ksA, nkA);
+      if (nkB && lut_both) search(lutB, ksB, nkB);
       if (rec_all) {
         double* rec = rec_all + (size_t)b * TcMax * 4;
         for (int i = t; i < Tc; i += nt) {
@@ -314,17 +293,55 @@ __global__ void __launch_bounds__(LDS_ARR ? 1024 : 512) k_tables(DevParams* para
           rec[4 * i] = x0; rec[4 * i + 1] = f0; rec[4 * i + 2] = sl; rec[4 * i + 3] = log1p(f0);
         }
       }
+      for (int i = t + 1; i < Tc; i += nt) {                      // interval (i-1, i): zt[i-1] <= x < zt[i]  (searchsorted right), as block_interp
+        if (zt[i - 1] <= P.zc0 && (P.zc0 < zt[i] || i == Tc - 1)) s_int[3] = i;
+        if (zt[i - 1] <= P.zc1 && (P.zc1 < zt[i] || i == Tc - 1)) s_int[4] = i;
+      }
+      bad = __syncthreads_or(bad);                                // barrier 1
+      auto spans = [&](const int* ks, int n, int slot) {
+        int lm = 0;
+        for (int q = t; q + 1 < n; q += nt) lm = max(lm, ks[q + 1] - ks[q]);
+        if (lm > 0) atomicMax(&s_int[slot], lm);
+      };
+      if (nkA) spans(ksA, nkA, 1);
+      if (nkB && lut_both) spans(ksB, nkB, 2);
+      __syncthreads();                                            // barrier 2
+      auto info = [&](const LutDesc& D, const int* ks, int n, int slot) {
+        const int first = ks[0], last = ks[n - 1];
+        const int i_lo = first > 0 ? first - 1 : 0, i_hi = last + 1 < Tc ? last + 1 : Tc - 1;
+        int* o = D.info + (size_t)b * 4;
+        o[0] = i_lo; o[1] = i_hi - i_lo + 1; o[2] = s_int[slot];
+        o[3] = (!bad && i_hi - i_lo + 1 <= D.cap && Tc <= 65535) ? 1 : 0;
+      };
+      auto interp_at = [&](double x, int i) {                     // jnp.interp(x, zt, It) from the published bracket (block_interp's arithmetic)
+        if (i < 1) i = 1;
+        const double f0 = It[i - 1], f1 = It[i], x0 = zt[i - 1], dx = zt[i] - x0;
+        double f = (fabs(dx) <= 4.930380657631324e-32) ? f0 : f0 + ((x - x0) / dx) * (f1 - f0);
+        if (x < zt[0]) f = It[0];
+        if (x > zt[Tc - 1]) f = It[Tc - 1];
+        return f;
+      };
+      if (t == 0) {
+        const int j = s_int[0];
+        Pg.z_bad = j < 0x7fffffff ? zt[j > 0 ? j - 1 : 0] : __builtin_inf();
+        Pg.dl_sorted = bad ? 0. : 1.;
+        if (nkA) info(lutA, ksA, nkA, 1);
+        if (nkB && lut_both) info(lutB, ksB, nkB, 2);
+        const double v0 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * interp_at(P.zc0, s_int[3])));
+        const double v1 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * interp_at(P.zc1, s_int[4])));
+        Pg.fR = P.fR_given != 0. ? P.fR : v1 - v0;      // a plug-in completeness hands its own fR(cosmo) over (chm_tab.fR)
+      }
+      if (nkB && !lut_both) {                                     // > 64 octaves of distances in all: the second table on its own
+        __syncthreads();
+        if (t == 0) s_int[2] = 0;
+        search(lutB, lut_ks, nkB);
+        __syncthreads();
+        spans(lut_ks, nkB, 2);
+        __syncthreads();
+        if (t == 0) info(lutB, lut_ks, nkB, 2);
+      }
     }
-    TS(6);
-    // fR = Vc(z1) - Vc(z0)                                                       completeness.py:54-58
-    double i0 = block_interp(P.zc0, zt, It, Tc, sh);
-    double i1 = block_interp(P.zc1, zt, It, Tc, sh);
-    if (t == 0) {
-      double v0 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * i0));
-      double v1 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * i1));
-      Pg.fR = P.fR_given != 0. ? P.fR : v1 - v0;      // a plug-in completeness hands its own fR(cosmo) over (chm_tab.fR)
-    }
-    TS(7); TS_PRINT;
+    TS(4); TS_PRINT;
   } else {
     double* mg = LDS_ARR ? larr : g_mg;
     double* tmp = LDS_ARR ? larr + Tm : g_tmp;
