@@ -998,7 +998,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     if (out->N_exp) out->N_exp[b] = c.h_out[b * 3 + 2];
     if (out->partials) for (int k = 0; k < 3; k++) out->partials[b * 3 + k] = c.h_out[3 * nb + b * 3 + k];
   }
-  c.t_ngroups = ngroups; c.t_like = like != nullptr; c.t_sel = sel != nullptr && !fuse_sel;      // fused: the selection sums have no span of their own c.t_valid = timing; c.t_all = timing_all;
+  c.t_ngroups = ngroups; c.t_like = like != nullptr; c.t_sel = sel != nullptr && !fuse_sel; c.t_valid = timing; c.t_all = timing_all;      // (fused: the selection sums have no span of their own)
   return CHM_OK;
 }
 

@@ -788,3 +788,16 @@ def test_vectorised_call_and_sampler_glue(cfg_pix):
   assert lp[2] == -np.inf and np.all(lp[:2] == np.array([like(H0=h, alpha=a) for h, a in zip(H0[:2], al[:2])]))
   with pytest.raises(ValueError):
     like(H0=np.array([60., 70.]), alpha=np.array([3., 3.1, 3.2]))
+
+
+def test_last_timing_reports_the_stages_of_an_eager_call(cfg_pix):
+  """bench.py's roofline block divides by these HIP-event durations: a batched (eager) call must report positive times for the whole
+  evaluation, the sample stage, the GW kernel and the selection function; a graph-replayed scalar call carries no events (zeros)."""
+  cfg, ev, inj = cfg_pix
+  like, _, _ = H.build_product(ev, inj)
+  like.batch([dict(H0=60. + i) for i in range(12)])
+  ms = like.last_timing()
+  assert ms[0] > 0 and ms[2] > 0 and ms[3] > 0 and ms[4] > 0 and ms[0] >= ms[3], ms
+  for _ in range(4):
+    like(H0=70.)
+  assert not np.any(like.last_timing()[:7] > 0)
