@@ -801,3 +801,34 @@ def test_last_timing_reports_the_stages_of_an_eager_call(cfg_pix):
   for _ in range(4):
     like(H0=70.)
   assert not np.any(like.last_timing()[:7] > 0)
+
+
+@pytest.mark.parametrize('models', [dict(), dict(mass='bpl'), dict(mass='tpl', rate='power_law'), dict(cosmo='mg_flrw', cosmo_kw=dict(Xi0=1.6, n=2.1))],
+                         ids=['flrw-plp (k_selection_fast)', 'flrw-bpl', 'flrw-tpl-powerlaw', 'mg_flrw (k_selection)'])
+def test_selection_function_with_hostile_injections(cfg_pix, models):
+  """Injections the direct-index front end cannot key (zero, negative, NaN, infinite distances), distances below and beyond the table,
+  masses outside the population, an odd count (the last pair is half empty), duplicates: N_exp and the N_eff guard follow the
+  reference's nansum / sum (selection_function.py:38-47) in the fast and in the general kernel, batched and one draw at a time."""
+  cfg, ev, inj = cfg_pix
+  inj = {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in inj.items()}
+  n = len(inj['dL']) - (1 - len(inj['dL']) % 2)              # odd number of injections
+  for k in ('dL', 'm1det', 'm2det', 'p_draw'):
+    inj[k] = inj[k][:n]
+  inj['dL'][:12] = [0., -3., 1e-12, 1e-6, 2e6, 7e4, 1e-300, 5e-324, 1e300, inj['dL'][20], inj['dL'][20], 3e-3]
+  inj['m1det'][30:36] *= 60.
+  inj['m2det'][36:42] *= 1e-3
+  for bad in (None, np.nan, np.inf):
+    if bad is not None:
+      inj['dL'][13] = bad
+    for N_eff in (None, 5.):
+      _, pop_o, sel_o = H.build_oracle(ev, inj, models=models, N_eff=N_eff)
+      like_p, pop_p, sel_p = H.build_product(ev, inj, models=models, N_eff=N_eff)
+      lams = [dict(H0=58.), dict(H0=70.), dict(H0=93., Om0=0.4)] + [dict(H0=60. + j) for j in range(9)]
+      with np.errstate(all='ignore'):
+        ref = np.array([sel_o.N_exp(pop_o.update(**l)) for l in lams])
+      one = np.array([sel_p.N_exp(pop_p.update(**l)) for l in lams])
+      np.testing.assert_allclose(one, ref, rtol=1e-10, equal_nan=True)
+      allp = like_p.compute_all(**lams[1])
+      with np.errstate(all='ignore'):
+        assert np.isclose(np.exp(allp[2]), ref[1], rtol=1e-10, equal_nan=True) or (ref[1] == 0. and allp[2] == -np.inf)
+      like_p.close(); sel_p.close()
