@@ -696,7 +696,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   static const bool fuse_env = getenv("CHM_NO_ZF_SEL") == nullptr;
   const size_t lds_zfac_call = sizeof(double) * (size_t)2 * c.TcMax;
   const bool fuse_sel = fuse_env && !serial && like && sel && sel_fast && nb <= few_nb && !comm && !td.rate_g && !td.bkg_g && !td.jac_g &&
-                        like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && !getenv("CHM_MARG_GENERIC") && !getenv("CHM_ZF_FULL") &&
+                        like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && !getenv("CHM_MARG_GENERIC") && !getenv("CHM_ZF_FULL") &&
                         !getenv("CHM_GROUPS") && lds_zfac_call <= 64 * 1024 && like->L.E <= 65535;
   const bool one_stream = serial || fuse_sel;
   if (fuse_sel) { sB = sA; sC = sA; }
@@ -793,7 +793,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       const bool zf_ranged = (L.mode == CHM_MODE_MARG || L.mode == CHM_MODE_1D || L.mode == CHM_MODE_APPROX) && !getenv("CHM_ZF_FULL");
       // standard configuration (binning, cut_grid set) -> k_kde_marg_sub<32>, two pixels per wave (16 lanes per pixel measured
       // 30 % slower: 19 KB of LDS per wave halve the occupancy); anything else, or CHM_MARG_GENERIC=1, -> the general kernel
-      const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && !getenv("CHM_MARG_GENERIC");
+      const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && (L.Z & 1) == 0 && !getenv("CHM_MARG_GENERIC");
       const int zf_mode = !zf_ranged ? 0 : (L.mode == CHM_MODE_MARG ? 1 : 2);
       hipStream_t sz = (one_stream || zf_ranged) ? sg : ((g & 1) ? sA : sB);
       // ~2048 blocks in all: each stages the draw's (zt, It) tables in LDS once and walks over E_cnt / gridDim.x events
@@ -880,9 +880,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
           // (few draws per call: two items per wave -- twice the waves, half the serial chain of each: 0.238 -> 0.229 ms for the scalar call at C3)
           const int ipw = ipw_env == 2 || ipw_env == 4 ? ipw_env : ((PG2 >= 4 && nb > 8) ? 4 : 2);
           const size_t lds_sub = sizeof(double) * (3 * N + 3) * 2;
-#define LAUNCH_SUB2(I, BN) hipLaunchKernelGGL((k_kde_marg_sub2<32, I, BN>), dim3(nb, (PG2 + I - 1) / I, L.E_cnt), dim3(64), lds_sub, sg, L, dp)
-          if (L.num_bins == 200) { if (ipw == 4) LAUNCH_SUB2(4, 200); else LAUNCH_SUB2(2, 200); }      // the reference's default bin count (likelihood.py:59): compile-time
-          else { if (ipw == 4) LAUNCH_SUB2(4, 0); else LAUNCH_SUB2(2, 0); }
+#define LAUNCH_SUB2(I, BN, DU) hipLaunchKernelGGL((k_kde_marg_sub2<32, I, BN, DU>), dim3(nb, (PG2 + I - 1) / I, L.E_cnt), dim3(64), lds_sub, sg, L, dp)
+          if (L.p_gw_dump) { if (ipw == 4) LAUNCH_SUB2(4, 0, true); else LAUNCH_SUB2(2, 0, true); }    // p_gw3d requested (tests, hyperlikelihood.p_gw3d): the instantiation that stores it
+          else if (L.num_bins == 200) { if (ipw == 4) LAUNCH_SUB2(4, 200, false); else LAUNCH_SUB2(2, 200, false); }      // the reference's default bin count (likelihood.py:59): compile-time
+          else { if (ipw == 4) LAUNCH_SUB2(4, 0, false); else LAUNCH_SUB2(2, 0, false); }
 #undef LAUNCH_SUB2
           // events whose summed rounding bound matters against L_i (3e-10; the stated tolerance on L_i is 1e-9) get their heavy pixels redone with dense sums
           if (!L.no_dense) { HIPCHK(hipGetLastError()); allow_lds(k_marg_fixup, lds_kde); hipLaunchKernelGGL(k_marg_fixup, dim3(L.E_cnt, nb), dim3(64), lds_kde, sg, L, dp, 3e-10); }

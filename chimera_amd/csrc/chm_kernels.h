@@ -25,7 +25,6 @@ enum { PT_SW = 0, PT_SW2, PT_SD1, PT_SD2, PT_ZMIN, PT_ZMAX, PT_WD0, PT_WD1, PT_W
 #define SAMPLE_CHUNK 4096
 #define SAMPLE_WPB 8                   // waves per block of k_samples (512 threads): one partial record per wave and chunk
 #define NEVSTAT 12           // doubles per (draw, event) written by k_event_prep
-#define KDE_STASH 4           // doubles behind a pixel's three sum arrays in LDS (kde_sub_item -> kde_sub_item_robust)
 
 struct LikeDev {                  // device-resident shard of events (see chm_like_desc)
   int E, S, Z, P;
@@ -1041,6 +1040,9 @@ DEVFN void event_stats(const LikeDev& L, int b, int e, double* es) {
     if (fl == fl && fh == fh && gl <= gh && (gl == 0 || zg[gl] < lb) && (gh == Z - 1 || zg[gh] > ub)) { k_lo = gl; k_hi = gh; }
   }
   es[0] = st.zmin; es[1] = st.zmax; es[2] = st.sd; es[3] = st.norm; es[4] = st.n_eff; es[5] = st.sumw; es[6] = lb; es[7] = ub;
+  // pairs (k, k + 1), k even: the range starts at an even and ends at an odd grid point (one more point on either side at most; the
+  // standard GW kernel handles both points of a pair together, the per-z factors cover exactly [k_lo, k_hi])
+  k_lo &= ~1; k_hi = min(k_hi | 1, Z - 1);
   es[8] = (double)k_lo; es[9] = (double)k_hi;
   es[10] = (ub - lb) / (double)(L.G - 1); es[11] = (double)(L.G - 1) / (ub - lb);
 }
@@ -1446,13 +1448,14 @@ template <int SW> DEVFN double sg_last(double x, int sub) {
   return __hiloint2double(rh, rl);
 }
 // running maximum towards the last lane of the group (v_max_f64: NaN-ignoring; callers vote on NaNs separately)
+DEVFN double vmax_f64(double a, double b);
 template <int SW> DEVFN double sg_scan_max(double x) {
-  x = __builtin_fmax(x, dpp_move<0x111, 0xf, false>(x));
-  x = __builtin_fmax(x, dpp_move<0x112, 0xf, false>(x));
-  x = __builtin_fmax(x, dpp_move<0x114, 0xf, false>(x));
-  x = __builtin_fmax(x, dpp_move<0x118, 0xf, false>(x));
-  if (SW >= 32) x = __builtin_fmax(x, dpp_move<0x142, 0xa, false>(x));
-  if (SW >= 64) x = __builtin_fmax(x, dpp_move<0x143, 0xc, false>(x));
+  x = vmax_f64(x, dpp_move<0x111, 0xf, false>(x));
+  x = vmax_f64(x, dpp_move<0x112, 0xf, false>(x));
+  x = vmax_f64(x, dpp_move<0x114, 0xf, false>(x));
+  x = vmax_f64(x, dpp_move<0x118, 0xf, false>(x));
+  if (SW >= 32) x = vmax_f64(x, dpp_move<0x142, 0xa, false>(x));
+  if (SW >= 64) x = vmax_f64(x, dpp_move<0x143, 0xc, false>(x));
   return x;
 }
 
@@ -1478,112 +1481,167 @@ template <int SW> DEVFN double sg_max(double v) {
 #ifndef CHM_NRS
 #define CHM_NRS 256
 #endif
-template <int SW, int NR, int BINS>
+// Instruction-level helpers of the standard GW kernel.  On gfx950 every VALU instruction except the simplest 32-bit ones (v_mov_b32,
+// v_add/sub_u32, v_and_b32, v_ashrrev_i32, v_fma/mul_f32) occupies the SIMD for 4 cycles per wave64 -- fp64 arithmetic, 64-bit moves,
+// v_cndmask, v_med3, DPP moves and v_readlane alike (profiles/r03/issue_cost.txt) -- so the kernel is written for the fewest
+// instructions, whatever their type:
+//   * v_max_f64 / v_min_f64 as they are (llvm.maxnum/minnum put a canonicalising v_max_f64 x, x in front of every operand that was loaded);
+//   * double -> bin index on v_cvt_i32_f64 (truncates, saturates at +-2^31, NaN -> 0) and ONE v_med3_i32 for the two-sided clamp.
+DEVFN double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEVFN double vmin_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEVFN int cvt_i32_sat(double x) { int r; asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x)); return r; }
+DEVFN int med3_i32(int x, int lo, int hi) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi)); return r; }
+// DPP move of a double with zeros shifted in (bound_ctrl: no separate v_mov of the fill value) -- row_shr steps of the scans
+template <int CTRL>
+DEVFN double dpp_shr0(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi2, lo2);
+}
+// inclusive prefix sum over each group of SW consecutive lanes, 3 instructions per level inside a row of 16 lanes
+template <int SW> DEVFN double sg_scan_add0(double x) {
+  x += dpp_shr0<0x111>(x);
+  x += dpp_shr0<0x112>(x);
+  x += dpp_shr0<0x114>(x);
+  x += dpp_shr0<0x118>(x);
+  if (SW >= 32) x += dpp_move<0x142, 0xa, true>(x);       // row_bcast:15 into rows 1 and 3
+  if (SW >= 64) x += dpp_move<0x143, 0xc, true>(x);       // row_bcast:31 into rows 2 and 3
+  return x;
+}
+// running maximum towards the last lane of the group for values >= 0 (redshifts): zeros shifted in are neutral, 3 instructions per level
+template <int SW> DEVFN double sg_scan_max0(double x) {
+  x = vmax_f64(x, dpp_shr0<0x111>(x));
+  x = vmax_f64(x, dpp_shr0<0x112>(x));
+  x = vmax_f64(x, dpp_shr0<0x114>(x));
+  x = vmax_f64(x, dpp_shr0<0x118>(x));
+  if (SW >= 32) x = vmax_f64(x, dpp_move<0x142, 0xa, true>(x));
+  if (SW >= 64) x = vmax_f64(x, dpp_move<0x143, 0xc, true>(x));
+  return x;
+}
+// value of the LAST lane of this lane's group on the LDS crossbar (ds_bpermute: no VALU slots; v_readlane + v_cndmask cost ten)
+template <int SW> DEVFN double sg_last_perm(double x) {
+  const int src = ((int)threadIdx.x | (SW - 1)) << 2;
+  int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(x)), hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+
+// kde_sub_item<SW, NR, BINS, DUMP>: one pixel per group of SW lanes.  Preconditions checked by the host (chm_eval): binning with the
+// effective grid cut (cut_grid set), an even number of grid points Z (16-byte pairs (k, k+1), k even, never leave the row).
+// [r3] The grid loop was rewritten for the instruction count (191 -> ~110 VALU per pass of 2 x SW grid points):
+//   * bin ranges of a node by truncation: ja = clamp(trunc(t - hb + 1), 0, jl1) equals ceil(t - hb) except when t - hb is an integer
+//     (the bin with |u| = 1 exactly, kernel value 0), jb = clamp(trunc(t + hb + 1), ja, jl1) equals floor(t + hb) + 1 for t + hb >= 0 and
+//     clamps to ja = 0 below (t + hb < 0 implies t - hb < 0): three instructions per index instead of seven;
+//   * the prefix array of W c' is stored multiplied by -2 (exact), the node offsets of both nodes are per-pixel constants added to the
+//     bin coordinate of the lower node, scale * norm * gw_pdf and the NaN of a degenerate pixel are one factor;
+//   * the loads of a pass are unconditional (clamped pair index), both grid points of a lane sit in one exec region (k_hi is odd: event_stats),
+//     NaN grid points propagate through the interpolation weight instead of a separate test.
+template <int SW, int NR, int BINS, bool DUMP>
 DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, const double* es, const int b, const int e, const int p,
                         const int pp, const bool live, const bool poisoned, const int s0, const int s1, double (&zr)[NR], double (&wr)[NR]) {
 #pragma clang fp contract(fast)                  // a*b+c may fuse in this body; the bin index lives in bin_index_r() (contract off)
-  constexpr int PF = 1;                                     // p_cat passes requested before the histogram (1: 5.66 ms, 2: 5.75, 4: 5.84 at C3 / 128 draws)
-  const int lane = threadIdx.x, sub = lane / SW, sl = lane % SW;
+  const int lane = threadIdx.x, sl = lane % SW;
   const int S = L.S, Z = L.Z, B = BINS > 0 ? BINS : L.num_bins, G = L.G;      // BINS > 0: the bin count is a compile-time constant (LDS offsets, loop bounds)
   const double zmin = es[0], norm = es[3], lb = es[6], ub = es[7];
   double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
-  double* dump = (L.p_gw_dump && p < L.P) ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
+  double* dump = (DUMP && p < L.P) ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
   const double* zg = L.z_grids + (size_t)e * Z;
-  if (!live && p < L.P) { if (sl == 0) { *out_like = 0.; L.err_pix[((size_t)b * L.E + e) * L.P + p] = 0.; } if (dump) for (int k = sl; k < Z; k += SW) dump[k] = 0.; }
+  if (!live && p < L.P) { if (sl == 0) { *out_like = 0.; L.err_pix[((size_t)b * L.E + e) * L.P + p] = 0.; } if (DUMP) for (int k = sl; k < Z; k += SW) dump[k] = 0.; }
   const double* pc = L.p_cat + ((size_t)e * L.P + pp) * Z;
   const size_t zo = ((size_t)b * L.E + e) * Z;
   const double* bkgA = L.bkgA + zo;
   const double* Aw = L.Aw + zo;
-  int k_lo = (int)es[8], k_hi = (int)es[9];
-  k_lo &= ~1;
-  const bool vec2 = (Z & 1) == 0;                           // then every pair (k, k+1), k even, is 16-byte aligned and in bounds
-  // two consecutive grid points of one array for this lane
-  auto load2 = [&](const double* a, int k, double& v0, double& v1) {
-    v0 = 0.; v1 = 0.;
-    if (live && k <= k_hi) {
-      if (vec2) { double2 v = *reinterpret_cast<const double2*>(a + k); v0 = v.x; v1 = v.y; }
-      else { v0 = a[k]; if (k + 1 <= k_hi) v1 = a[k + 1]; }
-    }
+  const int k_lo = ((int)es[8]) & ~1, k_hi = (int)es[9];   // event_stats: k_hi is odd when Z is even -- both points of a pair are in range together
+  // two consecutive grid points of every array for this lane: 16-byte loads at a clamped (always valid) pair index -- lanes beyond k_hi
+  // load the row's last pair and never use it.  The three event-level rows are addressed as uniform base + 32-bit lane offset.
+  const int kcap = Z - 2;
+  struct Pass { double2 pc, z, bk, a; };
+  auto load_pass = [&](int k) {
+    const unsigned off = (unsigned)(k < kcap ? k : kcap) * 8u;
+    Pass q;
+    q.pc = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(pc) + off);
+    q.z = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(zg) + off);
+    q.bk = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(bkgA) + off);
+    q.a = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(Aw) + off);
+    return q;
   };
-  double pf0[PF], pf1[PF];
-#pragma unroll
-  for (int i = 0; i < PF; i++) load2(pc, k_lo + 2 * SW * i + 2 * sl, pf0[i], pf1[i]);
-  // grid, background and trapezoid factors of the first pass: in flight during the histogram phase
-  double zc0, zc1, bc0, bc1, ac0, ac1;
-  load2(zg, k_lo + 2 * sl, zc0, zc1); load2(bkgA, k_lo + 2 * sl, bc0, bc1); load2(Aw, k_lo + 2 * sl, ac0, ac1);
+  // p_cat, grid, background and trapezoid factors of the first pass: in flight during the histogram phase
+  const int k_first = k_lo + 2 * sl;
+  Pass cur = load_pass(k_first);
   // histogram of the pixel's samples on [min z, max z in pixel] (math.py:32-46, likelihood.py:180-183)
   const size_t so = ((size_t)b * L.E + e) * S;
   const double* wz = L.ws_z + so;
   const double* ww = L.ws_w + so;
   const double lo = zmin;
-  // hi = max(where(mask, z, min z)) (likelihood.py:180, math.py:36), NaN-propagating like jnp.max: v_max_f64 over the
-  // samples plus a "saw a NaN" vote of the pixel's lanes
+  // hi = max(where(mask, z, min z)) (likelihood.py:180, math.py:36).  jnp.max propagates NaN: a NaN among the pixel's z is a NaN among
+  // the event's z, and then lo -- jnp.min over all of them (combine_stats, NaN-propagating) -- is NaN already
   double hi = lo;
-  bool sawnan = lo != lo;
 #pragma unroll
-  for (int i = 0; i < NR; i++) { hi = __builtin_fmax(hi, zr[i]); sawnan = sawnan || (zr[i] != zr[i]); }
-  for (int s = s0 + sl + SW * NR; s < s1; s += SW) { double zz = wz[s]; hi = __builtin_fmax(hi, zz); sawnan = sawnan || (zz != zz); }
-  hi = sg_last<SW>(sg_scan_max<SW>(hi), sub);
-  {
-    const unsigned long long votes = __ballot(sawnan);
-    const unsigned long long mine = SW == 64 ? ~0ull : (((1ull << (SW & 63)) - 1ull) << (sub * SW));
-    if (votes & mine) hi = __builtin_nan("");
-  }
-  double* const Q0 = Q; double* const Q1 = Q + (B + 1); double* const Q2 = Q + 2 * (B + 1);      // P0 | P1 | P2, (B + 1) doubles each
+  for (int i = 0; i < NR; i++) hi = vmax_f64(hi, zr[i]);
+  for (int s = s0 + sl + SW * NR; s < s1; s += SW) hi = vmax_f64(hi, wz[s]);
+  double* const Q0 = Q; double* const Q1 = Q + (B + 1); double* const Q2 = Q + 2 * (B + 1);      // P0 | -2 P1 | P2, (B + 1) doubles each
+  hi = sg_last_perm<SW>(sg_scan_max0<SW>(hi));              // z >= 0: z_from_dGW interpolates a table that starts at z = 0 (cosmo.py:43-46)
+  if (lo != lo) hi = lo;
   for (int j = sl; j < B; j += SW) Q0[j] = 0.;
+  wave_sync();
   const double dB = (double)B;
   const double dhl = hi - lo, rhl = 1. / dhl;
   const double dbin = dhl * L.inv_B;                        // c'_j = c_j - lo = (j + 1/2) dbin for the uniform edges of math.py:37-39
-  wave_sync();
 #pragma unroll
   for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q0[bin_index_r(zr[i], lo, dhl, rhl, dB)], wr[i]); }
   for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q0[bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
   wave_sync();
-  // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins
+  // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins (a compile-time 7 for 200 bins on 32 lanes)
   const int per = (B + SW - 1) / SW;
   const int j0 = sl * per < B ? sl * per : B, j1 = min(j0 + per, B);
 #ifndef CHM_MAXPER
 #define CHM_MAXPER 8
 #endif
-  constexpr int MAXPER = CHM_MAXPER;                        // bins per lane held in registers (8: up to 256 bins at 32 lanes per pixel)
+  constexpr int MAXPER = BINS > 0 ? (BINS + SW - 1) / SW : CHM_MAXPER;      // bins per lane held in registers (8: up to 256 bins at 32 lanes per pixel)
   const bool small = per <= MAXPER;
   double wv[MAXPER];
   double s0w = 0., s1w = 0., s2w = 0., sq = 0.;
+  // bin centres of the lane's bins by repeated addition, c'_{j+1} = c'_j + dbin (one instruction per bin instead of convert, add, multiply;
+  // <= 8 roundings of 1e-16 relative on a centre, far below the bin width)
+  const double c_first = ((double)j0 + 0.5) * dbin;
   if (small) {                                              // the lane's bin counts: all loads in flight at once, summed in bin order
 #pragma unroll
     for (int i = 0; i < MAXPER; i++) wv[i] = (j0 + i < j1) ? Q0[j0 + i] : 0.;
+    double cc = c_first;
 #pragma unroll
-    for (int i = 0; i < MAXPER; i++) { double w = wv[i], cc = ((double)(j0 + i) + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
+    for (int i = 0; i < MAXPER; i++) { const double w = wv[i], t = w * cc; s0w += w; s1w += t; s2w = fma(t, cc, s2w); sq = fma(w, w, sq); cc += dbin; }
   } else {
     for (int j = j0; j < j1; j++) { double w = Q0[j], cc = ((double)j + 0.5) * dbin; s0w += w; s1w += w * cc; s2w += w * cc * cc; sq += w * w; }
   }
-  const double x0 = sg_scan_add<SW>(s0w), x1 = sg_scan_add<SW>(s1w), x2 = sg_scan_add<SW>(s2w);
-  const double tot = sg_last<SW>(x0, sub);
-  const double sum2 = sg_last<SW>(sg_scan_add<SW>(sq), sub);
+  const double x0 = sg_scan_add0<SW>(s0w), x1 = sg_scan_add0<SW>(s1w), x2 = sg_scan_add0<SW>(s2w);
+  const double tot = sg_last_perm<SW>(x0);
+  const double sum2 = sg_last_perm<SW>(sg_scan_add0<SW>(sq));
   // End of the last lane chunk of bins that holds any weight.  The prefix values of the lanes after it come out of different
   // summation trees and agree only to an ulp: a node that sees nothing but the empty bins above the data would get 1e-16 of the
   // peak where the dense sum (math.py:80) has an exact zero -- which decides log L_i when the catalogue term is only non-zero out
   // there.  The bin ranges are clipped to it (below the first weight every prefix is an exact zero already).
-  double fjl1;
+  int jl1;
   {
+    const int sub = lane / SW;
     const unsigned long long nz = __ballot(s0w != 0.);      // NaN counts as weight
     const unsigned long long mine = SW == 64 ? nz : ((nz >> (sub * (SW & 63))) & ((1ull << (SW & 63)) - 1ull));
     const int last = 63 - __clzll(mine);                    // -1: no weight at all (degenerate pixel, NaN below)
-    fjl1 = (double)min((last + 1) * per, B);
+    jl1 = min((last + 1) * per, B);
   }
   {
     double r0 = x0 - s0w, r1 = x1 - s1w, r2 = x2 - s2w;
     wave_sync();
     if (small) {
+      double cc = c_first;
 #pragma unroll
-      for (int i = 0; i < MAXPER; i++) if (j0 + i < j1) {
-        double w = wv[i], cc = ((double)(j0 + i) + 0.5) * dbin;
-        r0 += w; r1 += w * cc; r2 += w * cc * cc;
-        Q0[j0 + i + 1] = r0; Q1[j0 + i + 1] = r1; Q2[j0 + i + 1] = r2;
+      for (int i = 0; i < MAXPER; i++) {
+        const double w = wv[i], t = w * cc;
+        r0 += w; r1 += t; r2 = fma(t, cc, r2); cc += dbin;
+        if (j0 + i < j1) { Q0[j0 + i + 1] = r0; Q1[j0 + i + 1] = -2. * r1; Q2[j0 + i + 1] = r2; }
       }
     } else {                                                // many bins per lane: the count of bin j+1 shares the slot of P0[j+1]
       double a0 = r0, a1 = r1, a2 = r2;
-      for (int j = j0; j < j1; j++) { double w = Q0[j], cc = ((double)j + 0.5) * dbin; a1 += w * cc; a2 += w * cc * cc; Q1[j + 1] = a1; Q2[j + 1] = a2; }
+      for (int j = j0; j < j1; j++) { double w = Q0[j], cc = ((double)j + 0.5) * dbin; a1 += w * cc; a2 += w * cc * cc; Q1[j + 1] = -2. * a1; Q2[j + 1] = a2; }
       a0 = r0; for (int j = j0; j < j1; j++) a0 += Q0[j];
       for (int j = j1 - 1; j >= j0; j--) { double w = Q0[j]; Q0[j + 1] = a0; a0 -= w; }
     }
@@ -1592,7 +1650,8 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
     if (sl == 0) Q0[0] = 0.;
     wave_sync();
   }
-  const double neff_k = (tot * tot) / sum2;
+  // (quotients that feed smooth arithmetic only: reciprocal seed + two Newton steps instead of the IEEE division sequence)
+  const double neff_k = chm_div(tot * tot, sum2);
   const double stdc = dhl * L.std_unit;
   const double bw = kde_bandwidth_factor_fast(L.bw_method, L.bw_scalar, neff_k) * stdc;
   const bool degenerate = !(dbin > 0.) || !(bw > 0.) || !(bw < 1e300) || !(tot > 0. || tot < 0.);
@@ -1600,30 +1659,33 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   // c_j = lo + (j + 1/2) dbin:  ja = ceil(t - hb), jb = floor(t + hb) + 1 with t = (g - lo)/dbin - 1/2, hb = h/dbin; the next
   // node is t + dd, dd = de/dbin.  A bin whose |u| is within rounding of 1 may land on either side (kernel value < 1e-12).
   // one reciprocal serves 1/bw and the normalisation 3/4 / (bw sum w); 1/dbin = B / (hi - lo) re-uses the histogram's reciprocal
-  const double rbt = 1. / (bw * tot);
-  const double inv_dbin = dB * rhl, inv_bw = rbt * tot, inv_bw2 = inv_bw * inv_bw;
-  const double scale = 0.75 * rbt;
+  const double rbt = chm_div(1., bw * tot);
+  const double inv_dbin = dB * rhl, inv_bw = rbt * tot, m_inv_bw2 = -(inv_bw * inv_bw);
   const double hb = bw * inv_dbin;
   const double de = es[10], inv_de = es[11];                // spacing of jnp.linspace(lb, ub, G) and its inverse (k_event_prep)
   const double dd = de * inv_dbin;
   const double dG2 = (double)(G - 2);
   const double lbl = lb - lo;
-  const double ng = norm * L.gw_pdf[(size_t)e * L.P + pp]; // kde_interp * norm * gw_pdf[i]    likelihood.py:194
-  const double fR = params[b].fR;
   const double nan = __builtin_nan("");
+  const double ng = norm * L.gw_pdf[(size_t)e * L.P + pp]; // kde_interp * norm * gw_pdf[i]    likelihood.py:194
+  const double scale = 0.75 * rbt;
+  const double sng = degenerate ? nan : scale * ng;         // degenerate pixels give NaN wherever the interpolant is evaluated
+  const double fR = params[b].fR;
+  // bin coordinate of node 0 and the offsets of the four truncations (lower node: t - hb + 1, t + hb + 1; upper node: + dd)
+  const double t0 = fma(lbl, inv_dbin, -0.5);
+  const double oa1 = 1. - hb, oa2 = 1. + hb, ob1 = dd + oa1, ob2 = dd + oa2;
   // Support of THIS pixel's interpolated KDE on the event grid: the bin centres lie in [lo + dbin/2, hi - dbin/2], a node sees
   // none of them beyond bw, and an event-grid point combines the two nodes within de of it -- so p_gw is an exact zero for
   // z outside (lo - bw - de, hi + bw + de), typically a third of the event's range [lb, ub] (every pixel's histogram starts
   // at the event's min z but ends at the pixel's own max z, likelihood.py:180).  Degenerate pixels keep [lb, ub] (NaN there).
   const double zlo = degenerate ? lb : __builtin_fmax(lb, lo - bw - de), zhi = degenerate ? ub : __builtin_fmin(ub, hi + bw + de);
-  // density (without the common factor `scale`) at the node with g' = g - lo and bin position t
-  auto node = [&](double gp, double t) {
-    double fa = __builtin_fmin(__builtin_fmax(ceil(t - hb), 0.), fjl1);
-    double fb = __builtin_fmin(__builtin_fmax(floor(t + hb) + 1., fa), fjl1);
-    const int ia = (int)fa, ib = (int)fb;
-    double S0 = Q0[ib] - Q0[ia], S1 = Q1[ib] - Q1[ia], S2 = Q2[ib] - Q2[ia];
-    double qq = fma(gp, fma(gp, S0, -2. * S1), S2);         // sum W (g' - c')^2 over the support
-    return __builtin_fmax(S0 - qq * inv_bw2, 0.);           // a sum of non-negative kernel values (rounding may leave -1e-14 of the peak)
+  // density (without the common factor `scale`) at the node with g' = g - lo whose bin range comes from the truncations of xa, xb
+  auto node = [&](double gp, double xa, double xb) {
+    const int ia = med3_i32(cvt_i32_sat(xa), 0, jl1);
+    const int ib = med3_i32(cvt_i32_sat(xb), ia, jl1);
+    const double S0 = Q0[ib] - Q0[ia], S1 = Q1[ib] - Q1[ia], S2 = Q2[ib] - Q2[ia];   // S1 = -2 sum W c'
+    const double qq = fma(gp, fma(gp, S0, S1), S2);         // sum W (g' - c')^2 over the support
+    return __builtin_fmax(fma(m_inv_bw2, qq, S0), 0.);      // a sum of non-negative kernel values (rounding may leave -1e-14 of the peak)
   };
   // A-posteriori bound on what the prefix-sum form can have lost.  Every prefix value carries <= 12 roundings (7 additions in the lane,
   // 5 scan levels) relative to |P0| <= T, |P1| <= T R, |P2| <= T R^2 (T = sum w, R = hi - lo >= c'); a node's value
@@ -1635,53 +1697,52 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   const double rh = dhl * inv_bw;
   const double errD = (24. * 1.1102230246251565e-16) * fabs(tot) * (1. + (2. * rh + 1.) * (2. * rh + 1.));
   double acc = 0., accC = 0.;
-  if (dump && live) { for (int k = sl; k < Z; k += SW) if (k < k_lo || k > k_hi) dump[k] = 0.; }
-#pragma unroll 1
-  for (int it = 0; k_lo + 2 * SW * it <= k_hi; it++) {      // one pass = SW lanes x 2 consecutive grid points per pixel
-    const int k = k_lo + 2 * SW * it + 2 * sl;
-    // software pipeline: the loads of the next pass are issued before the arithmetic of this one
-    double zn0, zn1, bn0, bn1, an0, an1, pn0 = 0., pn1 = 0.;
-    const int kn = k + 2 * SW;
-    load2(zg, kn, zn0, zn1); load2(bkgA, kn, bn0, bn1); load2(Aw, kn, an0, an1);
-    if (it + 1 >= PF) load2(pc, kn, pn0, pn1);
-    double pc0 = pf0[0], pc1 = pf1[0];                      // this pass's p_cat: prefetched at kernel start or by the previous pass
-#pragma unroll
-    for (int i = 1; i < PF; i++) if (it == i) { pc0 = pf0[i]; pc1 = pf1[i]; }
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int kk = k + h;
-      if (kk <= k_hi && live) {
-        const double zk = h == 0 ? zc0 : zc1;
-        double pgw = 0.;
-        const bool ins = zk >= zlo && zk <= zhi;
-        if (ins) {                                          // inside: jnp.interp on the nodes; outside: 0 (left=0, right=0 or no bin in reach)
-          // bracket on the uniform effective grid: nodes x_i = lb + i de; a z within rounding of a node may pick either
-          // neighbouring segment -- the interpolant is continuous there
-          double tp = __builtin_fmin(floor((zk - lb) * inv_de), dG2);
-          double ga = fma(tp, de, lbl);                     // x_a - lo
-          double ta = fma(ga, inv_dbin, -0.5);
-          double da = node(ga, ta), db = node(ga + de, ta + dd);
-          double wgt = ((zk - lb) - tp * de) * inv_de;      // (z - x_a)/dx
-          double f = (da + wgt * (db - da)) * scale;
-          pgw = degenerate ? nan : f * ng;
-        } else if (zk != zk) pgw = nan;
-        if (dump) dump[kk] = pgw;
-        const double pcv = h == 0 ? pc0 : pc1;
-        if (pcv != -100.) { const double cz = (fR * pcv + (h == 0 ? bc0 : bc1)) * (h == 0 ? ac0 : ac1); acc += pgw * cz; accC += ins ? fabs(cz) : 0.; }   // catalog.py:202, likelihood.py:275
-      }
+  if (DUMP && live) { for (int k = sl; k < Z; k += SW) if (k < k_lo || k > k_hi) dump[k] = 0.; }
+  // one grid point: p_gw = interpolant of the two bracketing nodes (0 outside the pixel's support), integrand, bound.  The bound sums
+  // |C_k| over every unmasked grid point of [k_lo, k_hi], not only those inside the pixel's support: looser by the share of the event's
+  // range the pixel does not cover (a factor ~1.5), one addition instead of a comparison-dependent select.
+  auto point = [&](const int kk, const double zk, const double pcv, const double bk, const double ak) {
+    double pgw = 0.;
+    if (!(zk < zlo) && !(zk > zhi)) {                       // inside: jnp.interp on the nodes (a NaN grid point goes inside and comes out NaN through the weight)
+      // bracket on the uniform effective grid: nodes x_i = lb + i de, i = floor((z - lb)/de) in [0, G - 1] here (lb <= zlo, zhi <= ub);
+      // z = ub lands on the last node with weight 0 (jnp.interp's fp[-1]); a z within rounding of a node may pick either neighbouring
+      // segment -- the interpolant is continuous there
+      const double zrel = zk - lb;
+      const double tp = floor(zrel * inv_de);
+      const double ga = fma(tp, de, lbl);                   // x_a - lo
+      const double ta = fma(tp, dd, t0);                    // its bin coordinate (x_a - lo)/dbin - 1/2
+      const double da = node(ga, ta + oa1, ta + oa2), db = node(ga + de, ta + ob1, ta + ob2);
+      const double wgt = fma(-tp, de, zrel) * inv_de;       // (z - x_a)/dx
+      pgw = fma(wgt, db - da, da) * sng;
     }
-    zc0 = zn0; zc1 = zn1; bc0 = bn0; bc1 = bn1; ac0 = an0; ac1 = an1;
-    if (it + 1 >= PF) { pf0[0] = pn0; pf1[0] = pn1; }
+    if (DUMP) dump[kk] = pgw;
+    // (the empty volatile asm keeps this a branch on the exec mask: as selects it is four v_cndmask_b32 per point)
+    if (pcv != -100.) { asm volatile(""); const double cz = fma(fR, pcv, bk) * ak; acc = fma(pgw, cz, acc); accC += fabs(cz); }   // catalog.py:202, likelihood.py:275
+  };
+  auto do_pass = [&](const int k, const Pass& q) {
+    if (k <= k_hi && live) { point(k, q.z.x, q.pc.x, q.bk.x, q.a.x); point(k + 1, q.z.y, q.pc.y, q.bk.y, q.a.y); }
+  };
+  // one pass = SW lanes x 2 consecutive grid points per pixel.  Software pipeline in two alternating register sets: the loads of the next
+  // pass are issued before the arithmetic of this one and waited for where that pass begins (no register rotation, no wait at the loop end)
+  for (int kb = k_lo; kb <= k_hi; kb += 4 * SW) {
+    const int k = kb + 2 * sl;
+    const Pass nxt = load_pass(k + 2 * SW);
+    do_pass(k, cur);
+    if (kb + 2 * SW > k_hi) break;                          // uniform
+    cur = load_pass(k + 4 * SW);
+    do_pass(k + 2 * SW, nxt);
   }
-  acc = sg_scan_add<SW>(acc);                               // the group's last lane holds the pixel's integral
-  accC = sg_scan_add<SW>(accC);
+  // (same-address LDS atomics for these reductions -- ds_max_f64 / ds_add_f64 on one cell per pixel, no VALU slots -- were measured:
+  //  5.53 instead of 4.43 ms for the kernel, the LDS pipe serialises the 32 lanes of every such instruction)
+  acc = sg_scan_add0<SW>(acc);                              // the group's last lane holds the pixel's integral
+  accC = sg_scan_add0<SW>(accC);
   if (sl == SW - 1 && live) {
     *out_like = poisoned ? nan : acc;
     L.err_pix[((size_t)b * L.E + e) * L.P + p] = (degenerate || poisoned) ? 0. : errD * accC * fabs(scale * ng);     // NaN results stay NaN: nothing to redo
   }
 }
 
-template <int SW, int IPW, int BINS>
+template <int SW, int IPW, int BINS, bool DUMP>
 __global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevParams* params) {
   extern __shared__ double lds_all[];
   constexpr int NPW = 64 / SW;
@@ -1711,10 +1772,10 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevPar
   auto run = [&](const int pgi, const int p, const int pp, const int q0, const int q1, const bool first) {
     if (pgi >= PG) return;                                  // uniform
     const bool live = p < L.P && p < npx;
-    if (!ok) {                                              // uniform: every pixel of the event is 0 (or 0 * NaN)
+    if (!ok || !__any(live)) {                              // uniform: every pixel of the event (of this item: padded pixels) is 0 (or 0 * NaN)
       if (p < L.P) {
         if (sl == 0) { L.like_pix[((size_t)b * L.E + e) * L.P + p] = (live && poisoned) ? __builtin_nan("") : 0.; L.err_pix[((size_t)b * L.E + e) * L.P + p] = 0.; }
-        if (L.p_gw_dump) { double* d = L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z; for (int k = sl; k < Z; k += SW) d[k] = 0.; }
+        if (DUMP) { double* d = L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z; for (int k = sl; k < Z; k += SW) d[k] = 0.; }
       }
       return;
     }
@@ -1723,7 +1784,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevPar
     double zr[NR], wr[NR];
 #pragma unroll
     for (int j = 0; j < NR; j++) { int s = s0 + sl + SW * j; zr[j] = s < s1 ? wz[s] : lo; wr[j] = s < s1 ? ww[s] : 0.; }
-    kde_sub_item<SW, NR, BINS>(L, params, Q, es, b, e, p, pp, live, poisoned, s0, s1, zr, wr);
+    kde_sub_item<SW, NR, BINS, DUMP>(L, params, Q, es, b, e, p, pp, live, poisoned, s0, s1, zr, wr);
   };
   run(blockIdx.y, pA, ppA, a0, a1, true);
   run(blockIdx.y + H, pB, ppB, b0, b1, false);

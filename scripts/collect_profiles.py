@@ -28,6 +28,10 @@ PASSES = [
   "TCC_HIT_sum TCC_MISS_sum",
   "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES",
   "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES",
+  # [r3] the VALU stream by class: fp64 add / mul / fma / transcendental, 32- and 64-bit integer, conversions (bench.py prices fp64 at 4
+  # and everything else at 2 cycles per wave64 instruction; scripts/issue_cost.hip measures those costs on the card)
+  "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT",
+  "SQ_INSTS_VALU_FLOPS_FP64 SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU2 SQ_INSTS_LDS_ATOMIC SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM",
 ]
 
 
@@ -103,7 +107,23 @@ def main():
   cfg = json.loads(line[-1])['config'] if line else {}
   wl = {"config": (bench_args[bench_args.index('--config') + 1] if '--config' in bench_args else 'C3'), "E": cfg.get('E'), "P": cfg.get('P'),
         "Z": cfg.get('Z'), "S": cfg.get('S'), "nbatch": cfg.get('nbatch'), "mode": cfg.get('kind_p_gw3d') or '1d', "n_gpus": 1}
-  pmc = {"workload": wl, "command": ' '.join(base), "passes": PASSES,
+  # [r3] tie the counters to the binary they were collected from, and keep the static instruction mix of its hot loops beside them
+  sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+  import isa_mix
+  lib = os.environ.get('CHIMERA_LIB') or os.path.join(ROOT, 'chimera_amd', 'lib', 'libchimera_hip.so')
+  static, _, _ = isa_mix.analyse(lib, [short(k) for k in kernels], with_loops=True)
+  for k, e in static['kernels'].items():                      # the three largest loops are enough to read the hot loops off
+    e['loops'] = e.get('loops', [])[:3]
+  if only is not None:                                        # a partial collection: merge into what an earlier call of this round wrote for the SAME binary
+    try:
+      old = json.load(open(os.path.join(prof_dir, f'pmc_per_launch{tag}.json')))
+      if old.get('code_object_sha256') == static['code_object_sha256']:
+        for k, v in old.get('kernels', {}).items():
+          kernels[k] = dict(v, **kernels.get(k, {}))
+    except Exception:                                         # noqa: BLE001
+      pass
+  pmc = {"workload": wl, "command": ' '.join(base), "passes": PASSES, "code_object_sha256": static['code_object_sha256'],
+         "issue_cost_model": static['issue_cost_model'], "static_mix": static['kernels'],
          "note": "per kernel, averages per launch over the launches of a pass; FETCH_SIZE / WRITE_SIZE in KiB (rocprofv3); SQ_* in the "
                  "counters' own units (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles); every pass is its own run",
          "kernels": kernels}
