@@ -18,11 +18,15 @@ launcher only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT; the ranks m
 (a Unix-domain socket) for the RCCL unique id, the barriers and the max-over-ranks of the wall time.
 
 Roofline bookkeeping: the two kernels that make up ~90 % of a step -- the sample stage ``k_samples`` and
-the marginalized GW kernel ``k_kde_marg_sub2`` -- are fp64-VALU-issue bound, so each is reported against the fp64 vector peak
-(one wave64 fp64 instruction per SIMD per 4 cycles: 1024 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instructions/s = 78.6 TFLOP/s of
-FMAs) with its VALU wave-instruction count per launch taken from the committed PMC pass of the same command
-(profiles/rNN/pmc_per_launch*.json) and its duration measured live with HIP events; the HBM view (unique input/output bytes of
-the launch and the PMC-measured fabric traffic, both over the same live duration, against 8 TB/s) is printed next to it.
+the marginalized GW kernel ``k_kde_marg_sub2`` -- are bound by VALU ISSUE.  Each is priced with the issue costs measured on the card
+(scripts/issue_cost.hip -> profiles/r03/issue_cost.txt: 2 cycles per wave64 instruction for a few simple 32-bit opcodes, 16 for fp64
+reciprocal / square root, 8 for fp32 transcendentals, 4 for EVERYTHING else -- fp64 arithmetic, v_mov_b64, v_cndmask, DPP moves,
+v_readlane, 64-bit integer operations alike): busy cycles = PMC instruction counts of one launch (committed passes of this very command,
+profiles/rNN/pmc_per_launch*.json) x those costs, with the share of 2-cycle opcodes taken from the static mix of the kernel's hot loop
+(scripts/isa_mix.py, stored in the same file).  frac = busy cycles / (1024 SIMDs x 2.4 GHz x the launch's LIVE HIP-event duration); the
+same at the clock the chip held under the profile, and the real fp64 flops (FMA = 2, add / mul = 1: SQ_INSTS_VALU_FLOPS_FP64) against
+78.6 TFLOP/s are printed beside it.  The PMC file carries the sha256 of the gfx950 code object it was collected from: when the loaded
+library's differs, no fraction is printed.  The HBM view (unique bytes of the launch and PMC fabric traffic against 8 TB/s) is kept.
 """
 import argparse
 import glob
@@ -38,8 +42,10 @@ import numpy as np
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s measured copy)
 N_SIMD, CLK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; max shader clock (MI355X_MICROARCH.md, chip-level parameters)
-VALU_PEAK_GINST = N_SIMD * CLK_HZ / 4 / 1e9          # fp64: one wave64 instruction per SIMD per 4 cycles -> 614.4 G wave-inst/s
-FP64_PEAK_TFLOPS = VALU_PEAK_GINST * 64 * 2 / 1e3    # as FMAs: 78.6 TFLOP/s (the public fp64 vector figure)
+ISSUE_PEAK_TCYC = N_SIMD * CLK_HZ / 1e12             # VALU issue cycles per second of the whole chip at the maximum clock: 2.4576e12
+FP64_PEAK_TFLOPS = N_SIMD * CLK_HZ / 4 * 64 * 2 / 1e12    # one fp64 FMA per lane per 4 cycles: 78.6 TFLOP/s (the public fp64 vector figure)
+# issue cycles per wave64 instruction on one SIMD (profiles/r03/issue_cost.txt, measured by scripts/issue_cost.hip)
+CYC_FAST, CYC_VALU, CYC_TRANS32, CYC_TRANS64 = 2, 4, 8, 16
 NPART, SAMPLE_WPB, SAMPLE_CHUNK, NEVSTAT = 16, 8, 4096, 12    # workspace record sizes of chm_kernels.h
 
 
@@ -66,9 +72,32 @@ def sample_kernel_unique_bytes(E, S, nb, Tc=1500, Tm=1000):
   return E * S * 48 + E * 16 + nb * ((2 * Tc + 2 * Tm) * 8 + E * S * 16 + E * nc * NPART * 8)
 
 
-def load_pmc(keys):
-  """Newest committed PMC summary (profiles/rNN/pmc_per_launch*.json, written by scripts/collect_pmc.py from separate
-  rocprofv3 --pmc passes of this very command) whose workload keys match; None otherwise."""
+def code_object_sha256(lib_path):
+  """sha256 of the gfx950 code object inside a HIP shared library (the clang offload bundle's gfx950 entry) -- the key that ties a
+  committed PMC file to the binary it was collected from (scripts/isa_mix.py computes the same)."""
+  import hashlib
+  import struct
+  try:
+    d = open(lib_path, 'rb').read()
+    i = d.find(b'__CLANG_OFFLOAD_BUNDLE__')
+    n = struct.unpack_from('<Q', d, i + 24)[0]
+    o = i + 32
+    for _ in range(n):
+      off, size, tl = struct.unpack_from('<QQQ', d, o)
+      o += 24
+      triple = d[o:o + tl]
+      o += tl
+      if b'gfx950' in triple:
+        return hashlib.sha256(d[i + off:i + off + size]).hexdigest()
+  except Exception:                                 # noqa: BLE001
+    pass
+  return None
+
+
+def load_pmc(keys, sha=None):
+  """Newest committed PMC summary (profiles/rNN/pmc_per_launch*.json, written by scripts/collect_profiles.py from separate
+  rocprofv3 --pmc passes of this very command) whose workload keys match; None otherwise.  Returns (path, json, fresh): fresh is
+  False when the file names another code object than the loaded library's (then no fraction is derived from it)."""
   best = None
   for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'pmc_per_launch*.json'))):
     try:
@@ -78,7 +107,7 @@ def load_pmc(keys):
       continue
     w = j.get('workload')
     if isinstance(w, dict) and all(w.get(k) == v for k, v in keys.items()):
-      best = (os.path.relpath(f, ROOT), j)
+      best = (os.path.relpath(f, ROOT), j, bool(sha) and j.get('code_object_sha256') == sha)
   return best
 
 
@@ -87,7 +116,8 @@ def pmc_kernel(pmc, prefix):
     return None
   for name, c in pmc[1].get('kernels', {}).items():
     if name.startswith(prefix):
-      return dict(c, name=name)
+      st = (pmc[1].get('static_mix') or {}).get(name)
+      return dict(c, name=name, static=st)
   return None
 
 
@@ -99,24 +129,42 @@ def quartiles(x):
 def kernel_roofline(label, prefix, ms, unique_bytes, pmc):
   """One kernel against its two ceilings.  ms: live HIP-event duration of one launch."""
   k = pmc_kernel(pmc, prefix)
+  fresh = bool(pmc and pmc[2])
   sec = ms * 1e-3
-  out = {"kernel": k['name'] if k else prefix, "stage": label, "kernel_ms": ms, "bound": "fp64-valu",
+  out = {"kernel": k['name'] if k else prefix, "stage": label, "kernel_ms": ms, "bound": "valu-issue",
          "unique_bytes_per_launch": unique_bytes,
          "hbm_unique_GBs": unique_bytes / sec / 1e9 if sec > 0 else None,
-         "hbm_unique_frac": unique_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else None}
-  if k and sec > 0:
+         "hbm_unique_frac": unique_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else None,
+         "pmc_matches_loaded_code_object": fresh}
+  if k and sec > 0 and fresh:
     insts = k.get('SQ_INSTS_VALU')
     if insts:
-      out.update({"valu_inst_per_launch": insts, "valu_Ginst_s": insts / sec / 1e9, "valu_peak_Ginst_s": VALU_PEAK_GINST,
-                  "valu_frac": insts / sec / 1e9 / VALU_PEAK_GINST,
-                  "fp64_fma_equiv_TFLOPs": insts * 128 / sec / 1e12})
+      st = (k.get('static') or {}).get('hot_loop') or {}
+      nv = st.get('valu_total') or 0
+      fast_share = (st.get('fast', 0) / nv) if nv else 0.
+      n_t64 = k.get('SQ_INSTS_VALU_TRANS_F64')
+      if n_t64 is None:
+        n_t64 = insts * (st.get('f64_trans', 0) / nv if nv else 0.)
+      n_t32 = insts * (st.get('trans32', 0) / nv if nv else 0.)
+      n_fast = insts * fast_share
+      cycles = CYC_FAST * n_fast + CYC_TRANS64 * n_t64 + CYC_TRANS32 * n_t32 + CYC_VALU * (insts - n_fast - n_t64 - n_t32)
+      n_amf = sum(k.get(c, 0.) for c in ('SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_FMA_F64'))
+      flops = k.get('SQ_INSTS_VALU_FLOPS_FP64')
+      out.update({"valu_inst_per_launch": insts, "valu_issue_cycles_per_launch": cycles, "cycles_per_valu_inst": cycles / insts,
+                  "static_hot_loop": {kk: st.get(kk) for kk in ('valu_total', 'f64', 'f64_amf', 'f64_trans', 'fast', 'mov', 'cndmask', 'lane', 'valu', 'salu', 'lds', 'vmem')} if st else None,
+                  "fp64_add_mul_fma_share_pmc": n_amf / insts if n_amf else None,
+                  "valu_busy_Tcycle_s": cycles / sec / 1e12, "valu_busy_frac": cycles / sec / 1e12 / ISSUE_PEAK_TCYC,
+                  "fp64_TFLOPs_real": flops * 64 / sec / 1e12 if flops else None,
+                  "fp64_frac_of_78.6_TFLOPs": flops * 64 / sec / 1e12 / FP64_PEAK_TFLOPS if flops else None})
+      if k.get('GRBM_GUI_ACTIVE') and k.get('profiled_ms'):
+        clk = k['GRBM_GUI_ACTIVE'] / 8 / (k['profiled_ms'] * 1e-3)         # 8 XCDs count the launch's cycles
+        out["clock_GHz_under_profile"] = clk / 1e9
+        out["valu_busy_frac_at_held_clock"] = cycles / (N_SIMD * clk * k['profiled_ms'] * 1e-3)
     if k.get('FETCH_SIZE') is not None and k.get('WRITE_SIZE') is not None:
       # gfx950: FETCH_SIZE tallies 64 B per 128-B request of wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM)
       traffic = (2 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024
       out.update({"traffic_bytes_per_launch": traffic, "hbm_traffic_GBs": traffic / sec / 1e9,
                   "hbm_traffic_frac": traffic / sec / 1e9 / HBM_PEAK_GBS})
-    if k.get('GRBM_GUI_ACTIVE') and k.get('profiled_ms'):
-      out["clock_GHz_under_profile"] = k['GRBM_GUI_ACTIVE'] / 8 / (k['profiled_ms'] * 1e-3) / 1e9
   return out
 
 
@@ -277,7 +325,8 @@ def main():
     evals = args.steps * nb
     value = evals / dt
     El = like._e1 - like._e0
-    pmc = load_pmc(dict(config=args.config, E=El, P=P, Z=Z, S=S, nbatch=nb, mode=kind or '1d', n_gpus=1)) if world == 1 else None
+    lib_sha = code_object_sha256(_lib.LIB_PATH)
+    pmc = load_pmc(dict(config=args.config, E=El, P=P, Z=Z, S=S, nbatch=nb, mode=kind or '1d', n_gpus=1), lib_sha) if world == 1 else None
     kernels = []
     if kind == 'marginalized':
       kernels.append(kernel_roofline("marginalized GW kernel (histogram + KDE + interp + integrand + trapz)", "k_kde_marg_sub2", kt[3],
@@ -296,9 +345,10 @@ def main():
         full_pairs += int(np.sum(nmask * np.asarray(ev['neff_pixels'][like._e0:like._e1]))) * S
       kf = kernels[-1]
       sec = kt[3] * 1e-3
-      # the power-sum march costs 5 fp64 instructions per 4 pairs and lane (4 fma + 1 multiply): peak = 614.4 G wave-inst/s x 64 lanes / 1.25
+      # the power-sum march costs 5 fp64 instructions (4 cycles each) per 4 pairs and lane (4 fma + 1 multiply): peak = 614.4 G wave-inst/s x 64 lanes / 1.25
+      pk = N_SIMD * CLK_HZ / CYC_VALU / 1e9 * 64 / 1.25
       kf.update({"pairs_per_launch": full_pairs, "Gpairs_s": full_pairs / sec / 1e9 if sec > 0 else None,
-                 "peak_Gpairs_s": VALU_PEAK_GINST * 64 / 1.25, "pair_frac": full_pairs / sec / 1e9 / (VALU_PEAK_GINST * 64 / 1.25) if sec > 0 else None})
+                 "peak_Gpairs_s": pk, "pair_frac": full_pairs / sec / 1e9 / pk if sec > 0 else None})
     kernels.append(kernel_roofline("sample stage (z(dL), source-frame masses, population weights, event statistics)", "k_samples", kt[2],
                                    sample_kernel_unique_bytes(El, S, nb), pmc))
     # the selection kernel runs on its own stream beside the event kernels (its span there is not a kernel duration): timed standalone
@@ -323,21 +373,25 @@ def main():
     dom = max(kernels, key=lambda k_: k_["kernel_ms"] or 0.) if kind != 'full' else kernels[0]
     path_bytes = algorithmic_bytes(E, S, P, Z, I, 200, pixelated, kind == 'full')
     med, q1, q3 = quartiles(step_s) if step_s else (None, None, None)
-    roof = {"bound": "fp64-valu", "kernel": dom["kernel"],
-            "achieved": dom.get("fp64_fma_equiv_TFLOPs") if kind != 'full' else dom.get("Gpairs_s"),
-            "peak": FP64_PEAK_TFLOPS if kind != 'full' else dom.get("peak_Gpairs_s"), "unit": "TFLOP/s" if kind != 'full' else "Gpair/s",
-            "frac": dom.get("valu_frac") if kind != 'full' else dom.get("pair_frac"),
+    roof = {"bound": "valu-issue", "kernel": dom["kernel"],
+            "achieved": dom.get("valu_busy_Tcycle_s") if kind != 'full' else dom.get("Gpairs_s"),
+            "peak": ISSUE_PEAK_TCYC if kind != 'full' else dom.get("peak_Gpairs_s"), "unit": "Tcycle/s (VALU issue cycles of 1024 SIMDs)" if kind != 'full' else "Gpair/s",
+            "frac": dom.get("valu_busy_frac") if kind != 'full' else dom.get("pair_frac"),
+            "frac_at_held_clock": dom.get("valu_busy_frac_at_held_clock"),
+            "fp64_TFLOPs_real": dom.get("fp64_TFLOPs_real"), "fp64_peak_TFLOPs": FP64_PEAK_TFLOPS,
             "traffic": dom.get("traffic_bytes_per_launch"),
             "traffic_source": (pmc[0] + " (separate rocprofv3 --pmc passes of this command)") if pmc else None,
+            "code_object_sha256": lib_sha, "pmc_matches_loaded_code_object": bool(pmc and pmc[2]),
             "kernel_ms": dom["kernel_ms"],
             "hbm": {"unique_bytes_per_launch": dom["unique_bytes_per_launch"], "achieved": dom["hbm_unique_GBs"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": dom["hbm_unique_frac"], "traffic_frac": dom.get("hbm_traffic_frac")},
             "kernels": kernels,
-            "note": "both dominant kernels are fp64-VALU-issue bound: achieved = VALU wave-instructions of one launch (PMC SQ_INSTS_VALU, "
-                    "committed pass of this command) x 128 flop (a wave64 FMA) / the launch's LIVE HIP-event duration; peak = 1024 SIMDs x "
-                    "2.4 GHz / 4 cycles per fp64 wave-instruction x 128 = 78.6 TFLOP/s; frac is the share of fp64 issue slots used at the "
-                    "maximum clock (the chip holds less under load, see clock_GHz_under_profile).  hbm.* is the same launch against 8 TB/s: "
-                    "unique bytes (shared inputs once, per-draw arrays x nbatch) and PMC fabric traffic",
+            "note": "both dominant kernels are bound by VALU issue: achieved = issue cycles of one launch -- PMC instruction counts of the committed "
+                    "passes of this command priced with the costs measured on the card (profiles/r03/issue_cost.txt: 4 cycles per wave64 instruction "
+                    "for everything but a few simple 32-bit opcodes at 2, fp64 rcp/sqrt at 16) -- / the launch's LIVE HIP-event duration; peak = 1024 "
+                    "SIMDs x 2.4 GHz; frac_at_held_clock uses the clock under the profile.  fp64_TFLOPs_real counts FMA = 2, add / mul = 1 (PMC).  "
+                    "No fraction is printed when the PMC file was collected from another code object than the one loaded.  hbm.* is the same launch "
+                    "against 8 TB/s: unique bytes (shared inputs once, per-draw arrays x nbatch) and PMC fabric traffic",
             "path_bytes_per_eval": path_bytes,
             "path_frac": path_bytes * nb / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[0] > 0 else None,
             "stage_ms": {"eval": kt[0], "tables": kt[1], "samples": kt[2], "kde_integrate": kt[3],

@@ -137,7 +137,7 @@ def main():
     b = json.loads(open(os.path.join(out, f'bench{tag}.json')).read().strip().split('\n')[-1])
     print('value', b['value'], 'ms/step', b['ms_per_step'], 'single', b.get('single_call_ms'))
     for k in b['roofline']['kernels']:
-      print({x: k.get(x) for x in ('kernel', 'kernel_ms', 'valu_frac', 'hbm_unique_frac', 'hbm_traffic_frac', 'clock_GHz_under_profile')})
+      print({x: k.get(x) for x in ('kernel', 'kernel_ms', 'valu_busy_frac', 'valu_busy_frac_at_held_clock', 'fp64_TFLOPs_real', 'cycles_per_valu_inst', 'hbm_unique_frac', 'hbm_traffic_frac', 'clock_GHz_under_profile')})
   except Exception as e:                                             # noqa: BLE001
     print('bench line not parsed:', e)
   for k, v in kernels.items():

@@ -15,8 +15,10 @@
     salu, smem, lds, vmem, wait (s_waitcnt / s_nop), branch
 * with --loops: every natural loop (a backward branch to a label) of the selected kernels with its own mix, innermost loops first,
   so that the hot loops of k_kde_marg_sub2 / k_samples_fast can be read off without a GPU.
-Issue-cost model (MI355X_MICROARCH.md "SIMD-32, wave64 over 2 cycles"; fp64 at half rate = the public 78.6 vs 157.3 TFLOP/s; confirmed
-by scripts/issue_cost.hip on the card): cycles = 4 n_f64 + C_TRANS n_f64_trans + 2 n_other_valu.
+Issue-cost model = what scripts/issue_cost.hip measured on the card (profiles/r03/issue_cost.txt): cycles = 2 n_fast + 16 n_f64_trans +
+8 n_trans32 + 4 n_other, where "fast" are the few simple 32-bit opcodes that run at the SIMD-32's full rate (v_mov_b32, v_add/sub_u32,
+v_and_b32, v_ashrrev_i32, v_fma/mul_f32 ...); everything else -- fp64 arithmetic as well as v_mov_b64, v_cndmask, v_med3, DPP moves,
+v_readlane, compares, conversions, 64-bit integer operations -- occupies the SIMD for 4 cycles per wave64 instruction.
 """
 import collections
 import hashlib
@@ -29,7 +31,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
-CYC_F64, CYC_F64_TRANS, CYC_VALU = 4, 16, 2       # issue cycles per wave64 instruction on one SIMD (see profiles/r03/issue_cost.txt)
+# Issue cycles per wave64 instruction on one SIMD, measured on the card (profiles/r03/issue_cost.txt): only the simplest 32-bit VALU
+# operations run at the SIMD-32's full rate; fp64 arithmetic, 64-bit moves and integer operations, v_cndmask, v_med3, shifts by a VGPR
+# amount, DPP moves, v_readlane / v_writelane, compares and conversions all take 4 cycles; fp64 reciprocal / square root 16, fp32 exp/log 8.
+CYC_FAST, CYC_VALU, CYC_TRANS32, CYC_F64_TRANS = 2, 4, 8, 16
+CYC_F64 = CYC_VALU
+FAST = ('v_mov_b32', 'v_add_u32', 'v_sub_u32', 'v_subrev_u32', 'v_and_b32', 'v_or_b32', 'v_xor_b32', 'v_ashrrev_i32', 'v_lshrrev_b32',
+        'v_fma_f32', 'v_mul_f32', 'v_add_f32', 'v_sub_f32', 'v_fmac_f32', 'v_mac_f32')      # measured or same VOP2 family as a measured one
+TRANS32 = ('v_exp_f32', 'v_log_f32', 'v_rcp_f32', 'v_rsq_f32', 'v_sqrt_f32', 'v_sin_f32', 'v_cos_f32')
 
 TRANS64 = ('v_rcp_f64', 'v_rsq_f64', 'v_sqrt_f64')
 # fp64 flops per lane of one instruction (FMA = 2; add / mul / min / max = 1; the rest are not arithmetic flops)
@@ -100,12 +109,16 @@ def summarize(insts):
   c = collections.Counter(k for _, _, k, _ in insts)
   c['f64_amf'] = sum(1 for _, mn, k, _ in insts if k == 'f64' and mn.startswith(AMF64))
   nv = sum(c[k] for k in VALU_CLASSES)
-  cyc = CYC_F64 * c['f64'] + CYC_F64_TRANS * c['f64_trans'] + CYC_VALU * (nv - c['f64'] - c['f64_trans'])
+  def base(mn):
+    return re.sub(r'_(e32|e64|sdwa)$', '', mn)
+  c['fast'] = sum(1 for _, mn, k, ops in insts if k in VALU_CLASSES and base(mn) in FAST and not re.search(r',\s*s\d+\s*$', ops))    # (a v_mov_b32 from an SGPR takes 4)
+  c['trans32'] = sum(1 for _, mn, k, _ in insts if base(mn) in TRANS32)
+  cyc = CYC_FAST * c['fast'] + CYC_F64_TRANS * c['f64_trans'] + CYC_TRANS32 * c['trans32'] + CYC_VALU * (nv - c['fast'] - c['f64_trans'] - c['trans32'])
   fl = 0
   for _, mn, k, _ in insts:
     b = re.sub(r'_(e32|e64|dpp|sdwa)$', '', mn)
     fl += FLOPS64.get(b, 0)
-  out = {k: c[k] for k in ('f64', 'f64_amf', 'f64_trans', 'mov', 'cndmask', 'lane', 'valu', 'salu', 'smem', 'lds', 'vmem', 'wait', 'branch') if c[k]}
+  out = {k: c[k] for k in ('f64', 'f64_amf', 'f64_trans', 'fast', 'trans32', 'mov', 'cndmask', 'lane', 'valu', 'salu', 'smem', 'lds', 'vmem', 'wait', 'branch') if c[k]}
   out.update({'valu_total': nv, 'f64_share': round((c['f64'] + c['f64_trans']) / nv, 4) if nv else None, 'issue_cycles': cyc,
               'cycles_per_valu': round(cyc / nv, 3) if nv else None, 'f64_flop_per_lane': fl})
   return out
@@ -171,8 +184,10 @@ def analyse(lib, want=None, with_loops=False):
   names = [n for n in ks if ks[n]]
   dem = dict(zip(names, demangle(names)))
   res = {'code_object_sha256': sha, 'library': os.path.relpath(lib, ROOT), 'kernels': {},
-         'issue_cost_model': {'f64': CYC_F64, 'f64_trans': CYC_F64_TRANS, 'other_valu': CYC_VALU,
-                              'note': 'cycles per wave64 instruction on one SIMD-32; measured by scripts/issue_cost.hip'}}
+         'issue_cost_model': {'fast': CYC_FAST, 'valu': CYC_VALU, 'trans32': CYC_TRANS32, 'f64_trans': CYC_F64_TRANS, 'fast_opcodes': list(FAST),
+                              'note': 'cycles per wave64 instruction on one SIMD-32, measured by scripts/issue_cost.hip (profiles/r03/issue_cost.txt): 2 for '
+                                      'the listed simple 32-bit opcodes with VGPR / constant sources, 16 for v_rcp/v_rsq/v_sqrt_f64, 8 for fp32 '
+                                      'transcendentals, 4 for every other VALU instruction (all fp64 arithmetic, 64-bit moves, v_cndmask, DPP, v_readlane ...)'}}
   for n in names:
     d = dem[n]
     if want and not any(w in d for w in want):
@@ -189,6 +204,10 @@ def analyse(lib, want=None, with_loops=False):
         sm.update({'start': hex(s), 'end': hex(e), 'innermost': inner, 'instructions': len(body)})
         ll.append(sm)
       entry['loops'] = sorted(ll, key=lambda x: -x['valu_total'])
+      # the loop that stands for the kernel's dynamic mix: the largest one of at most 1600 instructions (a pass of the sample stage, an
+      # item of the GW kernel); kernels without a loop are priced with their whole body
+      cand = [l for l in entry['loops'] if l['instructions'] <= 1600]
+      entry['hot_loop'] = cand[0] if cand else entry['whole_kernel']
     res['kernels'][d] = entry
   return res, ks, dem
 

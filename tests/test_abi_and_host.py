@@ -300,12 +300,28 @@ def test_roofline_accounting_of_the_bench():
   s1, s128 = bench.sample_kernel_unique_bytes(E, S, 1), bench.sample_kernel_unique_bytes(E, S, 128)
   assert s128 - s1 == 127 * (s1 - E * S * 48 - E * 16)
   assert bench.HBM_PEAK_GBS == 8000.0
-  assert abs(bench.VALU_PEAK_GINST - 614.4) < 1e-9 and abs(bench.FP64_PEAK_TFLOPS - 78.6432) < 1e-3
-  # a kernel that issued one fp64 instruction per SIMD every 4 cycles for its whole life sits exactly at the peak
-  insts = bench.VALU_PEAK_GINST * 1e9 * 5e-3
-  r = bench.kernel_roofline('x', 'k_x', 5.0, 1e9, ('f.json', {'kernels': {'k_x<1>': {'SQ_INSTS_VALU': insts, 'FETCH_SIZE': 1e6, 'WRITE_SIZE': 1e6}}}))
-  assert abs(r['valu_frac'] - 1.0) < 1e-12 and abs(r['fp64_fma_equiv_TFLOPs'] - bench.FP64_PEAK_TFLOPS) < 1e-9
+  assert abs(bench.ISSUE_PEAK_TCYC - 2.4576) < 1e-12 and abs(bench.FP64_PEAK_TFLOPS - 78.6432) < 1e-3
+  assert (bench.CYC_FAST, bench.CYC_VALU, bench.CYC_TRANS32, bench.CYC_TRANS64) == (2, 4, 8, 16)        # profiles/r03/issue_cost.txt
+  # a kernel of fp64 FMAs only that issued one per SIMD every 4 cycles for its whole life sits exactly at both peaks
+  insts = 1024 * 2.4e9 / 4 * 5e-3
+  k = {'SQ_INSTS_VALU': insts, 'SQ_INSTS_VALU_FMA_F64': insts, 'SQ_INSTS_VALU_TRANS_F64': 0., 'SQ_INSTS_VALU_FLOPS_FP64': 2 * insts, 'FETCH_SIZE': 1e6, 'WRITE_SIZE': 1e6}
+  st = {'k_x<1>': {'hot_loop': {'valu_total': 100, 'fast': 0, 'f64': 100, 'f64_trans': 0, 'trans32': 0}}}
+  r = bench.kernel_roofline('x', 'k_x', 5.0, 1e9, ('f.json', {'kernels': {'k_x<1>': k}, 'static_mix': st}, True))
+  assert abs(r['valu_busy_frac'] - 1.0) < 1e-12 and abs(r['fp64_TFLOPs_real'] - bench.FP64_PEAK_TFLOPS) < 1e-9 and abs(r['cycles_per_valu_inst'] - 4.) < 1e-12
   assert abs(r['traffic_bytes_per_launch'] - 3e6 * 1024) < 1 and r['hbm_unique_frac'] == 1e9 / 5e-3 / 1e9 / 8000.
+  # a quarter of the stream on the 2-cycle opcodes, 1 % fp64 reciprocals: 0.25 * 2 + 0.01 * 16 + 0.74 * 4 cycles per instruction
+  st['k_x<1>']['hot_loop'].update(fast=25)
+  k.update(SQ_INSTS_VALU_TRANS_F64=0.01 * insts)
+  r = bench.kernel_roofline('x', 'k_x', 5.0, 1e9, ('f.json', {'kernels': {'k_x<1>': k}, 'static_mix': st}, True))
+  assert abs(r['cycles_per_valu_inst'] - (0.5 + 0.16 + 2.96)) < 1e-12 and abs(r['valu_busy_frac'] - 3.62 / 4.) < 1e-12
+  # counters collected from another code object than the loaded one: no fraction
+  r = bench.kernel_roofline('x', 'k_x', 5.0, 1e9, ('f.json', {'kernels': {'k_x<1>': k}, 'static_mix': st}, False))
+  assert 'valu_busy_frac' not in r and r['pmc_matches_loaded_code_object'] is False and 'traffic_bytes_per_launch' not in r
+  # the hash bench.py computes is the one scripts/isa_mix.py / collect_profiles.py store
+  sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+  import isa_mix
+  from chimera_amd import _lib
+  assert bench.code_object_sha256(_lib.LIB_PATH) == isa_mix.code_object(_lib.LIB_PATH)[1]
   src = open(os.path.join(ROOT, 'chimera_amd', 'csrc', 'chimera_hip.hip')).read()
   assert 'k_kde_marg_sub2<' in src and 'k_samples<' in src             # the kernel-name prefixes the bench line matches
 
@@ -333,10 +349,10 @@ def test_compiler_resource_report_of_the_kernels(lib):
     import __graft_entry__ as g
     g.build(force=True)
   res = json.load(open(path))
-  for k in ('k_tables<true>', 'k_tables<false>', 'k_samples_fast<2, false, false>', 'k_kde_marg_sub2<32, 4, 200>', 'k_selection_fast<2>', 'k_full_kde',
+  for k in ('k_tables<true>', 'k_tables<false>', 'k_samples_fast<2, false, false>', 'k_kde_marg_sub2<32, 4, 200, false>', 'k_selection_fast<2>', 'k_full_kde',
             'k_zfactors<true, false>', 'k_zfactors<true, true>', 'k_marg_fixup', 'k_reduce_final'):
     assert k in res, (k, sorted(res))
   for k in ('k_tables<true>', 'k_tables<false>'):
     assert res[k]['scratch_bytes_per_lane'] == 0 and res[k]['vgpr_spills'] == 0, (k, res[k])
-  assert res['k_kde_marg_sub2<32, 4, 200>']['waves_per_simd'] >= 4 and res['k_samples_fast<2, false, false>']['waves_per_simd'] >= 4
+  assert res['k_kde_marg_sub2<32, 4, 200, false>']['waves_per_simd'] >= 4 and res['k_samples_fast<2, false, false>']['waves_per_simd'] >= 4
   assert res['k_full_kde']['waves_per_simd'] >= 3 and res['k_full_kde']['vgpr_spills'] == 0
