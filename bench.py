@@ -184,6 +184,7 @@ def main():
   ap.add_argument('--no-graph', action='store_true', help='no HIP-graph replay of few-draw calls (keeps the per-kernel HIP-event timings for --nbatch <= 8)')
   ap.add_argument('--host-comm', action='store_true', help='reduce the partial sums through the host sockets instead of RCCL')
   ap.add_argument('--force-comm', action='store_true', help='build the rendezvous and the RCCL communicator even for one rank (rehearses the N > 1 path)')
+  ap.add_argument('--inflight', type=int, default=1, help='evaluations in flight per rank: 2 = two lanes (hyperlikelihood.lane) driven by two host threads, the steps alternate between them')
   ap.add_argument('--cpu-events', type=int, default=1000, help='events of the workload the CPU baseline evaluates (1000 = all of C3)')
   ap.add_argument('--cpu-evals', type=int, default=20, help='timed CPU evaluations (median + IQR)')
   args = ap.parse_args()
@@ -287,8 +288,21 @@ def main():
   # chm_params (hyperlikelihood._params_array) is part of the call and stays inside it
   draws = [lambdas(k) for k in range(args.warmup + args.steps)]
   vals = []
+  # --inflight 2: a second lane on the same resident data (chm_like_clone / chm_sel_clone: own streams, tables, workspaces; with a
+  # communicator its own RCCL communicator), one host thread per lane, the steps alternate between the lanes
+  lanes, lane_comms, pool = [like], [], None
+  if args.inflight > 1:
+    from concurrent.futures import ThreadPoolExecutor
+    for i in range(1, args.inflight):
+      lc = None
+      if comm is not None:
+        lc = HostComm(world, rank, device, rendezvous=rdzv) if isinstance(comm, HostComm) else Comm(world, rank, device, rendezvous=rdzv)
+        lane_comms.append(lc)
+      lanes.append(like.lane(comm=lc))
+    pool = ThreadPoolExecutor(max_workers=args.inflight)
   for w in range(args.warmup):
-    vals.append(like.batch(draws[w]))
+    for ln in (lanes if w < 2 else lanes[:1]):             # every lane allocates its workspaces outside the timed region
+      vals.append(ln.batch(draws[w]))
   import gc
   gc.collect()
   gc.freeze()                                   # nothing in a step creates reference cycles: keep the cyclic collector off the clock
@@ -296,11 +310,23 @@ def main():
   kt = np.zeros(8)
   step_s = []
   t1 = time.perf_counter()
-  for k in range(args.steps):
-    ta = time.perf_counter()
-    vals.append(like.batch(draws[args.warmup + k]))          # synchronous: returns after the HIP stream has drained
-    step_s.append(time.perf_counter() - ta)
-    kt += like.last_timing()
+  if pool is None:
+    for k in range(args.steps):
+      ta = time.perf_counter()
+      vals.append(like.batch(draws[args.warmup + k]))          # synchronous: returns after the HIP stream has drained
+      step_s.append(time.perf_counter() - ta)
+      kt += like.last_timing()
+  else:
+    from collections import deque
+    pending = deque()
+    for k in range(args.steps):
+      if len(pending) == args.inflight:
+        vals.append(pending.popleft().result())
+      pending.append(pool.submit(lanes[k % args.inflight].batch, draws[args.warmup + k]))
+    while pending:
+      vals.append(pending.popleft().result())
+    for ln in lanes:
+      _lib.check(L.chm_device_synchronize(device))
   sync()
   dt = time.perf_counter() - t1
   if rdzv is not None:
@@ -403,7 +429,7 @@ def main():
       "dtype": "f64", "data": "synthetic (seed 20250926; chimera_amd/synth.py)",
       "config": {"workload": f"{args.config}: {E} events x {P} pixels x {Z} z-bins, {S} samples/event, {I} detected injections, "
                              f"PLP + Madau-Dickinson + {'modified-GW-propagation (Xi0, n) flat-LCDM' if mg else 'flat-LCDM'}, {kind or '1d'}, binning 200, cut_grid 2",
-                 "E": E, "P": P, "Z": Z, "S": S, "I": I, "kind_p_gw3d": kind, "nbatch": nb,
+                 "E": E, "P": P, "Z": Z, "S": S, "I": I, "kind_p_gw3d": kind, "nbatch": nb, "inflight": args.inflight,
                  "parallelism": f"events+injections sharded over {world} GPU(s)" + (f"; {comm_kind}" if comm_kind else ""),
                  "cells_per_s": value * E * max(P, 1) * Z},
       "step_ms": {"median": 1e3 * med, "q25": 1e3 * q1, "q75": 1e3 * q3, "n": len(step_s)} if step_s else None,
@@ -425,10 +451,18 @@ def main():
                                    "abs_diff": abs(g - cb["log_hyper_H0_67"]), "tolerance": 1e-7 * float(np.sqrt(E))}
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(out) + '\n').encode())
+  if pool is not None:
+    pool.shutdown()
+  for ln in lanes[1:]:
+    if ln.selection_function is not None:
+      ln.selection_function.close()
+    ln.close()
   like.close()
   sel.close()
   if rdzv is not None:
     rdzv.barrier()
+  for lc in lane_comms:
+    lc.close()
   if comm is not None:
     comm.close()
   if rdzv is not None:

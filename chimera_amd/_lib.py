@@ -67,7 +67,7 @@ class chm_tab(C.Structure):
 
 
 SYMBOLS = ['chm_version', 'chm_device_count', 'chm_last_error', 'chm_like_create', 'chm_like_destroy',
-           'chm_sel_create', 'chm_sel_destroy', 'chm_eval', 'chm_eval_tabulated', 'chm_model_eval', 'chm_model_tables',
+           'chm_sel_create', 'chm_sel_destroy', 'chm_like_clone', 'chm_sel_clone', 'chm_eval', 'chm_eval_tabulated', 'chm_model_eval', 'chm_model_tables',
            'chm_comm_unique_id', 'chm_comm_init_rank', 'chm_comm_destroy', 'chm_comm_allreduce_sum', 'chm_comm_nranks',
            'chm_device_synchronize',
            'chm_last_timing', 'chm_pcat_compute', 'chm_kde2d_pixels',
@@ -92,6 +92,8 @@ def lib():
   L.chm_like_create.argtypes = [C.POINTER(chm_like_desc), C.POINTER(vp)]
   L.chm_like_destroy.argtypes = [vp]
   L.chm_sel_create.argtypes = [C.POINTER(chm_sel_desc), C.POINTER(vp)]
+  L.chm_like_clone.argtypes = [vp, C.POINTER(vp)]
+  L.chm_sel_clone.argtypes = [vp, C.POINTER(vp)]
   L.chm_sel_destroy.argtypes = [vp]
   L.chm_eval.argtypes = [vp, vp, vp, C.POINTER(chm_params), C.c_int32, C.c_int64, C.POINTER(chm_out)]
   L.chm_eval_tabulated.argtypes = [vp, vp, vp, C.POINTER(chm_params), C.c_int32, C.c_int64, C.POINTER(chm_tab), C.POINTER(chm_out)]

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstddef>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -199,10 +200,18 @@ static int ctx_tables(Ctx& c, const chm_params* params, int nb, const double* fR
 // ------------------------------------------------------------------------------------------------------
 // handles
 // ------------------------------------------------------------------------------------------------------
+// Device arrays uploaded once by *_create.  A handle and its clones (chm_like_clone / chm_sel_clone: a second evaluation lane on the same
+// resident data, with its own streams, tables and workspaces) share them; the last one to be destroyed frees them.
+struct OwnedArrays {
+  std::vector<void*> v;
+  int device = 0;
+  ~OwnedArrays() { (void)hipSetDevice(device); for (void* p : v) (void)hipFree(p); }
+  void push_back(void* p) { v.push_back(p); }
+};
 struct chm_like {
   Ctx ctx;
   LikeDev L;
-  std::vector<void*> owned;
+  std::shared_ptr<OwnedArrays> owned_sp = std::make_shared<OwnedArrays>();
   int nb_ws = 0;
   bool ws_dump = false;
   // k_samples_fast: sample tiles (uploaded once), key range of the shard's distances, per-call direct-index tables
@@ -217,7 +226,7 @@ struct chm_like {
 struct chm_sel {
   Ctx ctx;
   SelDev S;
-  std::vector<void*> owned;
+  std::shared_ptr<OwnedArrays> owned_sp = std::make_shared<OwnedArrays>();
   int nb_ws = 0;
   // k_selection_fast: key range of the shard's distances, per-call direct-index tables (as chm_like::F)
   LutDesc lut = {};
@@ -232,8 +241,8 @@ struct chm_comm {
   double* d_buf = nullptr; int cap = 0;
 };
 
-template <class T>
-static int upload(std::vector<void*>& owned, const T* host, size_t n, const T** dev, hipStream_t s) {
+template <class T, class Own>
+static int upload(Own& owned, const T* host, size_t n, const T** dev, hipStream_t s) {
   *dev = nullptr;
   if (!host || n == 0) return CHM_OK;
   T* d = nullptr;
@@ -287,6 +296,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
   chm_like* h = new chm_like();
   int rc = ctx_init(h->ctx, d->device);
   if (rc) { delete h; return rc; }
+  h->owned_sp->device = d->device;
   hipStream_t s = h->ctx.stream;
   LikeDev& L = h->L;
   memset(&L, 0, sizeof(L));
@@ -299,7 +309,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
   L.bw_scalar = d->bw_scalar; L.cut_grid = d->cut_grid; L.pe_neff = d->pe_neff;
   { const double B = (double)(d->num_bins > 0 ? d->num_bins : 1); L.inv_B = 1. / B; L.std_unit = sqrt((B * B - 1.) / 12.) / B; }   // math.py:67 on uniform centres
   if (L.mode != CHM_MODE_FULL && L.G < 2) { chm_like_destroy(h); return fail(CHM_E_ARG, "chm_like_create: Z//2 must be >= 2 when cut_grid is set"); }
-#define UP(field, src, n) do { rc = upload(h->owned, (src) ? (src) + (size_t)e0 * (n) : (src), (size_t)E * (n), &L.field, s); if (rc) { chm_like_destroy(h); return rc; } } while (0)
+#define UP(field, src, n) do { rc = upload(*h->owned_sp, (src) ? (src) + (size_t)e0 * (n) : (src), (size_t)E * (n), &L.field, s); if (rc) { chm_like_destroy(h); return rc; } } while (0)
   std::vector<double> tmp;                                   // must outlive the async copies below
   std::vector<std::vector<double>> sorted, logs;
   std::vector<int> seg, perm_all;                            // perm_all: original index of every pixel-sorted sample (for chm_tab)
@@ -322,16 +332,16 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
       }
     }
     const double** dst[4] = { &L.dL, &L.m1det, &L.m2det, &L.pe_prior };
-    for (int a = 0; a < 4; a++) { rc = upload(h->owned, (const double*)sorted[a].data(), E * S, dst[a], s); if (rc) { chm_like_destroy(h); return rc; } }
+    for (int a = 0; a < 4; a++) { rc = upload(*h->owned_sp, (const double*)sorted[a].data(), E * S, dst[a], s); if (rc) { chm_like_destroy(h); return rc; } }
     logs.assign(2, std::vector<double>(E * S));
     for (size_t k = 0; k < E * S; k++) { logs[0][k] = std::log(sorted[1][k]); logs[1][k] = std::log(sorted[2][k]); }
-    rc = upload(h->owned, (const int*)seg.data(), E * (P + 1), &L.seg_off, s); if (rc) { chm_like_destroy(h); return rc; }
-    rc = upload(h->owned, (const int*)perm_all.data(), E * S, &L.perm, s); if (rc) { chm_like_destroy(h); return rc; }
+    rc = upload(*h->owned_sp, (const int*)seg.data(), E * (P + 1), &L.seg_off, s); if (rc) { chm_like_destroy(h); return rc; }
+    rc = upload(*h->owned_sp, (const int*)perm_all.data(), E * S, &L.perm, s); if (rc) { chm_like_destroy(h); return rc; }
   } else {
     UP(dL, d->dL, S); UP(m1det, d->m1det, S); UP(m2det, d->m2det, S);
     tmp.resize(E * S);
     for (size_t k = 0; k < E * S; k++) tmp[k] = 1. / d->pe_prior[(size_t)e0 * S + k];          // the device keeps 1/pe_prior
-    rc = upload(h->owned, (const double*)tmp.data(), E * S, &L.pe_prior, s); if (rc) { chm_like_destroy(h); return rc; }
+    rc = upload(*h->owned_sp, (const double*)tmp.data(), E * S, &L.pe_prior, s); if (rc) { chm_like_destroy(h); return rc; }
     logs.assign(2, std::vector<double>(E * S));
     for (size_t k = 0; k < E * S; k++) { logs[0][k] = std::log(d->m1det[(size_t)e0 * S + k]); logs[1][k] = std::log(d->m2det[(size_t)e0 * S + k]); }
   }
@@ -354,7 +364,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
       }
       for (size_t k = S; k < NT * SF_TILE; k++) { double* o = tiles.data() + ((e * NT + k / SF_TILE) * 6) * SF_TILE + k % SF_TILE; o[4 * SF_TILE] = 0.; o[5 * SF_TILE] = 0.; }
     }
-    rc = upload(h->owned, (const double*)tiles.data(), tiles.size(), &h->F.tiles, s); if (rc) { chm_like_destroy(h); return rc; }
+    rc = upload(*h->owned_sp, (const double*)tiles.data(), tiles.size(), &h->F.tiles, s); if (rc) { chm_like_destroy(h); return rc; }
     h->F.NT = (int)NT;
   }
   // smallest / largest finite distance of every event: the bracket of its table searches (k_samples)
@@ -381,10 +391,10 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
       if (h->F.lut.nk > LUT_MAXKEYS) h->fast_ok = false;     // distances spanning > 64 octaves: the general kernel
     }
   }
-  rc = upload(h->owned, (const double*)dlo.data(), E, &L.dl_lo, s); if (rc) { chm_like_destroy(h); return rc; }
-  rc = upload(h->owned, (const double*)dhi.data(), E, &L.dl_hi, s); if (rc) { chm_like_destroy(h); return rc; }
-  rc = upload(h->owned, (const double*)logs[0].data(), E * S, &L.lm1det, s); if (rc) { chm_like_destroy(h); return rc; }
-  rc = upload(h->owned, (const double*)logs[1].data(), E * S, &L.lm2det, s); if (rc) { chm_like_destroy(h); return rc; }
+  rc = upload(*h->owned_sp, (const double*)dlo.data(), E, &L.dl_lo, s); if (rc) { chm_like_destroy(h); return rc; }
+  rc = upload(*h->owned_sp, (const double*)dhi.data(), E, &L.dl_hi, s); if (rc) { chm_like_destroy(h); return rc; }
+  rc = upload(*h->owned_sp, (const double*)logs[0].data(), E * S, &L.lm1det, s); if (rc) { chm_like_destroy(h); return rc; }
+  rc = upload(*h->owned_sp, (const double*)logs[1].data(), E * S, &L.lm2det, s); if (rc) { chm_like_destroy(h); return rc; }
   if (d->mode == CHM_MODE_FULL) { UP(ra, d->ra, S); UP(dec, d->dec, S); }
   UP(z_grids, d->z_grids, Z);
   { hipError_t e1 = hipMalloc(&h->d_zg_i, sizeof(int) * E * Z), e2 = hipMalloc(&h->d_zg_t, sizeof(double) * E * Z), e3 = hipMalloc(&h->d_zg_lz, sizeof(double) * E * Z);
@@ -393,8 +403,8 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
   std::vector<double> fracB(L.num_bins > 0 ? L.num_bins + 1 : 1), fracG(L.G > 0 ? L.G : 1);
   for (size_t i = 0; i < fracB.size(); i++) fracB[i] = (double)i / (double)(L.num_bins > 0 ? L.num_bins : 1);
   for (size_t i = 0; i < fracG.size(); i++) fracG[i] = (double)i / (double)(L.G > 1 ? L.G - 1 : 1);
-  rc = upload(h->owned, (const double*)fracB.data(), fracB.size(), &L.fracB, s); if (rc) { chm_like_destroy(h); return rc; }
-  rc = upload(h->owned, (const double*)fracG.data(), fracG.size(), &L.fracG, s); if (rc) { chm_like_destroy(h); return rc; }
+  rc = upload(*h->owned_sp, (const double*)fracB.data(), fracB.size(), &L.fracB, s); if (rc) { chm_like_destroy(h); return rc; }
+  rc = upload(*h->owned_sp, (const double*)fracG.data(), fracG.size(), &L.fracG, s); if (rc) { chm_like_destroy(h); return rc; }
   if (pixelated) {
     UP(p_cat, d->p_cat, P * Z); UP(P_compl, d->P_compl, Z); UP(gw_pdf, d->gw_loc2d_pdf, P);
     if (d->ra_pix) UP(ra_pix, d->ra_pix, P);
@@ -426,9 +436,31 @@ extern "C" int chm_like_destroy(chm_like* h) {
   if (h->ctx.stream3) (void)hipStreamSynchronize(h->ctx.stream3);
   like_free_ws(h);
   (void)hipFree(h->d_zg_i); (void)hipFree(h->d_zg_t); (void)hipFree(h->d_zg_lz);
-  for (void* p : h->owned) (void)hipFree(p);
   ctx_destroy(h->ctx);
-  delete h;
+  delete h;                                                 // the uploaded arrays go with the last handle that shares them
+  return CHM_OK;
+}
+
+// A second evaluation lane on the SAME resident data: the clone shares every array chm_like_create
+// uploaded and owns its streams, per-draw tables, workspaces, grid brackets and graph.  Two host threads, each calling chm_eval on its
+// own lane, keep two evaluations in flight on one GPU: the tables, launch path and reduction tail of one call run under the kernels of
+// the other (per-call fixed costs are ~0.15 ms of a 125-event shard's 1.6 ms step).  A lane is as thread-unsafe as any handle.
+extern "C" int chm_like_clone(const chm_like* src, chm_like** out) {
+  if (!src || !out) return fail(CHM_E_ARG, "chm_like_clone: null argument");
+  *out = nullptr;
+  chm_like* h = new chm_like();
+  int rc = ctx_init(h->ctx, src->ctx.device);
+  if (rc) { delete h; return rc; }
+  h->owned_sp = src->owned_sp;
+  h->L = src->L;
+  LikeDev& L = h->L;                                        // workspaces are the clone's own (allocated by the first call)
+  L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.Aw = L.evstat = L.effg = L.pgw1d = L.like_pix = L.err_pix = L.p_gw_dump = nullptr;
+  L.krange = nullptr; L.tab_pm = L.tab_rate = L.tab_bkg = L.tab_jac = nullptr; L.zg_i = nullptr; L.zg_t = L.zg_lz = nullptr;
+  h->F = src->F; h->fast_ok = src->fast_ok; h->dl_gmin = src->dl_gmin; h->dl_gmax = src->dl_gmax;
+  const size_t EZ = (size_t)L.E * L.Z;
+  hipError_t e1 = hipMalloc(&h->d_zg_i, sizeof(int) * EZ), e2 = hipMalloc(&h->d_zg_t, sizeof(double) * EZ), e3 = hipMalloc(&h->d_zg_lz, sizeof(double) * EZ);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { chm_like_destroy(h); return fail(CHM_E_NOMEM, "chm_like_clone: grid bracket arrays"); }
+  *out = h;
   return CHM_OK;
 }
 
@@ -471,21 +503,22 @@ extern "C" int chm_sel_create(const chm_sel_desc* d, chm_sel** out) {
   chm_sel* h = new chm_sel();
   int rc = ctx_init(h->ctx, d->device);
   if (rc) { delete h; return rc; }
+  h->owned_sp->device = d->device;
   SelDev& S = h->S;
   memset(&S, 0, sizeof(S));
   size_t n = (size_t)(i1 - i0);
   S.I = (long long)n; S.N_inj = d->N_inj; S.has_neff = std::isnan(d->N_eff) ? 0 : 1; S.N_eff = d->N_eff;
   hipStream_t s = h->ctx.stream;
-#define UP(field, src) do { rc = upload(h->owned, (src) + i0, n, &S.field, s); if (rc) { chm_sel_destroy(h); return rc; } } while (0)
+#define UP(field, src) do { rc = upload(*h->owned_sp, (src) + i0, n, &S.field, s); if (rc) { chm_sel_destroy(h); return rc; } } while (0)
   UP(dL, d->dL); UP(m1det, d->m1det); UP(m2det, d->m2det);
 #undef UP
   std::vector<double> ipd(n);
   for (size_t k = 0; k < n; k++) ipd[k] = 1. / d->p_draw[i0 + k];                                 // the device keeps 1/p_draw
-  rc = upload(h->owned, (const double*)ipd.data(), n, &S.p_draw, s); if (rc) { chm_sel_destroy(h); return rc; }
+  rc = upload(*h->owned_sp, (const double*)ipd.data(), n, &S.p_draw, s); if (rc) { chm_sel_destroy(h); return rc; }
   std::vector<double> l1(n), l2(n);                                                               // log(m_det), once (alive until the sync below)
   for (size_t k = 0; k < n; k++) { l1[k] = log(d->m1det[i0 + k]); l2[k] = log(d->m2det[i0 + k]); }
-  rc = upload(h->owned, (const double*)l1.data(), n, &S.lm1det, s); if (rc) { chm_sel_destroy(h); return rc; }
-  rc = upload(h->owned, (const double*)l2.data(), n, &S.lm2det, s); if (rc) { chm_sel_destroy(h); return rc; }
+  rc = upload(*h->owned_sp, (const double*)l1.data(), n, &S.lm1det, s); if (rc) { chm_sel_destroy(h); return rc; }
+  rc = upload(*h->owned_sp, (const double*)l2.data(), n, &S.lm2det, s); if (rc) { chm_sel_destroy(h); return rc; }
   long long nblk = (S.I + SEL_TILE - 1) / SEL_TILE;
   S.nblocks = (int)(nblk < 1 ? 1 : (nblk > 2048 ? 2048 : nblk));
   {                                                         // key range of the shard's positive finite distances (direct-index table)
@@ -513,9 +546,23 @@ extern "C" int chm_sel_destroy(chm_sel* h) {
   if (h->ctx.stream2) (void)hipStreamSynchronize(h->ctx.stream2);
   if (h->ctx.stream3) (void)hipStreamSynchronize(h->ctx.stream3);
   (void)hipFree(h->S.partial); (void)hipFree(h->d_lut); (void)hipFree(h->d_lutinfo);
-  for (void* p : h->owned) (void)hipFree(p);
   ctx_destroy(h->ctx);
   delete h;
+  return CHM_OK;
+}
+
+// second evaluation lane on the same resident injections (see chm_like_clone)
+extern "C" int chm_sel_clone(const chm_sel* src, chm_sel** out) {
+  if (!src || !out) return fail(CHM_E_ARG, "chm_sel_clone: null argument");
+  *out = nullptr;
+  chm_sel* h = new chm_sel();
+  int rc = ctx_init(h->ctx, src->ctx.device);
+  if (rc) { delete h; return rc; }
+  h->owned_sp = src->owned_sp;
+  h->S = src->S;
+  h->S.partial = nullptr; h->S.tab_pm = h->S.tab_rate = h->S.tab_bkg = h->S.tab_jac = nullptr;
+  h->lut = src->lut; h->fast_ok = src->fast_ok; h->dl_gmin = src->dl_gmin; h->dl_gmax = src->dl_gmax;
+  *out = h;
   return CHM_OK;
 }
 
@@ -620,12 +667,13 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   }
   static const bool timing_env = getenv("CHM_NO_TIMING") == nullptr;  // CHM_NO_TIMING=1: no timing events in the streams (chm_last_timing returns zeros)
   // Few draws per call (the reference's scalar call): the launch sequence is replayed from a HIP graph -- no timing events, no
-  // per-event outputs, no communicator, no caller tables.  A configuration runs eagerly the first time it is seen (function
-  // attributes, workspaces), is captured the second time and replayed afterwards.
+  // per-event outputs, no caller tables.  A configuration runs eagerly the first time it is seen (function attributes, workspaces), is
+  // captured the second time and replayed afterwards.  [r3] With a communicator the graph ends at the rank's partial sums; the RCCL
+  // all-reduce and k_combine follow it on the same stream (the 8-GPU job keeps the replayed path of the scalar call).
   static const int graph_max_nb = getenv("CHM_GRAPH_MAX_NB") ? atoi(getenv("CHM_GRAPH_MAX_NB")) : 8;
   static const bool zc_env = getenv("CHM_NO_ZERO_COPY") == nullptr;
-  const bool zero_copy = zc_env && nb <= 8 && !comm;      // parameters read from / results written to pinned host memory by the kernels themselves
-  const bool graph_ok = nb <= graph_max_nb && !comm && !tab && !want_dump && !out->log_like_evs && !out->numlike_evs;
+  const bool zero_copy = zc_env && nb <= 8;               // parameters read from / results written to pinned host memory by the kernels themselves
+  const bool graph_ok = nb <= graph_max_nb && !tab && !want_dump && !out->log_like_evs && !out->numlike_evs;
   int Tc_host = 0, Tm_host = 0;
   rc = ctx_tables_host(c, params, nb, tab ? tab->fR : nullptr, &Tc_host, &Tm_host); if (rc) return rc;
   if (like && (like->L.E + 255) / 256 * nb > c.evpart_cap) {       // block sums of log L_i for shards beyond 4096 events (k_reduce_events)
@@ -695,7 +743,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   static const int few_nb = getenv("CHM_FEW_NB") ? atoi(getenv("CHM_FEW_NB")) : 8;
   static const bool fuse_env = getenv("CHM_NO_ZF_SEL") == nullptr;
   const size_t lds_zfac_call = sizeof(double) * (size_t)2 * c.TcMax;
-  const bool fuse_sel = fuse_env && !serial && like && sel && sel_fast && nb <= few_nb && !comm && !td.rate_g && !td.bkg_g && !td.jac_g &&
+  const bool fuse_sel = fuse_env && !serial && like && sel && sel_fast && nb <= few_nb && !td.rate_g && !td.bkg_g && !td.jac_g &&
                         like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && !getenv("CHM_MARG_GENERIC") && !getenv("CHM_ZF_FULL") &&
                         !getenv("CHM_GROUPS") && lds_zfac_call <= 64 * 1024 && like->L.E <= 65535;
   const bool one_stream = serial || fuse_sel;
@@ -716,10 +764,18 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
             Tc_host, Tm_host, use_fast, lutA.key0, lutA.nk, lutA.cap, (long long)lds_fast, params[0].mass_model, out->partials != nullptr,
             sel_fast, lutB.key0, lutB.nk, lutB.cap, (long long)lds_sel, (long long)(intptr_t)lutB.lut, fuse_sel,
             (long long)(intptr_t)c.d_evpart, (long long)(intptr_t)(like ? like->L.ws_z : nullptr), (long long)(intptr_t)(sel ? sel->S.partial : nullptr),
-            zg_use, zg_make };
+            zg_use, zg_make, (long long)(intptr_t)comm };
     if (c.gexec && key == c.gkey) {                           // replay
       const double hp1 = host_prof_on() ? now_us() : 0.;
       HIPCHK(hipGraphLaunch(c.gexec, sA));
+      if (comm) {                                             // the graph ends at the rank's partials: all-reduce + combination behind it
+        NCCLCHK(ncclAllReduce(c.d_partials, c.d_partials, (size_t)nb * 3, ncclDouble, ncclSum, comm->comm, sA));
+        hipLaunchKernelGGL(k_combine, dim3((nb + 63) / 64), dim3(64), 0, sA, nb, (const DevParams*)c.d_params, (const double*)c.d_partials,
+                           comm ? (double)E_total : (like ? (double)like->L.E : 0.), sel ? sel->S.N_inj : 1., sel ? sel->S.N_eff : 0.,
+                           sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, zero_copy ? c.h_out : c.d_out3);
+        HIPCHK(hipGetLastError());
+        if (!zero_copy) HIPCHK(hipMemcpyAsync(c.h_out, c.d_out3, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
+      }
       const double hp2 = host_prof_on() ? now_us() : 0.;
       HIPCHK(hipStreamSynchronize(sA));
       if (host_prof_on()) { const double hp3 = now_us(); g_hp.pre.push_back(hp1 - hp0); g_hp.launch.push_back(hp2 - hp1); g_hp.sync.push_back(hp3 - hp2); }
@@ -740,8 +796,9 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   }
   const bool timing = timing_env && !capturing;
   // with a communicator (multi-GPU shards: short calls) only the whole evaluation and the GW kernel are timed: each event record
-  // costs ~3 us of stream time (measured: 35 us per call for the full set)
-  const bool timing_all = timing && !comm;
+  // costs ~3 us of stream time (measured: 35 us per call for the full set); CHM_TIMING_ALL=1 keeps the full set (diagnosing a multi-GPU line)
+  static const bool timing_all_env = getenv("CHM_TIMING_ALL") != nullptr;
+  const bool timing_all = timing && (!comm || timing_all_env);
   // an error inside a capture must end it before returning
   struct CaptureGuard { hipStream_t s; bool* on; ~CaptureGuard() { if (*on) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); } } } cguard{sA, &capturing};
   if (timing) HIPCHK(hipEventRecord(c.ev[0], sA));
@@ -967,10 +1024,22 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   }
   HIPCHK(hipGetLastError());
   if (out->partials) HIPCHK(hipMemcpyAsync(c.h_out + 3 * nb, c.d_partials, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
+  auto end_capture = [&]() -> int {                           // instantiate what was captured so far and launch it
+    hipGraph_t graph = nullptr;
+    capturing = false;
+    HIPCHK(hipStreamEndCapture(sA, &graph));
+    hipError_t ge = hipGraphInstantiate(&c.gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ge != hipSuccess) { c.gexec = nullptr; return fail(CHM_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ge)); }
+    c.gkey = key;
+    HIPCHK(hipGraphLaunch(c.gexec, sA));
+    return CHM_OK;
+  };
   if (multi) {
+    if (capturing) { rc = end_capture(); if (rc) return rc; }      // the collective stays outside the graph
     NCCLCHK(ncclAllReduce(c.d_partials, c.d_partials, (size_t)nb * 3, ncclDouble, ncclSum, comm->comm, sA));
     hipLaunchKernelGGL(k_combine, dim3((nb + 63) / 64), dim3(64), 0, sA, nb, dp, (const double*)c.d_partials, Etot,
-                       sel ? sel->S.N_inj : 1., sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, c.d_out3);
+                       sel ? sel->S.N_inj : 1., sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, out3);
     HIPCHK(hipGetLastError());
   }
   if (!zero_copy) HIPCHK(hipMemcpyAsync(c.h_out, c.d_out3, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
@@ -982,16 +1051,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     const double* src = like->L.mode == CHM_MODE_1D ? like->L.pgw1d : like->L.p_gw_dump;
     HIPCHK(hipMemcpyAsync(out->p_gw, src, sizeof(double) * nb * El * Pd * like->L.Z, hipMemcpyDeviceToHost, sA));
   }
-  if (capturing) {
-    hipGraph_t graph = nullptr;
-    capturing = false;
-    HIPCHK(hipStreamEndCapture(sA, &graph));
-    hipError_t ge = hipGraphInstantiate(&c.gexec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (ge != hipSuccess) { c.gexec = nullptr; return fail(CHM_E_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ge)); }
-    c.gkey = key;
-    HIPCHK(hipGraphLaunch(c.gexec, sA));
-  }
+  if (capturing) { rc = end_capture(); if (rc) return rc; }
   HIPCHK(hipStreamSynchronize(sA));
   for (int b = 0; b < nb; b++) {
     if (out->log_hyper) out->log_hyper[b] = c.h_out[b * 3];

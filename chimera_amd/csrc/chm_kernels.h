@@ -667,14 +667,18 @@ static_assert(SAMPLE_WPB % CHM_SF_WAVES == 0, "records per chunk must be a multi
 // registers do not spill.  Measured for calls of one draw, where every block of the grid is resident at once: the scalar call takes
 // 0.242 instead of 0.232 ms -- the fourth wave per SIMD hides more latency than the prefetch (profiles/r02/ab_scalar_call_*.txt)
 template <int MASS, bool FULL, bool PF = (CHM_SF_PREFETCH != 0)>
-__global__ void __launch_bounds__(64 * CHM_SF_WAVES, PF ? (CHM_SF_MINW < 3 ? CHM_SF_MINW : 3) : CHM_SF_MINW) k_samples_fast(LikeDev L, SampFast F, const DevParams* params, const double* zt_all,
+__global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast(LikeDev L, SampFast F, const DevParams* params, const double* zt_all,
                                                                     const double* dLt_all, const double* mg_all, const double* cdf_all,
                                                                     const double* rec_all, int TcMax, int TmMax) {
 #pragma clang fp contract(fast)                  // sums of products may fuse; z comes from z_from_lut_x2 / jnp_interp (contract off) untouched
   extern __shared__ double lds[];
   constexpr int NT_ = 64 * CHM_SF_WAVES;
   const int b = blockIdx.x % L.nb, bx = blockIdx.x / L.nb, nbx = gridDim.x / L.nb, t = threadIdx.x, lane = t & 63;
-  const DevParams P = params[b];      // by value: uniform loads at kernel start -> scalar registers, nothing re-read in the loops
+  DevParams P = params[b];            // by value: uniform loads at kernel start, nothing re-read in the loops
+#ifndef CHM_SF_NPV
+#define CHM_SF_NPV 4
+#endif
+  mass_params_to_vgpr<MASS, FULL ? 0 : CHM_SF_NPV>(P);       // (mass-model parameters in vector registers: the scalar file cannot hold the whole draw)
   const double* g_zt = zt_all + (size_t)b * TcMax;
   const double* g_dLt = dLt_all + (size_t)b * TcMax;
   const int Tc = P.Tc, Tm = P.Tm;
@@ -2280,7 +2284,11 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
   __syncthreads();
   const DevParams& P = Ps;
 #else
-  const DevParams P = params[b];
+  DevParams P = params[b];
+#ifndef CHM_SELF_NPV
+#define CHM_SELF_NPV 13
+#endif
+  mass_params_to_vgpr<MASS, CHM_SELF_NPV>(P);
 #endif
   const double* g_zt = zt_all + (size_t)b * TcMax;
   const double* g_dLt = dLt_all + (size_t)b * TcMax;

@@ -18,11 +18,27 @@
 // a*b + c as ONE three-address v_fma_f64 with the coefficient c held in a VGPR pair.  In the large kernels the compiler turns a
 // Horner step with a register-resident coefficient into v_mov_b64 + v_fmac_f64 (two issue slots, seen in the gfx950 ISA of
 // k_samples: 260 of 1134 VALU instructions in the loop were such copies); spelling the instruction out halves the polynomial cost.
+// [r3] The coefficient c is an immediate: two s_mov_b32 into a scratch SGPR pair (s[100:101], declared clobbered) right in front of the
+// v_fma_f64 that reads it as its one scalar operand.  The ~20 coefficients of exp / log then occupy no registers at all -- in VGPRs they
+// took 40 registers or two v_mov_b32 (2 cycles each) per use, in allocated SGPRs the register allocator spilled them to VGPR lanes
+// (v_readlane: 4 cycles) -- and the s_mov_b32 issue on the scalar unit beside the VALU stream (v_fma_f64 + SALU pairs: 4.8 against
+// 4.4 cycles, profiles/r03/issue_cost.txt).  CHM_FMA_COEF_VGPR restores the round-2 form for A/B runs.
+#ifndef CHM_FMA_COEF_VGPR
+template <unsigned LO, unsigned HI>
+DEVFN double fm_fma_k(double a, double b) {
+  double d;
+  asm("s_mov_b32 s100, %3\n\ts_mov_b32 s101, %4\n\tv_fma_f64 %0, %1, %2, s[100:101]" : "=v"(d) : "v"(a), "v"(b), "n"(LO), "n"(HI) : "s100", "s101");
+  return d;
+}
+#define FM_BITS(c) __builtin_bit_cast(unsigned long long, (double)(c))
+#define FM_FMA(a, b, c) fm_fma_k<(unsigned)(FM_BITS(c) & 0xffffffffull), (unsigned)(FM_BITS(c) >> 32)>((a), (b))
+#else
 DEVFN double FM_FMA(double a, double b, double c) {
   double d;
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
   return d;
 }
+#endif
 
 // a / b without the IEEE special-case scaffolding (v_div_scale / v_div_fmas / v_div_fixup): reciprocal seed, two Newton steps,
 // quotient and one residual correction -- 8 instructions instead of 11, the correctly rounded quotient except for rare last-bit
@@ -100,7 +116,7 @@ DEVFN double chm_exp_nb(double x) {
 // log(x) for finite x > 0 (NaN propagates); fdlibm e_log.c scheme, < 1 ulp
 DEVFN double chm_log_pos(double x) {
   const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-  const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+  constexpr double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
                Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
                Lg7 = 1.479819860511658591e-01;
   double m = FM_FREXP_M(x);

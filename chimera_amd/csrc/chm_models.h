@@ -417,6 +417,29 @@ DEVFN double p_m1m2(const DevParams& p, double m1, double m2, A1 mg, A2 cdf) {
 // (mass.py:340) is applied to the same cases (0/0 at m1 = m2 = m_low).
 // MASS >= 0: the mass model is a compile-time constant (k_samples_fast / k_selection instantiate the hot loops per model, so the
 // other models' parameters never occupy scalar registers); MASS = -1: read from the draw (generic kernels).
+// The mass-model parameters the per-sample / per-injection loops read, moved from scalar into VECTOR registers (a uniform value in every
+// lane; the empty asm hides the uniformity from the compiler).  The kernels that call p_m1m2_fused hold ~35 doubles of the draw, a dozen
+// pointers and the exec-mask stack in 102 SGPRs: the allocator spilled half of them to VGPR lanes and re-read them with v_readlane inside
+// the loops (84 of 860 VALU instructions per pass of k_selection_fast), while -- with the polynomial coefficients out of the VGPRs -- a
+// quarter of the vector registers stood empty.
+#ifndef CHM_NO_PARAM_VGPR
+#define CHM_TO_VGPR(x) asm volatile("" : "+v"(x))
+#else
+#define CHM_TO_VGPR(x)
+#endif
+// N: how many of them (in the order of their use count in p_m1m2_fused<MASS>) -- as many as the kernel's vector registers take without spilling
+template <int MASS, int N>
+DEVFN void mass_params_to_vgpr(DevParams& p) {
+  int n = 0;
+#define CHM_TV(x) do { if (n++ < N) CHM_TO_VGPR(x); } while (0)
+  CHM_TV(p.m[0]); CHM_TV(p.m[1]); CHM_TV(p.lmg0); CHM_TV(p.inv_dlmg); CHM_TV(p.inv_norm_p_m1); CHM_TV(p.m[3]);
+  if (MASS != 0) { CHM_TV(p.m[4]); CHM_TV(p.m[5]); }
+  CHM_TV(p.m[2]);
+  if (MASS == 1) { CHM_TV(p.bpl_mbreak); }
+  if (MASS == 2) { CHM_TV(p.m[6]); CHM_TV(p.inv_2s2); CHM_TV(p.g_c0); CHM_TV(p.inv_plnorm); CHM_TV(p.inv_tg_norm); CHM_TV(p.tg_hi); }
+#undef CHM_TV
+}
+
 template <int MASS = -1, class A1, class A2>
 DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, double lm2, A1 mg, A2 cdf) {
 #pragma clang fp contract(fast)                  // smooth arithmetic only (no rounding-sensitive predicate): a*b+c may fuse

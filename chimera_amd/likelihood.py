@@ -162,6 +162,28 @@ class hyperlikelihood(object):
       _lib.lib().chm_like_destroy(h)
     self._handles = {}
 
+  def lane(self, comm=None):
+    """A second evaluation lane on the data this object already holds in HBM (``chm_like_clone``; the selection function gets a
+    lane of its own): the same methods, results identical to the last bit, its own streams, tables and workspaces.  One host
+    thread per lane -- ``chm_eval`` runs outside the GIL -- keeps two evaluations in flight on one GPU: the per-call fixed costs
+    (tables, launch path, reduction tail) of one hide under the kernels of the other, which is what decides the scaling of small
+    per-GPU shards (bench.py ``--inflight 2``).  A lane of a sharded likelihood needs its own communicator (``comm=``):
+    collectives of one communicator must be issued in the same order by every rank, two host threads do not guarantee that."""
+    import copy
+    if self.comm is not None and getattr(self.comm, 'nranks', 1) >= 1 and comm is None:
+      raise ValueError("hyperlikelihood.lane: a lane of a likelihood with a communicator needs a communicator of its own (comm=)")
+    self._handle()
+    new = copy.copy(self)
+    new._handles = {}
+    new.comm = comm
+    for mode, (h, _) in self._handles.items():
+      h2 = C.c_void_p()
+      _lib.check(_lib.lib().chm_like_clone(h, C.byref(h2)))
+      new._handles[mode] = (h2, None)
+    if self.selection_function is not None:
+      new.selection_function = self.selection_function.lane(comm=comm)
+    return new
+
   def __del__(self):
     try:
       self.close()

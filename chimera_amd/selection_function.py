@@ -49,6 +49,18 @@ class selection_function(object):
       _lib.lib().chm_sel_destroy(self._h)
       self._h = None
 
+  def lane(self, comm=None):
+    """A second evaluation lane on the injections already resident in HBM (``chm_sel_clone``); see ``hyperlikelihood.lane``."""
+    import copy
+    if self.comm is not None and comm is None:
+      raise ValueError("selection_function.lane: a lane of a sharded selection function needs a communicator of its own (comm=)")
+    h = self._handle()
+    new = copy.copy(self)
+    new.comm = comm
+    new._h = C.c_void_p()
+    _lib.check(_lib.lib().chm_sel_clone(h, C.byref(new._h)))
+    return new
+
   def __del__(self):
     try:
       self.close()

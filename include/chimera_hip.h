@@ -165,6 +165,15 @@ int chm_like_destroy(chm_like* h);
 int chm_sel_create(const chm_sel_desc* desc, chm_sel** out);
 int chm_sel_destroy(chm_sel* h);
 
+/* A second evaluation LANE on the data a handle already holds in HBM: the clone shares every array *_create uploaded (reference
+ * counted: handles may be destroyed in any order) and owns its streams, per-draw tables, workspaces and captured graph.  One host
+ * thread per lane, each calling chm_eval on its own lane, keeps two evaluations in flight on one GPU -- what a sampler that evaluates
+ * several walkers per step (emcee's log_prob_fn over a pool, CHIMERA/utils/emcee_utils.py:281-288) can use, and what hides the per-call
+ * fixed costs of the small shards of a multi-GPU run (CHIMERA/parallel.py:94-99).  With a communicator every lane needs its OWN
+ * chm_comm (collectives of one communicator must be issued in one order by every rank).                                          */
+int chm_like_clone(const chm_like* src, chm_like** out);
+int chm_sel_clone(const chm_sel* src, chm_sel** out);
+
 /* hyperlikelihood.compute_all / __call__ for nb draws (likelihood.py:307-338).  `like` or `sel` may be NULL:
  * with sel == NULL only the numerator outputs are produced; with like == NULL only N_exp.
  * With comm != NULL the shard partials are summed over ranks with one RCCL all-reduce of 3*nb doubles

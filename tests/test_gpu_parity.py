@@ -236,7 +236,43 @@ def test_rccl_single_rank_communicator(cfg_pix):
   like, _, _ = H.build_product(ev, inj, comm=comm)
   ref, _, _ = H.build_product(ev, inj)
   assert like(H0=70.) == ref(H0=70.)
+  # [r3] the scalar call keeps its HIP-graph replay under a communicator: the first call of a configuration runs eagerly, the second is
+  # captured (the graph ends at the rank's partial sums, ncclAllReduce + k_combine follow on the stream), later ones are replayed --
+  # every one of them must give the single-process value to the last bit, and the batched call the same numbers
+  hs = [66., 71.5, 68.25, 74., 69.125, 72.75]
+  got = [like(H0=h) for h in hs]
+  want = [ref(H0=h) for h in hs]
+  assert got == want, (got, want)
+  np.testing.assert_array_equal(like.batch([dict(H0=h) for h in hs]), np.asarray(want))
   comm.close()
+
+
+def test_two_evaluations_in_flight_on_lanes_of_one_handle(cfg_pix):
+  """[r3] hyperlikelihood.lane(): a second evaluation lane on the same resident data (chm_like_clone / chm_sel_clone).  Every lane
+  gives the parent's numbers to the last bit -- scalar calls (graph replay), batches, per-event outputs -- also when two host threads
+  keep one evaluation per lane in flight at the same time, and the shared arrays outlive whichever handle is destroyed first."""
+  from concurrent.futures import ThreadPoolExecutor
+  cfg, ev, inj = cfg_pix
+  like, _, _ = H.build_product(ev, inj)
+  hs = np.linspace(62., 78., 12)
+  want = np.array([like(H0=float(h)) for h in hs])
+  lane = like.lane()
+  assert lane._handles and lane.selection_function is not like.selection_function
+  got = np.array([lane(H0=float(h)) for h in hs])
+  np.testing.assert_array_equal(got, want)
+  np.testing.assert_array_equal(lane.batch([dict(H0=float(h)) for h in hs]), want)
+  np.testing.assert_array_equal(lane.compute_all(H0=70.)[0], like.compute_all(H0=70.)[0])
+  # two threads, one lane each, many overlapping calls: scalar calls on one, batches on the other
+  with ThreadPoolExecutor(max_workers=2) as ex:
+    for rep in range(6):
+      fa = ex.submit(lambda: [like(H0=float(h)) for h in hs])
+      fb = ex.submit(lambda: lane.batch([dict(H0=float(h)) for h in hs[::-1]]))
+      np.testing.assert_array_equal(np.array(fa.result()), want)
+      np.testing.assert_array_equal(fb.result(), want[::-1])
+  # the parent goes first: the lane keeps the uploaded arrays alive
+  like.selection_function.close(); like.close()
+  np.testing.assert_array_equal(np.array([lane(H0=float(h)) for h in hs]), want)
+  lane.selection_function.close(); lane.close()
 
 
 def _hostcomm_worker(rank, world, addr, outdir):
