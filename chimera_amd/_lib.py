@@ -52,7 +52,8 @@ class chm_sel_desc(C.Structure):
 
 class chm_pcat_desc(C.Structure):
   _fields_ = [('E', C.c_int32), ('P', C.c_int32), ('Z', C.c_int32), ('device', C.c_int32),
-              ('z_grids', c_dp), ('offsets', C.POINTER(C.c_int64)), ('gal_z', c_dp), ('gal_sig', c_dp), ('gal_w', c_dp)]
+              ('z_grids', c_dp), ('offsets', C.POINTER(C.c_int64)), ('gal_z', c_dp), ('gal_sig', c_dp), ('gal_w', c_dp),
+              ('weight_grid', c_dp)]
 
 
 class chm_out(C.Structure):

@@ -54,7 +54,8 @@ class pixelated_catalog(object):
     self.completeness = completeness
     self.p_bkg = self.completeness.p_bkg
     self.fR = self.completeness.fR
-    self.z_range = tuple(float(v) for v in completeness.z_range)
+    # (the built-in dVdz completeness carries z_range for the device-side fR; a plug-in completeness hands fR over per call and needs none)
+    self.z_range = tuple(float(v) for v in getattr(completeness, 'z_range', (0.073, 1.3)))
     self.attr_gal_cat = ['max_npixels', 'neff_pixels']
     self.data_gal_cat = ['p_cat', 'N_gal', 'P_compl']
     if gal_cat_file is not None:
@@ -82,10 +83,6 @@ class pixelated_catalog(object):
         raise ValueError("pixelated_catalog: `cosmo`, `z_grids` and `data_gw_pixelated` are needed to compute p_cat")
       if sumgauss not in ("dVdz", "pbkg"):
         raise ValueError("sumgauss must be 'dVdz' or 'pbkg'")
-      if sumgauss == "pbkg" and not isinstance(completeness, dVdz_completeness):
-        # _sum_gaussians_pbkg (catalog.py:223-231) weights the Gaussians by the completeness' own p_bkg; the device kernel weights by
-        # dVc/dz, which is the same thing only for the built-in dVdz completeness
-        raise NotImplementedError("pixelated_catalog(sumgauss='pbkg') with a plug-in completeness: k_pcat weights by dVc/dz only")
       self.cosmo, self.z_grids, self.data_gw_pixelated = cosmo, np.ascontiguousarray(z_grids, dtype=np.float64), data_gw_pixelated
       self.z_err, self.sumgauss = z_err, sumgauss
       if data_gal is None:
@@ -156,6 +153,12 @@ class pixelated_catalog(object):
     d.E, d.P, d.Z, d.device = E, P, Z, _lib.default_device()
     d.z_grids, d.offsets = _lib.dptr(zgrids), offsets.ctypes.data_as(C.POINTER(C.c_int64))
     d.gal_z, d.gal_sig, d.gal_w = _lib.dptr(gz), _lib.dptr(gs), _lib.dptr(gw)
+    wgrid = None
+    if getattr(self, 'sumgauss', 'dVdz') == 'pbkg' and not isinstance(self.completeness, dVdz_completeness):
+      # _sum_gaussians_pbkg (catalog.py:223-231): the Gaussians are weighted by the completeness model's own p_bkg(cosmo, z) -- evaluated
+      # here on the event grids and handed to k_pcat (for the built-in dVdz completeness p_bkg IS dVc/dz, the kernel's default weight)
+      wgrid = np.ascontiguousarray(np.broadcast_to(np.asarray(self.p_bkg(self.cosmo, zgrids), dtype=np.float64), (E, Z)))
+      d.weight_grid = _lib.dptr(wgrid)
     p_cat = np.empty((E, P, Z))
     par = make_params(cosmo=self.cosmo)
     _lib.check(_lib.lib().chm_pcat_compute(C.byref(par), C.byref(d), _lib.dptr(p_cat)))

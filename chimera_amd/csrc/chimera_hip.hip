@@ -185,7 +185,7 @@ static int ctx_tables_enqueue(Ctx& c, int nb, int Tc, int Tm, LutDesc lutA = Lut
     if (tl > 14 * 1024 && tl > tl_allowed) { (void)hipFuncSetAttribute((const void*)k_tables<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl); tl_allowed = tl; }
     hipLaunchKernelGGL(k_tables<true>, dim3(nb, 2), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt, hsrc);
   } else {
-    hipLaunchKernelGGL(k_tables<false>, dim3(nb, 2), dim3(512), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt, hsrc);
+    hipLaunchKernelGGL(k_tables<false>, dim3(nb, 2), dim3(CHM_TABLES_LONG_NT), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt, hsrc);
   }
   HIPCHK(hipGetLastError());
   return CHM_OK;
@@ -1174,6 +1174,7 @@ extern "C" int chm_pcat_compute(const chm_params* cosmo, const chm_pcat_desc* d,
     CKR(upload(owned, d->gal_z, (size_t)nnz, &D.gal_z, c.stream));
     CKR(upload(owned, d->gal_sig, (size_t)nnz, &D.gal_sig, c.stream));
     CKR(upload(owned, d->gal_w, (size_t)nnz, &D.gal_w, c.stream));
+    if (d->weight_grid) CKR(upload(owned, d->weight_grid, (size_t)d->E * d->Z, &D.weight_grid, c.stream));
   }
 #undef CKR
   hipError_t he = hipMalloc(&D.p_cat, sizeof(double) * npix * d->Z);

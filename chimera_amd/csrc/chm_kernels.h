@@ -182,8 +182,11 @@ DEVFN double lut_key_floor(int key) { return __hiloint2double(key << LUT_SHIFT, 
 #endif
 // (the long-table variant, LDS_ARR = false, runs 512-thread blocks: at 1024 threads it sits at the 128-register limit and any spill there
 //  has ended in a memory-aperture fault on the MI355X boxes, see tests/test_abi_and_host.py)
+#ifndef CHM_TABLES_LONG_NT
+#define CHM_TABLES_LONG_NT 512
+#endif
 template <bool LDS_ARR>
-__global__ void __launch_bounds__(LDS_ARR ? 1024 : 512) k_tables(DevParams* params, double* zt_all, double* It_all,
+__global__ void __launch_bounds__(LDS_ARR ? 1024 : CHM_TABLES_LONG_NT) k_tables(DevParams* params, double* zt_all, double* It_all,
                                                   double* dLt_all, double* mg_all, double* cdf_all, double* tmp_all, int TcMax, int TmMax,
                                                   LutDesc lutA, LutDesc lutB, double* rec_all, const double* tab_zt, const double* tab_dLt, const DevParams* hsrc) {
   extern __shared__ double larr[];
@@ -193,6 +196,12 @@ __global__ void __launch_bounds__(LDS_ARR ? 1024 : 512) k_tables(DevParams* para
   __shared__ DevParams Ps;                          // block-local copy of the draw: constants derived here are shared through LDS
   const int b = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
   DevParams& Pg = params[b];
+#ifdef CHM_TABLES_FORCE_SCRATCH
+  // diagnostics (scripts/probe_tables_scratch.py): a dynamically indexed private array puts CHM_TABLES_FORCE_SCRATCH doubles per lane into the
+  // private segment -- the round-2 builds of this kernel that spilled registers at 1024 threads died with a memory-aperture violation
+  volatile double pad_[CHM_TABLES_FORCE_SCRATCH];
+  for (int i = 0; i < CHM_TABLES_FORCE_SCRATCH; i++) pad_[(i + t) % CHM_TABLES_FORCE_SCRATCH] = (double)(t + i);
+#endif
   if (t == 0) { s_int[0] = 0x7fffffff; s_int[1] = 0; s_int[2] = 0; s_int[3] = -1; s_int[4] = -1; }
   if (t < (int)(sizeof(DevParams) / sizeof(double))) {
     // hsrc: the draw comes straight from the pinned host copy (no copy node in front of this kernel); block y = 1 then fills the device
@@ -341,6 +350,9 @@ __global__ void __launch_bounds__(LDS_ARR ? 1024 : 512) k_tables(DevParams* para
       }
     }
     TS(4); TS_PRINT;
+#ifdef CHM_TABLES_FORCE_SCRATCH
+    if (pad_[(t + b) % CHM_TABLES_FORCE_SCRATCH] == -1.) g_tmp[0] = pad_[t % CHM_TABLES_FORCE_SCRATCH];
+#endif
   } else {
     double* mg = LDS_ARR ? larr : g_mg;
     double* tmp = LDS_ARR ? larr + Tm : g_tmp;
@@ -2531,6 +2543,7 @@ struct PcatDev {
   const double* z_grids;
   const long long* offsets;
   const double *gal_z, *gal_sig, *gal_w;
+  const double* weight_grid;      // (E,Z) or NULL: p_bkg of a plug-in completeness on the event grids (sumgauss='pbkg', catalog.py:223-231)
   double* p_cat;
 };
 
@@ -2545,7 +2558,8 @@ __global__ void __launch_bounds__(256) k_pcat(PcatDev D, const DevParams* params
   for (int k = t; k < Z; k += nt) {
     double z = zg[k];
     zz[k] = z;
-    dv[k] = dVcdz_from_dCt(P, dCt_at_z(P, z, g.zt, g.It), z);      // dVcdz_at_z(cosmo, zgrid)   catalog.py:219
+    dv[k] = D.weight_grid ? D.weight_grid[(size_t)e * Z + k]         // p_bkg(cosmo, zgrid), caller-evaluated   catalog.py:229
+                          : dVcdz_from_dCt(P, dCt_at_z(P, z, g.zt, g.It), z);      // dVcdz_at_z(cosmo, zgrid)   catalog.py:219
     acc[k] = 0.;
   }
   __syncthreads();

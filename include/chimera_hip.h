@@ -218,6 +218,9 @@ typedef struct chm_pcat_desc {
   const double*  gal_z;          /* (nnz,) galaxy redshifts                   catalog.py:159             */
   const double*  gal_sig;        /* (nnz,) z_err * (1 + z_gal)                catalog.py:115,160         */
   const double*  gal_w;          /* (nnz,) host weights                       catalog.py:114,162         */
+  const double*  weight_grid;    /* (E,Z) or NULL.  NULL: the Gaussians are weighted by dVc/dz of `cosmo` (_sum_gaussians_ucv,
+                                  * catalog.py:212-221).  Given: by these values -- p_bkg(cosmo, z_grid) of the completeness model,
+                                  * evaluated by the caller (_sum_gaussians_pbkg, catalog.py:223-231; sumgauss='pbkg')            */
 } chm_pcat_desc;
 int chm_pcat_compute(const chm_params* cosmo, const chm_pcat_desc* desc, double* p_cat /* (E,P,Z) */);
 

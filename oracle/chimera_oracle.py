@@ -493,12 +493,29 @@ def sum_gaussians_ucv(z_grid, mu, sigma, cosmo, weights=None):
     return np.sum(weights * gauss / norm, axis=1) / np.sum(weights)
 
 
-def compute_p_cat_event(z_grid, gal_z, gal_zerr, gal_w, gal_pix, good_pix, max_npixels, cosmo):
-  """catalog.py:152-178: per-pixel sum of galaxy Gaussians; non-finite -> 0; padded with -100."""
+def sum_gaussians_pbkg(z_grid, mu, sigma, cosmo, p_bkg, weights=None):
+  """catalog.py:223-231: as sum_gaussians_ucv with the completeness model's p_bkg(cosmo, z) in place of dVc/dz."""
+  if len(mu) == 0:
+    return np.zeros_like(z_grid)
+  if weights is None:
+    weights = np.ones(len(mu))
+  zgrid = z_grid[:, None]
+  gauss = _gaussian(zgrid, mu, sigma) * np.asarray(p_bkg(cosmo, zgrid))
+  norm = trapz(gauss, zgrid, axis=0)
+  with np.errstate(all='ignore'):
+    return np.sum(weights * gauss / norm, axis=1) / np.sum(weights)
+
+
+def compute_p_cat_event(z_grid, gal_z, gal_zerr, gal_w, gal_pix, good_pix, max_npixels, cosmo, p_bkg=None):
+  """catalog.py:152-178: per-pixel sum of galaxy Gaussians; non-finite -> 0; padded with -100.  p_bkg: sumgauss='pbkg' (:164-171)."""
   sel = (gal_z > z_grid[0]) & (gal_z < z_grid[-1])                              # catalog.py:148
   gal_z, gal_zerr, gal_w, gal_pix = gal_z[sel], gal_zerr[sel], gal_w[sel], gal_pix[sel]
-  p_cat = np.array([sum_gaussians_ucv(z_grid, gal_z[gal_pix == p], gal_zerr[gal_pix == p], cosmo,
-                                      weights=gal_w[gal_pix == p]) for p in good_pix])
+  if p_bkg is not None:
+    p_cat = np.array([sum_gaussians_pbkg(z_grid, gal_z[gal_pix == p], gal_zerr[gal_pix == p], cosmo, p_bkg,
+                                         weights=gal_w[gal_pix == p]) for p in good_pix])
+  else:
+    p_cat = np.array([sum_gaussians_ucv(z_grid, gal_z[gal_pix == p], gal_zerr[gal_pix == p], cosmo,
+                                        weights=gal_w[gal_pix == p]) for p in good_pix])
   p_cat[~np.isfinite(p_cat)] = 0.
   if len(good_pix) < max_npixels:
     p_cat = np.concatenate([p_cat, np.full((max_npixels - len(good_pix), len(z_grid)), -100.)], axis=0)

@@ -202,8 +202,8 @@ def test_catalog_and_completeness_plugins(tmp_path):
     def P_compl(self, z): return np.ones_like(z)
     def fR(self, c): return 1.
     def p_bkg(self, c, z, distances=None): return np.ones_like(z)
-  with pytest.raises(NotImplementedError):                   # _sum_gaussians_pbkg with a foreign p_bkg is not what k_pcat computes
-    pixelated_catalog(foreign(), cosmo=object(), z_grids=zg, data_gw_pixelated=object(), data_gal={'z': np.array([0.5])}, sumgauss='pbkg')
+  with pytest.raises(ValueError):                            # sumgauss is 'dVdz' or 'pbkg' (catalog.py:164-171); 'pbkg' with a foreign
+    pixelated_catalog(foreign(), cosmo=object(), z_grids=zg, data_gw_pixelated=object(), data_gal={'z': np.array([0.5])}, sumgauss='flat')   # p_bkg runs on the GPU: tests/test_gpu_parity.py
   with pytest.raises(ValueError):
     pixelated_catalog(comp)
   assert empty_catalog().max_npixels is None

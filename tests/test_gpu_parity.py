@@ -3,6 +3,7 @@
 Stated fp64 tolerance: tables rtol 1e-13; per-event L_i rtol 1e-9; p_gw rtol 1e-9 (+ tiny atol at
 the edge of the Epanechnikov support); log-hyperlikelihood atol 1e-7*sqrt(E).
 """
+import os
 import numpy as np
 import pytest
 
@@ -223,6 +224,21 @@ def test_sharded_partials_add_up(cfg_pix, kind):
   like_o, pop_o, sel_o = H.build_oracle(ev, inj, kind=kind)
   got = H.combine_partials(np.sum(parts, axis=0), cfg['E'], pop_o.update(**lam), inj['N_inj'], 5.)
   np.testing.assert_allclose(got, like_o(**lam), rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
+
+
+def test_k_tables_runs_with_a_private_segment_at_1024_threads():
+  """[r3] Round 2 held k_tables to zero scratch after builds that spilled two registers at 1024 threads per block died with
+  HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.  Builds of the kernel that DO use scratch (64 B per lane, forced) -- the short-table variant
+  at 1024 threads beside 33 KB static + dynamic LDS, the long-table variant at 512 and at 1024 threads -- run and reproduce the default
+  build's tables and likelihoods (scripts/probe_tables_scratch.py, each variant in its own process): the private segment at that block
+  size is not the cause."""
+  import subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  for name, flags in (('ts512', ['-DCHM_TABLES_FORCE_SCRATCH=6']), ('ts1024', ['-DCHM_TABLES_LONG_NT=1024', '-DCHM_TABLES_FORCE_SCRATCH=6'])):
+    subprocess.check_call(['bash', os.path.join(root, 'scripts', 'build_variant.sh'), name] + flags, cwd=root)
+  p = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'probe_tables_scratch.py')], cwd=root, capture_output=True, text=True, timeout=600)
+  assert p.returncode == 0, p.stdout + p.stderr
+  assert 'ts512: rc 0' in p.stdout and 'ts1024: rc 0' in p.stdout, p.stdout
 
 
 def test_rccl_single_rank_communicator(cfg_pix):
@@ -514,6 +530,45 @@ def test_precompute_p_cat_matches_oracle():
       assert gc.N_gal[e] == ngal
     assert gc.P_compl.shape == (cfg['E'], 1, 96) and gc.max_npixels == cfg['P']
     np.testing.assert_array_equal(gc.neff_pixels, ev['neff_pixels'])
+
+
+def test_precompute_p_cat_with_the_background_of_a_plugin_completeness():
+  """[r3] pixelated_catalog(sumgauss='pbkg') with a user-written completeness model (CHIMERA/catalog/catalog.py:164-171, 223-231): the
+  galaxy Gaussians are weighted by the model's own p_bkg(cosmo, z), evaluated on the host on the event grids and handed to k_pcat
+  (chm_pcat_desc.weight_grid).  Against the oracle's _sum_gaussians_pbkg; with p_bkg = dVc/dz it must reproduce the 'dVdz' catalogue."""
+  import chimera_amd as CH
+  from chimera_amd import synth
+  from chimera_amd.catalog import pixelated_catalog, dVdz_completeness
+
+  class tilted_completeness(object):                     # a plug-in: the reference's interface P_compl / fR / p_bkg (completeness.py:22-67)
+    def __init__(self, tilt): self.tilt = tilt
+    def P_compl(self, zgrids): return np.where(np.asarray(zgrids) < 0.9, 1., 0.)
+    def fR(self, cosmo, normalized=False): return 1.
+    def p_bkg(self, cosmo, z):
+      z = np.asarray(z, dtype=np.float64)
+      return CH.cosmo.dVcdz_at_z(cosmo, z) * (1. + z) ** self.tilt
+
+  cfg, ev, inj = synth.make_config('C2', E=5, S=64, P=4, Z=80, I=100, ragged=True)
+  gal = synth.make_galaxy_sample(ev, ev['z_grids'], ngal_mean=10)
+  w = np.random.default_rng(8).uniform(0.5, 2., gal['z'].size)
+  th = CH.data.theta_pe_det(dL=ev['dL'], pixels_opt_nsides=ev['pixels_opt_nsides'], ra_pix=ev['ra_pix'], opt_nsides=ev['opt_nsides'])
+  cp, co = CH.cosmo.flrw(H0=70., Om0=0.25, z_max=5.), O.flrw(H0=70., Om0=0.25, z_max=5.)
+  kw = dict(cosmo=cp, z_grids=ev['z_grids'], data_gal=gal, data_gw_pixelated=th, z_err=0.01, weights=w)
+  for tilt in (-1.7, 0.):
+    gc = pixelated_catalog(tilted_completeness(tilt), sumgauss='pbkg', **kw)
+    for e in range(cfg['E']):
+      ns = ev['opt_nsides'][e]
+      good = ev['pixels_opt_nsides'][e][ev['pixels_opt_nsides'][e] != -100]
+      isin = np.isin(gal[f'pix{ns}'], good)
+      pc, ngal = O.compute_p_cat_event(ev['z_grids'][e], gal['z'][isin], 0.01 * (1 + gal['z'][isin]), w[isin], gal[f'pix{ns}'][isin], good, cfg['P'],
+                                       co, p_bkg=lambda c, z: O.dVcdz_at_z(c, z) * (1. + z) ** tilt)
+      np.testing.assert_allclose(gc.p_cat[e], pc, rtol=1e-10, atol=1e-300, err_msg=f'event {e} tilt {tilt}')
+      assert gc.N_gal[e] == ngal
+  ref = pixelated_catalog(dVdz_completeness(), **kw)       # tilt 0: p_bkg is dVc/dz, the default weight of the kernel
+  np.testing.assert_allclose(gc.p_cat, ref.p_cat, rtol=1e-12, atol=1e-300)
+  other = pixelated_catalog(tilted_completeness(-1.7), sumgauss='pbkg', **kw)
+  live = ref.p_cat > 0
+  assert np.max(np.abs(other.p_cat[live] / ref.p_cat[live] - 1.)) > 1e-3          # the tilt does change the catalogue term
 
 
 # ----------------------------------------------------------------------------------------------------------
