@@ -562,7 +562,7 @@ __global__ void __launch_bounds__(64 * SAMPLE_WPB) k_samples(LikeDev L, const De
         if (s + h < s_end) {
           double d = z - z_ref;
           v[0] += w; v[1] += w * w; v[2] += d; v[3] += d * d;
-          v[4] = __builtin_fmin(v[4], z); v[5] = __builtin_fmax(v[5], z);       // a NaN z is caught through sum(d) below
+          v[4] = vmin_f64(v[4], z); v[5] = vmax_f64(v[5], z);                   // a NaN z is caught through sum(d) below
           if (FULL) {                             // un-normalised weighted moments of (z, ra, dec) about the reference
             double d1 = L.ra[eo + s + h] - ra_ref, d2 = L.dec[eo + s + h] - dec_ref;
             m[0] += w * d; m[1] += w * d1; m[2] += w * d2;
@@ -618,8 +618,8 @@ struct SampFast {
 // log(1 + z) from the node record below z: 1 + z_0 = (1 + z)(1 - v), v = (z - z_0)/(1 + z) in [0, 0.017] for the reference's
 // logspace nodes, so log(1 + z) = log(1 + z_0) + v + v^2/2 + ... (8 terms: remainder < 1e-17 relative) -- 10 instructions, no log.
 // v > 0.02 (a coarser user table) or a lane without a record: chm_log_pos.
-DEVFN double log1pz_from_node(double z, double z0, double lz0, double r) {
-  const double v = (z - z0) * r;
+DEVFN double log1pz_from_node(double z, double z0, double lz0, double r, double& v) {
+  v = (z - z0) * r;
   double p = 0.125;
   p = FM_FMA(p, v, 1. / 7.); p = FM_FMA(p, v, 1. / 6.); p = FM_FMA(p, v, 0.2); p = FM_FMA(p, v, 0.25);
   p = FM_FMA(p, v, 1. / 3.); p = __builtin_fma(p, v, 0.5); p = __builtin_fma(p, v, 1.0);
@@ -654,10 +654,10 @@ DEVFN void z_from_lut_x2(double xa, double xb, const double* rec, const unsigned
   }
   const int ja = (pa < 1 ? 1 : (pa > Tc - 1 ? Tc - 1 : pa)) - 1 - i_lo, jb = (pb < 1 ? 1 : (pb > Tc - 1 ? Tc - 1 : pb)) - 1 - i_lo;
   const double4 ra = *reinterpret_cast<const double4*>(rec + 4 * ja), rb = *reinterpret_cast<const double4*>(rec + 4 * jb);
-  za = __builtin_fma(xa - ra.x, ra.z, ra.y);
-  zb = __builtin_fma(xb - rb.x, rb.z, rb.y);
-  if (xa > x_last) za = z_last;                           // jnp.interp clamps to fp[-1] (x < xp[0] = dL(z = 0) = 0 cannot occur for a valid key)
-  if (xb > x_last) zb = z_last;
+  // jnp.interp clamps to fp[-1] beyond the last node (x < xp[0] = dL(z = 0) = 0 cannot occur for a valid key): the table is sorted here
+  // (`fits`), so the interpolant of the last interval exceeds z_last exactly for x > x_last -- one v_min_f64 instead of a compare and two selects
+  za = vmin_f64(__builtin_fma(xa - ra.x, ra.z, ra.y), z_last);
+  zb = vmin_f64(__builtin_fma(xb - rb.x, rb.z, rb.y), z_last);
   z0a = ra.y; z0b = rb.y; lz0a = ra.w; lz0b = rb.w;
   bad = !oka || !okb;
 }
@@ -768,20 +768,22 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
         // m_src = m_det/(1+z) (pop_wrapper.py:70); w = p_m1m2 / pe_prior (pop_wrapper.py:79; the tile holds 1/pe_prior)
         const double z = zz[h];
         const double zp1 = 1. + z;
-        const double r = chm_div(1., zp1);
+        const double r = chm_rcp(zp1);
         const double m1 = md1[h] * r, m2 = md2[h] * r;
         // log(m_src) = log(m_det) - log(1+z): one log for both masses, from the node record when there is one
         double lz;
         if (FITS) {
-          lz = log1pz_from_node(z, z0[h], lz0[h], r);
-          if (__any(bad || !((z - z0[h]) * r <= 0.02))) { if (bad || !((z - z0[h]) * r <= 0.02)) lz = chm_log_pos(zp1); }
+          double v;
+          lz = log1pz_from_node(z, z0[h], lz0[h], r, v);
+          const bool nolog = bad || !(v <= 0.02);
+          if (__any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
         } else lz = chm_log_pos(zp1);
         const double w = p_m1m2_fused<MASS>(P, m1, m2, l1[h] - lz, l2[h] - lz, mg, cdf) * ipr[h];
         wv[h] = w;
         if (s + h < s_end) {
           const double d = z - z_ref;
           v[0] += w; v[1] += w * w; v[2] += d; v[3] += d * d;
-          v[4] = __builtin_fmin(v[4], z); v[5] = __builtin_fmax(v[5], z);       // a NaN z is caught through sum(d) below
+          v[4] = vmin_f64(v[4], z); v[5] = vmax_f64(v[5], z);                   // a NaN z is caught through sum(d) below
           if (FULL) {                             // un-normalised weighted moments of (z, ra, dec) about the reference
             const double d1 = L.ra[eo + s + h] - ra_ref, d2 = L.dec[eo + s + h] - dec_ref;
             m[0] += w * d; m[1] += w * d1; m[2] += w * d2;
@@ -1464,7 +1466,6 @@ template <int SW> DEVFN double sg_last(double x, int sub) {
   return __hiloint2double(rh, rl);
 }
 // running maximum towards the last lane of the group (v_max_f64: NaN-ignoring; callers vote on NaNs separately)
-DEVFN double vmax_f64(double a, double b);
 template <int SW> DEVFN double sg_scan_max(double x) {
   x = vmax_f64(x, dpp_move<0x111, 0xf, false>(x));
   x = vmax_f64(x, dpp_move<0x112, 0xf, false>(x));
@@ -1502,11 +1503,8 @@ template <int SW> DEVFN double sg_max(double v) {
 // v_cndmask, v_med3, DPP moves and v_readlane alike (profiles/r03/issue_cost.txt) -- so the kernel is written for the fewest
 // instructions, whatever their type:
 //   * v_max_f64 / v_min_f64 as they are (llvm.maxnum/minnum put a canonicalising v_max_f64 x, x in front of every operand that was loaded);
-//   * double -> bin index on v_cvt_i32_f64 (truncates, saturates at +-2^31, NaN -> 0) and ONE v_med3_i32 for the two-sided clamp.
-DEVFN double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-DEVFN double vmin_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-DEVFN int cvt_i32_sat(double x) { int r; asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x)); return r; }
-DEVFN int med3_i32(int x, int lo, int hi) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi)); return r; }
+//   * double -> bin index on v_cvt_i32_f64 (truncates, saturates at +-2^31, NaN -> 0) and ONE v_med3_i32 for the two-sided clamp
+//   (vmax_f64, vmin_f64, cvt_i32_sat, med3_i32: chm_math.h).
 // DPP move of a double with zeros shifted in (bound_ctrl: no separate v_mov of the fill value) -- row_shr steps of the scans
 template <int CTRL>
 DEVFN double dpp_shr0(double x) {
@@ -2357,10 +2355,11 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
       for (int h = 0; h < 2; h++) {
         const double z = zz[h];
         const double zp1 = 1. + z;
-        const double r = chm_div(1., zp1);
+        const double r = chm_rcp(zp1);
         const double m1 = md1[h] * r, m2 = md2[h] * r;
-        double lz = log1pz_from_node(z, z0[h], lz0[h], r);
-        const bool nolog = !fits || bad || !((z - z0[h]) * r <= 0.02);
+        double vv;
+        double lz = log1pz_from_node(z, z0[h], lz0[h], r, vv);
+        const bool nolog = !fits || bad || !(vv <= 0.02);
         if (__any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
         const double pm = p_m1m2_fused<MASS>(P, m1, m2, l1[h] - lz, l2[h] - lz, mg, cdf);
         const double Ez = E_at_z_lr(P, z, zp1, r, lz);

@@ -18,7 +18,7 @@
 // a*b + c as ONE three-address v_fma_f64 with the coefficient c held in a VGPR pair.  In the large kernels the compiler turns a
 // Horner step with a register-resident coefficient into v_mov_b64 + v_fmac_f64 (two issue slots, seen in the gfx950 ISA of
 // k_samples: 260 of 1134 VALU instructions in the loop were such copies); spelling the instruction out halves the polynomial cost.
-// [r3] The coefficient c is an immediate: two s_mov_b32 into a scratch SGPR pair (s[100:101], declared clobbered) right in front of the
+// [r3] The coefficient c is an immediate: two s_mov_b32 into a scratch SGPR pair (s[98:99], declared clobbered; s[100:101] are reserved by the compiler on gfx950) right in front of the
 // v_fma_f64 that reads it as its one scalar operand.  The ~20 coefficients of exp / log then occupy no registers at all -- in VGPRs they
 // took 40 registers or two v_mov_b32 (2 cycles each) per use, in allocated SGPRs the register allocator spilled them to VGPR lanes
 // (v_readlane: 4 cycles) -- and the s_mov_b32 issue on the scalar unit beside the VALU stream (v_fma_f64 + SALU pairs: 4.8 against
@@ -27,7 +27,7 @@
 template <unsigned LO, unsigned HI>
 DEVFN double fm_fma_k(double a, double b) {
   double d;
-  asm("s_mov_b32 s100, %3\n\ts_mov_b32 s101, %4\n\tv_fma_f64 %0, %1, %2, s[100:101]" : "=v"(d) : "v"(a), "v"(b), "n"(LO), "n"(HI) : "s100", "s101");
+  asm("s_mov_b32 s98, %3\n\ts_mov_b32 s99, %4\n\tv_fma_f64 %0, %1, %2, s[98:99]" : "=v"(d) : "v"(a), "v"(b), "n"(LO), "n"(HI) : "s98", "s99");
   return d;
 }
 #define FM_BITS(c) __builtin_bit_cast(unsigned long long, (double)(c))
@@ -39,6 +39,15 @@ DEVFN double FM_FMA(double a, double b, double c) {
   return d;
 }
 #endif
+
+// Single instructions the compiler does not emit on its own: v_max_f64 / v_min_f64 without the canonicalising v_max_f64 x, x that
+// llvm.maxnum / minnum put in front of every loaded operand (IEEE maxNum / minNum: a quiet NaN operand yields the other one);
+// v_cvt_i32_f64 (truncation toward zero, saturation at +-2^31, NaN -> 0: a C++ cast of an out-of-range double is undefined);
+// v_med3_i32 as the two-sided clamp min(max(x, lo), hi) for lo <= hi.
+DEVFN double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEVFN double vmin_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEVFN int cvt_i32_sat(double x) { int r; asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x)); return r; }
+DEVFN int med3_i32(int x, int lo, int hi) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi)); return r; }
 
 // a / b without the IEEE special-case scaffolding (v_div_scale / v_div_fmas / v_div_fixup): reciprocal seed, two Newton steps,
 // quotient and one residual correction -- 8 instructions instead of 11, the correctly rounded quotient except for rare last-bit
@@ -111,6 +120,25 @@ DEVFN double chm_exp_nb(double x) {
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
   return __builtin_ldexp(p, (int)n);
+}
+
+// exp(x) for the smoothing denominators 1 + e^x of the mass models (mass.py:255-264), x = delta_m/a + delta_m/b unbounded in both
+// directions: the argument is clamped to [-745.2, 700] (v_max / v_min: a NaN x comes out as a bound, the callers test their windows
+// separately) and goes through chm_exp_nb -- every value is finite.  The caller restores the reference's exact zero of the smoothing
+// factor for x > 745.14 (where its exp(-x) underflows); in between, 1/(1 + e^700) = 1e-304 stands for e^-x in (1e-324, 1e-304).
+DEVFN double chm_exp_clamped(double x) {
+  double lo, hi;
+  asm("v_max_f64 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(-745.2));
+  asm("v_min_f64 %0, %1, %2" : "=v"(hi) : "v"(lo), "v"(700.));
+  return chm_exp_nb(hi);
+}
+
+// 1 / b for b well inside the normal range: reciprocal seed + two Newton steps (~1 ulp; chm_div(1, b) spends three more instructions on
+// the correctly rounded quotient).  For factors of smooth arithmetic: 1/(1 + z) of the det -> src conversion.
+DEVFN double chm_rcp(double b) {
+  double r = FM_RCP(b);
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  return __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
 }
 
 // log(x) for finite x > 0 (NaN propagates); fdlibm e_log.c scheme, < 1 ulp

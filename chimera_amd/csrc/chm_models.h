@@ -448,17 +448,19 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
   const bool in2 = (m_low <= m2 && m2 <= m1);               // tpl_notnorm(m2, beta, m_low, m1)   mass.py:240-245,322
   const double e5 = in2 ? (mass_model == 0 ? p.m[3] : p.m[4]) * lm2 : 0.;
   // primary numerator (without smoothing), times m2^beta                                         mass.py:285-305
+  // [r3] chm_exp_nb: every exponential below is selected by a window predicate on finite masses, so an argument outside the range of exp
+  // only ever produces a value that is discarded (or the inf / 0 that v_ldexp_f64 saturates to) -- no range checks (6 instructions each)
   double Pn;
   if (mass_model == 0) {
-    Pn = (m_low <= m1 && m1 <= m_high) ? chm_exp(-p.m[2] * lm1 + e5) : 0.;
+    Pn = (m_low <= m1 && m1 <= m_high) ? chm_exp_nb(-p.m[2] * lm1 + e5) : 0.;
   } else if (mass_model == 1) {
-    double a = (m_low <= m1 && m1 <= p.bpl_mbreak) ? chm_exp(-p.m[2] * lm1 + e5) : 0.;
-    double b = (p.bpl_mbreak <= m1 && m1 <= m_high) ? chm_exp(-p.m[3] * lm1 + e5) : 0.;
+    double a = (m_low <= m1 && m1 <= p.bpl_mbreak) ? chm_exp_nb(-p.m[2] * lm1 + e5) : 0.;
+    double b = (p.bpl_mbreak <= m1 && m1 <= m_high) ? chm_exp_nb(-p.m[3] * lm1 + e5) : 0.;
     Pn = a + b * p.bpl_pl1 / p.bpl_pl2;
   } else {
-    double Pw = (m_low <= m1 && m1 <= m_high) ? chm_exp(-p.m[3] * lm1 + e5) * p.inv_plnorm : 0.;
+    double Pw = (m_low <= m1 && m1 <= m_high) ? chm_exp_nb(-p.m[3] * lm1 + e5) * p.inv_plnorm : 0.;
     double G = 0.;
-    if (m_low <= m1 && m1 <= p.tg_hi) { double d = m1 - p.m[6]; G = chm_exp((p.g_c0 - (d * d) * p.inv_2s2) + e5) * p.inv_tg_norm; }
+    if (m_low <= m1 && m1 <= p.tg_hi) { double d = m1 - p.m[6]; G = chm_exp_nb((p.g_c0 - (d * d) * p.inv_2s2) + e5) * p.inv_tg_norm; }
     Pn = (1. - p.m[2]) * Pw + p.m[2] * G;
   }
   // smoothing denominators                                                                       mass.py:255-264
@@ -473,24 +475,37 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
     if (w2) { double a = m2 - m_low + eps, b = m2 - m_low - dm + eps; ab2 = a * b; s2 = a + b; }
     if (w1 || w2) {
       double r = chm_div(dm, ab1 * ab2);
-      if (w1) D1 = 1. + chm_exp((s1 * ab2) * r);
-      if (w2) D2 = 1. + chm_exp((s2 * ab1) * r);
+      const double x1 = (s1 * ab2) * r, x2 = (s2 * ab1) * r;
+      if (w1) D1 = 1. + chm_exp_clamped(x1);
+      if (w2) D2 = 1. + chm_exp_clamped(x2);
+      zero = zero || (w1 && x1 > 745.14) || (w2 && x2 > 745.14);      // exp(-logaddexp(0, x)) underflows to an exact 0 there   mass.py:264
     }
   }
   // interp(m1; m_grid, cdf_m2) as (f0 dx + (m1 - x0) df) / dx                                     mass.py:339
+  // [r3] the bracket comes from the position of log(m1) on the (logspace) grid; one look at the two nodes it names decides whether the
+  // neighbouring interval is the right one instead (rounding of the position, a grid that is not exactly logspace) -- the stepping loops
+  // run only then
   const int n = p.Tm;
   double t = (lm1 - p.lmg0) * p.inv_dlmg;
   int i = (t >= 0.) ? (t < (double)n ? (int)t + 1 : n - 1) : 1;
   i = i < 1 ? 1 : (i > n - 1 ? n - 1 : i);
-  while (i > 1 && mg[i - 1] > m1) i--;
-  while (i < n - 1 && mg[i] <= m1) i++;
-  double x0 = mg[i - 1], x1 = mg[i], f0 = cdf[i - 1], f1 = cdf[i];
+  double x0 = mg[i - 1], x1 = mg[i];
+  if (__any((i > 1 && x0 > m1) || (i < n - 1 && x1 <= m1))) {
+    while (i > 1 && mg[i - 1] > m1) i--;
+    while (i < n - 1 && mg[i] <= m1) i++;
+    x0 = mg[i - 1]; x1 = mg[i];
+  }
+  const double f0 = cdf[i - 1], f1 = cdf[i];
   double dx = x1 - x0;
   double cn = f0 * dx + (m1 - x0) * (f1 - f0);
   if (fabs(dx) <= 4.930380657631324e-32) { cn = f0; dx = 1.; }
   if (m1 < (double)mg[0]) cn = cdf[0] * dx;
   if (m1 > (double)mg[n - 1]) cn = cdf[n - 1] * dx;
-  double w = ((Pn * p.inv_norm_p_m1) * dx) / ((D1 * D2) * cn);      // IEEE division: the denominator is inf where a smoothing factor is 0
+  // one quotient without IEEE special cases: every factor is finite (chm_exp_clamped), the product of two saturated denominators is
+  // capped at 1e300 (a factor 1e-300 on the weight); a zero interpolant (m1 at the lowest node) gives NaN here and 0 below
+  const double num = (Pn * p.inv_norm_p_m1) * dx, den = vmin_f64((D1 * D2) * cn, 1e300);
+  double w = chm_div(num, den);
+  if (__any(den == 0.)) { if (den == 0.) w = num / den; }   // m1 at the lowest node of the grid: the IEEE quotient (x/0 = inf, 0/0 = NaN) as the reference forms it
   // sec = 0 -> p_m2m1 = 0 (or 0/0 = NaN -> 0): w = p_m1 * 0
   if (zero || (w != w && cn == 0.)) w = Pn * 0.;
   if (m1 != m1) w = m1;
