@@ -66,6 +66,10 @@ struct Ctx {
 
 static int ctx_init(Ctx& c, int device) {
   c.device = device;
+  // hipStreamSynchronize spins instead of sleeping on an interrupt: the scalar call waits ~0.17 ms per evaluation, the wake-up is part of
+  // its latency (CHM_SYNC_BLOCK=1 keeps the runtime's default).  Must precede the device's first use; later calls fail harmlessly.
+  static const bool spin = getenv("CHM_SYNC_BLOCK") == nullptr;
+  if (spin) { (void)hipSetDevice(device); (void)hipSetDeviceFlags(hipDeviceScheduleSpin); (void)hipGetLastError(); }
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
@@ -422,7 +426,7 @@ static void like_free_ws(chm_like* h) {
   LikeDev& L = h->L;
   (void)hipFree(L.ws_z); (void)hipFree(L.ws_w); (void)hipFree(L.part); (void)hipFree(L.jac); (void)hipFree(L.prate); (void)hipFree(L.bkgA);
   (void)hipFree(h->d_lut); (void)hipFree(h->d_lutinfo); h->d_lut = nullptr; h->d_lutinfo = nullptr;
-  (void)hipFree(L.err_pix); L.err_pix = nullptr;
+  (void)hipFree(L.err_pix); L.err_pix = nullptr; (void)hipFree(L.ev_li); (void)hipFree(L.ev_ll); L.ev_li = L.ev_ll = nullptr;
   (void)hipFree(L.pgw1d); (void)hipFree(L.like_pix); (void)hipFree(L.p_gw_dump); (void)hipFree(L.Aw); (void)hipFree(L.evstat); (void)hipFree(L.effg); (void)hipFree(L.krange); L.krange = nullptr;
   L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.pgw1d = L.like_pix = L.p_gw_dump = L.Aw = L.evstat = L.effg = nullptr;
   h->nb_ws = 0; h->ws_dump = false;
@@ -454,7 +458,7 @@ extern "C" int chm_like_clone(const chm_like* src, chm_like** out) {
   h->owned_sp = src->owned_sp;
   h->L = src->L;
   LikeDev& L = h->L;                                        // workspaces are the clone's own (allocated by the first call)
-  L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.Aw = L.evstat = L.effg = L.pgw1d = L.like_pix = L.err_pix = L.p_gw_dump = nullptr;
+  L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.Aw = L.evstat = L.effg = L.pgw1d = L.like_pix = L.err_pix = L.p_gw_dump = L.ev_li = L.ev_ll = nullptr;
   L.krange = nullptr; L.tab_pm = L.tab_rate = L.tab_bkg = L.tab_jac = nullptr; L.zg_i = nullptr; L.zg_t = L.zg_lz = nullptr;
   h->F = src->F; h->fast_ok = src->fast_ok; h->dl_gmin = src->dl_gmin; h->dl_gmax = src->dl_gmax;
   const size_t EZ = (size_t)L.E * L.Z;
@@ -481,7 +485,7 @@ static int like_ensure_ws(chm_like* h, int nb, bool dump) {
     HIPCHK(hipMalloc(&L.Aw, sizeof(double) * n * E * Z));
     HIPCHK(hipMalloc(&L.krange, sizeof(int) * n * E * 2));
   }
-  if (L.mode == CHM_MODE_MARG) { HIPCHK(hipMalloc(&L.err_pix, sizeof(double) * n * E * Pd)); HIPCHK(hipMalloc(&L.Aw, sizeof(double) * n * E * Z)); HIPCHK(hipMalloc(&L.evstat, sizeof(double) * n * E * NEVSTAT));
+  if (L.mode == CHM_MODE_MARG) { HIPCHK(hipMalloc(&L.err_pix, sizeof(double) * n * E * Pd)); HIPCHK(hipMalloc(&L.ev_li, sizeof(double) * n * E)); HIPCHK(hipMalloc(&L.ev_ll, sizeof(double) * n * E)); HIPCHK(hipMalloc(&L.Aw, sizeof(double) * n * E * Z)); HIPCHK(hipMalloc(&L.evstat, sizeof(double) * n * E * NEVSTAT));
                                  HIPCHK(hipMalloc(&L.effg, sizeof(double) * n * E * L.G)); }
   HIPCHK(hipMalloc(&L.like_pix, sizeof(double) * n * E * Pd));
   if (h->fast_ok) { HIPCHK(hipMalloc(&h->d_lut, sizeof(unsigned short) * n * (h->F.lut.nk + 1))); HIPCHK(hipMalloc(&h->d_lutinfo, sizeof(int) * n * 4)); }
@@ -519,8 +523,9 @@ extern "C" int chm_sel_create(const chm_sel_desc* d, chm_sel** out) {
   for (size_t k = 0; k < n; k++) { l1[k] = log(d->m1det[i0 + k]); l2[k] = log(d->m2det[i0 + k]); }
   rc = upload(*h->owned_sp, (const double*)l1.data(), n, &S.lm1det, s); if (rc) { chm_sel_destroy(h); return rc; }
   rc = upload(*h->owned_sp, (const double*)l2.data(), n, &S.lm2det, s); if (rc) { chm_sel_destroy(h); return rc; }
-  long long nblk = (S.I + SEL_TILE - 1) / SEL_TILE;
+  long long nblk = (S.I + SEL_TILE / 2 - 1) / (SEL_TILE / 2);       // records of block partial sums per draw (tiles of 512 injections at the finest)
   S.nblocks = (int)(nblk < 1 ? 1 : (nblk > 2048 ? 2048 : nblk));
+  S.tile = SEL_TILE / 2;                                    // k_selection_fast: one pass of 256 threads x 2 injections per tile (the same grouping of the sums for every call size)
   {                                                         // key range of the shard's positive finite distances (direct-index table)
     double gmin = INFINITY, gmax = 0.;
     for (size_t k = 0; k < n; k++) { const double x = d->dL[i0 + k]; if (std::isfinite(x) && x >= 2.2250738585072014e-308) { gmin = x < gmin ? x : gmin; gmax = x > gmax ? x : gmax; } }
@@ -822,6 +827,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   // ---- events: groups of events alternate between two streams, so that the (VALU-bound) sample stage of one group
   //      overlaps the (latency-bound) GW-kernel stage of the previous one
   int nblk_ev = 0, ngroups = 0;
+  bool ev_from_fixup = false;                                // k_marg_fixup formed L_i and log L_i of every event (standard marginalized kernel)
   if (like) {
     const LikeDev& L0 = like->L;
     const int Pd = L0.P > 0 ? L0.P : 1;
@@ -855,10 +861,11 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       hipStream_t sz = (one_stream || zf_ranged) ? sg : ((g & 1) ? sA : sB);
       // ~2048 blocks in all: each stages the draw's (zt, It) tables in LDS once and walks over E_cnt / gridDim.x events
       const int zf_target = 2048 / nb > 1 ? 2048 / nb : 1;
-      const int zf_units = zf_mode ? (L.E_cnt + 3) / 4 : L.E_cnt;     // ranged: four events (waves) per block pass
-      const int zf_blocks = zf_units < zf_target ? zf_units : zf_target;
       // few draws per call, standard marginalized configuration: the per-z-factor kernel forms the event statistics itself
       const bool zf_stats = zf_mode == 1 && marg_std && tab_zfac && nb <= few_nb;
+      const int zf_epb = zf_stats ? 4 / CHM_ZF_WPE_FEW : 4;       // ranged: events per block pass (a wave per event; CHM_ZF_WPE_FEW waves per event for few draws)
+      const int zf_units = zf_mode ? (L.E_cnt + zf_epb - 1) / zf_epb : L.E_cnt;
+      const int zf_blocks = zf_units < zf_target ? zf_units : zf_target;
       auto launch_zfactors = [&]() {
         if (fuse_sel) {                                     // + the selection sums: blocks [zf_blocks, zf_blocks + gx)
           SelDev S = sel->S;
@@ -900,12 +907,14 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       const bool fullm = L.mode == CHM_MODE_FULL;
       if (use_fast) {
         SampFast F = like->F; F.lut = lutA;
-#define LAUNCH_FAST(M, FU) do { allow_lds((k_samples_fast<M, FU>), lds_fast); \
-          hipLaunchKernelGGL((k_samples_fast<M, FU>), g1, dim3(64 * CHM_SF_WAVES), lds_fast, sg, L, F, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm); } while (0)
+#define LAUNCH_FAST_(M, FU, NTL) do { allow_lds((k_samples_fast<M, FU, NTL>), lds_fast); \
+          hipLaunchKernelGGL((k_samples_fast<M, FU, NTL>), g1, dim3(64 * CHM_SF_WAVES), lds_fast, sg, L, F, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm); } while (0)
+#define LAUNCH_FAST(M, FU) do { if (nb <= few_nb && !(FU)) LAUNCH_FAST_(M, FU, true); else LAUNCH_FAST_(M, FU, false); } while (0)    /* few draws: tiles streamed non-temporally */
         const int mm = params[0].mass_model;
         if (fullm) { if (mm == 0) LAUNCH_FAST(0, true); else if (mm == 1) LAUNCH_FAST(1, true); else LAUNCH_FAST(2, true); }
         else { if (mm == 0) LAUNCH_FAST(0, false); else if (mm == 1) LAUNCH_FAST(1, false); else LAUNCH_FAST(2, false); }
 #undef LAUNCH_FAST
+#undef LAUNCH_FAST_
       } else if (tab_samp) {
         if (fullm) { allow_lds(k_samples<true, true>, lds_samp);
           hipLaunchKernelGGL((k_samples<true, true>), g1, dim3(64 * SAMPLE_WPB), lds_samp, sg, L, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
@@ -943,7 +952,9 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
           else { if (ipw == 4) LAUNCH_SUB2(4, 0, false); else LAUNCH_SUB2(2, 0, false); }
 #undef LAUNCH_SUB2
           // events whose summed rounding bound matters against L_i (3e-10; the stated tolerance on L_i is 1e-9) get their heavy pixels redone with dense sums
-          if (!L.no_dense) { HIPCHK(hipGetLastError()); allow_lds(k_marg_fixup, lds_kde); hipLaunchKernelGGL(k_marg_fixup, dim3(L.E_cnt, nb), dim3(64), lds_kde, sg, L, dp, 3e-10); }
+          // (with CHM_NO_DENSE_NODE=1 the kernel redoes nothing; it always forms the per-event L_i / log L_i the reduction reads)
+          HIPCHK(hipGetLastError()); allow_lds(k_marg_fixup, lds_kde); hipLaunchKernelGGL(k_marg_fixup, dim3(L.E_cnt, nb), dim3(64), lds_kde, sg, L, dp, 3e-10);
+          ev_from_fixup = true;
         }
         else { allow_lds(k_kde_marg, lds_kde); hipLaunchKernelGGL(k_kde_marg, dim3(L.E_cnt * Pd, nb), dim3(64), lds_kde, sg, L, dp); }
       } else {
@@ -1008,7 +1019,8 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   double* out3 = zero_copy ? c.h_out : c.d_out3;           // zero_copy: the last kernel stores the 3 doubles per draw in pinned host memory
   if (like && !one_kernel) {
     hipLaunchKernelGGL(k_reduce_events, dim3(nblk_ev, nb), dim3(256), 0, sA, like->L.E, like->L.P > 0 ? like->L.P : 1,
-                       (const double*)like->L.like_pix, c.d_evpart, d_lle, d_nle);
+                       (const double*)like->L.like_pix, c.d_evpart, d_lle, d_nle, ev_from_fixup ? (const double*)like->L.ev_li : nullptr,
+                       ev_from_fixup ? (const double*)like->L.ev_ll : nullptr);
     HIPCHK(hipGetLastError());
   }
   if (sel && !fuse_sel) HIPCHK(hipStreamWaitEvent(sA, c.evb[2], 0));     // join: selection sums
@@ -1016,7 +1028,8 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     hipLaunchKernelGGL(k_reduce_final, dim3(nb), dim3(1024), 0, sA, like ? like->L.E : 0, like ? (like->L.P > 0 ? like->L.P : 1) : 1,
                        like ? (const double*)like->L.like_pix : nullptr, sel ? sel->S.nblocks : 0,
                        sel ? (const double*)sel->S.partial : nullptr, c.d_partials, dp, Etot, sel ? sel->S.N_inj : 1.,
-                       sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, multi ? 0 : 1, out3, d_lle, d_nle);
+                       sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, multi ? 0 : 1, out3, d_lle, d_nle,
+                       ev_from_fixup ? (const double*)like->L.ev_li : nullptr, ev_from_fixup ? (const double*)like->L.ev_ll : nullptr);
   } else {
     hipLaunchKernelGGL(k_final, dim3(nb), dim3(256), 0, sA, nblk_ev, (const double*)c.d_evpart, sel ? sel->S.nblocks : 0,
                        sel ? (const double*)sel->S.partial : nullptr, c.d_partials, dp, Etot, sel ? sel->S.N_inj : 1.,

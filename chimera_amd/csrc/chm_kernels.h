@@ -60,6 +60,7 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   double *pgw1d;                  // (nb,E,Z)   1d / approximate
   double *like_pix;               // (nb,E,max(P,1))
   double *err_pix;                // (nb,E,P)  marginalized, standard kernel: bound on what the prefix-sum form may have lost (k_marg_fixup)
+  double *ev_li, *ev_ll;          // (nb,E)    marginalized, standard kernel: L_i and nan_to_num(log L_i) of every event, formed by k_marg_fixup
   double *p_gw_dump;              // optional (nb,E,P,Z) or NULL
 };
 
@@ -678,7 +679,7 @@ static_assert(SAMPLE_WPB % CHM_SF_WAVES == 0, "records per chunk must be a multi
 // PF: the next tile's loads are issued before the arithmetic of the current one, compiled for 3 waves per SIMD so that the twelve extra
 // registers do not spill.  Measured for calls of one draw, where every block of the grid is resident at once: the scalar call takes
 // 0.242 instead of 0.232 ms -- the fourth wave per SIMD hides more latency than the prefetch (profiles/r02/ab_scalar_call_*.txt)
-template <int MASS, bool FULL, bool PF = (CHM_SF_PREFETCH != 0)>
+template <int MASS, bool FULL, bool NT = false, bool PF = (CHM_SF_PREFETCH != 0)>
 __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast(LikeDev L, SampFast F, const DevParams* params, const double* zt_all,
                                                                     const double* dLt_all, const double* mg_all, const double* cdf_all,
                                                                     const double* rec_all, int TcMax, int TmMax) {
@@ -744,7 +745,10 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
     double2 a, bb, cc, dd, ee, ff;
     auto load_tile = [&](int s_, double2& a_, double2& b_, double2& c_, double2& d_, double2& e_, double2& f_) {
       const double2* tp = tbase + (size_t)(s_ / SF_TILE) * (6 * SF_TILE / 2);
-      a_ = tp[0]; b_ = tp[SF_TILE / 2]; c_ = tp[2 * SF_TILE / 2]; d_ = tp[3 * SF_TILE / 2]; e_ = tp[4 * SF_TILE / 2]; f_ = tp[5 * SF_TILE / 2];
+      // NT (few draws per call): every tile is read once per call -- streamed past the caches, so that the z / w written below stay in the
+      // memory-side cache for the GW kernel; with many draws per call the tiles are shared by the draws' blocks and stay cacheable
+      auto ld = [&](const double2* q) { if (NT) { double2 v; v.x = __builtin_nontemporal_load(&q->x); v.y = __builtin_nontemporal_load(&q->y); return v; } return *q; };
+      a_ = ld(tp); b_ = ld(tp + SF_TILE / 2); c_ = ld(tp + 2 * SF_TILE / 2); d_ = ld(tp + 3 * SF_TILE / 2); e_ = ld(tp + 4 * SF_TILE / 2); f_ = ld(tp + 5 * SF_TILE / 2);
     };
     const int s_first = c * SAMPLE_CHUNK + 2 * t;
     if (PF && s_first < s_end) load_tile(s_first, a, bb, cc, dd, ee, ff);
@@ -1158,8 +1162,15 @@ DEVFN void zfactors_body(const LikeDev& L, const DevParams* params, const double
   const int Z = L.Z;
   // ranged: a WAVE per event (the support of an event's KDE is ~Z/3 points: 64-lane passes waste less than 256-thread ones);
   // whole grids: the block walks over the events
-  const int lane0 = ranged ? (t & 63) : t, stride = ranged ? 64 : nt;
-  const int ev_first = ranged ? bx * (nt >> 6) + (t >> 6) : bx, ev_step = ranged ? nbx * (nt >> 6) : nbx;
+  // [r3] STATS (few draws per call: the scalar call): CHM_ZF_WPE_FEW waves per event -- a wave per event left three quarters of the chip's
+  // wave slots empty at 1000 events x 1 draw and walked ~9 dependent passes per event
+#ifndef CHM_ZF_WPE_FEW
+#define CHM_ZF_WPE_FEW 2
+#endif
+  const int wpe = (STATS && ranged) ? CHM_ZF_WPE_FEW : 1;  // waves per event
+  const int epb = (nt >> 6) / wpe;                         // events per block pass
+  const int lane0 = ranged ? ((t >> 6) % wpe) * 64 + (t & 63) : t, stride = ranged ? 64 * wpe : nt;
+  const int ev_first = ranged ? bx * epb + (t >> 6) / wpe : bx, ev_step = ranged ? nbx * epb : nbx;
   for (int ei = ev_first; ei < L.E_cnt; ei += ev_step) {
     const int e = L.e_off + ei;
     const size_t zo = ((size_t)b * L.E + e) * Z;
@@ -1399,15 +1410,42 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
 // kernel's body (dense kernel sums where the bins in reach are light, epan_prefix_eval), in pixel order.  For ordinary data the bound
 // is ~1e-11 L_i: the wave reads 2 P doubles and exits.  After it, every L_i agrees with the dense form to ~tol + the general kernel's
 // own 1e-10.
+// L_i = sum of the event's pixel integrals IN PIXEL ORDER (jnp.sum over axis 1, likelihood.py:280; the order pixel_sum() keeps) by one wave:
+// lane p holds pixel p, the running sum walks the lanes (v_readlane: 3 instructions per pixel, no memory round trips)
+DEVFN double wave_pixel_sum(const double* lp, int Pd) {
+  const int lane = threadIdx.x & 63;
+  double Li = 0.;
+  for (int p0 = 0; p0 < Pd; p0 += 64) {
+    const double x = p0 + lane < Pd ? lp[p0 + lane] : 0.;
+    const int n = min(64, Pd - p0);
+    for (int q = 0; q < n; q++) Li += __shfl(x, q, 64);
+  }
+  return Li;
+}
+// log L_i with jnp.nan_to_num(x, nan=-inf): NaN -> -inf, -inf -> -DBL_MAX, +inf -> DBL_MAX   (likelihood.py:296-297)
+DEVFN double log_like_of(double Li) {
+  double ll = log(Li);
+  if (ll != ll) ll = -__builtin_inf();
+  else if (ll == -__builtin_inf()) ll = -1.7976931348623157e308;
+  else if (ll == __builtin_inf()) ll = 1.7976931348623157e308;
+  return ll;
+}
+
 __global__ void __launch_bounds__(64) k_marg_fixup(LikeDev L, const DevParams* params, double tol) {
   extern __shared__ double lds[];
   const int lane = threadIdx.x, e = L.e_off + blockIdx.x, b = blockIdx.y;
   const size_t po = ((size_t)b * L.E + e) * L.P;
+  // [r3] the event's L_i and log L_i leave this kernel (ev_li, ev_ll): the reduction kernel then sums E numbers per draw instead of walking
+  // E x P pixel integrals and taking E logarithms in one block (11 -> 4 us on the scalar call's critical path)
+  auto publish = [&]() {
+    const double Li = wave_pixel_sum(L.like_pix + po, L.P);
+    if (lane == 0) { L.ev_li[(size_t)b * L.E + e] = Li; L.ev_ll[(size_t)b * L.E + e] = log_like_of(Li); }
+  };
   // L_i and the summed bound over the event's pixels (P <= 1024)
   double li = 0., es = 0.;
   for (int p = lane; p < L.P; p += 64) { li += L.like_pix[po + p]; es += L.err_pix[po + p]; }
   li = wave_sum(li); es = wave_sum(es);
-  if (!(es > tol * fabs(li))) return;                   // the event is within the tolerance as it stands (also: NaN anywhere -> stays NaN)
+  if (L.no_dense || !(es > tol * fabs(li))) { publish(); return; }      // the event is within the tolerance as it stands (also: NaN anywhere -> stays NaN)
   const double share = tol * fabs(li) / (double)L.P;    // redo the pixels above their equal share: what is left sums to <= tol L_i
   for (int p0 = 0; p0 < L.P; p0 += 64) {
     const int p = p0 + lane;
@@ -1420,6 +1458,9 @@ __global__ void __launch_bounds__(64) k_marg_fixup(LikeDev L, const DevParams* p
       kde_marg_general(L, params, b, e, p0 + q, lds, true);
     }
   }
+  __syncthreads();                                      // the redone pixels were stored by lane 0 of this wave
+  __threadfence_block();
+  publish();
 }
 
 // ordering point for LDS traffic inside ONE wave (its lanes exchange data through the wave's private LDS slice): LDS
@@ -1550,7 +1591,7 @@ template <int SW> DEVFN double sg_last_perm(double x) {
 //     bin coordinate of the lower node, scale * norm * gw_pdf and the NaN of a degenerate pixel are one factor;
 //   * the loads of a pass are unconditional (clamped pair index), both grid points of a lane sit in one exec region (k_hi is odd: event_stats),
 //     NaN grid points propagate through the interpolation weight instead of a separate test.
-template <int SW, int NR, int BINS, bool DUMP>
+template <int SW, int NR, int BINS, bool DUMP, bool NT>
 DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, const double* es, const int b, const int e, const int p,
                         const int pp, const bool live, const bool poisoned, const int s0, const int s1, double (&zr)[NR], double (&wr)[NR]) {
 #pragma clang fp contract(fast)                  // a*b+c may fuse in this body; the bin index lives in bin_index_r() (contract off)
@@ -1573,7 +1614,14 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   auto load_pass = [&](int k) {
     const unsigned off = (unsigned)(k < kcap ? k : kcap) * 8u;
     Pass q;
-    q.pc = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(pc) + off);
+    // p_cat is read once per (event, pixel, call): few-draw calls (IPW = 2) stream it past the caches (non-temporal), so that the z / w the
+    // sample stage has just written are still in the memory-side cache when this kernel asks for them; with many draws per call the
+    // rows are shared by the draws' waves and stay cacheable
+    const double2* pcp = reinterpret_cast<const double2*>(reinterpret_cast<const char*>(pc) + off);
+#ifndef CHM_NO_NT
+    if (NT) { q.pc.x = __builtin_nontemporal_load(&pcp->x); q.pc.y = __builtin_nontemporal_load(&pcp->y); } else
+#endif
+    q.pc = *pcp;
     q.z = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(zg) + off);
     q.bk = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(bkgA) + off);
     q.a = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(Aw) + off);
@@ -1798,7 +1846,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevPar
     double zr[NR], wr[NR];
 #pragma unroll
     for (int j = 0; j < NR; j++) { int s = s0 + sl + SW * j; zr[j] = s < s1 ? wz[s] : lo; wr[j] = s < s1 ? ww[s] : 0.; }
-    kde_sub_item<SW, NR, BINS, DUMP>(L, params, Q, es, b, e, p, pp, live, poisoned, s0, s1, zr, wr);
+    kde_sub_item<SW, NR, BINS, DUMP, (IPW <= 2)>(L, params, Q, es, b, e, p, pp, live, poisoned, s0, s1, zr, wr);
   };
   run(blockIdx.y, pA, ppA, a0, a1, true);
   run(blockIdx.y + H, pB, ppB, b0, b1, false);
@@ -2194,7 +2242,8 @@ struct SelDev {
   const double *tab_jac;          // (nb,I) plug-in cosmology: |ddL/dz| (1+z)^2 per injection
   double N_inj, N_eff; int has_neff, pad;
   double* partial;                // (nb, nblocks, 2)
-  int nblocks;
+  int nblocks;                    // records per draw: ceil(I / 512), at most 2048
+  int tile;                       // injections per block pass of k_selection_fast (512: one pass of the block; the scalar call gets ~200 selection blocks of one pass each)
 };
 
 // one injection: dN/dtheta_det / p_draw                                     pop_wrapper.py:102-111, selection_function.py:38
@@ -2326,9 +2375,10 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
   __syncthreads();
   double s1 = 0., s2 = 0.;
   const long long I = Sd.I;
-  for (long long base = (long long)bx * SEL_TILE; base < I; base += (long long)nbx * SEL_TILE) {
+  const int tile = Sd.tile > 0 ? Sd.tile : SEL_TILE;
+  for (long long base = (long long)bx * tile; base < I; base += (long long)nbx * tile) {
 #pragma unroll 1
-    for (int off = 2 * t; off < SEL_TILE; off += 512) {
+    for (int off = 2 * t; off < tile; off += 512) {
       const long long i = base + off;
       if (i >= I) break;
       const bool two = i + 1 < I;
@@ -2405,9 +2455,11 @@ __global__ void __launch_bounds__(256, CHM_SELF_MINW) k_zf_sel(LikeDev L, SelDev
                                                      const double* rec_all, int TcMax, int TmMax, int zf_blocks) {
   extern __shared__ double lds[];
   __shared__ double red[16];
-  if ((int)blockIdx.x < zf_blocks) zfactors_body<true, true>(L, params, zt_all, It_all, TcMax, 1, blockIdx.y, blockIdx.x, zf_blocks, lds);
-  else selection_fast_body<MASS>(Sd, lut, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.y, blockIdx.x - zf_blocks,
-                                 gridDim.x - zf_blocks, lds, red);
+  // the selection blocks come FIRST in the grid: blocks are dispatched in index order, and the ~100 selection blocks (16 us each) must
+  // start with the kernel, not after a thousand per-z-factor blocks have gone through
+  const int sel_blocks = (int)gridDim.x - zf_blocks;
+  if ((int)blockIdx.x >= sel_blocks) zfactors_body<true, true>(L, params, zt_all, It_all, TcMax, 1, blockIdx.y, blockIdx.x - sel_blocks, zf_blocks, lds);
+  else selection_fast_body<MASS>(Sd, lut, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.y, blockIdx.x, sel_blocks, lds, red);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2431,18 +2483,18 @@ DEVFN double pixel_sum(const double* lp, int Pd) {
 
 // k_reduce_events: one thread per event: L_i = sum_p like_pix (likelihood.py:280), log, nan_to_num (:296-297); block sums
 __global__ void __launch_bounds__(256) k_reduce_events(int E, int Pd, const double* like_pix, double* ev_partial /* (nb, nblk) */,
-                                                        double* log_like_evs, double* numlike_evs) {
+                                                        double* log_like_evs, double* numlike_evs, const double* ev_li, const double* ev_ll) {
   __shared__ double red[16];
   const int b = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
   double ll = 0.;
   if (e < E) {
-    const double* lp = like_pix + ((size_t)b * E + e) * Pd;
-    double Li = pixel_sum(lp, Pd);
-    ll = log(Li);
-    // jnp.nan_to_num(x, nan=-inf): NaN -> -inf, -inf -> -DBL_MAX, +inf -> DBL_MAX   
-    if (ll != ll) ll = -__builtin_inf();
-    else if (ll == -__builtin_inf()) ll = -1.7976931348623157e308;
-    else if (ll == __builtin_inf()) ll = 1.7976931348623157e308;
+    double Li;
+    if (ev_ll) { Li = ev_li[(size_t)b * E + e]; ll = ev_ll[(size_t)b * E + e]; }      // formed by k_marg_fixup (same sums, same order)
+    else {
+      const double* lp = like_pix + ((size_t)b * E + e) * Pd;
+      Li = pixel_sum(lp, Pd);
+      ll = log_like_of(Li);
+    }
     if (numlike_evs) numlike_evs[(size_t)b * E + e] = Li;
     if (log_like_evs) log_like_evs[(size_t)b * E + e] = ll;
   }
@@ -2498,17 +2550,19 @@ __global__ void __launch_bounds__(256) k_final(int nblk_ev, const double* ev_par
 __global__ void __launch_bounds__(1024) k_reduce_final(int E, int Pd, const double* like_pix, int nblk_sel, const double* sel_partial,
                                                         double* partials, const DevParams* params, double E_total, double N_inj,
                                                         double N_eff, int has_neff, int has_like, int has_sel, int do_combine,
-                                                        double* out3, double* log_like_evs, double* numlike_evs) {
+                                                        double* out3, double* log_like_evs, double* numlike_evs,
+                                                        const double* ev_li, const double* ev_ll) {
   __shared__ double red[16];
   const int b = blockIdx.x, t = threadIdx.x;
   double acc = 0., s1 = 0., s2 = 0.;
   for (int e = t; e < E; e += blockDim.x) {
-    const double* lp = like_pix + ((size_t)b * E + e) * Pd;
-    double Li = pixel_sum(lp, Pd);                                   // jnp.sum over pixels          likelihood.py:280
-    double ll = log(Li);                                             // likelihood.py:296,329
-    if (ll != ll) ll = -__builtin_inf();                             // nan_to_num(nan=-inf)        
-    else if (ll == -__builtin_inf()) ll = -1.7976931348623157e308;
-    else if (ll == __builtin_inf()) ll = 1.7976931348623157e308;
+    double Li, ll;
+    if (ev_ll) { Li = ev_li[(size_t)b * E + e]; ll = ev_ll[(size_t)b * E + e]; }      // formed by k_marg_fixup (same sums, same order)
+    else {
+      const double* lp = like_pix + ((size_t)b * E + e) * Pd;
+      Li = pixel_sum(lp, Pd);                                        // jnp.sum over pixels          likelihood.py:280
+      ll = log_like_of(Li);                                          // likelihood.py:296,329; nan_to_num(nan=-inf)
+    }
     if (numlike_evs) numlike_evs[(size_t)b * E + e] = Li;
     if (log_like_evs) log_like_evs[(size_t)b * E + e] = ll;
     acc += ll;

@@ -349,10 +349,10 @@ def test_compiler_resource_report_of_the_kernels(lib):
     import __graft_entry__ as g
     g.build(force=True)
   res = json.load(open(path))
-  for k in ('k_tables<true>', 'k_tables<false>', 'k_samples_fast<2, false, false>', 'k_kde_marg_sub2<32, 4, 200, false>', 'k_selection_fast<2>', 'k_full_kde',
+  for k in ('k_tables<true>', 'k_tables<false>', 'k_samples_fast<2, false, false, false>', 'k_kde_marg_sub2<32, 4, 200, false>', 'k_selection_fast<2>', 'k_full_kde',
             'k_zfactors<true, false>', 'k_zfactors<true, true>', 'k_marg_fixup', 'k_reduce_final'):
     assert k in res, (k, sorted(res))
   for k in ('k_tables<true>', 'k_tables<false>'):
     assert res[k]['scratch_bytes_per_lane'] == 0 and res[k]['vgpr_spills'] == 0, (k, res[k])
-  assert res['k_kde_marg_sub2<32, 4, 200, false>']['waves_per_simd'] >= 4 and res['k_samples_fast<2, false, false>']['waves_per_simd'] >= 4
+  assert res['k_kde_marg_sub2<32, 4, 200, false>']['waves_per_simd'] >= 4 and res['k_samples_fast<2, false, false, false>']['waves_per_simd'] >= 4
   assert res['k_full_kde']['waves_per_simd'] >= 3 and res['k_full_kde']['vgpr_spills'] == 0
