@@ -329,8 +329,24 @@ def main():
       _lib.check(L.chm_device_synchronize(device))
   sync()
   dt = time.perf_counter() - t1
+  dt_rank = dt
+  multi_info = None
   if rdzv is not None:
     dt = float(rdzv.allreduce_max(np.array([dt]))[0])        # max over ranks
+    dt_min = -float(rdzv.allreduce_max(np.array([-dt_rank]))[0])
+    # the collective of one step on its own: 3 * nbatch doubles through the communicator the evaluations used (after the timed region)
+    ar = []
+    if comm is not None and hasattr(comm, 'allreduce_sum'):
+      x = np.zeros(3 * nb)
+      for j in range(25):
+        rdzv.barrier()
+        ta = time.perf_counter()
+        comm.allreduce_sum(x)
+        ar.append(1e6 * (time.perf_counter() - ta))
+    multi_info = {"rank_ms_per_step": {"max": 1e3 * dt / max(args.steps, 1), "min": 1e3 * dt_min / max(args.steps, 1)},
+                  "allreduce_us": {"median": float(np.median(ar[5:])), "calls": len(ar) - 5, "doubles": 3 * nb,
+                                   "note": "host call to return, incl. H2D / D2H of the buffer: an upper bound on what the in-stream collective adds"} if len(ar) > 5 else None,
+                  "inflight": args.inflight}
   kt /= max(args.steps, 1)
 
   single = None
@@ -433,6 +449,7 @@ def main():
                  "parallelism": f"events+injections sharded over {world} GPU(s)" + (f"; {comm_kind}" if comm_kind else ""),
                  "cells_per_s": value * E * max(P, 1) * Z},
       "step_ms": {"median": 1e3 * med, "q25": 1e3 * q1, "q75": 1e3 * q3, "n": len(step_s)} if step_s else None,
+      "multi_gpu": multi_info,
       "single_call_ms": single["median_ms"] if single else None,
       "single_call": single,
       "roofline": roof,

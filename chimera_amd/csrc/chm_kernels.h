@@ -1760,29 +1760,58 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   const double errD = (24. * 1.1102230246251565e-16) * fabs(tot) * (1. + (2. * rh + 1.) * (2. * rh + 1.));
   double acc = 0., accC = 0.;
   if (DUMP && live) { for (int k = sl; k < Z; k += SW) if (k < k_lo || k > k_hi) dump[k] = 0.; }
-  // one grid point: p_gw = interpolant of the two bracketing nodes (0 outside the pixel's support), integrand, bound.  The bound sums
-  // |C_k| over every unmasked grid point of [k_lo, k_hi], not only those inside the pixel's support: looser by the share of the event's
-  // range the pixel does not cover (a factor ~1.5), one addition instead of a comparison-dependent select.
-  auto point = [&](const int kk, const double zk, const double pcv, const double bk, const double ak) {
-    double pgw = 0.;
-    if (!(zk < zlo) && !(zk > zhi)) {                       // inside: jnp.interp on the nodes (a NaN grid point goes inside and comes out NaN through the weight)
-      // bracket on the uniform effective grid: nodes x_i = lb + i de, i = floor((z - lb)/de) in [0, G - 1] here (lb <= zlo, zhi <= ub);
-      // z = ub lands on the last node with weight 0 (jnp.interp's fp[-1]); a z within rounding of a node may pick either neighbouring
-      // segment -- the interpolant is continuous there
-      const double zrel = zk - lb;
-      const double tp = floor(zrel * inv_de);
-      const double ga = fma(tp, de, lbl);                   // x_a - lo
-      const double ta = fma(tp, dd, t0);                    // its bin coordinate (x_a - lo)/dbin - 1/2
-      const double da = node(ga, ta + oa1, ta + oa2), db = node(ga + de, ta + ob1, ta + ob2);
-      const double wgt = fma(-tp, de, zrel) * inv_de;       // (z - x_a)/dx
-      pgw = fma(wgt, db - da, da) * sng;
-    }
+  // p_gw at a grid point = interpolant of the two effective-grid nodes that bracket it (0 outside the pixel's support); each point takes its
+  // own two nodes.  (CHM_GW_SHARE3: the two points (k, k + 1) of a lane share THREE node evaluations when their brackets start at the same
+  // or at consecutive nodes -- 20 instructions fewer per pass on paper, slower on the card: the wider live set spills and the uniform test
+  // serialises the pass.)
+  // Bracket of z: nodes x_i = lb + i de, i = floor((z - lb)/de) in [0, G - 1] inside the support (lb <= zlo, zhi <= ub); z = ub lands on the
+  // last node with weight 0 (jnp.interp's fp[-1]); a z within rounding of a node may pick either neighbouring segment -- the interpolant is
+  // continuous there.  A NaN grid point counts as inside and comes out NaN through the interpolation weight.
+  const double oc1 = dd + ob1, oc2 = dd + ob2, de2 = de + de;
+  auto interp = [&](const double zrel, const double tp, const double da, const double db) {
+    const double wgt = fma(-tp, de, zrel) * inv_de;         // (z - x_a)/dx
+    return fma(wgt, db - da, da) * sng;
+  };
+  auto single = [&](const double zk) {                      // one point on its own two nodes
+    const double zrel = zk - lb;
+    const double tp = floor(zrel * inv_de);
+    const double ga = fma(tp, de, lbl);                     // x_a - lo
+    const double ta = fma(tp, dd, t0);                      // its bin coordinate (x_a - lo)/dbin - 1/2
+    return interp(zrel, tp, node(ga, ta + oa1, ta + oa2), node(ga + de, ta + ob1, ta + ob2));
+  };
+  // integrand and bound.  The bound sums |C_k| over every unmasked grid point of [k_lo, k_hi], not only those inside the pixel's support:
+  // looser by the share of the event's range the pixel does not cover (a factor ~1.5), one addition instead of a comparison-dependent select.
+  auto integrand = [&](const int kk, const double pgw, const double pcv, const double bk, const double ak) {
     if (DUMP) dump[kk] = pgw;
     // (the empty volatile asm keeps this a branch on the exec mask: as selects it is four v_cndmask_b32 per point)
     if (pcv != -100.) { asm volatile(""); const double cz = fma(fR, pcv, bk) * ak; acc = fma(pgw, cz, acc); accC += fabs(cz); }   // catalog.py:202, likelihood.py:275
   };
   auto do_pass = [&](const int k, const Pass& q) {
-    if (k <= k_hi && live) { point(k, q.z.x, q.pc.x, q.bk.x, q.a.x); point(k + 1, q.z.y, q.pc.y, q.bk.y, q.a.y); }
+    if (k <= k_hi && live) {
+      const double z0 = q.z.x, z1 = q.z.y;
+      const bool in0 = !(z0 < zlo) && !(z0 > zhi), in1 = !(z1 < zlo) && !(z1 > zhi);
+      double pg0 = 0., pg1 = 0.;
+      if (in0 || in1) {
+#ifdef CHM_GW_SHARE3                                         // measured: 4.96 against 4.81 ms for the kernel (profiles/r03/ab_gw_three_node_sharing.txt) -- off
+        const double zr0 = z0 - lb, zr1 = z1 - lb;
+        const double tp0 = floor(zr0 * inv_de), tp1 = floor(zr1 * inv_de);
+        const double dtp = tp1 - tp0;
+        const bool same = dtp == 0.;
+        if (__all(same || dtp == 1.)) {                     // uniform: every lane at work here shares nodes between its two points
+          const double ga = fma(tp0, de, lbl), ta = fma(tp0, dd, t0);
+          const double n0 = node(ga, ta + oa1, ta + oa2), n1 = node(ga + de, ta + ob1, ta + ob2), n2 = node(ga + de2, ta + oc1, ta + oc2);
+          const double f0 = interp(zr0, tp0, n0, n1), f1 = interp(zr1, tp1, same ? n0 : n1, same ? n1 : n2);
+          pg0 = in0 ? f0 : 0.; pg1 = in1 ? f1 : 0.;
+        } else
+#endif
+        {
+          if (in0) pg0 = single(z0);
+          if (in1) pg1 = single(z1);
+        }
+      }
+      integrand(k, pg0, q.pc.x, q.bk.x, q.a.x);
+      integrand(k + 1, pg1, q.pc.y, q.bk.y, q.a.y);
+    }
   };
   // one pass = SW lanes x 2 consecutive grid points per pixel.  Software pipeline in two alternating register sets: the loads of the next
   // pass are issued before the arithmetic of this one and waited for where that pass begins (no register rotation, no wait at the loop end)
@@ -2039,11 +2068,12 @@ __global__ void __launch_bounds__(256) k_integrate_1d(LikeDev L, const DevParams
 #endif
 #define FULL_RH 8             // grid points of a chunk reduced through LDS at a time
 #ifndef FULL_MINW
-#define FULL_MINW 3
+#define FULL_MINW 4           // [r3] 128 VGPRs: the 16 spilled registers sit outside the march (272 against 260 evaluations/s at C3 / 4 draws)
 #endif
 __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const DevParams* params) {
   __shared__ double sa[FULL_TILE], sc[FULL_TILE];
   __shared__ double racc[256 * FULL_RH];                   // per-thread partial sums of a pass, FULL_RH grid points at a time (blockDim.x = 256)
+  __shared__ double chd[256];                              // per chunk of a pass: D^2 / 2 of its uniform grid (the common factors of the march), < 0: none
   __shared__ double red[16];
   __shared__ double wh[12];
   const int t = threadIdx.x, nt = blockDim.x;
@@ -2149,7 +2179,7 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
         double x0 = wz[s0 + s], x1 = L.ra[eo + s0 + s], x2 = L.dec[eo + s0 + s];
         double d1 = (x1 * l11 + x2 * l21) - q1, d2 = x2 * l22 - q2;
         sa[s] = x0 * l00 + x1 * l10 + x2 * l20;
-        sc[s] = (ww[s0 + s] * inv_sumw) * chm_exp(log_norm - 0.5 * (d1 * d1 + d2 * d2));
+        sc[s] = (ww[s0 + s] * inv_sumw) * chm_exp_nb(log_norm - 0.5 * (d1 * d1 + d2 * d2));      // (no range checks: a huge negative argument ends in v_ldexp_f64's 0)
       }
       __syncthreads();
       if (has && any) {
@@ -2190,11 +2220,11 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
         }
       }
     }
-    // a marched chunk holds sum_j c_j g_j0 u_j^i in acc[i]: the common factor exp(-i^2 D^2 / 2) of grid point i completes the Gaussians
-    if (has && any && uni) {
-#pragma unroll
-      for (int i = 0; i < FULL_LK; i++) acc[i] *= chm_exp(-hD2 * (double)(i * i));
-    }
+    // a marched chunk holds sum_j c_j g_j0 u_j^i in acc[i]: the common factor exp(-i^2 D^2 / 2) of grid point i completes the Gaussians.
+    // [r3] It is applied once per grid point AFTER the slices' partial sums have met (below), not by each of the NS threads of the chunk to
+    // its 32 partial sums (32 exps per thread: 6 % of the kernel's instructions); chd[chunk] = D^2 / 2, or < 0 for a chunk without the factor.
+    __syncthreads();
+    if (has && sl == 0) chd[t / NS] = (any && uni) ? hD2 : -1.;
     // the NS partial sums of every grid point meet in LDS (FULL_RH points of each chunk at a time); then one thread per grid point
     // forms p_gw and the integrand
 #pragma unroll
@@ -2210,6 +2240,7 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
         if (k > k_last) continue;
         double v = 0.;
         for (int q = 0; q < NS; q++) v += racc[i * 256 + cl * NS + q];
+        { const double hq = chd[cl]; const int ii = h0 + i; if (hq >= 0.) v *= chm_exp(-hq * (double)(ii * ii)); }
         const double z = zg[k];
         const bool inm = (z <= zhi) && (z >= zlo);
         double pgw = inm ? v * st.norm : 0.;              // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
