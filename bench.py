@@ -329,6 +329,22 @@ def main():
       _lib.check(L.chm_device_synchronize(device))
   sync()
   dt = time.perf_counter() - t1
+  # per-kernel durations for the roofline block: a few more steps with every event kernel on ONE lane (CHM_GROUPS=1: the library's default
+  # for large shards overlaps the sample stage of one event group with the GW kernel of the previous one on two streams, where a kernel's
+  # HIP-event span is not its duration) -- outside the timed region, same draws
+  kt_timed_eval = kt[0] / max(args.steps, 1)
+  if pool is None and world == 1:
+    os.environ['CHM_GROUPS'] = '1'
+    kt = np.zeros(8)
+    ntot = max(4, min(args.steps, 24))               # as sustained as the timed region (the chip clocks higher in short bursts): the last half counts
+    nser = 0
+    for k in range(ntot):
+      like.batch(draws[args.warmup + (k % max(args.steps, 1))])
+      if k >= ntot // 2:
+        kt += like.last_timing(); nser += 1
+    del os.environ['CHM_GROUPS']
+    kt *= max(args.steps, 1) / nser
+    sync()
   dt_rank = dt
   multi_info = None
   if rdzv is not None:
@@ -436,7 +452,9 @@ def main():
                     "against 8 TB/s: unique bytes (shared inputs once, per-draw arrays x nbatch) and PMC fabric traffic",
             "path_bytes_per_eval": path_bytes,
             "path_frac": path_bytes * nb / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[0] > 0 else None,
-            "stage_ms": {"eval": kt[0], "tables": kt[1], "samples": kt[2], "kde_integrate": kt[3],
+            "stage_ms": {"note": "per-kernel times from steps with the event kernels on one lane (CHM_GROUPS=1) after the timed region; "
+                                 "eval_timed = HIP-event time of a step inside the timed region (event groups on two lanes)",
+                         "eval_timed": kt_timed_eval, "eval": kt[0], "tables": kt[1], "samples": kt[2], "kde_integrate": kt[3],
                          "selection": kt[4], "selection_standalone": sel_ms, "reduce": kt[5], "events_wall": kt[6], "event_groups": kt[7]}}
     out = {
       "metric": "log-likelihood evals/sec (full hyperposterior call), N_ev x N_pix x N_z",

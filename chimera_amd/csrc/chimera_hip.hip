@@ -636,7 +636,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   const double hp0 = host_prof_on() ? now_us() : 0.;
   if (comm && comm->device != c.device) return fail(CHM_E_ARG, "chm_eval: comm lives on a different device");
   HIPCHK(hipSetDevice(c.device));
-  static const bool serial = getenv("CHM_SERIAL") != nullptr;     // diagnostics: everything on one stream
+  const bool serial = getenv("CHM_SERIAL") != nullptr;            // diagnostics: everything on one stream (read per call: bench.py times the kernels on their own after its timed region)
   hipStream_t sA = c.stream, sB = serial ? c.stream : c.stream2, sC = serial ? c.stream : c.stream3;      // (all three = sA for fused few-draw calls, below)
   const bool want_dump = like && out->p_gw != nullptr;
   int rc;
@@ -803,7 +803,11 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   // with a communicator (multi-GPU shards: short calls) only the whole evaluation and the GW kernel are timed: each event record
   // costs ~3 us of stream time (measured: 35 us per call for the full set); CHM_TIMING_ALL=1 keeps the full set (diagnosing a multi-GPU line)
   static const bool timing_all_env = getenv("CHM_TIMING_ALL") != nullptr;
-  const bool timing_all = timing && (!comm || timing_all_env);
+  // (per-kernel events only for calls whose kernels follow each other on one lane: with event groups on two streams the spans overlap and
+  //  the 4 records per group would cost more stream time than they inform -- bench.py times the kernels in a CHM_GROUPS=1 pass)
+  const char* eg0 = getenv("CHM_GROUPS");
+  const bool grouped = like && nb > few_nb && !(eg0 && atoi(eg0) == 1) && !serial && like->L.E >= 500;
+  const bool timing_all = timing && ((!comm && !grouped) || timing_all_env);
   // an error inside a capture must end it before returning
   struct CaptureGuard { hipStream_t s; bool* on; ~CaptureGuard() { if (*on) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); } } } cguard{sA, &capturing};
   if (timing) HIPCHK(hipEventRecord(c.ev[0], sA));
@@ -835,8 +839,13 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     const size_t lds_kde = sizeof(double) * (2 * N + (L0.binning ? 3 * (N + 1) : 0) + 2 * (size_t)L0.G);
     if (L0.mode != CHM_MODE_FULL && lds_kde > 150 * 1024)
       return fail(CHM_E_ARG, "chm_eval: KDE working set exceeds the LDS (binning=False needs 2*S + 2*G doubles <= 150 KiB)");
-    static const int env_groups = getenv("CHM_GROUPS") ? atoi(getenv("CHM_GROUPS")) : 0;
-    ngroups = env_groups > 0 ? env_groups : 1;      // >1: event groups alternate between two streams (measured: no net gain at C3)
+    // [r3] Event groups alternate between two streams: the sample stage of one group runs beside the GW kernel of the previous one.  Both
+    // are VALU-issue bound at ~80 % of the slots with the chip to themselves; side by side they fill each other's stalls: 9.74 -> 9.43 ms per
+    // 128-draw step at C3 with 4 - 8 groups (profiles/r03/ab_event_groups_and_lanes.txt; 12 / 16 groups: 9.6).  One group per 250 events, at
+    // most 8; CHM_GROUPS=n overrides (1: one group).  Few-draw calls stay a single chain (one_stream).
+    const char* eg = getenv("CHM_GROUPS");
+    const int env_groups = eg ? atoi(eg) : 0;
+    ngroups = env_groups > 0 ? env_groups : (nb > few_nb ? (L0.E / 250 < 1 ? 1 : (L0.E / 250 > 8 ? 8 : L0.E / 250)) : 1);
     if (ngroups > 16) ngroups = 16;
     if (ngroups > L0.E) ngroups = L0.E;
     if (one_stream) ngroups = 1;
