@@ -333,7 +333,8 @@ def main():
   # for large shards overlaps the sample stage of one event group with the GW kernel of the previous one on two streams, where a kernel's
   # HIP-event span is not its duration) -- outside the timed region, same draws
   kt_timed_eval = kt[0] / max(args.steps, 1)
-  if pool is None and world == 1:
+  if pool is None and world == 1 and nb > 8:             # (calls of few draws are a single chain anyway)
+    prev_groups = os.environ.get('CHM_GROUPS')
     os.environ['CHM_GROUPS'] = '1'
     kt = np.zeros(8)
     ntot = max(4, min(args.steps, 24))               # as sustained as the timed region (the chip clocks higher in short bursts): the last half counts
@@ -342,7 +343,10 @@ def main():
       like.batch(draws[args.warmup + (k % max(args.steps, 1))])
       if k >= ntot // 2:
         kt += like.last_timing(); nser += 1
-    del os.environ['CHM_GROUPS']
+    if prev_groups is None:
+      del os.environ['CHM_GROUPS']
+    else:
+      os.environ['CHM_GROUPS'] = prev_groups
     kt *= max(args.steps, 1) / nser
     sync()
   dt_rank = dt

@@ -750,7 +750,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   const size_t lds_zfac_call = sizeof(double) * (size_t)2 * c.TcMax;
   const bool fuse_sel = fuse_env && !serial && like && sel && sel_fast && nb <= few_nb && !td.rate_g && !td.bkg_g && !td.jac_g &&
                         like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && !getenv("CHM_MARG_GENERIC") && !getenv("CHM_ZF_FULL") &&
-                        !getenv("CHM_GROUPS") && lds_zfac_call <= 64 * 1024 && like->L.E <= 65535;
+                        !(getenv("CHM_GROUPS") && atoi(getenv("CHM_GROUPS")) > 1) && lds_zfac_call <= 64 * 1024 && like->L.E <= 65535;
   const bool one_stream = serial || fuse_sel;
   if (fuse_sel) { sB = sA; sC = sA; }
   // draw-independent brackets of the event grids on the z table: usable when every draw of the call has one (z_max, z_grid_res) and the

@@ -66,7 +66,7 @@ def main():
   if not skip_trace:
     for serial in (False, True):
       d = os.path.join(out, 'trace_serial' if serial else 'trace')
-      e = dict(env, CHM_SERIAL='1') if serial else env
+      e = dict(env, CHM_SERIAL='1', CHM_GROUPS='1') if serial else env
       rc = run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--'] + quick,
                os.path.join(out, f"trace{'_serial' if serial else ''}{tag}.log"), env=e)
       print('kernel-trace', 'serial' if serial else 'default', 'rc', rc, flush=True)
@@ -79,8 +79,10 @@ def main():
     if only is not None and pi not in only:
       continue
     d = os.path.join(out, f'pmc{pi}')
+    # CHM_GROUPS=1: one launch of every kernel per step covers the whole workload (the default splits large shards into event groups on two
+    # streams) -- the launch the roofline block of bench.py times after its timed region
     rc = run(['rocprofv3', '--kernel-trace', '--pmc'] + counters.split() + ['--output-format', 'csv', '-d', d, '--'] + quick +
-             ['--steps', '3', '--warmup', '1'], os.path.join(out, f'pmc{pi}{tag}.log'))
+             ['--steps', '3', '--warmup', '1'], os.path.join(out, f'pmc{pi}{tag}.log'), env=dict(env, CHM_GROUPS='1'))
     print('pmc pass', pi, counters, 'rc', rc, flush=True)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(d, '*', '*counter_collection.csv')):
