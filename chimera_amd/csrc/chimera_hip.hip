@@ -961,9 +961,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
           else { if (ipw == 4) LAUNCH_SUB2(4, 0, false); else LAUNCH_SUB2(2, 0, false); }
 #undef LAUNCH_SUB2
           // events whose summed rounding bound matters against L_i (3e-10; the stated tolerance on L_i is 1e-9) get their heavy pixels redone with dense sums
-          // (with CHM_NO_DENSE_NODE=1 the kernel redoes nothing; it always forms the per-event L_i / log L_i the reduction reads)
-          HIPCHK(hipGetLastError()); allow_lds(k_marg_fixup, lds_kde); hipLaunchKernelGGL(k_marg_fixup, dim3(L.E_cnt, nb), dim3(64), lds_kde, sg, L, dp, 3e-10);
-          ev_from_fixup = true;
+          // few draws per call: the kernel also forms the per-event L_i / log L_i the reduction then reads (with CHM_NO_DENSE_NODE=1 it redoes nothing)
+          L.ev_publish = nb <= few_nb ? 1 : 0;
+          if (!L.no_dense || L.ev_publish) { HIPCHK(hipGetLastError()); allow_lds(k_marg_fixup, lds_kde); hipLaunchKernelGGL(k_marg_fixup, dim3(L.E_cnt, nb), dim3(64), lds_kde, sg, L, dp, 3e-10); }
+          ev_from_fixup = L.ev_publish != 0;
         }
         else { allow_lds(k_kde_marg, lds_kde); hipLaunchKernelGGL(k_kde_marg, dim3(L.E_cnt * Pd, nb), dim3(64), lds_kde, sg, L, dp); }
       } else {

@@ -30,6 +30,7 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   int E, S, Z, P;
   int mode, kernel, bw_method, binning, num_bins, G, has_cut, NC;
   int e_off, E_cnt;               // event group handled by this launch: events [e_off, e_off + E_cnt)
+  int ev_publish;                 // k_marg_fixup writes every event's L_i / log L_i (ev_li, ev_ll): few-draw calls, where the one-block reduction is on the critical path
   int nb, no_dense;               // draws in this call; no_dense (diagnostics, CHM_NO_DENSE_NODE=1): the standard GW kernel keeps the prefix differences everywhere
                                   // (hot kernels fold the draw into blockIdx.x, draw fastest, so that the
                                   // blocks working on the same samples / p_cat rows for different draws run together and share L2)
@@ -1412,13 +1413,24 @@ __global__ void __launch_bounds__(64) k_kde_marg(LikeDev L, const DevParams* par
 // own 1e-10.
 // L_i = sum of the event's pixel integrals IN PIXEL ORDER (jnp.sum over axis 1, likelihood.py:280; the order pixel_sum() keeps) by one wave:
 // lane p holds pixel p, the running sum walks the lanes (v_readlane: 3 instructions per pixel, no memory round trips)
+DEVFN double wave_pixel_sum_regs(double x, int n) {       // lane q < n holds pixel q (n <= 64): the running sum walks the lanes in pixel order
+  const int xl = __double2loint(x), xh = __double2hiint(x);
+  double Li = 0.;
+#pragma unroll
+  for (int q = 0; q < 64; q++)                            // compile-time lane: v_readlane_b32 x 2 + v_add_f64 per pixel (a run-time lane means an LDS round trip per pixel)
+    if (q < n) Li += __hiloint2double(__builtin_amdgcn_readlane(xh, q), __builtin_amdgcn_readlane(xl, q));
+  return Li;
+}
 DEVFN double wave_pixel_sum(const double* lp, int Pd) {
   const int lane = threadIdx.x & 63;
   double Li = 0.;
   for (int p0 = 0; p0 < Pd; p0 += 64) {
     const double x = p0 + lane < Pd ? lp[p0 + lane] : 0.;
     const int n = min(64, Pd - p0);
-    for (int q = 0; q < n; q++) Li += __shfl(x, q, 64);
+    const int xl = __double2loint(x), xh = __double2hiint(x);
+#pragma unroll
+    for (int q = 0; q < 64; q++)
+      if (q < n) Li += __hiloint2double(__builtin_amdgcn_readlane(xh, q), __builtin_amdgcn_readlane(xl, q));
   }
   return Li;
 }
@@ -1435,17 +1447,21 @@ __global__ void __launch_bounds__(64) k_marg_fixup(LikeDev L, const DevParams* p
   extern __shared__ double lds[];
   const int lane = threadIdx.x, e = L.e_off + blockIdx.x, b = blockIdx.y;
   const size_t po = ((size_t)b * L.E + e) * L.P;
-  // [r3] the event's L_i and log L_i leave this kernel (ev_li, ev_ll): the reduction kernel then sums E numbers per draw instead of walking
-  // E x P pixel integrals and taking E logarithms in one block (11 -> 4 us on the scalar call's critical path)
-  auto publish = [&]() {
-    const double Li = wave_pixel_sum(L.like_pix + po, L.P);
-    if (lane == 0) { L.ev_li[(size_t)b * L.E + e] = Li; L.ev_ll[(size_t)b * L.E + e] = log_like_of(Li); }
+  // [r3] few-draw calls (ev_publish): the event's L_i and log L_i leave this kernel (ev_li, ev_ll) and the reduction kernel sums E numbers per
+  // draw instead of walking E x P pixel integrals and taking E logarithms in ONE block (11 -> 4 us on the scalar call's critical path).  With
+  // many draws per call the reduction runs a block per draw side by side and this kernel's 128 000 single-wave blocks are better left short
+  // (publishing there: 70 -> 150 us per 128 draws)
+  auto publish = [&](const double Li) {
+    if (lane == 0 && L.ev_publish) { L.ev_li[(size_t)b * L.E + e] = Li; L.ev_ll[(size_t)b * L.E + e] = log_like_of(Li); }
   };
   // L_i and the summed bound over the event's pixels (P <= 1024)
-  double li = 0., es = 0.;
-  for (int p = lane; p < L.P; p += 64) { li += L.like_pix[po + p]; es += L.err_pix[po + p]; }
+  double li = 0., es = 0., x0 = 0.;
+  for (int p = lane; p < L.P; p += 64) { const double x = L.like_pix[po + p]; if (p < 64) x0 = x; li += x; es += L.err_pix[po + p]; }
   li = wave_sum(li); es = wave_sum(es);
-  if (L.no_dense || !(es > tol * fabs(li))) { publish(); return; }      // the event is within the tolerance as it stands (also: NaN anywhere -> stays NaN)
+  if (L.no_dense || !(es > tol * fabs(li))) {             // the event is within the tolerance as it stands (also: NaN anywhere -> stays NaN)
+    if (L.ev_publish) publish(L.P <= 64 ? wave_pixel_sum_regs(x0, L.P) : wave_pixel_sum(L.like_pix + po, L.P));      // (the pixel integrals are in registers already)
+    return;
+  }
   const double share = tol * fabs(li) / (double)L.P;    // redo the pixels above their equal share: what is left sums to <= tol L_i
   for (int p0 = 0; p0 < L.P; p0 += 64) {
     const int p = p0 + lane;
@@ -1460,7 +1476,7 @@ __global__ void __launch_bounds__(64) k_marg_fixup(LikeDev L, const DevParams* p
   }
   __syncthreads();                                      // the redone pixels were stored by lane 0 of this wave
   __threadfence_block();
-  publish();
+  if (L.ev_publish) publish(wave_pixel_sum(L.like_pix + po, L.P));
 }
 
 // ordering point for LDS traffic inside ONE wave (its lanes exchange data through the wave's private LDS slice): LDS
