@@ -355,4 +355,9 @@ def test_compiler_resource_report_of_the_kernels(lib):
   for k in ('k_tables<true>', 'k_tables<false>'):
     assert res[k]['scratch_bytes_per_lane'] == 0 and res[k]['vgpr_spills'] == 0, (k, res[k])
   assert res['k_kde_marg_sub2<32, 4, 200, false>']['waves_per_simd'] >= 4 and res['k_samples_fast<2, false, false, false>']['waves_per_simd'] >= 4
-  assert res['k_full_kde']['waves_per_simd'] >= 3 and res['k_full_kde']['vgpr_spills'] == 0
+  # [r3] k_full_kde runs at 4 waves per SIMD (128 VGPRs); the registers it spills for that are touched outside the pair march (272 against 260
+  # evaluations/s measured at C3 / 4 draws per call with and without), so the bound is on how many, not on none
+  assert res['k_full_kde']['waves_per_simd'] >= 4 and res['k_full_kde']['vgpr_spills'] <= 16
+  # the two hot kernels: no more than one spilled pair (the per-item set-up; nothing in the pass loop -- scripts/isa_mix.py --dump shows where)
+  for k in ('k_kde_marg_sub2<32, 4, 200, false>', 'k_samples_fast<2, false, false, false>'):
+    assert res[k]['vgpr_spills'] <= 2 and res[k]['scratch_bytes_per_lane'] <= 16, (k, res[k])

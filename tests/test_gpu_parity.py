@@ -226,6 +226,32 @@ def test_sharded_partials_add_up(cfg_pix, kind):
   np.testing.assert_allclose(got, like_o(**lam), rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
 
 
+@pytest.mark.parametrize('kind', ['marginalized', 'approximate', None])
+def test_event_groups_on_two_streams_give_the_one_lane_values(kind):
+  """[r3] Shards of >= 500 events are evaluated in event groups that alternate between two streams when a call carries more than 8 draws
+  (the sample stage of one group beside the GW kernel of the previous one).  The values must be those of the same call with one group
+  (CHM_GROUPS=1, read per call), bit for bit -- every event's log-likelihood and the hyper-likelihood -- and agree with the C restatement."""
+  from oracle import oracle_c as OC
+  pix = kind is not None
+  cfg, ev, inj = H.small_config(E=640, S=96, P=3, Z=40, I=4000, seed=31, ragged=True, pixelated=pix)
+  like, _, _ = H.build_product(ev, inj, pixelated=pix, kind=kind)
+  lams = [dict(H0=float(h)) for h in np.linspace(62., 78., 11)]
+  pops = [like.population.update(**l) for l in lams]
+  grouped = like._eval(pops, want=('log_like_evs',))
+  os.environ['CHM_GROUPS'] = '1'
+  try:
+    one = like._eval(pops, want=('log_like_evs',))
+  finally:
+    del os.environ['CHM_GROUPS']
+  np.testing.assert_array_equal(grouped['log_like_evs'], one['log_like_evs'])
+  np.testing.assert_array_equal(grouped['log_hyper'], one['log_hyper'])
+  np.testing.assert_array_equal(like.batch(lams), one['log_hyper'])
+  like_o, _, _ = H.build_oracle(ev, inj, pixelated=pix, kind=kind)
+  ref = OC.compute_all(like_o, lams[4], nthreads=8)
+  H.assert_loglike_close(grouped['log_like_evs'][4], ref[0], rtol=RTOL_L, atol=1e-9)
+  np.testing.assert_allclose(grouped['log_hyper'][4], ref[3], rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
+
+
 def test_k_tables_runs_with_a_private_segment_at_1024_threads():
   """[r3] Round 2 held k_tables to zero scratch after builds that spilled two registers at 1024 threads per block died with
   HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.  Builds of the kernel that DO use scratch (64 B per lane, forced) -- the short-table variant
