@@ -63,6 +63,7 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   double *err_pix;                // (nb,E,P)  marginalized, standard kernel: bound on what the prefix-sum form may have lost (k_marg_fixup)
   double *ev_li, *ev_ll;          // (nb,E)    marginalized, standard kernel: L_i and nan_to_num(log L_i) of every event, formed by k_marg_fixup
   double *p_gw_dump;              // optional (nb,E,P,Z) or NULL
+  int *full_todo;                 // (nb,E,P)  full mode: 1 = the pixel is left to the general kernel by k_full_kde_chain
 };
 
 struct EvStats { double zmin, zmax, sd, norm, n_eff, sumw; };
@@ -2086,7 +2087,8 @@ __global__ void __launch_bounds__(256) k_integrate_1d(LikeDev L, const DevParams
 #ifndef FULL_MINW
 #define FULL_MINW 4           // [r3] 128 VGPRs: the 16 spilled registers sit outside the march (272 against 260 evaluations/s at C3 / 4 draws)
 #endif
-__global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const DevParams* params) {
+__global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const DevParams* params, const int* todo) {
+  if (todo && !todo[((size_t)blockIdx.y * L.E + L.e_off + blockIdx.x / L.P) * L.P + blockIdx.x % L.P]) return;      // done by k_full_kde_chain
   __shared__ double sa[FULL_TILE], sc[FULL_TILE];
   __shared__ double racc[256 * FULL_RH];                   // per-thread partial sums of a pass, FULL_RH grid points at a time (blockDim.x = 256)
   __shared__ double chd[256];                              // per chunk of a pass: D^2 / 2 of its uniform grid (the common factors of the march), < 0: none
@@ -2276,6 +2278,236 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
   }
   accl = block_reduce<RED_SUM>(accl, red);
   if (t == 0) *out_like = grid_is_poisoned(P.z_bad, zg, Z) ? __builtin_nan("") : 0.5 * accl;   // NaN factors on the grid: 0 * NaN
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_full_kde_chain [r3]: the same 3-D KDE + integrand, SAMPLE-stationary   likelihood.py:211-260, math.py:154-229
+// ------------------------------------------------------------------------------------------------------
+// k_full_kde hands a chunk of 32 grid points to a group of threads and pays two exps per (sample, chunk) to start the march of the power sums
+// (3.7 VALU instructions per (sample, grid point) pair, 1.25 of them the march).  On a stretch of the grid that is uniform from end to end the
+// starting values of chunk c+1 follow from those of chunk c without an exp: with t_c = t_0 + c LK D, d_c = a_j - t_c,
+//   c_j exp(-d_{c+1}^2 / 2) = [c_j exp(-d_c^2 / 2) u_c^LK] K1,   u_{c+1} = exp(d_{c+1} D) = u_c K2,   K1 = exp(-(LK D)^2 / 2), K2 = exp(-LK D^2),
+// and the bracket is what the march leaves in its running product.  So here a thread OWNS up to FULLC_SPT samples (their (pw, u) pairs stay in
+// registers), walks the chunks of the stretch one after the other, and the block adds the 256 threads' power sums of a chunk through LDS: one
+// wave's 64 x LK sums per round, every thread adding eight of them to its running partial sum of (grid point t/8, slot t%8), three DPP steps at
+// the end -- a fixed order, the result does not depend on the schedule.  Two exps per sample and block instead of two per sample and chunk.
+// A sample further than 37 kernel widths from the first point of the stretch (its Gaussian underflows there) starts with (0, 0) and is
+// looked at again before every chunk (a bit per owned sample; re-read and started with two exps once it is inside 37 widths of the chunk's
+// first point: it was >= 22 widths from every point of the chunks it missed, which span <= 15 widths each).
+// Blocks this form does not cover (a stretch that is not uniform to 1e-11 of its step, a chunk spanning > 15 kernel widths, more than
+// 256 x FULLC_SPT samples) are flagged in todo[] and done by k_full_kde, which skips the others.
+// Round-off: the running product takes LK/4 + 1 roundings per chunk and 4 x the step factor's (one more per chunk): <~ 1e-13 relative at the
+// far end of a 250-point stretch (test tolerance on p_gw and L_i: 1e-9).
+#ifndef FULLC_LK
+#define FULLC_LK 32
+#endif
+#define FULLC_SPT 16          // samples a thread keeps in registers: events of up to 4096 samples
+#ifndef FULLC_MINW
+#define FULLC_MINW 3
+#endif
+#define FULLC_NPT 1024        // grid points of the stretch (longer: general kernel)
+#define FULLC_ROW 72          // doubles per grid point in the exchange buffer: 64 lanes + 8 (the eight points a wave reads fall in distinct banks)
+__global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, const DevParams* params, int* todo) {
+  constexpr int LK = FULLC_LK;
+  __shared__ double xw[4][8 * FULLC_ROW];                  // per wave: eight grid points x 64 lanes of power sums on their way across the lanes
+  __shared__ double vw[4][FULLC_NPT];                      // per wave: its samples' sums at every grid point of the stretch
+  __shared__ double cf[LK];
+  __shared__ double red[16];
+  __shared__ double wh[16];
+  const int t = threadIdx.x, nt = 256;
+  const int p = blockIdx.x % L.P, e = L.e_off + blockIdx.x / L.P, b = blockIdx.y;
+  const DevParams& P = params[b];
+  const int S = L.S, Z = L.Z;
+  const size_t so = ((size_t)b * L.E + e) * S;
+  const size_t eo = (size_t)e * S;
+  const double* wz = L.ws_z + so;
+  const double* ww = L.ws_w + so;
+  int* my_todo = todo + ((size_t)b * L.E + e) * L.P + p;
+  double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
+  double* dump = L.p_gw_dump ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
+  if (p >= L.neff_pixels[e]) {                            // result[ev, :npix] only (likelihood.py:253)
+    if (t == 0) { *out_like = 0.; *my_todo = 0; }
+    if (dump) for (int k = t; k < Z; k += nt) dump[k] = 0.;
+    return;
+  }
+  const double* part = L.part + ((size_t)b * L.E + e) * L.NC * NPART;
+  const EvStats st = combine_stats(part, L.NC, S);
+  const bool ok = !(st.n_eff < L.pe_neff);                // `if n_effs[ev] < pe_neff: continue`   likelihood.py:234
+  if (t == 0) {
+    // weighted covariance of (z, ra, dec), inv_cov / factor^2, its lower Cholesky factor and log_norm (math.py:173-195, 215): as in k_full_kde
+    double sw = 0., sw2 = 0., a[3] = {0., 0., 0.}, m[6] = {0., 0., 0., 0., 0., 0.};
+    for (int c = 0; c < L.NC; c++) {
+      const double* q = part + (size_t)c * NPART;
+      sw += q[PT_SW]; sw2 += q[PT_SW2];
+      a[0] += q[PT_WD0]; a[1] += q[PT_WD1]; a[2] += q[PT_WD2];
+      m[0] += q[PT_W00]; m[1] += q[PT_W01]; m[2] += q[PT_W02]; m[3] += q[PT_W11]; m[4] += q[PT_W12]; m[5] += q[PT_W22];
+    }
+    double sW2 = sw2 / (sw * sw);
+    double m0 = a[0] / sw, m1 = a[1] / sw, m2 = a[2] / sw;
+    double den = 1. - sW2;
+    double c00 = (m[0] / sw - m0 * m0) / den, c01 = (m[1] / sw - m0 * m1) / den, c02 = (m[2] / sw - m0 * m2) / den;
+    double c11 = (m[3] / sw - m1 * m1) / den, c12 = (m[4] / sw - m1 * m2) / den, c22 = (m[5] / sw - m2 * m2) / den;
+    double neff = 1. / sW2;
+    double factor = kde_bandwidth_factor(L.bw_method, L.bw_scalar, neff, 3);
+    double a00 = c11 * c22 - c12 * c12, a01 = c02 * c12 - c01 * c22, a02 = c01 * c12 - c02 * c11;
+    double a11 = c00 * c22 - c02 * c02, a12 = c01 * c02 - c00 * c12, a22 = c00 * c11 - c01 * c01;
+    double det = c00 * a00 + c01 * a01 + c02 * a02;
+    double f2 = factor * factor;
+    double i00 = a00 / det / f2, i01 = a01 / det / f2, i02 = a02 / det / f2;
+    double i11 = a11 / det / f2, i12 = a12 / det / f2, i22 = a22 / det / f2;
+    double l00 = sqrt(i00), l10 = i01 / l00, l20 = i02 / l00;
+    double l11 = sqrt(i11 - l10 * l10), l21 = (i12 - l20 * l10) / l11;
+    double l22 = sqrt(i22 - l20 * l20 - l21 * l21);
+    wh[0] = l00; wh[1] = l10; wh[2] = l11; wh[3] = l20; wh[4] = l21; wh[5] = l22;
+    wh[6] = (chm_log(l00) + chm_log(l11) + chm_log(l22)) - 0.5 * 3. * chm_log(2. * CHM_PI);
+  }
+  __syncthreads();
+  const double l00 = wh[0], l10 = wh[1], l11 = wh[2], l20 = wh[3], l21 = wh[4], l22 = wh[5], log_norm = wh[6];
+  const double zhi = st.zmax + L.cut_grid * st.sd, zlo = st.zmin - L.cut_grid * st.sd;      // z mask, likelihood.py:225
+  const double* zg = L.z_grids + (size_t)e * Z;
+  const double rp = L.ra_pix[(size_t)e * L.P + p], dp = L.dec_pix[(size_t)e * L.P + p];
+  const double q1 = rp * l11 + dp * l21, q2 = dp * l22, t_base = rp * l10 + dp * l20;      // whitened query (math.py:196)
+  const size_t zo = ((size_t)b * L.E + e) * Z;
+  const double* pc = L.p_cat + ((size_t)e * L.P + p) * Z;
+
+  double kf = 1e300, kl = -1.;
+  for (int k = t; k < Z; k += nt) { double z = zg[k]; if (z <= zhi && z >= zlo) { kf = fmin(kf, (double)k); kl = fmax(kl, (double)k); } }
+  kf = block_reduce<RED_MIN>(kf, red); kl = block_reduce<RED_MAX>(kl, red);
+  const int k_first = kl >= 0. ? (int)kf : 0, k_last = (int)kl;
+  const int npt = k_last - k_first + 1;
+  if (!ok || npt <= 0) {                                   // nothing to integrate: the general kernel's answer for these, without it
+    if (t == 0) { *out_like = grid_is_poisoned(P.z_bad, zg, Z) ? __builtin_nan("") : 0.; *my_todo = 0; }
+    if (dump) for (int k = t; k < Z; k += nt) dump[k] = 0.;
+    return;
+  }
+  // is the stretch uniform, and a chunk of it no wider than 15 kernel widths?
+  const double z_f = zg[k_first];
+  const double dz = npt > 1 ? (zg[k_last] - z_f) / (double)(npt - 1) : 0.;
+  double dev = 0.;
+  for (int k = k_first + t; k <= k_last; k += nt) dev = fmax(dev, fabs(zg[k] - (z_f + (double)(k - k_first) * dz)));
+  dev = block_reduce<RED_MAX>(dev, red);
+  const double D = dz * l00;
+  const bool chain = npt > 1 && dev <= 1e-11 * fabs(dz) && fabs(D) * (double)LK <= 15. && S <= nt * FULLC_SPT && npt <= FULLC_NPT;
+  if (!chain) { if (t == 0) *my_todo = 1; return; }        // (k_full_kde writes the whole pixel, dump included)
+  if (t == 0) *my_todo = 0;
+  if (dump) for (int k = t; k < Z; k += nt) if (k < k_first || k > k_last) dump[k] = 0.;
+  if (t < LK) cf[t] = chm_exp(-0.5 * D * D * (double)(t * t));      // the factor of grid point i of a chunk that is common to all samples
+  // what a sample's start needs sits in LDS: after the first chunk it is a rare path, and its twelve constants would occupy registers of the march
+  if (t == 0) { wh[7] = q1; wh[8] = q2; wh[9] = 1. / st.sumw; wh[10] = D; }
+  __syncthreads();
+  // block-uniform values of the march in scalar registers (the march holds 64 + 64 vector registers of sums and sample states)
+  auto uni = [](double x) -> double {
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+  };
+  const double K1 = uni(chm_exp(-0.5 * (D * (double)LK) * (D * (double)LK))), K2 = uni(chm_exp(-(double)LK * D * D));
+  const double t0 = uni(z_f * l00 + t_base), Du = uni(D);
+  const int spt = (S + nt - 1) / nt;
+
+  // one sample's starting values at a chunk whose first point sits at tc.  1: started; 0: further than 37 widths ahead (stays (0, 0), looked at
+  // again at the next chunk); -1: further than 37 widths behind -- the chunks move away from it, it never enters
+  auto start = [&](int s, double tc, double& pw, double& u) -> int {
+    const double x0 = wz[s], x1 = L.ra[eo + s], x2 = L.dec[eo + s];
+    const double d1 = (x1 * wh[2] + x2 * wh[4]) - wh[7], d2 = x2 * wh[5] - wh[8];
+    const double d = (x0 * wh[0] + x1 * wh[1] + x2 * wh[3]) - tc;
+    const double e1 = -0.5 * (d * d), Dl = wh[10];
+    const bool in = e1 > -700.;
+    // one exp for W_j exp(log_norm - b_j / 2) exp(-d^2 / 2) (a huge negative argument ends in v_ldexp_f64's 0); |d D| <= 37.5 x 15 / LK
+    pw = in ? (ww[s] * wh[9]) * chm_exp_nb(fmax(wh[6] + e1 - 0.5 * (d1 * d1 + d2 * d2), -800.)) : 0.;
+    u = in ? chm_exp_nb(d * Dl) : 0.;
+    return in ? 1 : (d * Dl > 0. ? 0 : -1);
+  };
+  double pw[FULLC_SPT], uu[FULLC_SPT];
+  unsigned waiting = 0;                                    // bit j: owned sample j has not started yet
+#pragma unroll
+  for (int j = 0; j < FULLC_SPT; j++) {
+    pw[j] = 0.; uu[j] = 0.;
+    const int s = t + j * nt;
+    if (s < S && start(s, t0, pw[j], uu[j]) == 0) waiting |= 1u << j;
+  }
+
+  // The four waves walk the chunks on their own.  After a chunk a wave adds its 64 lanes' power sums through its private exchange buffer, eight
+  // grid points at a time: every lane writes eight sums, lane l adds lanes l%8, l%8 + 8, ... of point l/8 and three DPP steps complete the
+  // point in lane 8 (l/8) + 7, which files it in the wave's row of vw.  No barrier before the end of the stretch; a fixed order of additions.
+  const int lane = t & 63, wv = t >> 6;
+  double* xb = xw[wv];
+  double* vrow = vw[wv];
+  const int nch = (npt + LK - 1) / LK;
+  for (int c = 0; c < nch; c++) {
+    const double tc = t0 + (double)(c * LK) * Du;
+    if (c > 0 && waiting) {                                // rare: one copy of the start code, the sample's registers picked by compile-time selects
+      unsigned wm = waiting;
+      while (wm) {
+        const int j = __builtin_ctz(wm);
+        wm &= wm - 1;
+        double np, nu;
+        const int r = start(t + j * nt, tc, np, nu);
+        if (r != 0) waiting &= ~(1u << j);
+        if (r == 1) {
+#pragma unroll
+          for (int jj = 0; jj < FULLC_SPT; jj++) { pw[jj] = jj == j ? np : pw[jj]; uu[jj] = jj == j ? nu : uu[jj]; }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int ng = min(LK, npt - c * LK);                  // grid points of this chunk (the last one may be short: whole groups of four beyond it are skipped)
+    double acc[LK];
+#pragma unroll
+    for (int i = 0; i < LK; i++) acc[i] = 0.;
+#pragma unroll
+    for (int j = 0; j < FULLC_SPT; j++) {
+      if (j < spt) {
+        double q = pw[j];
+        const double u = uu[j];
+        const double u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
+#pragma unroll
+        for (int i = 0; i < LK; i += 4) {
+          acc[i] += q;
+          acc[i + 1] = __builtin_fma(q, u, acc[i + 1]);
+          acc[i + 2] = __builtin_fma(q, u2, acc[i + 2]);
+          acc[i + 3] = __builtin_fma(q, u3, acc[i + 3]);
+          q *= u4;
+        }
+        pw[j] = q * K1; uu[j] = u * K2;
+      }
+      __builtin_amdgcn_sched_barrier(0);                   // one sample after the other: hoisting the u^2, u^3, u^4 of all sixteen costs 96 registers
+    }
+#pragma unroll
+    for (int h = 0; h < LK; h += 8) {
+      if (h < ng) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) xb[i * FULLC_ROW + lane] = acc[h + i];
+        const double* src = xb + (lane >> 3) * FULLC_ROW + (lane & 7);
+        double v = 0.;
+#pragma unroll
+        for (int q = 0; q < 8; q++) v += src[8 * q];
+        v += dpp_move<0x111, 0xf, true>(v); v += dpp_move<0x112, 0xf, true>(v); v += dpp_move<0x114, 0xf, true>(v);
+        if ((lane & 7) == 7) vrow[c * LK + h + (lane >> 3)] = v;
+      }
+    }
+  }
+  __syncthreads();
+  // p_gw and the integrand of every grid point of the stretch   catalog.py:202, pop_wrapper.py:87, likelihood.py:252-275
+  double accl = 0.;
+  for (int k = k_first + t; k <= k_last; k += nt) {
+    const int r = k - k_first;
+    const double val = ((vw[0][r] + vw[1][r]) + (vw[2][r] + vw[3][r])) * cf[r % LK];
+    const double z = zg[k];
+    const bool inm = (z <= zhi) && (z >= zlo);
+    const double pgw = inm ? val * st.norm : 0.;           // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
+    if (dump) dump[k] = pgw;
+    const double pcv = pc[k];
+    double y = 0.;
+    if (pcv != -100.) {
+      const double p_gal = P.fR * pcv + L.bkgA[zo + k];
+      const double p_z = p_gal * L.prate[zo + k];
+      y = (p_z != -100.) ? pgw * p_z / L.jac[zo + k] : 0.;
+    }
+    const double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
+    accl += y * ((z - zl) + (zr - z));                     // trapezoid: y_k enters the two adjacent intervals
+  }
+  accl = block_reduce<RED_SUM>(accl, red);
+  if (t == 0) *out_like = grid_is_poisoned(P.z_bad, zg, Z) ? __builtin_nan("") : 0.5 * accl;
 }
 
 // ------------------------------------------------------------------------------------------------------
