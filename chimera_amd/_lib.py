@@ -71,7 +71,7 @@ SYMBOLS = ['chm_version', 'chm_device_count', 'chm_last_error', 'chm_like_create
            'chm_sel_create', 'chm_sel_destroy', 'chm_like_clone', 'chm_sel_clone', 'chm_eval', 'chm_eval_tabulated', 'chm_model_eval', 'chm_model_tables',
            'chm_comm_unique_id', 'chm_comm_init_rank', 'chm_comm_destroy', 'chm_comm_allreduce_sum', 'chm_comm_nranks',
            'chm_device_synchronize',
-           'chm_last_timing', 'chm_pcat_compute', 'chm_kde2d_pixels',
+           'chm_last_timing', 'chm_like_full_general_pixels', 'chm_pcat_compute', 'chm_kde2d_pixels',
            'chm_kde1d', 'chm_binning1d', 'chm_gkde_nd', 'chm_trapz', 'chm_cumtrapz']
 
 _lib = None
@@ -107,6 +107,7 @@ def lib():
   L.chm_comm_nranks.argtypes = [vp]
   L.chm_device_synchronize.argtypes = [C.c_int32]
   L.chm_last_timing.argtypes = [vp, vp, c_dp]
+  L.chm_like_full_general_pixels.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64)]
   L.chm_pcat_compute.argtypes = [C.POINTER(chm_params), C.POINTER(chm_pcat_desc), c_dp]
   L.chm_kde2d_pixels.argtypes = [C.c_int32, C.c_int32, C.c_int32, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, C.c_int32]
   i32, i64, f64 = C.c_int32, C.c_int64, C.c_double

@@ -942,7 +942,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         // [r3] sample-stationary kernel first; the pixels it cannot do (non-uniform stretch of the grid, very coarse grid, > 4096 samples) are
         // flagged in full_todo and done by the general kernel, whose other blocks return at once.  CHM_FULL_CHAIN=0: general kernel only.
-        static const bool full_chain = !(getenv("CHM_FULL_CHAIN") && atoi(getenv("CHM_FULL_CHAIN")) == 0);
+        const bool full_chain = !(getenv("CHM_FULL_CHAIN") && atoi(getenv("CHM_FULL_CHAIN")) == 0);      // (read per call: tests compare the two)
         if (full_chain) { hipLaunchKernelGGL(k_full_kde_chain, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp, L.full_todo); HIPCHK(hipGetLastError()); }
         hipLaunchKernelGGL(k_full_kde, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp, full_chain ? (const int*)L.full_todo : (const int*)nullptr);
       } else if (L.mode == CHM_MODE_MARG) {
@@ -1088,6 +1088,19 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     if (out->partials) for (int k = 0; k < 3; k++) out->partials[b * 3 + k] = c.h_out[3 * nb + b * 3 + k];
   }
   c.t_ngroups = ngroups; c.t_like = like != nullptr; c.t_sel = sel != nullptr && !fuse_sel; c.t_valid = timing; c.t_all = timing_all;      // (fused: the selection sums have no span of their own)
+  return CHM_OK;
+}
+
+extern "C" int chm_like_full_general_pixels(chm_like* like, int32_t nb, int64_t* count) {
+  if (!like || !count || nb < 1) return fail(CHM_E_ARG, "chm_like_full_general_pixels: null argument");
+  *count = 0;
+  const LikeDev& L = like->L;
+  if (L.mode != CHM_MODE_FULL || !L.full_todo || nb > like->nb_ws) return CHM_OK;
+  HIPCHK(hipSetDevice(like->ctx.device));
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<int> f((size_t)nb * L.E * L.P);
+  HIPCHK(hipMemcpy(f.data(), L.full_todo, sizeof(int) * f.size(), hipMemcpyDeviceToHost));
+  for (int v : f) *count += v != 0;
   return CHM_OK;
 }
 

@@ -253,6 +253,14 @@ class hyperlikelihood(object):
     _lib.check(_lib.lib().chm_last_timing(self._handle(), sel, _lib.dptr(ms)))
     return ms
 
+  def full_general_pixels(self, nb=1):
+    """Diagnostics of kind_p_gw3d='full': (draw, event, pixel) triples of the last evaluation of nb draws that the sample-stationary KDE
+    kernel left to the general one (include/chimera_hip.h: chm_like_full_general_pixels)."""
+    import ctypes
+    n = ctypes.c_int64(0)
+    _lib.check(_lib.lib().chm_like_full_general_pixels(self._handle(), int(nb), ctypes.byref(n)))
+    return int(n.value)
+
   # -- reference surface: GW kernels -------------------------------------------------------------------
   def p_gw1d(self, pop_lambdas):
     """likelihood.py:105-144 -> (Nevents, z_int_res)."""

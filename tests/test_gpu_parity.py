@@ -252,6 +252,48 @@ def test_event_groups_on_two_streams_give_the_one_lane_values(kind):
   np.testing.assert_allclose(grouped['log_hyper'][4], ref[3], rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
 
 
+@pytest.mark.parametrize('case', ['wide_kernels', 'narrow_kernels', 'jittered_grid', 'many_samples', 'coarse_grid'])
+def test_full_mode_sample_stationary_and_general_kernels(case):
+  """[r3] kind_p_gw3d='full' runs the sample-stationary KDE kernel (k_full_kde_chain: the power sums of a sample are carried from one chunk of
+  the grid to the next, no exp per chunk) and leaves to the general kernel the pixels it cannot do.  Cases: Scott bandwidth (every sample
+  starts at the first chunk); a bandwidth of 0.12 on a 900-point grid (the stretch inside the mask spans ~100 kernel widths: most samples
+  start at a later chunk -- the 'waiting' path -- and leave the 37-width window again); a grid jittered by 1e-7 of its step (not uniform:
+  general kernel); 4500 samples per event (more than a thread block keeps in registers: general kernel); a 60-point grid with narrow kernels
+  (a chunk spans > 15 widths: general kernel, one exp per pair).  Every case against the NumPy oracle (all pairs, one exp each) to the stated
+  1e-9, with the kernel that ran checked through chm_like_full_general_pixels, and the two kernels against each other."""
+  kw = dict(E=3, S=700, P=3, Z=900, I=1500, seed=41)
+  like_kw = {}
+  if case == 'narrow_kernels':
+    like_kw = dict(bw_method=0.12)
+  if case == 'many_samples':
+    kw.update(S=4500, E=2, P=2, Z=300)
+  if case == 'coarse_grid':
+    kw.update(Z=60); like_kw = dict(bw_method=0.05)
+  cfg, ev, inj = H.small_config(ragged=True, **kw)
+  if case == 'jittered_grid':
+    zg = np.array(ev['z_grids'])
+    dz = np.diff(zg, axis=1).mean(axis=1, keepdims=True)
+    zg[:, 1:-1] += 1e-7 * dz * np.random.default_rng(5).uniform(-1., 1., size=zg[:, 1:-1].shape)
+    ev = dict(ev, z_grids=zg)
+  like_o, _, _ = H.build_oracle(ev, inj, kind='full', like_kw=like_kw)
+  like_p, _, _ = H.build_product(ev, inj, kind='full', like_kw=like_kw)
+  lam = dict(H0=69.)
+  _compare(like_p, like_o, lam, cfg['E'])
+  res = like_p._eval([like_p.population.update(**lam)], want=('log_like_evs',))
+  general = like_p.full_general_pixels(1)
+  npix = int(np.sum(ev['neff_pixels']))
+  if case in ('wide_kernels', 'narrow_kernels'):
+    assert general == 0, (case, general, npix)
+  else:
+    assert general == npix, (case, general, npix)
+  os.environ['CHM_FULL_CHAIN'] = '0'
+  try:
+    ref = like_p._eval([like_p.population.update(**lam)], want=('log_like_evs',))      # general kernel only
+  finally:
+    del os.environ['CHM_FULL_CHAIN']
+  H.assert_loglike_close(res['log_like_evs'][0], ref['log_like_evs'][0], rtol=1e-11, atol=1e-11)
+
+
 def test_k_tables_runs_with_a_private_segment_at_1024_threads():
   """[r3] Round 2 held k_tables to zero scratch after builds that spilled two registers at 1024 threads per block died with
   HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.  Builds of the kernel that DO use scratch (64 B per lane, forced) -- the short-table variant
