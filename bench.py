@@ -395,7 +395,7 @@ def main():
                                      gw_kernel_unique_bytes(El, S, P, Z, nb), pmc))
     full_pairs = None
     if kind == 'full':
-      kernels.append(kernel_roofline("3-D Gaussian KDE + integrand", "k_full_kde", kt[3], El * S * 32 * nb + El * P * Z * 8, pmc))
+      kernels.append(kernel_roofline("3-D Gaussian KDE + integrand (sample-stationary kernel; the general kernel's share of the stage is its empty blocks)", "k_full_kde_chain", kt[3], El * S * 32 * nb + El * P * Z * 8, pmc))
       # sample x query pairs of one step (E npix Z_eff S): the masked stretch of every event grid, [min z - c std, max z + c std]
       # (likelihood.py:222-225), from the source-frame z of the last step's draws (z_from_dGW on the device, outside the timed region)
       full_pairs = 0

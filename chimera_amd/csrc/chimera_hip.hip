@@ -426,7 +426,7 @@ static void like_free_ws(chm_like* h) {
   LikeDev& L = h->L;
   (void)hipFree(L.ws_z); (void)hipFree(L.ws_w); (void)hipFree(L.part); (void)hipFree(L.jac); (void)hipFree(L.prate); (void)hipFree(L.bkgA);
   (void)hipFree(h->d_lut); (void)hipFree(h->d_lutinfo); h->d_lut = nullptr; h->d_lutinfo = nullptr;
-  (void)hipFree(L.err_pix); L.err_pix = nullptr; (void)hipFree(L.ev_li); (void)hipFree(L.ev_ll); L.ev_li = L.ev_ll = nullptr; (void)hipFree(L.full_todo); L.full_todo = nullptr;
+  (void)hipFree(L.err_pix); L.err_pix = nullptr; (void)hipFree(L.ev_li); (void)hipFree(L.ev_ll); L.ev_li = L.ev_ll = nullptr; (void)hipFree(L.full_todo); L.full_todo = nullptr; (void)hipFree(L.full_ev); (void)hipFree(L.full_s); L.full_ev = L.full_s = nullptr;
   (void)hipFree(L.pgw1d); (void)hipFree(L.like_pix); (void)hipFree(L.p_gw_dump); (void)hipFree(L.Aw); (void)hipFree(L.evstat); (void)hipFree(L.effg); (void)hipFree(L.krange); L.krange = nullptr;
   L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.pgw1d = L.like_pix = L.p_gw_dump = L.Aw = L.evstat = L.effg = nullptr;
   h->nb_ws = 0; h->ws_dump = false;
@@ -458,7 +458,7 @@ extern "C" int chm_like_clone(const chm_like* src, chm_like** out) {
   h->owned_sp = src->owned_sp;
   h->L = src->L;
   LikeDev& L = h->L;                                        // workspaces are the clone's own (allocated by the first call)
-  L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.Aw = L.evstat = L.effg = L.pgw1d = L.like_pix = L.err_pix = L.p_gw_dump = L.ev_li = L.ev_ll = nullptr; L.full_todo = nullptr;
+  L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.Aw = L.evstat = L.effg = L.pgw1d = L.like_pix = L.err_pix = L.p_gw_dump = L.ev_li = L.ev_ll = nullptr; L.full_todo = nullptr; L.full_ev = L.full_s = nullptr;
   L.krange = nullptr; L.tab_pm = L.tab_rate = L.tab_bkg = L.tab_jac = nullptr; L.zg_i = nullptr; L.zg_t = L.zg_lz = nullptr;
   h->F = src->F; h->fast_ok = src->fast_ok; h->dl_gmin = src->dl_gmin; h->dl_gmax = src->dl_gmax;
   const size_t EZ = (size_t)L.E * L.Z;
@@ -488,7 +488,12 @@ static int like_ensure_ws(chm_like* h, int nb, bool dump) {
   if (L.mode == CHM_MODE_MARG) { HIPCHK(hipMalloc(&L.err_pix, sizeof(double) * n * E * Pd)); HIPCHK(hipMalloc(&L.ev_li, sizeof(double) * n * E)); HIPCHK(hipMalloc(&L.ev_ll, sizeof(double) * n * E)); HIPCHK(hipMalloc(&L.Aw, sizeof(double) * n * E * Z)); HIPCHK(hipMalloc(&L.evstat, sizeof(double) * n * E * NEVSTAT));
                                  HIPCHK(hipMalloc(&L.effg, sizeof(double) * n * E * L.G)); }
   HIPCHK(hipMalloc(&L.like_pix, sizeof(double) * n * E * Pd));
-  if (L.mode == CHM_MODE_FULL) HIPCHK(hipMalloc(&L.full_todo, sizeof(int) * n * E * Pd));
+  if (L.mode == CHM_MODE_FULL) {
+    HIPCHK(hipMalloc(&L.full_todo, sizeof(int) * n * E * Pd));
+    HIPCHK(hipMalloc(&L.full_ev, sizeof(double) * n * E * FULLEV));
+    HIPCHK(hipMalloc(&L.full_s, sizeof(double) * 5 * n * E * S));
+    L.nb_alloc = (int)n;
+  }
   if (h->fast_ok) { HIPCHK(hipMalloc(&h->d_lut, sizeof(unsigned short) * n * (h->F.lut.nk + 1))); HIPCHK(hipMalloc(&h->d_lutinfo, sizeof(int) * n * 4)); }
   if (dump && L.mode != CHM_MODE_1D) HIPCHK(hipMalloc(&L.p_gw_dump, sizeof(double) * n * E * Pd * Z));
   h->nb_ws = nb; h->ws_dump = dump;
@@ -943,7 +948,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         // [r3] sample-stationary kernel first; the pixels it cannot do (non-uniform stretch of the grid, very coarse grid, > 4096 samples) are
         // flagged in full_todo and done by the general kernel, whose other blocks return at once.  CHM_FULL_CHAIN=0: general kernel only.
         const bool full_chain = !(getenv("CHM_FULL_CHAIN") && atoi(getenv("CHM_FULL_CHAIN")) == 0);      // (read per call: tests compare the two)
-        if (full_chain) { hipLaunchKernelGGL(k_full_kde_chain, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp, L.full_todo); HIPCHK(hipGetLastError()); }
+        if (full_chain) {
+          hipLaunchKernelGGL(k_full_prep, dim3(L.E_cnt, nb), dim3(256), 0, sg, L); HIPCHK(hipGetLastError());
+          hipLaunchKernelGGL(k_full_kde_chain, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp, L.full_todo); HIPCHK(hipGetLastError());
+        }
         hipLaunchKernelGGL(k_full_kde, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp, full_chain ? (const int*)L.full_todo : (const int*)nullptr);
       } else if (L.mode == CHM_MODE_MARG) {
         if (marg_std) { if (!zf_stats && !fuse_sel) hipLaunchKernelGGL(k_event_stats, dim3((L.E_cnt + 255) / 256, nb), dim3(256), 0, sg, L); }

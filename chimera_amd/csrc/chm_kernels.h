@@ -64,6 +64,9 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   double *ev_li, *ev_ll;          // (nb,E)    marginalized, standard kernel: L_i and nan_to_num(log L_i) of every event, formed by k_marg_fixup
   double *p_gw_dump;              // optional (nb,E,P,Z) or NULL
   int *full_todo;                 // (nb,E,P)  full mode: 1 = the pixel is left to the general kernel by k_full_kde_chain
+  double *full_ev;                // (nb,E,FULLEV) full mode: k_full_prep's record of every (draw, event)
+  double *full_s;                 // (5,nb_alloc,E,S) full mode: whitened coordinates a, y1, y2, normalised weight, step factor U of every sample
+  int nb_alloc, pad_full;         // draws the workspaces are allocated for (the stride of full_s's five planes)
 };
 
 struct EvStats { double zmin, zmax, sd, norm, n_eff, sumw; };
@@ -2305,31 +2308,30 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
 #ifndef FULLC_MINW
 #define FULLC_MINW 3
 #endif
+#ifndef FULLC_NPT
 #define FULLC_NPT 1024        // grid points of the stretch (longer: general kernel)
+#endif
 #define FULLC_ROW 72          // doubles per grid point in the exchange buffer: 64 lanes + 8 (the eight points a wave reads fall in distinct banks)
-__global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, const DevParams* params, int* todo) {
+// per (draw, event) record of k_full_prep (doubles): what the pixels of an event share
+enum { FE_L00 = 0, FE_L10, FE_L11, FE_L20, FE_L21, FE_L22, FE_LOGNORM, FE_ZLO, FE_ZHI, FE_NORM, FE_OK, FE_KFIRST, FE_KLAST, FE_CHAIN, FE_D, FE_K1, FE_K2,
+       FE_AREF, FE_ZF, FE_CF /* FULLC_LK factors */, FULLEV = FE_CF + FULLC_LK };
+
+// k_full_prep [r3]: once per (draw, event) what k_full_kde_chain's blocks (one per pixel) would each derive again -- the whitening of the event's
+// samples (math.py:173-196), the masked stretch of its grid (likelihood.py:222-226) and whether it is uniform, the constants of the march --
+// and per sample the whitened coordinates (a, y1, y2), the normalised weight and U = exp((a - a_ref) D): the step factor of a sample in a pixel
+// is exp((a - t_0p) D) = U V_p with one exp per PIXEL, V_p = exp((a_ref - t_0p) D)  (a_ref: the stretch's first point at the mean ra, dec).
+__global__ void __launch_bounds__(256) k_full_prep(LikeDev L) {
   constexpr int LK = FULLC_LK;
-  __shared__ double xw[4][8 * FULLC_ROW];                  // per wave: eight grid points x 64 lanes of power sums on their way across the lanes
-  __shared__ double vw[4][FULLC_NPT];                      // per wave: its samples' sums at every grid point of the stretch
-  __shared__ double cf[LK];
   __shared__ double red[16];
-  __shared__ double wh[16];
+  __shared__ double wh[12];
   const int t = threadIdx.x, nt = 256;
-  const int p = blockIdx.x % L.P, e = L.e_off + blockIdx.x / L.P, b = blockIdx.y;
-  const DevParams& P = params[b];
+  const int e = L.e_off + blockIdx.x, b = blockIdx.y;
   const int S = L.S, Z = L.Z;
   const size_t so = ((size_t)b * L.E + e) * S;
   const size_t eo = (size_t)e * S;
   const double* wz = L.ws_z + so;
   const double* ww = L.ws_w + so;
-  int* my_todo = todo + ((size_t)b * L.E + e) * L.P + p;
-  double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
-  double* dump = L.p_gw_dump ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
-  if (p >= L.neff_pixels[e]) {                            // result[ev, :npix] only (likelihood.py:253)
-    if (t == 0) { *out_like = 0.; *my_todo = 0; }
-    if (dump) for (int k = t; k < Z; k += nt) dump[k] = 0.;
-    return;
-  }
+  double* fe = L.full_ev + ((size_t)b * L.E + e) * FULLEV;
   const double* part = L.part + ((size_t)b * L.E + e) * L.NC * NPART;
   const EvStats st = combine_stats(part, L.NC, S);
   const bool ok = !(st.n_eff < L.pe_neff);                // `if n_effs[ev] < pe_neff: continue`   likelihood.py:234
@@ -2360,26 +2362,17 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
     double l22 = sqrt(i22 - l20 * l20 - l21 * l21);
     wh[0] = l00; wh[1] = l10; wh[2] = l11; wh[3] = l20; wh[4] = l21; wh[5] = l22;
     wh[6] = (chm_log(l00) + chm_log(l11) + chm_log(l22)) - 0.5 * 3. * chm_log(2. * CHM_PI);
+    wh[7] = L.ra[eo] + m1; wh[8] = L.dec[eo] + m2;        // weighted mean ra, dec (the moments are taken about the event's first sample)
   }
   __syncthreads();
-  const double l00 = wh[0], l10 = wh[1], l11 = wh[2], l20 = wh[3], l21 = wh[4], l22 = wh[5], log_norm = wh[6];
+  const double l00 = wh[0], l10 = wh[1], l11 = wh[2], l20 = wh[3], l21 = wh[4], l22 = wh[5];
   const double zhi = st.zmax + L.cut_grid * st.sd, zlo = st.zmin - L.cut_grid * st.sd;      // z mask, likelihood.py:225
   const double* zg = L.z_grids + (size_t)e * Z;
-  const double rp = L.ra_pix[(size_t)e * L.P + p], dp = L.dec_pix[(size_t)e * L.P + p];
-  const double q1 = rp * l11 + dp * l21, q2 = dp * l22, t_base = rp * l10 + dp * l20;      // whitened query (math.py:196)
-  const size_t zo = ((size_t)b * L.E + e) * Z;
-  const double* pc = L.p_cat + ((size_t)e * L.P + p) * Z;
-
   double kf = 1e300, kl = -1.;
   for (int k = t; k < Z; k += nt) { double z = zg[k]; if (z <= zhi && z >= zlo) { kf = fmin(kf, (double)k); kl = fmax(kl, (double)k); } }
   kf = block_reduce<RED_MIN>(kf, red); kl = block_reduce<RED_MAX>(kl, red);
   const int k_first = kl >= 0. ? (int)kf : 0, k_last = (int)kl;
   const int npt = k_last - k_first + 1;
-  if (!ok || npt <= 0) {                                   // nothing to integrate: the general kernel's answer for these, without it
-    if (t == 0) { *out_like = grid_is_poisoned(P.z_bad, zg, Z) ? __builtin_nan("") : 0.; *my_todo = 0; }
-    if (dump) for (int k = t; k < Z; k += nt) dump[k] = 0.;
-    return;
-  }
   // is the stretch uniform, and a chunk of it no wider than 15 kernel widths?
   const double z_f = zg[k_first];
   const double dz = npt > 1 ? (zg[k_last] - z_f) / (double)(npt - 1) : 0.;
@@ -2387,34 +2380,87 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
   for (int k = k_first + t; k <= k_last; k += nt) dev = fmax(dev, fabs(zg[k] - (z_f + (double)(k - k_first) * dz)));
   dev = block_reduce<RED_MAX>(dev, red);
   const double D = dz * l00;
-  const bool chain = npt > 1 && dev <= 1e-11 * fabs(dz) && fabs(D) * (double)LK <= 15. && S <= nt * FULLC_SPT && npt <= FULLC_NPT;
-  if (!chain) { if (t == 0) *my_todo = 1; return; }        // (k_full_kde writes the whole pixel, dump included)
+  const bool chain = ok && npt > 1 && dev <= 1e-11 * fabs(dz) && fabs(D) * (double)LK <= 15. && S <= nt * FULLC_SPT && npt <= FULLC_NPT;
+  const double a_ref = z_f * l00 + wh[7] * l10 + wh[8] * l20;
+  if (t < LK) fe[FE_CF + t] = chm_exp(-0.5 * D * D * (double)(t * t));      // the factor of grid point i of a chunk that is common to all samples
+  if (t == 0) {
+    for (int i = 0; i < 7; i++) fe[i] = wh[i];
+    fe[FE_ZLO] = zlo; fe[FE_ZHI] = zhi; fe[FE_NORM] = st.norm; fe[FE_OK] = ok ? 1. : 0.;
+    fe[FE_KFIRST] = (double)k_first; fe[FE_KLAST] = (double)k_last; fe[FE_CHAIN] = chain ? 1. : 0.;
+    fe[FE_D] = D; fe[FE_K1] = chm_exp(-0.5 * (D * (double)LK) * (D * (double)LK)); fe[FE_K2] = chm_exp(-(double)LK * D * D);
+    fe[FE_AREF] = a_ref; fe[FE_ZF] = z_f * l00;
+  }
+  if (!chain) return;
+  const double inv_sumw = 1. / st.sumw;
+  double* fa = L.full_s + so; double* fy1 = fa + (size_t)L.nb_alloc * L.E * S; double* fy2 = fy1 + (size_t)L.nb_alloc * L.E * S;
+  double* fw = fy2 + (size_t)L.nb_alloc * L.E * S; double* fu = fw + (size_t)L.nb_alloc * L.E * S;
+  for (int s = t; s < S; s += nt) {
+    const double x0 = wz[s], x1 = L.ra[eo + s], x2 = L.dec[eo + s];
+    const double a = x0 * l00 + x1 * l10 + x2 * l20;
+    fa[s] = a; fy1[s] = x1 * l11 + x2 * l21; fy2[s] = x2 * l22; fw[s] = ww[s] * inv_sumw;
+    fu[s] = chm_exp((a - a_ref) * D);                      // (NaN / inf coordinates propagate as they do through the direct form)
+  }
+}
+
+__global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, const DevParams* params, int* todo) {
+  constexpr int LK = FULLC_LK;
+  __shared__ double xw[4][8 * FULLC_ROW];                  // per wave: eight grid points x 64 lanes of power sums on their way across the lanes
+  __shared__ double vw[4][FULLC_NPT];                      // per wave: its samples' sums at every grid point of the stretch
+  __shared__ double red[16];
+  __shared__ double wh[8];
+  const int t = threadIdx.x, nt = 256;
+  const int p = blockIdx.x % L.P, e = L.e_off + blockIdx.x / L.P, b = blockIdx.y;
+  const DevParams& P = params[b];
+  const int S = L.S, Z = L.Z;
+  const size_t so = ((size_t)b * L.E + e) * S;
+  int* my_todo = todo + ((size_t)b * L.E + e) * L.P + p;
+  double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
+  double* dump = L.p_gw_dump ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
+  if (p >= L.neff_pixels[e]) {                            // result[ev, :npix] only (likelihood.py:253)
+    if (t == 0) { *out_like = 0.; *my_todo = 0; }
+    if (dump) for (int k = t; k < Z; k += nt) dump[k] = 0.;
+    return;
+  }
+  const double* fe = L.full_ev + ((size_t)b * L.E + e) * FULLEV;      // k_full_prep's record of the event (uniform address: scalar loads)
+  const double* zg = L.z_grids + (size_t)e * Z;
+  const int k_first = (int)fe[FE_KFIRST], k_last = (int)fe[FE_KLAST];
+  const int npt = k_last - k_first + 1;
+  if (fe[FE_OK] == 0. || npt <= 0) {                       // nothing to integrate: the general kernel's answer for these, without it
+    if (t == 0) { *out_like = grid_is_poisoned(P.z_bad, zg, Z) ? __builtin_nan("") : 0.; *my_todo = 0; }
+    if (dump) for (int k = t; k < Z; k += nt) dump[k] = 0.;
+    return;
+  }
+  if (fe[FE_CHAIN] == 0.) { if (t == 0) *my_todo = 1; return; }        // (k_full_kde writes the whole pixel, dump included)
   if (t == 0) *my_todo = 0;
   if (dump) for (int k = t; k < Z; k += nt) if (k < k_first || k > k_last) dump[k] = 0.;
-  if (t < LK) cf[t] = chm_exp(-0.5 * D * D * (double)(t * t));      // the factor of grid point i of a chunk that is common to all samples
-  // what a sample's start needs sits in LDS: after the first chunk it is a rare path, and its twelve constants would occupy registers of the march
-  if (t == 0) { wh[7] = q1; wh[8] = q2; wh[9] = 1. / st.sumw; wh[10] = D; }
+  const double rp = L.ra_pix[(size_t)e * L.P + p], dp = L.dec_pix[(size_t)e * L.P + p];
+  const double q1 = rp * fe[FE_L11] + dp * fe[FE_L21], q2 = dp * fe[FE_L22], t_base = rp * fe[FE_L10] + dp * fe[FE_L20];      // whitened query (math.py:196)
+  const size_t zo = ((size_t)b * L.E + e) * Z;
+  const double* pc = L.p_cat + ((size_t)e * L.P + p) * Z;
+  const double D = fe[FE_D], K1 = fe[FE_K1], K2 = fe[FE_K2];
+  const double t0 = fe[FE_ZF] + t_base;
+  // the pixel's factor of the step factors, u = U V; a pixel further than 30 / D widths from the mean direction forms them directly
+  const double varg = (fe[FE_AREF] - t0) * D;
+  const bool direct0 = !(fabs(varg) <= 30.);
+  const double V = direct0 ? 0. : chm_exp(varg);
+  // what a sample's start needs sits in LDS: after the first chunk it is a rare path whose constants would occupy registers of the march
+  if (t == 0) { wh[0] = q1; wh[1] = q2; wh[2] = fe[FE_LOGNORM]; wh[3] = D; wh[4] = V; }
   __syncthreads();
-  // block-uniform values of the march in scalar registers (the march holds 64 + 64 vector registers of sums and sample states)
-  auto uni = [](double x) -> double {
-    int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
-    return __hiloint2double(hi, lo);
-  };
-  const double K1 = uni(chm_exp(-0.5 * (D * (double)LK) * (D * (double)LK))), K2 = uni(chm_exp(-(double)LK * D * D));
-  const double t0 = uni(z_f * l00 + t_base), Du = uni(D);
   const int spt = (S + nt - 1) / nt;
+  const double* fa = L.full_s + so; const double* fy1 = fa + (size_t)L.nb_alloc * L.E * S; const double* fy2 = fy1 + (size_t)L.nb_alloc * L.E * S;
+  const double* fw = fy2 + (size_t)L.nb_alloc * L.E * S; const double* fu = fw + (size_t)L.nb_alloc * L.E * S;
 
   // one sample's starting values at a chunk whose first point sits at tc.  1: started; 0: further than 37 widths ahead (stays (0, 0), looked at
   // again at the next chunk); -1: further than 37 widths behind -- the chunks move away from it, it never enters
-  auto start = [&](int s, double tc, double& pw, double& u) -> int {
-    const double x0 = wz[s], x1 = L.ra[eo + s], x2 = L.dec[eo + s];
-    const double d1 = (x1 * wh[2] + x2 * wh[4]) - wh[7], d2 = x2 * wh[5] - wh[8];
-    const double d = (x0 * wh[0] + x1 * wh[1] + x2 * wh[3]) - tc;
-    const double e1 = -0.5 * (d * d), Dl = wh[10];
+  auto start = [&](int s, double tc, bool direct, double& pw, double& u) -> int {
+    const double d1 = fy1[s] - wh[0], d2 = fy2[s] - wh[1];
+    const double d = fa[s] - tc;
+    const double e1 = -0.5 * (d * d), Dl = wh[3];
     const bool in = e1 > -700.;
     // one exp for W_j exp(log_norm - b_j / 2) exp(-d^2 / 2) (a huge negative argument ends in v_ldexp_f64's 0); |d D| <= 37.5 x 15 / LK
-    pw = in ? (ww[s] * wh[9]) * chm_exp_nb(fmax(wh[6] + e1 - 0.5 * (d1 * d1 + d2 * d2), -800.)) : 0.;
-    u = in ? chm_exp_nb(d * Dl) : 0.;
+    pw = in ? fw[s] * chm_exp_nb(fmax(wh[2] + e1 - 0.5 * (d1 * d1 + d2 * d2), -800.)) : 0.;
+    if (direct) u = in ? chm_exp_nb(d * Dl) : 0.;
+    else u = in ? fu[s] * wh[4] : 0.;
     return in ? 1 : (d * Dl > 0. ? 0 : -1);
   };
   double pw[FULLC_SPT], uu[FULLC_SPT];
@@ -2423,7 +2469,7 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
   for (int j = 0; j < FULLC_SPT; j++) {
     pw[j] = 0.; uu[j] = 0.;
     const int s = t + j * nt;
-    if (s < S && start(s, t0, pw[j], uu[j]) == 0) waiting |= 1u << j;
+    if (s < S && start(s, t0, direct0, pw[j], uu[j]) == 0) waiting |= 1u << j;
   }
 
   // The four waves walk the chunks on their own.  After a chunk a wave adds its 64 lanes' power sums through its private exchange buffer, eight
@@ -2434,14 +2480,14 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
   double* vrow = vw[wv];
   const int nch = (npt + LK - 1) / LK;
   for (int c = 0; c < nch; c++) {
-    const double tc = t0 + (double)(c * LK) * Du;
+    const double tc = t0 + (double)(c * LK) * D;
     if (c > 0 && waiting) {                                // rare: one copy of the start code, the sample's registers picked by compile-time selects
       unsigned wm = waiting;
       while (wm) {
         const int j = __builtin_ctz(wm);
         wm &= wm - 1;
         double np, nu;
-        const int r = start(t + j * nt, tc, np, nu);
+        const int r = start(t + j * nt, tc, true, np, nu);
         if (r != 0) waiting &= ~(1u << j);
         if (r == 1) {
 #pragma unroll
@@ -2454,23 +2500,45 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
     double acc[LK];
 #pragma unroll
     for (int i = 0; i < LK; i++) acc[i] = 0.;
+    if (ng == LK) {
 #pragma unroll
-    for (int j = 0; j < FULLC_SPT; j++) {
-      if (j < spt) {
-        double q = pw[j];
-        const double u = uu[j];
-        const double u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
+      for (int j = 0; j < FULLC_SPT; j++) {
+        if (j < spt) {
+          double q = pw[j];
+          const double u = uu[j];
+          const double u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
 #pragma unroll
-        for (int i = 0; i < LK; i += 4) {
-          acc[i] += q;
-          acc[i + 1] = __builtin_fma(q, u, acc[i + 1]);
-          acc[i + 2] = __builtin_fma(q, u2, acc[i + 2]);
-          acc[i + 3] = __builtin_fma(q, u3, acc[i + 3]);
-          q *= u4;
+          for (int i = 0; i < LK; i += 4) {
+            acc[i] += q;
+            acc[i + 1] = __builtin_fma(q, u, acc[i + 1]);
+            acc[i + 2] = __builtin_fma(q, u2, acc[i + 2]);
+            acc[i + 3] = __builtin_fma(q, u3, acc[i + 3]);
+            q *= u4;
+          }
+          pw[j] = q * K1; uu[j] = u * K2;
         }
-        pw[j] = q * K1; uu[j] = u * K2;
+        __builtin_amdgcn_sched_barrier(0);                 // one sample after the other: hoisting the u^2, u^3, u^4 of all sixteen costs 96 registers
       }
-      __builtin_amdgcn_sched_barrier(0);                   // one sample after the other: hoisting the u^2, u^3, u^4 of all sixteen costs 96 registers
+    } else {                                               // the last chunk of the stretch: the groups of four beyond its end are left out (no state to carry on)
+#pragma unroll
+      for (int j = 0; j < FULLC_SPT; j++) {
+        if (j < spt) {
+          double q = pw[j];
+          const double u = uu[j];
+          const double u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
+#pragma unroll
+          for (int i = 0; i < LK; i += 4) {
+            if (i < ng) {
+              acc[i] += q;
+              acc[i + 1] = __builtin_fma(q, u, acc[i + 1]);
+              acc[i + 2] = __builtin_fma(q, u2, acc[i + 2]);
+              acc[i + 3] = __builtin_fma(q, u3, acc[i + 3]);
+              q *= u4;
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 #pragma unroll
     for (int h = 0; h < LK; h += 8) {
@@ -2491,10 +2559,10 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
   double accl = 0.;
   for (int k = k_first + t; k <= k_last; k += nt) {
     const int r = k - k_first;
-    const double val = ((vw[0][r] + vw[1][r]) + (vw[2][r] + vw[3][r])) * cf[r % LK];
+    const double val = ((vw[0][r] + vw[1][r]) + (vw[2][r] + vw[3][r])) * fe[FE_CF + r % LK];
     const double z = zg[k];
-    const bool inm = (z <= zhi) && (z >= zlo);
-    const double pgw = inm ? val * st.norm : 0.;           // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
+    const bool inm = (z <= fe[FE_ZHI]) && (z >= fe[FE_ZLO]);
+    const double pgw = inm ? val * fe[FE_NORM] : 0.;       // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
     if (dump) dump[k] = pgw;
     const double pcv = pc[k];
     double y = 0.;

@@ -116,7 +116,7 @@ def headline(rnd):
       extra = ''
       if tag == '_full':
         k = x['roofline']['kernels'][0]
-        extra = '; `k_full_kde` %.2f ms per launch = %.2f Tpair/s = %.3f of the power-sum ceiling' % (k['kernel_ms'], k['Gpairs_s'] / 1e3, k['pair_frac'])
+        extra = '; `%s` %.2f ms per launch = %.2f Tpair/s = %.3f of the power-sum ceiling' % (k['kernel'], k['kernel_ms'], k['Gpairs_s'] / 1e3, k['pair_frac'])
       out.append('| %s | %.0f evals/s (%.3f ms per step; scalar call %.3f ms)%s | `bench%s.json` |' % (label, x['value'], x['ms_per_step'], x.get('single_call_ms') or 0., extra, tag))
   out.append('| One-time hand-over of the host arrays | %.2f s; not part of `value` | `bench.json: setup_s.upload_once` |' % b['setup_s']['upload_once'])
   return '\n'.join(out)
