@@ -416,7 +416,11 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
     UP(neff_pixels, d->neff_pixels, 1);
   }
 #undef UP
-  hipError_t he = hipStreamSynchronize(s);
+  // the logs of the detector-frame masses as the device forms them (k_fill_logs): over the host's std::log values in both copies
+  hipLaunchKernelGGL(k_fill_logs, dim3(1024), dim3(256), 0, s, L.m1det, L.m2det, const_cast<double*>(L.lm1det), const_cast<double*>(L.lm2det),
+                     const_cast<double*>(h->F.tiles), (int)E, (int)S, h->F.NT);
+  hipError_t he = hipGetLastError();
+  if (he == hipSuccess) he = hipStreamSynchronize(s);
   if (he != hipSuccess) { chm_like_destroy(h); return fail(CHM_E_HIP, std::string("chm_like_create: ") + hipGetErrorString(he)); }
   *out = h;
   return CHM_OK;

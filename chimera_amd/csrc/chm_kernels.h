@@ -668,6 +668,20 @@ DEVFN void z_from_lut_x2(double xa, double xb, const double* rec, const unsigned
   bad = !oka || !okb;
 }
 
+// [r3] log(m1det), log(m2det) of every posterior sample, formed on the device at upload with chm_log -- the function the few-draw variant of
+// k_samples_fast applies to the masses themselves instead of reading these two planes (a quarter of its HBM traffic): the two variants see
+// the same bits, a batched call stays the scalar call bit for bit.
+__global__ void __launch_bounds__(256) k_fill_logs(const double* m1, const double* m2, double* l1, double* l2, double* tiles, int E, int S, int NTl) {
+  const size_t n = (size_t)E * S;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const double a = chm_log(m1[i]), b = chm_log(m2[i]);
+    l1[i] = a; l2[i] = b;
+    const size_t e = i / S, k = i % S;
+    double* o = tiles + ((e * NTl + k / SF_TILE) * 6) * SF_TILE + k % SF_TILE;
+    o[4 * SF_TILE] = a; o[5 * SF_TILE] = b;
+  }
+}
+
 // build-time knobs of the fast sample stage (A/B through scripts/build_variant.sh): waves per block (each chunk always has SAMPLE_WPB
 // partial records: with fewer waves the surplus records are written neutral), waves per SIMD the register budget is cut for,
 // loads of the next tile issued before the arithmetic of the current one
@@ -690,6 +704,14 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
                                                                     const double* rec_all, int TcMax, int TmMax) {
 #pragma clang fp contract(fast)                  // sums of products may fuse; z comes from z_from_lut_x2 / jnp_interp (contract off) untouched
   extern __shared__ double lds[];
+#ifndef CHM_SF_LOGS_INLINE
+#define CHM_SF_LOGS_INLINE 0      // measured (profiles/r03/ab_scalar_call_r03.txt): 66.6 against 59.8 us for the one-draw kernel with the logs formed here -- off
+#endif
+#ifndef CHM_SF_STAGGER
+#define CHM_SF_STAGGER 0          // few draws per call: every other block starts CHM_SF_STAGGER x ~1 us late (load and arithmetic phases of the two halves interleave)
+#endif
+  if (NT && CHM_SF_STAGGER > 0 && (blockIdx.x & 1)) { for (int i = 0; i < CHM_SF_STAGGER; i++) __builtin_amdgcn_s_sleep(32); }
+  constexpr bool LOGS_HERE = NT && (CHM_SF_LOGS_INLINE != 0);
   constexpr int NT_ = 64 * CHM_SF_WAVES;
   const int b = blockIdx.x % L.nb, bx = blockIdx.x / L.nb, nbx = gridDim.x / L.nb, t = threadIdx.x, lane = t & 63;
   DevParams P = params[b];            // by value: uniform loads at kernel start, nothing re-read in the loops
@@ -753,7 +775,8 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
       // NT (few draws per call): every tile is read once per call -- streamed past the caches, so that the z / w written below stay in the
       // memory-side cache for the GW kernel; with many draws per call the tiles are shared by the draws' blocks and stay cacheable
       auto ld = [&](const double2* q) { if (NT) { double2 v; v.x = __builtin_nontemporal_load(&q->x); v.y = __builtin_nontemporal_load(&q->y); return v; } return *q; };
-      a_ = ld(tp); b_ = ld(tp + SF_TILE / 2); c_ = ld(tp + 2 * SF_TILE / 2); d_ = ld(tp + 3 * SF_TILE / 2); e_ = ld(tp + 4 * SF_TILE / 2); f_ = ld(tp + 5 * SF_TILE / 2);
+      a_ = ld(tp); b_ = ld(tp + SF_TILE / 2); c_ = ld(tp + 2 * SF_TILE / 2); d_ = ld(tp + 3 * SF_TILE / 2);
+      if (!LOGS_HERE) { e_ = ld(tp + 4 * SF_TILE / 2); f_ = ld(tp + 5 * SF_TILE / 2); }
     };
     const int s_first = c * SAMPLE_CHUNK + 2 * t;
     if (PF && s_first < s_end) load_tile(s_first, a, bb, cc, dd, ee, ff);
@@ -763,7 +786,9 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
       if (PF) { if (s + 2 * NT_ < s_end) load_tile(s + 2 * NT_, na, nb_, nc, nd, ne, nf); }
       else load_tile(s, a, bb, cc, dd, ee, ff);
       const double dl[2] = { a.x, a.y }, md1[2] = { bb.x, bb.y }, md2[2] = { cc.x, cc.y }, ipr[2] = { dd.x, dd.y };
-      const double l1[2] = { ee.x, ee.y }, l2[2] = { ff.x, ff.y };
+      // few draws per call (NT): the kernel waits for HBM -- the logs of the masses are formed here (k_fill_logs's values) instead of read
+      // (inside the loop over the two samples below: one sample's pair of logs at a time, four at once spill)
+      const double l1[2] = { LOGS_HERE ? 0. : ee.x, LOGS_HERE ? 0. : ee.y }, l2[2] = { LOGS_HERE ? 0. : ff.x, LOGS_HERE ? 0. : ff.y };
       double zz[2], wv[2], z0[2] = { 0., 0. }, lz0[2] = { 0., 0. };
       bool bad = true;
       if (FITS) {                                     // z = z_from_dGW(dL) (cosmo.py:260-264)
@@ -787,7 +812,8 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
           const bool nolog = bad || !(v <= 0.02);
           if (__any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
         } else lz = chm_log_pos(zp1);
-        const double w = p_m1m2_fused<MASS>(P, m1, m2, l1[h] - lz, l2[h] - lz, mg, cdf) * ipr[h];
+        const double lm1 = LOGS_HERE ? chm_log(md1[h]) : l1[h], lm2 = LOGS_HERE ? chm_log(md2[h]) : l2[h];
+        const double w = p_m1m2_fused<MASS>(P, m1, m2, lm1 - lz, lm2 - lz, mg, cdf) * ipr[h];
         wv[h] = w;
         if (s + h < s_end) {
           const double d = z - z_ref;
