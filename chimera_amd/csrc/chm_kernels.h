@@ -698,7 +698,13 @@ static_assert(SAMPLE_WPB % CHM_SF_WAVES == 0, "records per chunk must be a multi
 // PF: the next tile's loads are issued before the arithmetic of the current one, compiled for 3 waves per SIMD so that the twelve extra
 // registers do not spill.  Measured for calls of one draw, where every block of the grid is resident at once: the scalar call takes
 // 0.242 instead of 0.232 ms -- the fourth wave per SIMD hides more latency than the prefetch (profiles/r02/ab_scalar_call_*.txt)
-template <int MASS, bool FULL, bool NT = false, bool PF = (CHM_SF_PREFETCH != 0)>
+#ifndef CHM_SF_PREFETCH_NT
+#define CHM_SF_PREFETCH_NT 0
+#endif
+#ifndef CHM_SF_NPV_PF
+#define CHM_SF_NPV_PF 0
+#endif
+template <int MASS, bool FULL, bool NT = false, bool PF = (CHM_SF_PREFETCH != 0) || (NT && CHM_SF_PREFETCH_NT != 0)>
 __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast(LikeDev L, SampFast F, const DevParams* params, const double* zt_all,
                                                                     const double* dLt_all, const double* mg_all, const double* cdf_all,
                                                                     const double* rec_all, int TcMax, int TmMax) {
@@ -718,7 +724,7 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
 #ifndef CHM_SF_NPV
 #define CHM_SF_NPV 4
 #endif
-  mass_params_to_vgpr<MASS, FULL ? 0 : CHM_SF_NPV>(P);       // (mass-model parameters in vector registers: the scalar file cannot hold the whole draw)
+  mass_params_to_vgpr<MASS, FULL ? 0 : (PF ? CHM_SF_NPV_PF : CHM_SF_NPV)>(P);       // (mass-model parameters in vector registers: the scalar file cannot hold the whole draw)
   const double* g_zt = zt_all + (size_t)b * TcMax;
   const double* g_dLt = dLt_all + (size_t)b * TcMax;
   const int Tc = P.Tc, Tm = P.Tm;
