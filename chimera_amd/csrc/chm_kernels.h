@@ -2724,7 +2724,7 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
 #else
   DevParams P = params[b];
 #ifndef CHM_SELF_NPV
-#define CHM_SELF_NPV 13
+#define CHM_SELF_NPV 12       // 127 VGPRs: four waves per SIMD (13: 129 registers, three waves; C4 step 2.47 -> 2.42 ms on one box)
 #endif
   mass_params_to_vgpr<MASS, CHM_SELF_NPV>(P);
 #endif

@@ -358,6 +358,7 @@ def test_compiler_resource_report_of_the_kernels(lib):
   # [r3] k_full_kde runs at 4 waves per SIMD (128 VGPRs); the registers it spills for that are touched outside the pair march (272 against 260
   # evaluations/s measured at C3 / 4 draws per call with and without), so the bound is on how many, not on none
   assert res['k_full_kde']['waves_per_simd'] >= 4 and res['k_full_kde']['vgpr_spills'] <= 16
+  assert res['k_selection_fast<2>']['waves_per_simd'] >= 4 and res['k_selection_fast<2>']['vgpr_spills'] == 0
   # the sample-stationary 3-D kernel keeps 64 + 64 registers of sums and sample states: three waves per SIMD, nothing in scratch
   assert res['k_full_kde_chain']['waves_per_simd'] >= 3 and res['k_full_kde_chain']['scratch_bytes_per_lane'] == 0
   # the two hot kernels: no more than one spilled pair (the per-item set-up; nothing in the pass loop -- scripts/isa_mix.py --dump shows where)
