@@ -701,6 +701,9 @@ static_assert(SAMPLE_WPB % CHM_SF_WAVES == 0, "records per chunk must be a multi
 #ifndef CHM_SF_PREFETCH_NT
 #define CHM_SF_PREFETCH_NT 0
 #endif
+#ifndef CHM_SF_RELOAD
+#define CHM_SF_RELOAD 0
+#endif
 #ifndef CHM_SF_NPV_PF
 #define CHM_SF_NPV_PF 0
 #endif
@@ -819,7 +822,13 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
           if (__any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
         } else lz = chm_log_pos(zp1);
         const double lm1 = LOGS_HERE ? chm_log(md1[h]) : l1[h], lm2 = LOGS_HERE ? chm_log(md2[h]) : l2[h];
+#if CHM_SF_RELOAD
+        const DevParams* pl = params + b;                   // (experiment) the mass model's parameters behind scalar loads at the point of use
+        asm volatile("" : "+s"(pl));
+        const double w = p_m1m2_fused<MASS>(*pl, m1, m2, lm1 - lz, lm2 - lz, mg, cdf) * ipr[h];
+#else
         const double w = p_m1m2_fused<MASS>(P, m1, m2, lm1 - lz, lm2 - lz, mg, cdf) * ipr[h];
+#endif
         wv[h] = w;
         if (s + h < s_end) {
           const double d = z - z_ref;
