@@ -806,6 +806,10 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
           if (bad) { zz[0] = jnp_interp(dl[0], g_dLt, g_zt, Tc, false, 0., 0.); zz[1] = jnp_interp(dl[1], g_dLt, g_zt, Tc, false, 0., 0.); }
         }
       } else z_from_dGW_x2(P, dl[0], dl[1], g_dLt, g_zt, zz[0], zz[1]);
+#if CHM_SF_RELOAD
+      const DevParams* pl = params + b;                     // (experiment) the mass model's parameters behind scalar loads issued once per pass
+      asm volatile("" : "+s"(pl));
+#endif
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         // m_src = m_det/(1+z) (pop_wrapper.py:70); w = p_m1m2 / pe_prior (pop_wrapper.py:79; the tile holds 1/pe_prior)
@@ -823,8 +827,6 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
         } else lz = chm_log_pos(zp1);
         const double lm1 = LOGS_HERE ? chm_log(md1[h]) : l1[h], lm2 = LOGS_HERE ? chm_log(md2[h]) : l2[h];
 #if CHM_SF_RELOAD
-        const DevParams* pl = params + b;                   // (experiment) the mass model's parameters behind scalar loads at the point of use
-        asm volatile("" : "+s"(pl));
         const double w = p_m1m2_fused<MASS>(*pl, m1, m2, lm1 - lz, lm2 - lz, mg, cdf) * ipr[h];
 #else
         const double w = p_m1m2_fused<MASS>(P, m1, m2, lm1 - lz, lm2 - lz, mg, cdf) * ipr[h];
