@@ -807,8 +807,20 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
         }
       } else z_from_dGW_x2(P, dl[0], dl[1], g_dLt, g_zt, zz[0], zz[1]);
 #if CHM_SF_RELOAD
-      const DevParams* pl = params + b;                     // (experiment) the mass model's parameters behind scalar loads issued once per pass
-      asm volatile("" : "+s"(pl));
+      // (experiment) the mass model's parameters behind scalar loads issued once per pass: the pointer is laundered (no hoisting out of the loop)
+      // and sits in the constant address space (s_load, not a uniform vector load)
+      DevParams Pq_;
+      {
+        typedef const __attribute__((address_space(4))) double* cdp_t;
+        cdp_t cd = (cdp_t)(params + b);
+        asm volatile("" : "+s"(cd));
+        double* dst = reinterpret_cast<double*>(&Pq_);
+#pragma unroll
+        for (int i = 4; i < (int)(sizeof(DevParams) / 8); i++) dst[i] = cd[i];
+        Pq_.cosmo_model = P.cosmo_model; Pq_.mass_model = P.mass_model; Pq_.rate_model = P.rate_model; Pq_.Tc = P.Tc; Pq_.Tm = P.Tm;
+        Pq_.scale_free = P.scale_free; Pq_.has_catalog = P.has_catalog; Pq_.pad0 = 0;
+      }
+      const DevParams* pl = &Pq_;
 #endif
 #pragma unroll
       for (int h = 0; h < 2; h++) {
