@@ -96,6 +96,11 @@ class hyperlikelihood(object):
     self._plugins = population_plugins(self.population)        # (mass, rate, completeness) evaluated on the host?
     if any(self._plugins):
       self.max_draws_per_call = 4                              # the caller-evaluated tables are (draws, events, samples) arrays
+    elif self._mode == 'full':
+      # the 3-D mode keeps seven (draws, events, samples) arrays of doubles on the device (z, w and the whitened coordinates of k_full_prep):
+      # batches are cut so that they stay below ~48 GB
+      per_draw = 7 * 8 * max(1, self._e1 - self._e0) * max(1, int(np.shape(self.theta_gw_det.dL)[-1]))
+      self.max_draws_per_call = int(max(1, min(256, 48e9 // per_draw)))
     logger.info(f'Created hyperlikelihood model. Using {self.nevents} GW events.')
 
   # -- device handles ----------------------------------------------------------------------------------
