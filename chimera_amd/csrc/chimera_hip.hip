@@ -722,7 +722,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       cap = (cap + 7) / 8 * 8;
       lutA = like->F.lut;
       lutA.cap = (int)cap; lutA.lut = like->d_lut; lutA.info = like->d_lutinfo;
-      lds_fast = sizeof(double) * (4 * (size_t)cap + 2 * (size_t)Tm_call) + ((size_t)(lutA.nk + 1) * 2 + 15) / 16 * 16;
+      lds_fast = sizeof(double) * (CHM_EXPTAB_N + 4 * (size_t)cap + 2 * (size_t)Tm_call) + ((size_t)(lutA.nk + 1) * 2 + 15) / 16 * 16;
       if (lds_fast > 96 * 1024) use_fast = false;
     }
   }
@@ -748,7 +748,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       cap = (cap + 7) / 8 * 8;
       lutB = sel->lut;
       lutB.cap = (int)cap; lutB.lut = sel->d_lut; lutB.info = sel->d_lutinfo;
-      lds_sel = sizeof(double) * (4 * (size_t)cap + 2 * (size_t)Tm_call) + ((size_t)(lutB.nk + 1) * 2 + 15) / 16 * 16;
+      lds_sel = sizeof(double) * (CHM_EXPTAB_N + 4 * (size_t)cap + 2 * (size_t)Tm_call) + ((size_t)(lutB.nk + 1) * 2 + 15) / 16 * 16;
       if (lds_sel > 64 * 1024) sel_fast = false;
     }
   }

@@ -736,12 +736,20 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
   const bool fits = info[3] != 0;
   const int key0 = F.lut.key0, nk = F.lut.nk, cap = F.lut.cap;
   // LDS: node records of the table slice [cap x 4], m_grid [Tm], cdf_m2 [Tm], direct-index table [nk + 1] (u16)
-  double* rec = lds; double* mg = rec + 4 * (size_t)cap; double* cdf = mg + Tm;
+  // [r3] + the 256-entry table of the mass model's exps first (chm_exp_tab: 13 instead of 17 VALU instructions per exp, four exps per sample)
+  double* etab = lds;
+  double* rec = lds + CHM_EXPTAB_N; double* mg = rec + 4 * (size_t)cap; double* cdf = mg + Tm;
   unsigned short* luts = reinterpret_cast<unsigned short*>(cdf + Tm);
+#if CHM_EXPTAB
+  const ExpTab ex = { etab };
+#else
+  const ExpPoly ex = {};
+#endif
   {
     const double* gm = mg_all + (size_t)b * TmMax;
     const double* gc = cdf_all + (size_t)b * TmMax;
     const unsigned short* gl = F.lut.lut + (size_t)b * (nk + 1);
+    for (int i = t; i < CHM_EXPTAB_N; i += NT_) etab[i] = exp_table_entry(i);
     for (int i = t; i < Tm; i += NT_) { mg[i] = gm[i]; cdf[i] = gc[i]; }
     if (fits) {
       const double2* gr = reinterpret_cast<const double2*>(rec_all + ((size_t)b * TcMax + i_lo) * 4);
@@ -839,9 +847,9 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
         } else lz = chm_log_pos(zp1);
         const double lm1 = LOGS_HERE ? chm_log(md1[h]) : l1[h], lm2 = LOGS_HERE ? chm_log(md2[h]) : l2[h];
 #if CHM_SF_RELOAD
-        const double w = p_m1m2_fused<MASS>(*pl, m1, m2, lm1 - lz, lm2 - lz, mg, cdf) * ipr[h];
+        const double w = p_m1m2_fused<MASS>(*pl, m1, m2, lm1 - lz, lm2 - lz, mg, cdf, ex) * ipr[h];
 #else
-        const double w = p_m1m2_fused<MASS>(P, m1, m2, lm1 - lz, lm2 - lz, mg, cdf) * ipr[h];
+        const double w = p_m1m2_fused<MASS>(P, m1, m2, lm1 - lz, lm2 - lz, mg, cdf, ex) * ipr[h];
 #endif
         wv[h] = w;
         if (s + h < s_end) {
@@ -2747,7 +2755,7 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
 #else
   DevParams P = params[b];
 #ifndef CHM_SELF_NPV
-#define CHM_SELF_NPV 12       // 127 VGPRs: four waves per SIMD (13: 129 registers, three waves; C4 step 2.47 -> 2.42 ms on one box)
+#define CHM_SELF_NPV 11       // 127 VGPRs: four waves per SIMD (one more: three waves; C4 step 2.47 -> 2.42 ms on one box)
 #endif
   mass_params_to_vgpr<MASS, CHM_SELF_NPV>(P);
 #endif
@@ -2758,12 +2766,19 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
   const int i_lo = info[0], ns = info[1], lmax = info[2];
   const bool fits = info[3] != 0;
   const int key0 = lut.key0, nk = lut.nk, cap = lut.cap;
-  double* rec = lds; double* mg = rec + 4 * (size_t)cap; double* cdf = mg + Tm;
+  double* etab = lds;                                        // [r3] the table of the mass model's exps (chm_exp_tab), as in k_samples_fast
+  double* rec = lds + CHM_EXPTAB_N; double* mg = rec + 4 * (size_t)cap; double* cdf = mg + Tm;
   unsigned short* luts = reinterpret_cast<unsigned short*>(cdf + Tm);
+#if CHM_EXPTAB
+  const ExpTab ex = { etab };
+#else
+  const ExpPoly ex = {};
+#endif
   {
     const double* gm = mg_all + (size_t)b * TmMax;
     const double* gc = cdf_all + (size_t)b * TmMax;
     const unsigned short* gl = lut.lut + (size_t)b * (nk + 1);
+    for (int i = t; i < CHM_EXPTAB_N; i += 256) etab[i] = exp_table_entry(i);
     for (int i = t; i < Tm; i += 256) { mg[i] = gm[i]; cdf[i] = gc[i]; }
     if (fits) {
       const double2* gr = reinterpret_cast<const double2*>(rec_all + ((size_t)b * TcMax + i_lo) * 4);
@@ -2813,12 +2828,12 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
         double lz = log1pz_from_node(z, z0[h], lz0[h], r, vv);
         const bool nolog = !fits || bad || !(vv <= 0.02);
         if (__any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
-        const double pm = p_m1m2_fused<MASS>(P, m1, m2, l1[h] - lz, l2[h] - lz, mg, cdf);
+        const double pm = p_m1m2_fused<MASS>(P, m1, m2, l1[h] - lz, l2[h] - lz, mg, cdf, ex);
         const double Ez = E_at_z_lr(P, z, zp1, r, lz);
         const double dCt = dl[h] * r;                                    // original distances: cosmo.py:191-192,215-216
         const double X = __builtin_fma(dCt, Ez, P.dH * zp1);
         double rnum, rden;
-        merger_rate_nd(P, z, lz, rnum, rden);
+        merger_rate_nd(P, z, lz, rnum, rden, ex);
         const double num = ((c0 * pm) * (dCt * dCt)) * (rnum * ipd[h]);
         const double den = (rden * fabs(X)) * ((zp1 * zp1) * zp1);
         const double dN = num / den;

@@ -133,6 +133,47 @@ DEVFN double chm_exp_clamped(double x) {
   return chm_exp_nb(hi);
 }
 
+// [r3] exp(x) through a table of 2^(j/256) (256 doubles in LDS, exp_table_fill): x = (256 k + j) ln2/256 + r, |r| <= ln2/512, e^r by its degree-4
+// Taylor sum (remainder < 4e-17) -- 13 VALU instructions against the 17 of chm_exp_nb (the table read is an LDS instruction).  Same contract
+// as chm_exp_nb: no range checks (a huge |x| ends in v_ldexp_f64's 0 / inf, NaN propagates through the polynomial); ~1.5 ulp.
+#define CHM_EXPTAB_N 256
+#ifndef CHM_EXPTAB
+#define CHM_EXPTAB 1           // 0: the fast sample / selection kernels keep the polynomial exp (A/B builds)
+#endif
+DEVFN double chm_exp_tab(double x, const double* T) {
+  const double SC = 3.69329930467574632e+02;               // 256 / ln 2
+  const double L_HI = 6.93147180369123816490e-01 / 256., L_LO = 1.90821492927058770002e-10 / 256.;      // ln2/256 in two pieces (exact scalings of fdlibm's)
+  double n = __builtin_rint(x * SC);
+  double r = __builtin_fma(-n, L_HI, x);
+  r = __builtin_fma(-n, L_LO, r);
+  const int ni = (int)n;
+  const double tj = T[ni & (CHM_EXPTAB_N - 1)];
+  double p = FM_FMA(r, 4.16666666666666644e-02, 1.66666666666666657e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(tj * p, ni >> 8);
+}
+DEVFN double chm_exp_tab_clamped(double x, const double* T) {      // chm_exp_clamped with the table
+  double lo, hi;
+  asm("v_max_f64 %0, %1, %2" : "=v"(lo) : "v"(x), "v"(-745.2));
+  asm("v_min_f64 %0, %1, %2" : "=v"(hi) : "v"(lo), "v"(700.));
+  return chm_exp_tab(hi, T);
+}
+// entry j of the table: 2^(j/256) = exp(j ln2/256) with the argument formed in two pieces (as chm_pow10): chm_exp's own 0.63 ulp
+DEVFN double exp_table_entry(int j) {
+  const double C_HI = 6.93147180369123816490e-01 / 256., C_LO = 1.90821492927058770002e-10 / 256.;
+  const double a = (double)j * C_HI;                       // exact: j < 2^8, C_HI ends in 20 zero bits
+  const double v = chm_exp(a);
+  return __builtin_fma(v, (double)j * C_LO, v);
+}
+// the two forms of exp the mass model is instantiated with
+// (pw: x^y from log x, the pow_l of chm_models.h -- with the range tests of chm_exp in the polynomial form)
+struct ExpPoly { DEVFN double nb(double x) const { return chm_exp_nb(x); } DEVFN double clamped(double x) const { return chm_exp_clamped(x); }
+                 DEVFN double pw(double lx, double y) const { return chm_exp(y * lx); } };
+struct ExpTab { const double* T; DEVFN double nb(double x) const { return chm_exp_tab(x, T); } DEVFN double clamped(double x) const { return chm_exp_tab_clamped(x, T); }
+                DEVFN double pw(double lx, double y) const { return chm_exp_tab(y * lx, T); } };
+
 // 1 / b for b well inside the normal range: reciprocal seed + two Newton steps (~1 ulp; chm_div(1, b) spends three more instructions on
 // the correctly rounded quotient).  For factors of smooth arithmetic: 1/(1 + z) of the det -> src conversion.
 DEVFN double chm_rcp(double b) {

@@ -440,8 +440,8 @@ DEVFN void mass_params_to_vgpr(DevParams& p) {
 #undef CHM_TV
 }
 
-template <int MASS = -1, class A1, class A2>
-DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, double lm2, A1 mg, A2 cdf) {
+template <int MASS = -1, class A1, class A2, class EX = ExpPoly>
+DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, double lm2, A1 mg, A2 cdf, const EX ex = EX()) {
 #pragma clang fp contract(fast)                  // smooth arithmetic only (no rounding-sensitive predicate): a*b+c may fuse
   const int mass_model = MASS >= 0 ? MASS : p.mass_model;
   const double m_low = p.m[0], m_high = p.m[1];
@@ -452,15 +452,15 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
   // only ever produces a value that is discarded (or the inf / 0 that v_ldexp_f64 saturates to) -- no range checks (6 instructions each)
   double Pn;
   if (mass_model == 0) {
-    Pn = (m_low <= m1 && m1 <= m_high) ? chm_exp_nb(-p.m[2] * lm1 + e5) : 0.;
+    Pn = (m_low <= m1 && m1 <= m_high) ? ex.nb(-p.m[2] * lm1 + e5) : 0.;
   } else if (mass_model == 1) {
-    double a = (m_low <= m1 && m1 <= p.bpl_mbreak) ? chm_exp_nb(-p.m[2] * lm1 + e5) : 0.;
-    double b = (p.bpl_mbreak <= m1 && m1 <= m_high) ? chm_exp_nb(-p.m[3] * lm1 + e5) : 0.;
+    double a = (m_low <= m1 && m1 <= p.bpl_mbreak) ? ex.nb(-p.m[2] * lm1 + e5) : 0.;
+    double b = (p.bpl_mbreak <= m1 && m1 <= m_high) ? ex.nb(-p.m[3] * lm1 + e5) : 0.;
     Pn = a + b * p.bpl_pl1 / p.bpl_pl2;
   } else {
-    double Pw = (m_low <= m1 && m1 <= m_high) ? chm_exp_nb(-p.m[3] * lm1 + e5) * p.inv_plnorm : 0.;
+    double Pw = (m_low <= m1 && m1 <= m_high) ? ex.nb(-p.m[3] * lm1 + e5) * p.inv_plnorm : 0.;
     double G = 0.;
-    if (m_low <= m1 && m1 <= p.tg_hi) { double d = m1 - p.m[6]; G = chm_exp_nb((p.g_c0 - (d * d) * p.inv_2s2) + e5) * p.inv_tg_norm; }
+    if (m_low <= m1 && m1 <= p.tg_hi) { double d = m1 - p.m[6]; G = ex.nb((p.g_c0 - (d * d) * p.inv_2s2) + e5) * p.inv_tg_norm; }
     Pn = (1. - p.m[2]) * Pw + p.m[2] * G;
   }
   // smoothing denominators                                                                       mass.py:255-264
@@ -476,8 +476,8 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
     if (w1 || w2) {
       double r = chm_div(dm, ab1 * ab2);
       const double x1 = (s1 * ab2) * r, x2 = (s2 * ab1) * r;
-      if (w1) D1 = 1. + chm_exp_clamped(x1);
-      if (w2) D2 = 1. + chm_exp_clamped(x2);
+      if (w1) D1 = 1. + ex.clamped(x1);
+      if (w2) D2 = 1. + ex.clamped(x2);
       zero = zero || (w1 && x1 > 745.14) || (w2 && x2 > 745.14);      // exp(-logaddexp(0, x)) underflows to an exact 0 there   mass.py:264
     }
   }
@@ -531,12 +531,14 @@ DEVFN double merger_rate_l(const DevParams& p, double z, double lzp1) {
 DEVFN double merger_rate(const DevParams& p, double z) { return merger_rate_l(p, z, chm_log(1. + z)); }
 // merger_rate_l as a quotient num/den (k_selection_fast folds den into its one division); the same value classes: a cut model is
 // 0 / den above its z cut, (1 + ...) overflowing to inf gives 0 as the division does.
-DEVFN void merger_rate_nd(const DevParams& p, double z, double lzp1, double& num, double& den) {
+// (EX: the exp the powers go through -- ExpTab in the fast selection kernel: v_ldexp_f64 saturates where chm_exp tests its range)
+template <class EX = ExpPoly>
+DEVFN void merger_rate_nd(const DevParams& p, double z, double lzp1, double& num, double& den, const EX ex = EX()) {
   const double g = p.r[0];
-  const double a = pow_l(lzp1, g);
+  const double a = ex.pw(lzp1, g);
   if (p.rate_model == 0) { num = a; den = 1.; return; }
   if (p.rate_model == 2) { num = z < p.r[3] ? a : 0.; den = p.tpl_rate_norm; return; }
-  den = 1. + pow_l(lzp1 - p.l1pzp, g + p.r[1]);
+  den = 1. + ex.pw(lzp1 - p.l1pzp, g + p.r[1]);
   num = p.md_norm * a;
   if (p.rate_model != 1 && !(z < p.r[3])) num = 0.;
 }
