@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/profiles_r03; mkdir -p $O
 python3 scripts/collect_profiles.py r03 > $O/collect_C3.log 2>&1; tail -14 $O/collect_C3.log
 python3 scripts/collect_profiles.py r03 --tag nbatch1 -- --nbatch 1 --no-graph --steps 200 --warmup 20 > $O/collect_nb1.log 2>&1; tail -8 $O/collect_nb1.log
-python3 scripts/collect_profiles.py r03 --tag full --passes 0,1,3,5 -- --mode full --nbatch 4 --steps 5 --warmup 2 > $O/collect_full.log 2>&1; tail -6 $O/collect_full.log
+python3 scripts/collect_profiles.py r03 --tag full --passes 0,1,3,5 -- --mode full --nbatch 4 --steps 10 --warmup 3 > $O/collect_full.log 2>&1; tail -6 $O/collect_full.log
 python3 scripts/collect_profiles.py r03 --tag C4 --passes 0,1,3,5 -- --config C4 > $O/collect_C4.log 2>&1; tail -4 $O/collect_C4.log
 for c in C1 C2; do timeout -k 10 300 python3 bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err; done
 timeout -k 10 600 python3 bench.py --config C5 --nbatch 16 --steps 10 --warmup 2 --cpu-evals 3 > $O/bench_C5.json 2> $O/bench_C5.err
