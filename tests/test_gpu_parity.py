@@ -226,14 +226,14 @@ def test_sharded_partials_add_up(cfg_pix, kind):
   np.testing.assert_allclose(got, like_o(**lam), rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
 
 
-@pytest.mark.parametrize('kind', ['marginalized', 'approximate', None])
+@pytest.mark.parametrize('kind', ['marginalized', 'approximate', 'full', None])
 def test_event_groups_on_two_streams_give_the_one_lane_values(kind):
   """[r3] Shards of >= 500 events are evaluated in event groups that alternate between two streams when a call carries more than 8 draws
   (the sample stage of one group beside the GW kernel of the previous one).  The values must be those of the same call with one group
   (CHM_GROUPS=1, read per call), bit for bit -- every event's log-likelihood and the hyper-likelihood -- and agree with the C restatement."""
   from oracle import oracle_c as OC
   pix = kind is not None
-  cfg, ev, inj = H.small_config(E=640, S=96, P=3, Z=40, I=4000, seed=31, ragged=True, pixelated=pix)
+  cfg, ev, inj = H.small_config(E=640, S=96, P=3, Z=40 if kind != 'full' else 400, I=4000, seed=31, ragged=True, pixelated=pix)
   like, _, _ = H.build_product(ev, inj, pixelated=pix, kind=kind)
   lams = [dict(H0=float(h)) for h in np.linspace(62., 78., 11)]
   pops = [like.population.update(**l) for l in lams]
