@@ -1221,12 +1221,19 @@ DEVFN void zfactors_body(const LikeDev& L, const DevParams* params, const double
   const DevParams P = params[b];      // by value: uniform loads at kernel start -> scalar registers, nothing re-read in the loops
   const double* zt = zt_all + (size_t)b * TcMax;
   const double* It = It_all + (size_t)b * TcMax;
+#if CHM_EXPTAB
+  __shared__ double etab[CHM_EXPTAB_N];             // [r3] the two powers of the merger rate through the table exp (chm_exp_tab)
+  for (int i = t; i < CHM_EXPTAB_N; i += nt) etab[i] = exp_table_entry(i);
+  const ExpTab ex = { etab };
+#else
+  const ExpPoly ex = {};
+#endif
   if (LDS_TAB) {                                    // staged once per block; the block then walks over its events
     double* a = lds; double* c = lds + P.Tc;
     for (int i = t; i < P.Tc; i += nt) { a[i] = zt[i]; c[i] = It[i]; }
-    __syncthreads();
     zt = a; It = c;
   }
+  if (LDS_TAB || CHM_EXPTAB) __syncthreads();
   const int Z = L.Z;
   // ranged: a WAVE per event (the support of an event's KDE is ~Z/3 points: 64-lane passes waste less than 256-thread ones);
   // whole grids: the block walks over the events
@@ -1286,7 +1293,7 @@ DEVFN void zfactors_body(const LikeDev& L, const DevParams* params, const double
       const double jac = L.tab_jac ? L.tab_jac[zo + k] : ddLdz_from_dCt_rE(P, dCt, zp1, rEz, lzp1) * (zp1 * zp1);
       double rnum, rden = 1.;
       if (L.tab_rate) rnum = L.tab_rate[zo + k];                                                       // plug-in rate model: tabulated
-      else merger_rate_nd(P, z, lzp1, rnum, rden);
+      else merger_rate_nd(P, z, lzp1, rnum, rden, ex);
       if (!ranged) { L.jac[zo + k] = jac; L.prate[zo + k] = rnum / (rden * zp1); }
       const double p_bkg = L.tab_bkg ? L.tab_bkg[zo + k] : (4. * CHM_PI * P.dH) * (dCt * dCt) * rEz;   // plug-in completeness: tabulated; cosmo.py:188-197
       // a 1-D handle built from a catalogue population (hyperlikelihood.p_gw1d on a pixelated object) carries no P_compl
