@@ -2381,6 +2381,9 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
 #ifndef FULLC_NPT
 #define FULLC_NPT 1024        // grid points of the stretch (longer: general kernel)
 #endif
+#ifndef FULLC_REDUCE16
+#define FULLC_REDUCE16 0       // sixteen points x one half of the wave per exchange (44 instead of 68 VALU per chunk): measured 8.41-8.53 against 8.26-8.30 ms -- off
+#endif
 #define FULLC_ROW 72          // doubles per grid point in the exchange buffer: 64 lanes + 8 (the eight points a wave reads fall in distinct banks)
 // per (draw, event) record of k_full_prep (doubles): what the pixels of an event share
 enum { FE_L00 = 0, FE_L10, FE_L11, FE_L20, FE_L21, FE_L22, FE_LOGNORM, FE_ZLO, FE_ZHI, FE_NORM, FE_OK, FE_KFIRST, FE_KLAST, FE_CHAIN, FE_D, FE_K1, FE_K2,
@@ -2610,19 +2613,47 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#if FULLC_REDUCE16
+    // sixteen grid points at a time, the two halves of the wave one after the other: the 32 lanes of a half write their sixteen sums, lane l
+    // adds lanes l%4, l%4 + 4, ... of point l/4 to its running sum (both halves), two DPP steps complete the point in lane 4 (l/4) + 3
+    // (44 instead of 68 VALU instructions per chunk; rows of 32 + 4 doubles: the eight points a half-wave reads fall in distinct banks)
+#pragma unroll
+    for (int h = 0; h < LK; h += 16) {
+      if (h < ng) {
+        double v = 0.;
+#pragma unroll
+        for (int lh = 0; lh < 2; lh++) {
+          if ((lane >> 5) == lh) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) xb[i * 36 + (lane & 31)] = acc[h + i];
+          }
+          wave_sync();                                       // the lanes read each other's sums: no access moves across (LDS itself runs in issue order)
+          const double* src = xb + (lane >> 2) * 36 + (lane & 3);
+#pragma unroll
+          for (int q = 0; q < 8; q++) v += src[4 * q];
+          wave_sync();
+        }
+        v += dpp_move<0x111, 0xf, true>(v); v += dpp_move<0x112, 0xf, true>(v);
+        if ((lane & 3) == 3) vrow[c * LK + h + (lane >> 2)] = v;
+      }
+    }
+#else
 #pragma unroll
     for (int h = 0; h < LK; h += 8) {
       if (h < ng) {
 #pragma unroll
         for (int i = 0; i < 8; i++) xb[i * FULLC_ROW + lane] = acc[h + i];
+        wave_sync();
         const double* src = xb + (lane >> 3) * FULLC_ROW + (lane & 7);
         double v = 0.;
 #pragma unroll
         for (int q = 0; q < 8; q++) v += src[8 * q];
+        wave_sync();
         v += dpp_move<0x111, 0xf, true>(v); v += dpp_move<0x112, 0xf, true>(v); v += dpp_move<0x114, 0xf, true>(v);
         if ((lane & 7) == 7) vrow[c * LK + h + (lane >> 3)] = v;
       }
     }
+#endif
   }
   __syncthreads();
   // p_gw and the integrand of every grid point of the stretch   catalog.py:202, pop_wrapper.py:87, likelihood.py:252-275
