@@ -2368,13 +2368,14 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
 // looked at again before every chunk (a bit per owned sample; re-read and started with two exps once it is inside 37 widths of the chunk's
 // first point: it was >= 22 widths from every point of the chunks it missed, which span <= 15 widths each).
 // Blocks this form does not cover (a stretch that is not uniform to 1e-11 of its step, a chunk spanning > 15 kernel widths, more than
-// 256 x FULLC_SPT samples) are flagged in todo[] and done by k_full_kde, which skips the others.
+// FULLC_NPT grid points inside the mask) are flagged in todo[] and done by k_full_kde, which skips the others.  Events of more than
+// 256 x FULLC_SPT samples are walked in sets of that many.
 // Round-off: the running product takes LK/4 + 1 roundings per chunk and 4 x the step factor's (one more per chunk): <~ 1e-13 relative at the
 // far end of a 250-point stretch (test tolerance on p_gw and L_i: 1e-9).
 #ifndef FULLC_LK
 #define FULLC_LK 32
 #endif
-#define FULLC_SPT 16          // samples a thread keeps in registers: events of up to 4096 samples
+#define FULLC_SPT 16          // samples a thread keeps in registers: 4096 per block and walk over the stretch
 #ifndef FULLC_MINW
 #define FULLC_MINW 3
 #endif
@@ -2453,7 +2454,7 @@ __global__ void __launch_bounds__(256) k_full_prep(LikeDev L) {
   for (int k = k_first + t; k <= k_last; k += nt) dev = fmax(dev, fabs(zg[k] - (z_f + (double)(k - k_first) * dz)));
   dev = block_reduce<RED_MAX>(dev, red);
   const double D = dz * l00;
-  const bool chain = ok && npt > 1 && dev <= 1e-11 * fabs(dz) && fabs(D) * (double)LK <= 15. && S <= nt * FULLC_SPT && npt <= FULLC_NPT;
+  const bool chain = ok && npt > 1 && dev <= 1e-11 * fabs(dz) && fabs(D) * (double)LK <= 15. && npt <= FULLC_NPT;
   const double a_ref = z_f * l00 + wh[7] * l10 + wh[8] * l20;
   if (t < LK) fe[FE_CF + t] = chm_exp(-0.5 * D * D * (double)(t * t));      // the factor of grid point i of a chunk that is common to all samples
   if (t == 0) {
@@ -2519,7 +2520,6 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
   // what a sample's start needs sits in LDS: after the first chunk it is a rare path whose constants would occupy registers of the march
   if (t == 0) { wh[0] = q1; wh[1] = q2; wh[2] = fe[FE_LOGNORM]; wh[3] = D; wh[4] = V; }
   __syncthreads();
-  const int spt = (S + nt - 1) / nt;
   const double* fa = L.full_s + so; const double* fy1 = fa + (size_t)L.nb_alloc * L.E * S; const double* fy2 = fy1 + (size_t)L.nb_alloc * L.E * S;
   const double* fw = fy2 + (size_t)L.nb_alloc * L.E * S; const double* fu = fw + (size_t)L.nb_alloc * L.E * S;
 
@@ -2536,22 +2536,25 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
     else u = in ? fu[s] * wh[4] : 0.;
     return in ? 1 : (d * Dl > 0. ? 0 : -1);
   };
+  const int lane = t & 63, wv = t >> 6;
+  double* xb = xw[wv];
+  double* vrow = vw[wv];
+  const int nch = (npt + LK - 1) / LK;
+  // events of more than 256 x FULLC_SPT samples: one set of 4096 samples after the other, a wave's sums of the later sets added to its row
+  for (int sb = 0; sb < S; sb += nt * FULLC_SPT) {
+  const int spt = (min(S - sb, nt * FULLC_SPT) + nt - 1) / nt;
   double pw[FULLC_SPT], uu[FULLC_SPT];
   unsigned waiting = 0;                                    // bit j: owned sample j has not started yet
 #pragma unroll
   for (int j = 0; j < FULLC_SPT; j++) {
     pw[j] = 0.; uu[j] = 0.;
-    const int s = t + j * nt;
+    const int s = sb + t + j * nt;
     if (s < S && start(s, t0, direct0, pw[j], uu[j]) == 0) waiting |= 1u << j;
   }
 
   // The four waves walk the chunks on their own.  After a chunk a wave adds its 64 lanes' power sums through its private exchange buffer, eight
   // grid points at a time: every lane writes eight sums, lane l adds lanes l%8, l%8 + 8, ... of point l/8 and three DPP steps complete the
   // point in lane 8 (l/8) + 7, which files it in the wave's row of vw.  No barrier before the end of the stretch; a fixed order of additions.
-  const int lane = t & 63, wv = t >> 6;
-  double* xb = xw[wv];
-  double* vrow = vw[wv];
-  const int nch = (npt + LK - 1) / LK;
   for (int c = 0; c < nch; c++) {
     const double tc = t0 + (double)(c * LK) * D;
     if (c > 0 && waiting) {                                // rare: one copy of the start code, the sample's registers picked by compile-time selects
@@ -2560,7 +2563,7 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
         const int j = __builtin_ctz(wm);
         wm &= wm - 1;
         double np, nu;
-        const int r = start(t + j * nt, tc, true, np, nu);
+        const int r = start(sb + t + j * nt, tc, true, np, nu);
         if (r != 0) waiting &= ~(1u << j);
         if (r == 1) {
 #pragma unroll
@@ -2634,7 +2637,7 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
           wave_sync();
         }
         v += dpp_move<0x111, 0xf, true>(v); v += dpp_move<0x112, 0xf, true>(v);
-        if ((lane & 3) == 3) vrow[c * LK + h + (lane >> 2)] = v;
+        if ((lane & 3) == 3) { double* o = vrow + c * LK + h + (lane >> 2); *o = sb == 0 ? v : *o + v; }
       }
     }
 #else
@@ -2650,10 +2653,11 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
         for (int q = 0; q < 8; q++) v += src[8 * q];
         wave_sync();
         v += dpp_move<0x111, 0xf, true>(v); v += dpp_move<0x112, 0xf, true>(v); v += dpp_move<0x114, 0xf, true>(v);
-        if ((lane & 7) == 7) vrow[c * LK + h + (lane >> 3)] = v;
+        if ((lane & 7) == 7) { double* o = vrow + c * LK + h + (lane >> 3); *o = sb == 0 ? v : *o + v; }
       }
     }
 #endif
+  }
   }
   __syncthreads();
   // p_gw and the integrand of every grid point of the stretch   catalog.py:202, pop_wrapper.py:87, likelihood.py:252-275

@@ -267,7 +267,7 @@ int chm_device_synchronize(int32_t device);
 int chm_last_timing(chm_like* like, chm_sel* sel, double ms[8]);
 /* Diagnostics of the 3-D mode (kind_p_gw3d='full', likelihood.py:211-260): how many (draw, event, pixel) triples of the last chm_eval of nb
  * draws on this handle were left to the general KDE kernel by the sample-stationary one (a stretch of the event's z grid that is not
- * uniform, a grid step of more than 15/32 kernel widths, more than 4096 samples, more than 1024 grid points inside the mask).  Both
+ * uniform, a grid step of more than 15/32 kernel widths, more than 1024 grid points inside the mask).  Both
  * kernels compute the same sums; the tests use the count to know which one they are looking at.                                          */
 int chm_like_full_general_pixels(chm_like* like, int32_t nb, int64_t* count);
 
