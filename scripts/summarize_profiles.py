@@ -132,9 +132,9 @@ def main():
       p = os.path.join(ROOT, doc)
       s = open(p).read()
       for name, txt in blocks.items():
-        pat = re.compile(r'(<!-- profiles:BEGIN %s -->\n).*?(\n<!-- profiles:END %s -->)' % (re.escape(name), re.escape(name)), re.S)
+        pat = re.compile(r'(<!-- profiles:BEGIN %s -->\n)(?:.*?\n)??(<!-- profiles:END %s -->)' % (re.escape(name), re.escape(name)), re.S)
         if pat.search(s):
-          s = pat.sub(lambda m: m.group(1) + txt + m.group(2), s)
+          s = pat.sub(lambda m: m.group(1) + txt + '\n' + m.group(2), s)
       open(p, 'w').write(s)
 
 
