@@ -90,7 +90,46 @@ DEVFN double chm_log(double x) {
   return v;
 }
 
+// [r3] table form of the exp of the mass model (chm_exp_tab / exp_table_entry of chm_math.h): T[j] = 2^(j/256) from chm_exp11 on a two-piece
+// argument, exp(x) = 2^k T[j] (1 + r + r^2/2 + r^3/6 + r^4/24)
+static double TAB[256];
+DEVFN double exp_table_entry(int j) {
+  const double C_HI = 6.93147180369123816490e-01 / 256., C_LO = 1.90821492927058770002e-10 / 256.;
+  const double a = (double)j * C_HI;
+  const double v = chm_exp11(a);
+  return __builtin_fma(v, (double)j * C_LO, v);
+}
+DEVFN double chm_exp_tab(double x) {
+  const double SC = 3.69329930467574632e+02;
+  const double L_HI = 6.93147180369123816490e-01 / 256., L_LO = 1.90821492927058770002e-10 / 256.;
+  double n = __builtin_rint(x * SC);
+  double r = __builtin_fma(-n, L_HI, x);
+  r = __builtin_fma(-n, L_LO, r);
+  const int ni = (int)n;
+  const double tj = TAB[ni & 255];
+  double p = __builtin_fma(r, 4.16666666666666644e-02, 1.66666666666666657e-01);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(tj * p, ni >> 8);
+}
+
 int main() {
+  for (int j = 0; j < 256; j++) TAB[j] = exp_table_entry(j);
+  {
+    std::mt19937_64 g(7);
+    std::uniform_real_distribution<double> ue(-700, 700), us(-1, 1);
+    double mt = 0, wt = 0, tabmax = 0;
+    for (int j = 0; j < 256; j++) { long double ref = exp2l((long double)j / 256.0L); double e = fabs((double)(((long double)TAB[j] - ref) / ref)); if (e > tabmax) tabmax = e; }
+    for (int i = 0; i < 20000000; i++) {
+      double x = i % 3 == 0 ? ue(g) : (i % 3 == 1 ? us(g) * 40 : us(g));
+      long double ref = expl((long double)x);
+      double e = fabs((double)(((long double)chm_exp_tab(x) - ref) / ref));
+      if (e > mt) { mt = e; wt = x; }
+    }
+    printf("table exp (chm_exp_tab) max rel err %.3e (at %g) = %.2f half-ulp; table entries max rel err %.3e = %.2f half-ulp; specials: exp_tab(-800)=%g exp_tab(800)=%g exp_tab(nan)=%g\n",
+           mt, wt, mt / 1.11e-16, tabmax, tabmax / 1.11e-16, chm_exp_tab(-800.), chm_exp_tab(800.), chm_exp_tab(NAN));
+  }
   std::mt19937_64 g(1);
   std::uniform_real_distribution<double> ue(-745, 709), ul(-700, 700), us(-1, 1);
   double maxe = 0, maxl = 0, maxe11 = 0; double we=0, wl=0;
