@@ -252,14 +252,14 @@ def test_event_groups_on_two_streams_give_the_one_lane_values(kind):
   np.testing.assert_allclose(grouped['log_hyper'][4], ref[3], rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
 
 
-@pytest.mark.parametrize('case', ['wide_kernels', 'narrow_kernels', 'jittered_grid', 'many_samples', 'coarse_grid'])
+@pytest.mark.parametrize('case', ['wide_kernels', 'narrow_kernels', 'jittered_grid', 'many_samples', 'coarse_grid', 'long_stretch'])
 def test_full_mode_sample_stationary_and_general_kernels(case):
   """[r3] kind_p_gw3d='full' runs the sample-stationary KDE kernel (k_full_kde_chain: the power sums of a sample are carried from one chunk of
   the grid to the next, no exp per chunk) and leaves to the general kernel the pixels it cannot do.  Cases: Scott bandwidth (every sample
   starts at the first chunk); a bandwidth of 0.12 on a 900-point grid (the stretch inside the mask spans ~100 kernel widths: most samples
   start at a later chunk -- the 'waiting' path -- and leave the 37-width window again); a grid jittered by 1e-7 of its step (not uniform:
   general kernel); 4500 samples per event (more than a thread block keeps in registers: walked in two sets); a 60-point grid with narrow kernels
-  (a chunk spans > 15 widths: general kernel, one exp per pair).  Every case against the NumPy oracle (all pairs, one exp each) to the stated
+  (a chunk spans > 15 widths: general kernel, one exp per pair); a 5000-point grid (> 1024 points inside the mask: general kernel).  Every case against the NumPy oracle (all pairs, one exp each) to the stated
   1e-9, with the kernel that ran checked through chm_like_full_general_pixels, and the two kernels against each other."""
   kw = dict(E=3, S=700, P=3, Z=900, I=1500, seed=41)
   like_kw = {}
@@ -269,6 +269,8 @@ def test_full_mode_sample_stationary_and_general_kernels(case):
     kw.update(S=4500, E=2, P=2, Z=600)
   if case == 'coarse_grid':
     kw.update(Z=60); like_kw = dict(bw_method=0.05)
+  if case == 'long_stretch':                         # > 1024 grid points inside the mask (the stretch does not fit the kernel's LDS rows): general kernel
+    kw.update(Z=5000, E=2, P=2, S=300)
   cfg, ev, inj = H.small_config(ragged=True, **kw)
   if case == 'jittered_grid':
     zg = np.array(ev['z_grids'])
