@@ -12,6 +12,7 @@
 
 #include "../../include/chimera_hip.h"
 #include "chm_kernels.h"
+#include "chm_fused.h"
 
 #define CHM_MAXP 1024
 static_assert(sizeof(chm_params) % 8 == 0, "chm_params layout");
@@ -226,6 +227,12 @@ struct chm_like {
   // draw-independent part of the per-z factors (k_grid_prep), made for the (z_max, z_grid_res) below
   int* d_zg_i = nullptr; double *d_zg_t = nullptr, *d_zg_lz = nullptr;
   double zg_zmax = -1.; int zg_Tc = 0;
+  // k_marg_fused (chm_fused.h): pixel of every sorted sample, largest distance of every pixel, plain-event flags (uploaded once, marginalized mode);
+  // widest event in octaves of distance / in keys of the direct-index table (LDS reserved per block)
+  FusedDesc FD = {};
+  bool fused_ok = false;
+  double ev_oct_max = 0.; int ev_nk_max = 0;
+  int* d_redo = nullptr;          // (shared with the clones) count of dense redos, diagnostics
 };
 struct chm_sel {
   Ctx ctx;
@@ -317,6 +324,8 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
   std::vector<double> tmp;                                   // must outlive the async copies below
   std::vector<std::vector<double>> sorted, logs;
   std::vector<int> seg, perm_all;                            // perm_all: original index of every pixel-sorted sample (for chm_tab)
+  std::vector<unsigned char> fused_pix, fused_plain;         // (alive until the stream is synchronised below)
+  std::vector<double> fused_dlmax;
   if (d->mode == CHM_MODE_MARG) {
     // marginalized: store every event's samples sorted by pixel, so that each (event, pixel) wave reads one contiguous
     // segment (the device-side form of `pe_pix == pixels[i]`, likelihood.py:179)
@@ -341,6 +350,44 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
     for (size_t k = 0; k < E * S; k++) { logs[0][k] = std::log(sorted[1][k]); logs[1][k] = std::log(sorted[2][k]); }
     rc = upload(*h->owned_sp, (const int*)seg.data(), E * (P + 1), &L.seg_off, s); if (rc) { chm_like_destroy(h); return rc; }
     rc = upload(*h->owned_sp, (const int*)perm_all.data(), E * S, &L.perm, s); if (rc) { chm_like_destroy(h); return rc; }
+    // inputs of the fused event kernel (chm_fused.h): the local pixel of every sorted sample (255: none), the largest distance of every
+    // pixel's samples, and which events hold only finite positive distances (their min / max z follow from the extreme distances)
+    if (P <= 64 && (S & 1) == 0) {
+      const size_t NTl = (S + SF_TILE - 1) / SF_TILE;
+      fused_pix.assign(E * NTl * SF_TILE, (unsigned char)255);
+      fused_dlmax.assign(E * P, NAN);
+      fused_plain.assign(E, 1);
+      double oct_max = 0.; int nk_max = 0;
+      for (size_t e = 0; e < E; e++) {
+        const double* x = sorted[0].data() + e * S;
+        const int* sg = &seg[e * (P + 1)];
+        double lo = INFINITY, hi = -INFINITY;
+        for (size_t k = 0; k < S; k++) {
+          if (!(std::isfinite(x[k]) && x[k] >= 2.2250738585072014e-308)) fused_plain[e] = 0;
+          else { lo = x[k] < lo ? x[k] : lo; hi = x[k] > hi ? x[k] : hi; }
+        }
+        for (size_t q = 0; q < P; q++) {
+          double m = -INFINITY;
+          for (int k = sg[q]; k < sg[q + 1]; k++) { fused_pix[e * NTl * SF_TILE + k] = (unsigned char)q; if (std::isfinite(x[k]) && x[k] > m) m = x[k]; }
+          if (m > -INFINITY) fused_dlmax[e * P + q] = m;
+        }
+        if (fused_plain[e] && lo <= hi) {
+          int64_t b0, b1; memcpy(&b0, &lo, 8); memcpy(&b1, &hi, 8);
+          const int nk = (int)(b1 >> (32 + LUT_SHIFT)) - (int)(b0 >> (32 + LUT_SHIFT)) + 1;
+          nk_max = nk > nk_max ? nk : nk_max;
+          const double oc = std::log2(hi / lo);
+          oct_max = oc > oct_max ? oc : oct_max;
+        }
+      }
+      h->ev_oct_max = oct_max; h->ev_nk_max = nk_max;
+      rc = upload(*h->owned_sp, (const unsigned char*)fused_pix.data(), fused_pix.size(), &h->FD.pix_id, s); if (rc) { chm_like_destroy(h); return rc; }
+      rc = upload(*h->owned_sp, (const double*)fused_dlmax.data(), fused_dlmax.size(), &h->FD.pix_dlmax, s); if (rc) { chm_like_destroy(h); return rc; }
+      rc = upload(*h->owned_sp, (const unsigned char*)fused_plain.data(), fused_plain.size(), &h->FD.ev_plain, s); if (rc) { chm_like_destroy(h); return rc; }
+      int* rc_ = nullptr;
+      if (hipMalloc(&rc_, sizeof(int)) == hipSuccess) { h->owned_sp->push_back(rc_); (void)hipMemsetAsync(rc_, 0, sizeof(int), s); h->d_redo = rc_; }
+      h->FD.redo_count = h->d_redo;
+      h->fused_ok = true;
+    }
   } else {
     UP(dL, d->dL, S); UP(m1det, d->m1det, S); UP(m2det, d->m2det, S);
     tmp.resize(E * S);
@@ -465,6 +512,7 @@ extern "C" int chm_like_clone(const chm_like* src, chm_like** out) {
   L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.Aw = L.evstat = L.effg = L.pgw1d = L.like_pix = L.err_pix = L.p_gw_dump = L.ev_li = L.ev_ll = nullptr; L.full_todo = nullptr; L.full_ev = L.full_s = nullptr;
   L.krange = nullptr; L.tab_pm = L.tab_rate = L.tab_bkg = L.tab_jac = nullptr; L.zg_i = nullptr; L.zg_t = L.zg_lz = nullptr;
   h->F = src->F; h->fast_ok = src->fast_ok; h->dl_gmin = src->dl_gmin; h->dl_gmax = src->dl_gmax;
+  h->FD = src->FD; h->fused_ok = src->fused_ok; h->ev_oct_max = src->ev_oct_max; h->ev_nk_max = src->ev_nk_max; h->d_redo = src->d_redo;
   const size_t EZ = (size_t)L.E * L.Z;
   hipError_t e1 = hipMalloc(&h->d_zg_i, sizeof(int) * EZ), e2 = hipMalloc(&h->d_zg_t, sizeof(double) * EZ), e3 = hipMalloc(&h->d_zg_lz, sizeof(double) * EZ);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { chm_like_destroy(h); return fail(CHM_E_NOMEM, "chm_like_clone: grid bracket arrays"); }
@@ -726,6 +774,44 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       if (lds_fast > 96 * 1024) use_fast = false;
     }
   }
+  // k_marg_fused (chm_fused.h): the standard marginalized configuration in ONE kernel per (event, draw) -- few-draw calls by default
+  // (CHM_FUSED=0: never, 2: calls of any size; read per call).  LDS per block: P histograms of num_bins + 1 doubles, the overlay region
+  // (the draw's mass tables + the widest event's slice of the distance tables + NW - 1 boundary rows | 4 NW prefix arrays) and ~2 KB.
+  FusedDesc FDc = {};
+  size_t lds_fused = 0;
+  const int fused_nw = 4;
+  bool use_fused = false;
+  {
+    const char* fe = getenv("CHM_FUSED");
+    const int fmode = fe ? atoi(fe) : 1;
+    static const int few_nb_f = getenv("CHM_FEW_NB") ? atoi(getenv("CHM_FEW_NB")) : 8;
+    if (like && like->fused_ok && use_fast && !tab && !want_dump && fmode > 0 && (nb <= few_nb_f || fmode >= 2) && !serial &&
+        like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && like->L.num_bins == 200 &&
+        !getenv("CHM_MARG_GENERIC") && !getenv("CHM_ZF_FULL")) {
+      int Tc_call = 0, Tm_call = 0;
+      double zmax_min = INFINITY;
+      for (int b = 0; b < nb; b++) {
+        Tc_call = params[b].z_grid_res > Tc_call ? params[b].z_grid_res : Tc_call;
+        Tm_call = params[b].mass_grid_res > Tm_call ? params[b].mass_grid_res : Tm_call;
+        zmax_min = params[b].z_max < zmax_min ? params[b].z_max : zmax_min;
+      }
+      const double per_oct = (double)(Tc_call - 2) / (std::log2(zmax_min) + 33.22);
+      long long cap = (long long)(like->ev_oct_max * per_oct * 1.3) + 16;
+      cap = cap > Tc_call ? Tc_call : cap;
+      cap = (cap + 1) / 2 * 2;
+      const int capk = (like->ev_nk_max + 2 + 3) / 4 * 4;
+      const long long HS = like->L.num_bins + 1, Hrows = like->L.P + (like->L.P & 1);
+      const long long ov_s = CHM_EXPTAB_N + 2LL * Tm_call + 4 * cap + capk / 4 + (fused_nw - 1) * HS, ov_p = 4LL * fused_nw * HS;
+      const long long ov = ov_s > ov_p ? ov_s : ov_p;
+      FDc = like->FD;
+      FDc.cap_rec = (int)cap; FDc.cap_keys = capk; FDc.overlay_doubles = (int)ov; FDc.tol = 3e-10;
+      lds_fused = sizeof(double) * (size_t)(Hrows * HS + 16 + 4 * fused_nw + 5 * Hrows + fused_nw + ov);
+      const size_t Nk = like->L.num_bins;
+      const size_t lds_redo = sizeof(double) * (2 * Nk + 3 * (Nk + 1) + 2 * (size_t)like->L.G);      // the dense redo runs the general kernel's body in the same LDS
+      if (lds_redo > lds_fused) lds_fused = lds_redo;
+      use_fused = lds_fused <= 160 * 1024;
+    }
+  }
   // k_selection_fast: built-in models of an FLRW draw (cosmo_model 0), the same mass model for every draw; table slice capacity as above
   LutDesc lutB = {};
   bool sel_fast = sel && sel->fast_ok && !td.pm_i && !td.rate_i && !td.bkg_i && !td.jac_i && !td.zt && !getenv("CHM_SELECTION_GENERIC");
@@ -758,7 +844,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   static const int few_nb = getenv("CHM_FEW_NB") ? atoi(getenv("CHM_FEW_NB")) : 8;
   static const bool fuse_env = getenv("CHM_NO_ZF_SEL") == nullptr;
   const size_t lds_zfac_call = sizeof(double) * (size_t)2 * c.TcMax;
-  const bool fuse_sel = fuse_env && !serial && like && sel && sel_fast && nb <= few_nb && !td.rate_g && !td.bkg_g && !td.jac_g &&
+  const bool fuse_sel = fuse_env && !use_fused && !serial && like && sel && sel_fast && nb <= few_nb && !td.rate_g && !td.bkg_g && !td.jac_g &&
                         like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && !getenv("CHM_MARG_GENERIC") && !getenv("CHM_ZF_FULL") &&
                         !(getenv("CHM_GROUPS") && atoi(getenv("CHM_GROUPS")) > 1) && lds_zfac_call <= 64 * 1024 && like->L.E <= 65535;
   const bool one_stream = serial || fuse_sel;
@@ -779,7 +865,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
             Tc_host, Tm_host, use_fast, lutA.key0, lutA.nk, lutA.cap, (long long)lds_fast, params[0].mass_model, out->partials != nullptr,
             sel_fast, lutB.key0, lutB.nk, lutB.cap, (long long)lds_sel, (long long)(intptr_t)lutB.lut, fuse_sel,
             (long long)(intptr_t)c.d_evpart, (long long)(intptr_t)(like ? like->L.ws_z : nullptr), (long long)(intptr_t)(sel ? sel->S.partial : nullptr),
-            zg_use, zg_make, (long long)(intptr_t)comm };
+            zg_use, zg_make, (long long)(intptr_t)comm, use_fused, (long long)lds_fused, FDc.cap_rec, FDc.cap_keys };
     if (c.gexec && key == c.gkey) {                           // replay
       const double hp1 = host_prof_on() ? now_us() : 0.;
       HIPCHK(hipGraphLaunch(c.gexec, sA));
@@ -872,6 +958,23 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       L.e_off = eb; L.E_cnt = ee - eb; L.nb = nb;
       // per-z factors of the group's events: on the other lane, concurrently with the sample stage -- except in marginalized
       // mode, where they follow k_event_prep on the group's own lane and cover only the support of each event's KDE
+      if (use_fused) {                                      // the whole event side of the call in one kernel (chm_fused.h)
+        SampFast Fq = like->F; Fq.lut = lutA;
+        L.ev_publish = 1;
+        if (timing_all) { HIPCHK(hipEventRecord(c.evg[4 * g], sg)); HIPCHK(hipEventRecord(c.evg[4 * g + 1], sg)); }
+        if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
+#define LAUNCH_FUSED_(M, NTL) do { allow_lds((k_marg_fused<M, 4, 200, NTL>), lds_fused); \
+          hipLaunchKernelGGL((k_marg_fused<M, 4, 200, NTL>), dim3((unsigned)L.E_cnt * nb), dim3(256), lds_fused, sg, L, Fq, FDc, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, c.rec, c.TcMax, c.TmMax); } while (0)
+#define LAUNCH_FUSED(M) do { if (nb <= few_nb) LAUNCH_FUSED_(M, true); else LAUNCH_FUSED_(M, false); } while (0)
+        const int mm = params[0].mass_model;
+        if (mm == 0) LAUNCH_FUSED(0); else if (mm == 1) LAUNCH_FUSED(1); else LAUNCH_FUSED(2);
+#undef LAUNCH_FUSED
+#undef LAUNCH_FUSED_
+        HIPCHK(hipGetLastError());
+        if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 3], sg));
+        ev_from_fixup = true;
+        continue;
+      }
       const bool zf_ranged = (L.mode == CHM_MODE_MARG || L.mode == CHM_MODE_1D || L.mode == CHM_MODE_APPROX) && !getenv("CHM_ZF_FULL");
       // standard configuration (binning, cut_grid set) -> k_kde_marg_sub<32>, two pixels per wave (16 lanes per pixel measured
       // 30 % slower: 19 KB of LDS per wave halve the occupancy); anything else, or CHM_MARG_GENERIC=1, -> the general kernel

@@ -1111,8 +1111,7 @@ DEVFN int wave_prefix3(const double* cen, const double* wgt, int N, double c_ref
 // Per-(draw, event) statistics for the marginalized kernels: the chunk partials of k_samples combined once for all the event's
 // pixels.  es[NEVSTAT]: zmin, zmax, std, norm, n_eff, sum w, lb, ub (effective-grid ends, likelihood.py:186-187), k_lo, k_hi
 // (event-grid points inside [lb, ub]), de, 1/de (spacing of jnp.linspace(lb, ub, G), likelihood.py:188)
-DEVFN void event_stats(const LikeDev& L, int b, int e, double* es) {
-  const EvStats st = combine_stats(L.part + ((size_t)b * L.E + e) * L.NC * NPART, L.NC, L.S);
+DEVFN void event_stats_from(const LikeDev& L, int e, const EvStats& st, double* es) {
   double lb = 0., ub = 0.;
   if (L.has_cut) eff_bounds(L.mode == 2, st.zmin, st.zmax, st.sd, L.cut_grid, lb, ub);
   else { lb = L.z_grids[(size_t)e * L.Z]; ub = L.z_grids[(size_t)e * L.Z + L.Z - 1]; }
@@ -1135,6 +1134,9 @@ DEVFN void event_stats(const LikeDev& L, int b, int e, double* es) {
   k_lo &= ~1; k_hi = min(k_hi | 1, Z - 1);
   es[8] = (double)k_lo; es[9] = (double)k_hi;
   es[10] = (ub - lb) / (double)(L.G - 1); es[11] = (double)(L.G - 1) / (ub - lb);
+}
+DEVFN void event_stats(const LikeDev& L, int b, int e, double* es) {
+  event_stats_from(L, e, combine_stats(L.part + ((size_t)b * L.E + e) * L.NC * NPART, L.NC, L.S), es);
 }
 
 // k_event_prep: one wave per (event, draw), four waves per block: event_stats -> evstat (nb,E,NEVSTAT) and, for the general kernel (k_kde_marg),
@@ -1210,6 +1212,46 @@ __global__ void __launch_bounds__(256) k_grid_prep(int E, int Z, const double* z
   }
 }
 
+// per-z factors of ONE grid point k of event e (draw P): bkgA[k] = (1 - P_compl) p_bkg (catalog.py:202), Aw[k] = prate/jac * trapezoid weight
+// (likelihood.py:270-278), and -- whole-grid launches only (!ranged) -- jac, prate.  Shared by zfactors_body and the fused event kernel.
+template <class AZ, class AI, class EX>
+DEVFN void zfactor_point(const LikeDev& L, const DevParams& P, const int e, const int k, const size_t zo, const double* zg, AZ zt, AI It,
+                       const int ranged, const EX& ex) {
+#pragma clang fp contract(fast)
+  const int Z = L.Z;
+  double z = zg[k];
+  const bool own_cosmo = !(L.tab_jac && L.tab_bkg);          // plug-in cosmology: Jacobian and p_bkg both come from the caller
+  double zp1 = 1. + z;
+  double dCt = 0., lzp1;
+  if (L.zg_i) {                                              // prepared bracket (k_grid_prep): no table search, no division, no log
+    const size_t q = (size_t)e * Z + k;
+    if (own_cosmo) dCt = dCt_from_dCr(P, P.dH * interp_pre(It, P.Tc, L.zg_i[q], L.zg_t[q]));      // cosmo.py:132-153
+    lzp1 = L.zg_lz[q];
+  } else {
+    if (own_cosmo) dCt = dCt_at_z(P, z, zt, It);
+    lzp1 = chm_log_pos(zp1);
+  }
+  // One reciprocal of E(z) serves the Jacobian (dH/E) and dVc/dz (.../E); the rate stays a quotient num/den until it meets the
+  // Jacobian, so that A_k = prate/jac tw costs one division instead of three (five IEEE divisions per grid point before: 248 VALU
+  // instructions per point, 129 M per launch at C3 / 128 draws).  Differences to the separate quotients: rounding (<= 4 ulp).
+  const double Ez = own_cosmo ? E_at_z_l(P, z, lzp1) : 1.;
+  const double rEz = chm_div(1., Ez);
+  const double jac = L.tab_jac ? L.tab_jac[zo + k] : ddLdz_from_dCt_rE(P, dCt, zp1, rEz, lzp1) * (zp1 * zp1);
+  double rnum, rden = 1.;
+  if (L.tab_rate) rnum = L.tab_rate[zo + k];                                                       // plug-in rate model: tabulated
+  else merger_rate_nd(P, z, lzp1, rnum, rden, ex);
+  if (!ranged) { L.jac[zo + k] = jac; L.prate[zo + k] = rnum / (rden * zp1); }
+  const double p_bkg = L.tab_bkg ? L.tab_bkg[zo + k] : (4. * CHM_PI * P.dH) * (dCt * dCt) * rEz;   // plug-in completeness: tabulated; cosmo.py:188-197
+  // a 1-D handle built from a catalogue population (hyperlikelihood.p_gw1d on a pixelated object) carries no P_compl
+  L.bkgA[zo + k] = (P.has_catalog && L.P_compl) ? (1. - L.P_compl[(size_t)e * Z + k]) * p_bkg : p_bkg;
+  if (L.Aw) {
+    // trapezoid weight of grid point k: y_k enters the two adjacent intervals (jnp.trapezoid, likelihood.py:278)
+    double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
+    double tw = 0.5 * ((z - zl) + (zr - z));
+    L.Aw[zo + k] = (rnum * tw) / ((rden * zp1) * jac);
+  }
+}
+
 // STATS (few draws per call, ranged == 1): the wave forms its event's statistics itself and writes them for the GW kernel -- no k_event_stats
 // launch in front of this kernel
 // (body shared by k_zfactors and k_zf_sel: block bx of nbx, draw b)
@@ -1272,39 +1314,7 @@ DEVFN void zfactors_body(const LikeDev& L, const DevParams* params, const double
       const int* kr = L.krange + ((size_t)b * L.E + e) * 2;
       k_first = kr[0]; k_last = kr[1];
     }
-    for (int k = k_first + lane0; k <= k_last; k += stride) {
-      double z = zg[k];
-      const bool own_cosmo = !(L.tab_jac && L.tab_bkg);          // plug-in cosmology: Jacobian and p_bkg both come from the caller
-      double zp1 = 1. + z;
-      double dCt = 0., lzp1;
-      if (L.zg_i) {                                              // prepared bracket (k_grid_prep): no table search, no division, no log
-        const size_t q = (size_t)e * Z + k;
-        if (own_cosmo) dCt = dCt_from_dCr(P, P.dH * interp_pre(It, P.Tc, L.zg_i[q], L.zg_t[q]));      // cosmo.py:132-153
-        lzp1 = L.zg_lz[q];
-      } else {
-        if (own_cosmo) dCt = dCt_at_z(P, z, zt, It);
-        lzp1 = chm_log_pos(zp1);
-      }
-      // One reciprocal of E(z) serves the Jacobian (dH/E) and dVc/dz (.../E); the rate stays a quotient num/den until it meets the
-      // Jacobian, so that A_k = prate/jac tw costs one division instead of three (five IEEE divisions per grid point before: 248 VALU
-      // instructions per point, 129 M per launch at C3 / 128 draws).  Differences to the separate quotients: rounding (<= 4 ulp).
-      const double Ez = own_cosmo ? E_at_z_l(P, z, lzp1) : 1.;
-      const double rEz = chm_div(1., Ez);
-      const double jac = L.tab_jac ? L.tab_jac[zo + k] : ddLdz_from_dCt_rE(P, dCt, zp1, rEz, lzp1) * (zp1 * zp1);
-      double rnum, rden = 1.;
-      if (L.tab_rate) rnum = L.tab_rate[zo + k];                                                       // plug-in rate model: tabulated
-      else merger_rate_nd(P, z, lzp1, rnum, rden, ex);
-      if (!ranged) { L.jac[zo + k] = jac; L.prate[zo + k] = rnum / (rden * zp1); }
-      const double p_bkg = L.tab_bkg ? L.tab_bkg[zo + k] : (4. * CHM_PI * P.dH) * (dCt * dCt) * rEz;   // plug-in completeness: tabulated; cosmo.py:188-197
-      // a 1-D handle built from a catalogue population (hyperlikelihood.p_gw1d on a pixelated object) carries no P_compl
-      L.bkgA[zo + k] = (P.has_catalog && L.P_compl) ? (1. - L.P_compl[(size_t)e * Z + k]) * p_bkg : p_bkg;
-      if (L.Aw) {
-        // trapezoid weight of grid point k: y_k enters the two adjacent intervals (jnp.trapezoid, likelihood.py:278)
-        double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
-        double tw = 0.5 * ((z - zl) + (zr - z));
-        L.Aw[zo + k] = (rnum * tw) / ((rden * zp1) * jac);
-      }
-    }
+    for (int k = k_first + lane0; k <= k_last; k += stride) zfactor_point(L, P, e, k, zo, zg, zt, It, ranged, ex);
   }
 }
 
@@ -1327,9 +1337,21 @@ __global__ void __launch_bounds__(256, CHM_ZF_WPE) k_zfactors(LikeDev L, const D
 // trapz(p_gw3d * p_z / jac) up to rounding (terms outside the range are exact zeros for finite inputs).
 // Dynamic LDS: cen[N], wgt[N], [P0,P1,P2 (N+1) when binning], eff[G], dens[G];  N = num_bins or S.
 #define MARG_PF 8            // prefetch depth: 8 x (64 lanes x 2 doubles) = 1024 grid points per pass
+// ordering point for LDS traffic inside ONE wave (its lanes exchange data through the wave's private LDS slice): LDS
+// instructions of a wave execute in issue order, so only the compiler has to be kept from moving accesses across it
+DEVFN void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // one (event, pixel, draw) by one wave (a block of 64 threads); own_eff: form the effective grid here instead of reading k_event_prep's
+// WSYNC: the wave is one of several in its block (the fused event kernel's dense redo): the ordering points are wave-level (the LDS slice is
+// this wave's alone) instead of block barriers
+template <bool WSYNC = false>
 DEVFN void kde_marg_general(const LikeDev& L, const DevParams* params, const int b, const int e, const int p, double* lds, const bool own_eff) {
-  const int lane = threadIdx.x;
+  auto bsync = [] { if (WSYNC) wave_sync(); else __syncthreads(); };
+  const int lane = threadIdx.x & 63;
   const DevParams& P = params[b];
   const int S = L.S, Z = L.Z, B = L.num_bins, G = L.G;
   const int N = L.binning ? B : S;
@@ -1392,16 +1414,16 @@ DEVFN void kde_marg_general(const LikeDev& L, const DevParams* params, const int
         data[j] = (e0 + e1) / 2.;
         wgt[j] = 0.;
       }
-      __syncthreads();
+      bsync();
       for (int s = s0 + lane; s < s1; s += 64) atomicAdd(&wgt[bin_index(wz[s], lo, hi, B)], ww[s]);
-      __syncthreads();
+      bsync();
     } else {
       for (int s = lane; s < S; s += 64) {
         bool in = s >= s0 && s < s1;
         data[s] = in ? wz[s] : zmin;                        // likelihood.py:180-181
         wgt[s] = in ? ww[s] : 0.;
       }
-      __syncthreads();
+      bsync();
     }
     // kde1d prologue (math.py:58-75): normalise weights, neff, std(dataset), bandwidth
     double a = 0.;
@@ -1419,19 +1441,19 @@ DEVFN void kde_marg_general(const LikeDev& L, const DevParams* params, const int
     // effective grid (likelihood.py:185-190), built once per event by k_event_prep
     if (own_eff) { for (int i = lane; i < G; i += 64) eff[i] = L.has_cut ? linspace_tab(lb, ub, G, i, L.fracG) : L.z_grids[(size_t)e * Z + i]; }       // likelihood.py:188,190
     else { const double* eg = L.effg + ((size_t)b * L.E + e) * G; for (int i = lane; i < G; i += 64) eff[i] = eg[i]; }
-    __syncthreads();
+    bsync();
     // density on the effective grid: always Epanechnikov here (kde1d is called without kernel=, likelihood.py:192)
     const double inv_bw = 1. / bw;
     const double dbin = (hi - lo) / (double)B;
     const bool fast = L.binning && dbin > 0. && bw > 0. && bw < 1e300 && tot == tot && (tot > 0. || tot < 0.);
     if (fast) {
       const int jl1 = wave_prefix3(data, wgt, N, lo, P0, P1, P2);
-      __syncthreads();
+      bsync();
       for (int i = lane; i < G; i += 64) dens[i] = epan_prefix_eval(eff[i], data, wgt, P0, P1, P2, N, lo, 1. / dbin, bw, inv_bw, lo, jl1);
     } else {
       for (int i = lane; i < G; i += 64) dens[i] = kde_dense_eval(eff[i], data, wgt, N, true, bw, inv_bw);
     }
-    __syncthreads();
+    bsync();
   }
 
   // (3) integrand over [k_lo, k_hi]
@@ -1551,14 +1573,6 @@ __global__ void __launch_bounds__(64) k_marg_fixup(LikeDev L, const DevParams* p
   __syncthreads();                                      // the redone pixels were stored by lane 0 of this wave
   __threadfence_block();
   if (L.ev_publish) publish(wave_pixel_sum(L.like_pix + po, L.P));
-}
-
-// ordering point for LDS traffic inside ONE wave (its lanes exchange data through the wave's private LDS slice): LDS
-// instructions of a wave execute in issue order, so only the compiler has to be kept from moving accesses across it
-DEVFN void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1681,17 +1695,21 @@ template <int SW> DEVFN double sg_last_perm(double x) {
 //     bin coordinate of the lower node, scale * norm * gw_pdf and the NaN of a degenerate pixel are one factor;
 //   * the loads of a pass are unconditional (clamped pair index), both grid points of a lane sit in one exec region (k_hi is odd: event_stats),
 //     NaN grid points propagate through the interpolation weight instead of a separate test.
-template <int SW, int NR, int BINS, bool DUMP, bool NT>
+// PRE (the fused event kernel, chm_fused.h): the pixel's histogram is already in Q[0, B) and its upper end `hi_pre` is known -- no sample is read
+// here; the prefix arrays -2 P1 | P2 go to Q12 (2 (B + 1) doubles) instead of behind P0, the pixel's integral and rounding bound to out_like / out_err.
+template <int SW, int NR, int BINS, bool DUMP, bool NT, bool PRE = false>
 DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, const double* es, const int b, const int e, const int p,
-                        const int pp, const bool live, const bool poisoned, const int s0, const int s1, double (&zr)[NR], double (&wr)[NR]) {
+                        const int pp, const bool live, const bool poisoned, const int s0, const int s1, double (&zr)[NR], double (&wr)[NR],
+                        const double hi_pre = 0., double* Q12 = nullptr, double* out_like_pre = nullptr, double* out_err_pre = nullptr) {
 #pragma clang fp contract(fast)                  // a*b+c may fuse in this body; the bin index lives in bin_index_r() (contract off)
   const int lane = threadIdx.x, sl = lane % SW;
   const int S = L.S, Z = L.Z, B = BINS > 0 ? BINS : L.num_bins, G = L.G;      // BINS > 0: the bin count is a compile-time constant (LDS offsets, loop bounds)
   const double zmin = es[0], norm = es[3], lb = es[6], ub = es[7];
-  double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
+  double* out_like = PRE ? out_like_pre : L.like_pix + ((size_t)b * L.E + e) * L.P + p;
+  double* out_err = PRE ? out_err_pre : L.err_pix + ((size_t)b * L.E + e) * L.P + p;
   double* dump = (DUMP && p < L.P) ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
   const double* zg = L.z_grids + (size_t)e * Z;
-  if (!live && p < L.P) { if (sl == 0) { *out_like = 0.; L.err_pix[((size_t)b * L.E + e) * L.P + p] = 0.; } if (DUMP) for (int k = sl; k < Z; k += SW) dump[k] = 0.; }
+  if (!live && p < L.P) { if (sl == 0) { *out_like = 0.; *out_err = 0.; } if (DUMP) for (int k = sl; k < Z; k += SW) dump[k] = 0.; }
   const double* pc = L.p_cat + ((size_t)e * L.P + pp) * Z;
   const size_t zo = ((size_t)b * L.E + e) * Z;
   const double* bkgA = L.bkgA + zo;
@@ -1727,22 +1745,28 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   const double lo = zmin;
   // hi = max(where(mask, z, min z)) (likelihood.py:180, math.py:36).  jnp.max propagates NaN: a NaN among the pixel's z is a NaN among
   // the event's z, and then lo -- jnp.min over all of them (combine_stats, NaN-propagating) -- is NaN already
-  double hi = lo;
+  double hi = PRE ? hi_pre : lo;
+  if (!PRE) {
 #pragma unroll
-  for (int i = 0; i < NR; i++) hi = vmax_f64(hi, zr[i]);
-  for (int s = s0 + sl + SW * NR; s < s1; s += SW) hi = vmax_f64(hi, wz[s]);
-  double* const Q0 = Q; double* const Q1 = Q + (B + 1); double* const Q2 = Q + 2 * (B + 1);      // P0 | -2 P1 | P2, (B + 1) doubles each
-  hi = sg_last_perm<SW>(sg_scan_max0<SW>(hi));              // z >= 0: z_from_dGW interpolates a table that starts at z = 0 (cosmo.py:43-46)
-  if (lo != lo) hi = lo;
-  for (int j = sl; j < B; j += SW) Q0[j] = 0.;
-  wave_sync();
+    for (int i = 0; i < NR; i++) hi = vmax_f64(hi, zr[i]);
+    for (int s = s0 + sl + SW * NR; s < s1; s += SW) hi = vmax_f64(hi, wz[s]);
+  }
+  double* const Q0 = Q; double* const Q1 = PRE ? Q12 : Q + (B + 1); double* const Q2 = PRE ? Q12 + (B + 1) : Q + 2 * (B + 1);      // P0 | -2 P1 | P2, (B + 1) doubles each
+  if (!PRE) {
+    hi = sg_last_perm<SW>(sg_scan_max0<SW>(hi));            // z >= 0: z_from_dGW interpolates a table that starts at z = 0 (cosmo.py:43-46)
+    if (lo != lo) hi = lo;
+    for (int j = sl; j < B; j += SW) Q0[j] = 0.;
+    wave_sync();
+  }
   const double dB = (double)B;
   const double dhl = hi - lo, rhl = 1. / dhl;
   const double dbin = dhl * L.inv_B;                        // c'_j = c_j - lo = (j + 1/2) dbin for the uniform edges of math.py:37-39
+  if (!PRE) {
 #pragma unroll
-  for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q0[bin_index_r(zr[i], lo, dhl, rhl, dB)], wr[i]); }
-  for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q0[bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
-  wave_sync();
+    for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q0[bin_index_r(zr[i], lo, dhl, rhl, dB)], wr[i]); }
+    for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q0[bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
+    wave_sync();
+  }
   // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins (a compile-time 7 for 200 bins on 32 lanes)
   const int per = (B + SW - 1) / SW;
   const int j0 = sl * per < B ? sl * per : B, j1 = min(j0 + per, B);
@@ -1919,7 +1943,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   accC = sg_scan_add0<SW>(accC);
   if (sl == SW - 1 && live) {
     *out_like = poisoned ? nan : acc;
-    L.err_pix[((size_t)b * L.E + e) * L.P + p] = (degenerate || poisoned) ? 0. : errD * accC * fabs(scale * ng);     // NaN results stay NaN: nothing to redo
+    *out_err = (degenerate || poisoned) ? 0. : errD * accC * fabs(scale * ng);     // NaN results stay NaN: nothing to redo
   }
 }
 
