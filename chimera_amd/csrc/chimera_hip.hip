@@ -325,7 +325,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
   std::vector<std::vector<double>> sorted, logs;
   std::vector<int> seg, perm_all;                            // perm_all: original index of every pixel-sorted sample (for chm_tab)
   std::vector<unsigned char> fused_pix, fused_plain;         // (alive until the stream is synchronised below)
-  std::vector<double> fused_dlmax;
+  std::vector<double> fused_dlmax, fused_lm1;
   if (d->mode == CHM_MODE_MARG) {
     // marginalized: store every event's samples sorted by pixel, so that each (event, pixel) wave reads one contiguous
     // segment (the device-side form of `pe_pix == pixels[i]`, likelihood.py:179)
@@ -357,6 +357,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
       fused_pix.assign(E * NTl * SF_TILE, (unsigned char)255);
       fused_dlmax.assign(E * P, NAN);
       fused_plain.assign(E, 1);
+      fused_lm1.assign(2 * E, NAN);
       double oct_max = 0.; int nk_max = 0;
       for (size_t e = 0; e < E; e++) {
         const double* x = sorted[0].data() + e * S;
@@ -371,6 +372,12 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
           for (int k = sg[q]; k < sg[q + 1]; k++) { fused_pix[e * NTl * SF_TILE + k] = (unsigned char)q; if (std::isfinite(x[k]) && x[k] > m) m = x[k]; }
           if (m > -INFINITY) fused_dlmax[e * P + q] = m;
         }
+        {                                                   // log of the extreme primary masses, a hair outwards (the device forms its own logs)
+          const double* m1 = sorted[1].data() + e * S;
+          double a = INFINITY, bq = 0.;
+          for (size_t k = 0; k < S; k++) if (std::isfinite(m1[k]) && m1[k] > 0.) { a = m1[k] < a ? m1[k] : a; bq = m1[k] > bq ? m1[k] : bq; }
+          if (a <= bq) { fused_lm1[2 * e] = std::log(a) - 1e-9; fused_lm1[2 * e + 1] = std::log(bq) + 1e-9; }
+        }
         if (fused_plain[e] && lo <= hi) {
           int64_t b0, b1; memcpy(&b0, &lo, 8); memcpy(&b1, &hi, 8);
           const int nk = (int)(b1 >> (32 + LUT_SHIFT)) - (int)(b0 >> (32 + LUT_SHIFT)) + 1;
@@ -383,6 +390,8 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
       rc = upload(*h->owned_sp, (const unsigned char*)fused_pix.data(), fused_pix.size(), &h->FD.pix_id, s); if (rc) { chm_like_destroy(h); return rc; }
       rc = upload(*h->owned_sp, (const double*)fused_dlmax.data(), fused_dlmax.size(), &h->FD.pix_dlmax, s); if (rc) { chm_like_destroy(h); return rc; }
       rc = upload(*h->owned_sp, (const unsigned char*)fused_plain.data(), fused_plain.size(), &h->FD.ev_plain, s); if (rc) { chm_like_destroy(h); return rc; }
+      { const double* dlm = nullptr; rc = upload(*h->owned_sp, (const double*)fused_lm1.data(), fused_lm1.size(), &dlm, s); if (rc) { chm_like_destroy(h); return rc; }
+        h->FD.lm1 = reinterpret_cast<const double2*>(dlm); }
       int* rc_ = nullptr;
       if (hipMalloc(&rc_, sizeof(int)) == hipSuccess) { h->owned_sp->push_back(rc_); (void)hipMemsetAsync(rc_, 0, sizeof(int), s); h->d_redo = rc_; }
       h->FD.redo_count = h->d_redo;
@@ -775,7 +784,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     }
   }
   // k_marg_fused (chm_fused.h): the standard marginalized configuration in ONE kernel per (event, draw) -- few-draw calls by default
-  // (CHM_FUSED=0: never, 2: calls of any size; read per call).  LDS per block: P histograms of num_bins + 1 doubles, the overlay region
+  // (CHM_FUSED=1: few-draw calls, 2: calls of any size; read per call; default off).  LDS per block: P histograms of num_bins + 1 doubles, the overlay region
   // (the draw's mass tables + the widest event's slice of the distance tables + NW - 1 boundary rows | 4 NW prefix arrays) and ~2 KB.
   FusedDesc FDc = {};
   size_t lds_fused = 0;
@@ -783,7 +792,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   bool use_fused = false;
   {
     const char* fe = getenv("CHM_FUSED");
-    const int fmode = fe ? atoi(fe) : 1;
+    const int fmode = fe ? atoi(fe) : 0;                    // off by default: measured slower than the separate kernels at every call size (profiles/r04/ab_fused_event_kernel.txt)
     static const int few_nb_f = getenv("CHM_FEW_NB") ? atoi(getenv("CHM_FEW_NB")) : 8;
     if (like && like->fused_ok && use_fast && !tab && !want_dump && fmode > 0 && (nb <= few_nb_f || fmode >= 2) && !serial &&
         like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && like->L.num_bins == 200 &&
@@ -801,10 +810,16 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       cap = (cap + 1) / 2 * 2;
       const int capk = (like->ev_nk_max + 2 + 3) / 4 * 4;
       const long long HS = like->L.num_bins + 1, Hrows = like->L.P + (like->L.P & 1);
-      const long long ov_s = CHM_EXPTAB_N + 2LL * Tm_call + 4 * cap + capk / 4 + (fused_nw - 1) * HS, ov_p = 4LL * fused_nw * HS;
+      // the window of the mass tables gets what the pixel pass's prefix arrays leave beside the other tables (at least 128 entries; all of a short table)
+      const long long ov_fix = CHM_EXPTAB_N + 4 * cap + capk / 4 + (fused_nw - 1) * HS, ov_p = 4LL * fused_nw * HS;
+      long long cap_m = (ov_p - ov_fix) / 2;
+      cap_m = cap_m < 128 ? 128 : cap_m;
+      cap_m = cap_m > Tm_call ? Tm_call : cap_m;
+      cap_m = (cap_m + 1) / 2 * 2;
+      const long long ov_s = ov_fix + 2 * cap_m;
       const long long ov = ov_s > ov_p ? ov_s : ov_p;
       FDc = like->FD;
-      FDc.cap_rec = (int)cap; FDc.cap_keys = capk; FDc.overlay_doubles = (int)ov; FDc.tol = 3e-10;
+      FDc.cap_rec = (int)cap; FDc.cap_keys = capk; FDc.cap_m = (int)cap_m; FDc.overlay_doubles = (int)ov; FDc.tol = 3e-10;
       lds_fused = sizeof(double) * (size_t)(Hrows * HS + 16 + 4 * fused_nw + 5 * Hrows + fused_nw + ov);
       const size_t Nk = like->L.num_bins;
       const size_t lds_redo = sizeof(double) * (2 * Nk + 3 * (Nk + 1) + 2 * (size_t)like->L.G);      // the dense redo runs the general kernel's body in the same LDS
@@ -865,7 +880,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
             Tc_host, Tm_host, use_fast, lutA.key0, lutA.nk, lutA.cap, (long long)lds_fast, params[0].mass_model, out->partials != nullptr,
             sel_fast, lutB.key0, lutB.nk, lutB.cap, (long long)lds_sel, (long long)(intptr_t)lutB.lut, fuse_sel,
             (long long)(intptr_t)c.d_evpart, (long long)(intptr_t)(like ? like->L.ws_z : nullptr), (long long)(intptr_t)(sel ? sel->S.partial : nullptr),
-            zg_use, zg_make, (long long)(intptr_t)comm, use_fused, (long long)lds_fused, FDc.cap_rec, FDc.cap_keys };
+            zg_use, zg_make, (long long)(intptr_t)comm, use_fused, (long long)lds_fused, FDc.cap_rec, FDc.cap_keys, FDc.cap_m };
     if (c.gexec && key == c.gkey) {                           // replay
       const double hp1 = host_prof_on() ? now_us() : 0.;
       HIPCHK(hipGraphLaunch(c.gexec, sA));

@@ -16,7 +16,7 @@
 // Block = NW waves, one (event, draw).  LDS (doubles unless noted):
 //   H[rows][B+1]   per-pixel histograms; row p becomes the prefix array P0 of pixel p in place (kde_sub_item<PRE>)
 //   misc           event statistics, per-wave partial sums, per-pixel {hi - lo, 1/(hi - lo)}, hi, integral, rounding bound
-//   overlay        sample pass: exp table | m_grid | cdf_m2 | the event's slice of the node records | of the direct-index table (u16) |
+//   overlay        sample pass: exp table | windows of m_grid, cdf_m2 | the event's slice of the node records | of the direct-index table (u16) |
 //                  NW - 1 boundary rows;  pixel pass: -2 P1 | P2 of the two pixels each wave has in hand
 // Determinism: wave w owns the contiguous tiles [w NT/NW, (w+1) NT/NW) of the (pixel-sorted) samples.  A pixel whose segment began in an
 // earlier wave's range is that wave's `boundary pixel`: its weights go to the wave's own boundary row, and the rows are added to the pixel's
@@ -27,9 +27,10 @@ struct FusedDesc {
   const unsigned char* pix_id;    // (E, NT*128) local pixel of every (pixel-sorted) sample, 255: in no pixel / padding
   const double* pix_dlmax;        // (E, P) largest distance among the pixel's samples (NaN: no sample)
   const unsigned char* ev_plain;  // (E) 1: every distance of the event is finite and positive
+  const double2* lm1;             // (E) log of the smallest / largest finite positive m1det of the event (NaN: none)
   int cap_rec, cap_keys;          // LDS rows / entries reserved for an event's slice of the node records / of the direct-index table
   int overlay_doubles;            // size of the overlay region
-  int pad;
+  int cap_m;                      // LDS entries reserved for the window of m_grid / cdf_m2 an event's source-frame masses can reach
   double tol;                     // dense redo when the summed rounding bound exceeds tol L_i (k_marg_fixup's criterion)
   int* redo_count;                // diagnostics: number of (event, draw) pairs that took the dense redo (may be NULL)
 };
@@ -47,6 +48,7 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
   constexpr int NT_ = 64 * NW;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int b = blockIdx.x % L.nb, e = L.e_off + blockIdx.x / L.nb;
+  PH_INIT;
   DevParams P = params[b];
   mass_params_to_vgpr<MASS, CHM_FUSED_NPV>(P);
   const int B = BINS > 0 ? BINS : L.num_bins, HS = B + 1, Pn = L.P, S = L.S, Z = L.Z;
@@ -63,8 +65,8 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
   int* const bnd = reinterpret_cast<int*>(err + Hrows);     // [NW] boundary pixel of every wave (-1: none), [NW] spare
   double* const ov = reinterpret_cast<double*>(bnd + 2 * NW);
   double* const etab = ov;
-  double* const mg = etab + CHM_EXPTAB_N; double* const cdf = mg + Tm;
-  double* const rec = cdf + Tm;
+  double* const mg = etab + CHM_EXPTAB_N; double* const cdf = mg + D.cap_m;
+  double* const rec = cdf + D.cap_m;
   unsigned short* const luts = reinterpret_cast<unsigned short*>(rec + 4 * (size_t)D.cap_rec);
   double* const Hb = rec + 4 * (size_t)D.cap_rec + (D.cap_keys + 3) / 4;      // [NW - 1][HS] boundary rows
 #if CHM_EXPTAB
@@ -92,23 +94,38 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
   const double xlo = L.dl_lo[e], xhi = L.dl_hi[e];
   const int klo = lut_key(xlo, key0s), khi = lut_key(xhi, key0s);
   bool fast = info[3] != 0 && D.ev_plain[e] != 0 && (unsigned)klo < (unsigned)nks && (unsigned)khi < (unsigned)nks && khi >= klo;
-  int rlo = 0, ns_e = 1, nk_e = 1;
+  int rlo = 0, rhi = 0, ns_e = 1, nk_e = 1;
   if (fast) {
     const int glo = gl[klo], ghi = gl[khi];
     rlo = glo > 0 ? glo - 1 : 0;
     rlo = rlo < i_lo ? i_lo : rlo;
-    int rhi = ghi + lmax; rhi = rhi > i_lo + ns - 1 ? i_lo + ns - 1 : rhi;
+    rhi = ghi + lmax; rhi = rhi > i_lo + ns - 1 ? i_lo + ns - 1 : rhi;
     ns_e = rhi - rlo + 1; nk_e = khi - klo + 1;
     fast = ns_e >= 1 && ns_e <= D.cap_rec && nk_e + 1 <= D.cap_keys;
   }
   const int key0e = key0s + klo;
   const double x_last = g_dLt[Tc - 1], z_last = g_zt[Tc - 1];
+  // window of the mass grid the event's source-frame primary masses can reach: log m1 = log m1det - log(1 + z) with log m1det in the event's
+  // [lm1.x, lm1.y] and z between the first and one past the last node record of its slice (their log(1 + z) are in the records); 4 entries of
+  // margin on either side (rounding of the position, the stepping loops of p_m1m2_fused).  A window that does not fit: tables read from L2.
+  const double* gm = mg_all + (size_t)b * TmMax;
+  const double* gc = cdf_all + (size_t)b * TmMax;
+  int mlo = 0, mlen = Tm;
+  bool mass_lds = Tm <= D.cap_m;
+  if (fast && !mass_lds) {
+    const double* recb = rec_all + (size_t)b * TcMax * 4;
+    const double lzA = recb[4 * rlo + 3], lzB = recb[4 * (rhi + 1 < Tc ? rhi + 1 : Tc - 1) + 3];
+    const double2 lmb = D.lm1[e];
+    auto pos = [&](double lm) { const double tt = (lm - P.lmg0) * P.inv_dlmg; const int i = (tt >= 0.) ? (tt < (double)Tm ? (int)tt + 1 : Tm - 1) : 1; return i < 1 ? 1 : (i > Tm - 1 ? Tm - 1 : i); };
+    int ia = pos(lmb.x - lzB) - 5, ib = pos(lmb.y - lzA) + 4;
+    ia = ia < 0 ? 0 : ia; ib = ib > Tm - 1 ? Tm - 1 : ib;
+    if (lmb.x == lmb.x && lmb.y == lmb.y && lzA == lzA && lzB == lzB && ib - ia + 1 <= D.cap_m) { mlo = ia; mlen = ib - ia + 1; mass_lds = true; }
+  }
+  const TabSlice mgs = { mg - mlo, P.mg_first, P.mg_last }, cdfs = { cdf - mlo, gc[0], P.cdf_last };
 
   auto stage_tables_ev = [&]() {
-    const double* gm = mg_all + (size_t)b * TmMax;
-    const double* gc = cdf_all + (size_t)b * TmMax;
     for (int i = t; i < CHM_EXPTAB_N; i += NT_) etab[i] = exp_table_entry(i);
-    for (int i = t; i < Tm; i += NT_) { mg[i] = gm[i]; cdf[i] = gc[i]; }
+    if (mass_lds) for (int i = t; i < mlen; i += NT_) { mg[i] = gm[mlo + i]; cdf[i] = gc[mlo + i]; }
     if (fast) {
       const double2* gr = reinterpret_cast<const double2*>(rec_all + ((size_t)b * TcMax + rlo) * 4);
       double2* lr = reinterpret_cast<double2*>(rec);
@@ -128,6 +145,7 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
   }
   if (lane == 0) bnd[w] = pfirst;
   __syncthreads();
+  PH(0);
 
   // ---- lo = min z, zmax = max z of the event, hi_p = max z of every pixel
   double lo, zmx;
@@ -163,6 +181,7 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
   }
   __syncthreads();
   lo = esv[0]; zmx = esv[13];
+  PH(1);
 
   // ---- sample pass: z, w, statistics, histogram scatter
   // reference point of the shifted sums (k_samples_fast's): the table node next to the event's smallest distance
@@ -172,7 +191,7 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
   const double dB = (double)B;
   double v[4] = { 0., 0., 0., 0. };                        // sw, sw2, sd1, sd2 of this lane
   // STORE: the rare dense redo needs z and w in the workspace (kde_marg_general reads them): same pass, no statistics, no histogram
-  auto passes = [&](auto fits_tag, auto store_tag) {
+  auto passes = [&](auto fits_tag, auto store_tag, auto mgA, auto cdfA) {
     constexpr bool FITS = decltype(fits_tag)::value, STORE = decltype(store_tag)::value;
     double* const Hrow_b = Hb + (size_t)(w > 0 ? w - 1 : 0) * HS;
 #pragma unroll 1
@@ -204,7 +223,7 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
           const bool nolog = bad || !(vv <= 0.02);
           if (__any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
         } else lz = chm_log_pos(zp1);
-        const double wgt = p_m1m2_fused<MASS>(P, m1, m2, l1[h] - lz, l2[h] - lz, mg, cdf, ex) * ipr[h];      // w = p_m1m2 / pe_prior (pop_wrapper.py:79)
+        const double wgt = p_m1m2_fused<MASS>(P, m1, m2, l1[h] - lz, l2[h] - lz, mgA, cdfA, ex) * ipr[h];      // w = p_m1m2 / pe_prior (pop_wrapper.py:79)
         wv[h] = wgt;
         if (!STORE && s + h < S) {
           const double d = z - z_ref;
@@ -224,7 +243,12 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
       }
     }
   };
-  if (fast) passes(std::true_type{}, std::false_type{}); else passes(std::false_type{}, std::false_type{});
+  auto run_passes = [&](auto store_tag) {
+    if (fast) { if (mass_lds) passes(std::true_type{}, store_tag, mgs, cdfs); else passes(std::true_type{}, store_tag, gm, gc); }
+    else { if (mass_lds) passes(std::false_type{}, store_tag, mgs, cdfs); else passes(std::false_type{}, store_tag, gm, gc); }
+  };
+  run_passes(std::false_type{});
+  PH(2);
 #pragma unroll
   for (int i = 0; i < 4; i++) v[i] = wave_sum_dpp(v[i]);
   if (lane == 0) { red[4 * w] = v[0]; red[4 * w + 1] = v[1]; red[4 * w + 2] = v[2]; red[4 * w + 3] = v[3]; }
@@ -250,6 +274,7 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
   }
   __syncthreads();
   const bool ok = esv[4] >= L.pe_neff;                      // likelihood.py:199 (same for every pixel of the event)
+  PH(3);
   const bool poisoned = grid_is_poisoned(P.z_bad, zg, Z);
   const int npx = L.neff_pixels[e];
   if (ok) {
@@ -259,6 +284,7 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
     for (int k = k_lo + t; k <= k_hi; k += NT_) zfactor_point(L, P, e, k, zo, zg, g_zt, g_It, 1, ex);
   }
   __syncthreads();                                          // bkgA / Aw stored; the overlay region is free for the prefix arrays
+  PH(4);
   // ---- pixel pass: every wave takes pairs of pixels, one after the other
   {
     const int sub = lane >> 5, sl = lane & 31;
@@ -281,6 +307,7 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
                                                   pxh[pp], Q12, lik + pr, err + pr);
     }
   }
+  PH(5);
   __syncthreads();
   // ---- L_i = sum over the pixels in pixel order (likelihood.py:280), rounding bound, dense redo where it matters (k_marg_fixup's rule)
   bool redo = false;
@@ -293,13 +320,14 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
     if (lane == 0) { esv[14] = redo ? 1. : 0.; if (!redo) { L.ev_li[be] = Li; L.ev_ll[be] = log_like_of(Li); } }
   }
   __syncthreads();
+  PH(6);
   if (esv[14] == 0.) return;
   // ---- rare: z and w of the event into the workspace, then the pixels above their equal share of the tolerance by the general kernel's
   //      body (dense sums where the bins are light), in pixel order
   stage_tables_ev();
   if (t < NEVSTAT) L.evstat[be * NEVSTAT + t] = esv[t];
   __syncthreads();
-  if (fast) passes(std::true_type{}, std::true_type{}); else passes(std::false_type{}, std::true_type{});
+  run_passes(std::true_type{});
   __threadfence_block();
   __syncthreads();
   if (w == 0) {

@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(LDS_ARR ? 1024 : CHM_TABLES_LONG_NT) k_tables(
     double acc = 0.;
     for (int k = t; k < Tm - 1; k += nt) acc += (mg[k + 1] - mg[k]) * (tmp[k + 1] + tmp[k]);
     acc = block_reduce<RED_SUM>(acc, sh);
-    if (t == 0) { Pg.norm_p_m1 = 0.5 * acc; Pg.inv_norm_p_m1 = 1. / (0.5 * acc); }
+    if (t == 0) { Pg.norm_p_m1 = 0.5 * acc; Pg.inv_norm_p_m1 = 1. / (0.5 * acc); Pg.cdf_last = cdf[Tm - 1]; }
   }
 }
 

@@ -30,6 +30,7 @@ struct DevParams {
   double lmg0, inv_dlmg;                 // log(m_low), (Tm-1)/(log(m_high) - log(m_low)): position of log(m) on the mass grid
   double inv_plnorm, inv_tg_norm, inv_2s2;   // reciprocals of plp_plnorm, tg_norm, 2 sigma_g^2
   double norm_p_m1, inv_norm_p_m1;       // mass.py:51
+  double cdf_last;                       // cdf_m2[Tm - 1] (k_tables): the value jnp.interp clamps to above the mass grid
   double fR;                             // completeness.py:54-58
   double fR_given;                       // != 0: fR was supplied by the caller (plug-in completeness), k_tables keeps it
   double z_bad;                          // first z at which the comoving-distance table is non-finite (+inf: nowhere), see grid_is_poisoned
@@ -440,6 +441,14 @@ DEVFN void mass_params_to_vgpr(DevParams& p) {
 #undef CHM_TV
 }
 
+// A window [off, off + len) of a per-draw table held in LDS, addressed with the table's own indices (p = window start - off); the end values
+// of the whole table travel with it (k_marg_fused stages only the stretch of m_grid / cdf_m2 an event's source-frame masses can reach)
+struct TabSlice { const double* p; double first, last; DEVFN double operator[](int i) const { return p[i]; } };
+template <class A> DEVFN double tab_first(A a) { return (double)a[0]; }
+template <class A> DEVFN double tab_last(A a, int n) { return (double)a[n - 1]; }
+DEVFN double tab_first(const TabSlice& a) { return a.first; }
+DEVFN double tab_last(const TabSlice& a, int) { return a.last; }
+
 template <int MASS = -1, class A1, class A2, class EX = ExpPoly>
 DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, double lm2, A1 mg, A2 cdf, const EX ex = EX()) {
 #pragma clang fp contract(fast)                  // smooth arithmetic only (no rounding-sensitive predicate): a*b+c may fuse
@@ -499,8 +508,8 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
   double dx = x1 - x0;
   double cn = f0 * dx + (m1 - x0) * (f1 - f0);
   if (fabs(dx) <= 4.930380657631324e-32) { cn = f0; dx = 1.; }
-  if (m1 < (double)mg[0]) cn = cdf[0] * dx;
-  if (m1 > (double)mg[n - 1]) cn = cdf[n - 1] * dx;
+  if (m1 < tab_first(mg)) cn = tab_first(cdf) * dx;
+  if (m1 > tab_last(mg, n)) cn = tab_last(cdf, n) * dx;
   // one quotient without IEEE special cases: every factor is finite (chm_exp_clamped), the product of two saturated denominators is
   // capped at 1e300 (a factor 1e-300 on the weight); a zero interpolant (m1 at the lowest node) gives NaN here and 0 below
   const double num = (Pn * p.inv_norm_p_m1) * dx, den = vmin_f64((D1 * D2) * cn, 1e300);
