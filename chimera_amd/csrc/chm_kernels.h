@@ -910,13 +910,13 @@ DEVFN int bin_index(double z, double lo, double hi, int B) {
 // bin_index() with the pixel-constant divisor d = hi - lo and r = 1/d (one IEEE division per pixel): the quotient is formed as
 // q0 = x r, q = q0 + r (x - q0 d) (fma residual), which IS the correctly rounded x/d for the operands met here (0 <= x <= d,
 // Markstein), so the bin of every sample is the one bin_index() gives; the clamp runs on v_max/v_min (NaN -> bin 0).
+// [r4] floor and the two-sided fp64 clamp became v_cvt_i32_f64 (truncation = floor for q >= 0, saturating, NaN -> 0) + two integer clamps on
+// one v_med3_i32: the same bin for every input (negative products -- z below lo -- truncate towards 0 or clamp to 0, as max(floor, 0) did).
 DEVFN int bin_index_r(double z, double lo, double d, double r, double dB) {
   double x = z - lo;
   double q = x * r;
   q = fma(fma(-q, d, x), r, q);
-  double f = floor(q * dB);
-  f = __builtin_fmin(__builtin_fmax(f, 0.), dB - 1.);
-  return (int)f;
+  return med3_i32(cvt_i32_sat(q * dB), 0, (int)dB - 1);
 }
 
 DEVFN double kde_bandwidth_factor(int bw_method, double bw_scalar, double neff, int d) {
@@ -1700,7 +1700,7 @@ template <int SW> DEVFN double sg_last_perm(double x) {
 template <int SW, int NR, int BINS, bool DUMP, bool NT, bool PRE = false>
 DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, const double* es, const int b, const int e, const int p,
                         const int pp, const bool live, const bool poisoned, const int s0, const int s1, double (&zr)[NR], double (&wr)[NR],
-                        const double hi_pre = 0., double* Q12 = nullptr, double* out_like_pre = nullptr, double* out_err_pre = nullptr) {
+                        const double hi_pre = 0., double* Q12 = nullptr, double* out_like_pre = nullptr, double* out_err_pre = nullptr, const int nit = NR) {
 #pragma clang fp contract(fast)                  // a*b+c may fuse in this body; the bin index lives in bin_index_r() (contract off)
   const int lane = threadIdx.x, sl = lane % SW;
   const int S = L.S, Z = L.Z, B = BINS > 0 ? BINS : L.num_bins, G = L.G;      // BINS > 0: the bin count is a compile-time constant (LDS offsets, loop bounds)
@@ -1717,11 +1717,31 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   const int k_lo = ((int)es[8]) & ~1, k_hi = (int)es[9];   // event_stats: k_hi is odd when Z is even -- both points of a pair are in range together
   // two consecutive grid points of every array for this lane: 16-byte loads at a clamped (always valid) pair index -- lanes beyond k_hi
   // load the row's last pair and never use it.  The three event-level rows are addressed as uniform base + 32-bit lane offset.
-  const int kcap = Z - 2;
-  struct Pass { double2 pc, z, bk, a; };
+  // [r4] CHM_GW_PAIRS = 0 (A/B builds): a lane takes the grid points k and k + SW of a pass instead of the pair (k, k + 1).  The bin index of a node
+  // advances ~1.1 bins per grid point: with pairs, consecutive lanes stood ~2.2 bins apart and the 32 lanes of a pixel wrapped the 32
+  // double-wide LDS banks more than twice in every read of the prefix arrays (a third of the LDS-active cycles of this kernel were bank
+  // conflicts, profiles/r03); with stride-1 lanes a read touches ~36 consecutive doubles.  The four rows are then read with 8-byte loads
+  // (k and k + SW at one address + an immediate offset).
+#ifndef CHM_GW_PAIRS
+#define CHM_GW_PAIRS 1          // measured (profiles/r04/ab_gw_kernel_r04.txt): stride-1 lanes 5.12 against 4.78 ms for the kernel -- the 8-byte loads cost more than the bank conflicts -- off
+#endif
+  const int kcap = CHM_GW_PAIRS ? Z - 2 : Z - 1;
+  struct Pass { double2 pc, z, bk, a; };                    // .x / .y: the lane's first / second grid point of the pass
   auto load_pass = [&](int k) {
     const unsigned off = (unsigned)(k < kcap ? k : kcap) * 8u;
     Pass q;
+#if !CHM_GW_PAIRS
+    {
+      const unsigned off2 = (unsigned)(k + SW < kcap ? k + SW : kcap) * 8u;       // (both clamped on their own: always valid addresses, used only in range)
+      auto at = [](const double* base, unsigned o) { return reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o); };
+#ifndef CHM_NO_NT
+      if (NT) { q.pc.x = __builtin_nontemporal_load(at(pc, off)); q.pc.y = __builtin_nontemporal_load(at(pc, off2)); } else
+#endif
+      { q.pc.x = *at(pc, off); q.pc.y = *at(pc, off2); }
+      q.z.x = *at(zg, off); q.z.y = *at(zg, off2); q.bk.x = *at(bkgA, off); q.bk.y = *at(bkgA, off2); q.a.x = *at(Aw, off); q.a.y = *at(Aw, off2);
+      return q;
+    }
+#endif
     // p_cat is read once per (event, pixel, call): few-draw calls (IPW = 2) stream it past the caches (non-temporal), so that the z / w the
     // sample stage has just written are still in the memory-side cache when this kernel asks for them; with many draws per call the
     // rows are shared by the draws' waves and stay cacheable
@@ -1736,7 +1756,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
     return q;
   };
   // p_cat, grid, background and trapezoid factors of the first pass: in flight during the histogram phase
-  const int k_first = k_lo + 2 * sl;
+  const int k_first = k_lo + (CHM_GW_PAIRS ? 2 * sl : sl);
   Pass cur = load_pass(k_first);
   // histogram of the pixel's samples on [min z, max z in pixel] (math.py:32-46, likelihood.py:180-183)
   const size_t so = ((size_t)b * L.E + e) * S;
@@ -1747,9 +1767,10 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   // the event's z, and then lo -- jnp.min over all of them (combine_stats, NaN-propagating) -- is NaN already
   double hi = PRE ? hi_pre : lo;
   if (!PRE) {
+    // nit (uniform): register rounds that hold a sample of one of the wave's pixels -- the rounds beyond it were not loaded and are not touched
 #pragma unroll
-    for (int i = 0; i < NR; i++) hi = vmax_f64(hi, zr[i]);
-    for (int s = s0 + sl + SW * NR; s < s1; s += SW) hi = vmax_f64(hi, wz[s]);
+    for (int i = 0; i < NR; i++) if (i < nit) hi = vmax_f64(hi, zr[i]);
+    if (nit >= NR) for (int s = s0 + sl + SW * NR; s < s1; s += SW) hi = vmax_f64(hi, wz[s]);
   }
   double* const Q0 = Q; double* const Q1 = PRE ? Q12 : Q + (B + 1); double* const Q2 = PRE ? Q12 + (B + 1) : Q + 2 * (B + 1);      // P0 | -2 P1 | P2, (B + 1) doubles each
   if (!PRE) {
@@ -1763,8 +1784,8 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   const double dbin = dhl * L.inv_B;                        // c'_j = c_j - lo = (j + 1/2) dbin for the uniform edges of math.py:37-39
   if (!PRE) {
 #pragma unroll
-    for (int i = 0; i < NR; i++) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q0[bin_index_r(zr[i], lo, dhl, rhl, dB)], wr[i]); }
-    for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q0[bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
+    for (int i = 0; i < NR; i++) if (i < nit) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q0[bin_index_r(zr[i], lo, dhl, rhl, dB)], wr[i]); }
+    if (nit >= NR) for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q0[bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
     wave_sync();
   }
   // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins (a compile-time 7 for 200 bins on 32 lanes)
@@ -1895,15 +1916,16 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   };
   // integrand and bound.  The bound sums |C_k| over every unmasked grid point of [k_lo, k_hi], not only those inside the pixel's support:
   // looser by the share of the event's range the pixel does not cover (a factor ~1.5), one addition instead of a comparison-dependent select.
-  auto integrand = [&](const int kk, const double pgw, const double pcv, const double bk, const double ak) {
-    if (DUMP) dump[kk] = pgw;
+  auto integrand = [&](const int kk, const double pgw, const double pcv, const double bk, const double ak, const bool inrange = true) {
+    if (DUMP) { if (inrange) dump[kk] = pgw; }
     // (the empty volatile asm keeps this a branch on the exec mask: as selects it is four v_cndmask_b32 per point)
-    if (pcv != -100.) { asm volatile(""); const double cz = fma(fR, pcv, bk) * ak; acc = fma(pgw, cz, acc); accC += fabs(cz); }   // catalog.py:202, likelihood.py:275
+    if (inrange && pcv != -100.) { asm volatile(""); const double cz = fma(fR, pcv, bk) * ak; acc = fma(pgw, cz, acc); accC += fabs(cz); }   // catalog.py:202, likelihood.py:275
   };
   auto do_pass = [&](const int k, const Pass& q) {
     if (k <= k_hi && live) {
       const double z0 = q.z.x, z1 = q.z.y;
-      const bool in0 = !(z0 < zlo) && !(z0 > zhi), in1 = !(z1 < zlo) && !(z1 > zhi);
+      const bool v1 = CHM_GW_PAIRS ? true : (k + SW <= k_hi);    // stride-1 lanes: the second point of the last pass may lie beyond the range
+      const bool in0 = !(z0 < zlo) && !(z0 > zhi), in1 = v1 && !(z1 < zlo) && !(z1 > zhi);
       double pg0 = 0., pg1 = 0.;
       if (in0 || in1) {
 #ifdef CHM_GW_SHARE3                                         // measured: 4.96 against 4.81 ms for the kernel (profiles/r03/ab_gw_three_node_sharing.txt) -- off
@@ -1924,13 +1946,13 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
         }
       }
       integrand(k, pg0, q.pc.x, q.bk.x, q.a.x);
-      integrand(k + 1, pg1, q.pc.y, q.bk.y, q.a.y);
+      integrand(k + (CHM_GW_PAIRS ? 1 : SW), pg1, q.pc.y, q.bk.y, q.a.y, v1);
     }
   };
   // one pass = SW lanes x 2 consecutive grid points per pixel.  Software pipeline in two alternating register sets: the loads of the next
   // pass are issued before the arithmetic of this one and waited for where that pass begins (no register rotation, no wait at the loop end)
   for (int kb = k_lo; kb <= k_hi; kb += 4 * SW) {
-    const int k = kb + 2 * sl;
+    const int k = kb + (CHM_GW_PAIRS ? 2 * sl : sl);
     const Pass nxt = load_pass(k + 2 * SW);
     do_pass(k, cur);
     if (kb + 2 * SW > k_hi) break;                          // uniform
@@ -1974,7 +1996,12 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevPar
   const double* wz = L.ws_z + so;
   const double* ww = L.ws_w + so;
   const double lo = es[0];
-  auto run = [&](const int pgi, const int p, const int pp, const int q0, const int q1, const bool first) {
+#ifndef CHM_GW_TOUCH
+#define CHM_GW_TOUCH 0
+#endif
+  // CHM_GW_TOUCH (A/B): while an item is worked on, one dword of every 128-byte line of the NEXT item's (z, w) segment is requested and dropped --
+  // the lines are then in L2 when the next item's loads ask for them (the segment was written by the sample stage milliseconds ago: an HBM round trip)
+  auto run = [&](const int pgi, const int p, const int pp, const int q0, const int q1, const bool first, const int nq0 = 0, const int nq1 = 0) {
     if (pgi >= PG) return;                                  // uniform
     const bool live = p < L.P && p < npx;
     if (!ok || !__any(live)) {                              // uniform: every pixel of the event (of this item: padded pixels) is 0 (or 0 * NaN)
@@ -1986,14 +2013,30 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevPar
     }
     if (!first) wave_sync();                                // the next item reuses the wave's LDS slice
     const int s0 = q0, s1 = live ? q1 : q0;
+    // [r4] rounds of SW samples per pixel actually needed by this wave's pixels (uniform): the mean segment holds 125 of the 256 samples the NR
+    // register rounds cover -- rounds beyond the longer of the wave's segments are neither loaded nor binned (5.1 of 8 on average at C3)
+    int nmax = 0;
+#pragma unroll
+    for (int g = 0; g < NPW; g++) nmax = max(nmax, __builtin_amdgcn_readlane(s1 - s0, g * SW));
+#ifdef CHM_GW_ALL_ROUNDS                                     // (A/B builds: the round-3 form, every register round loaded and binned)
+    const int nit = NR;
+#else
+    const int nit = min((nmax + SW - 1) / SW, NR);
+#endif
     double zr[NR], wr[NR];
 #pragma unroll
-    for (int j = 0; j < NR; j++) { int s = s0 + sl + SW * j; zr[j] = s < s1 ? wz[s] : lo; wr[j] = s < s1 ? ww[s] : 0.; }
-    kde_sub_item<SW, NR, BINS, DUMP, (IPW <= 2)>(L, params, Q, es, b, e, p, pp, live, poisoned, s0, s1, zr, wr);
+    for (int j = 0; j < NR; j++) if (j < nit) { int s = s0 + sl + SW * j; zr[j] = s < s1 ? wz[s] : lo; wr[j] = s < s1 ? ww[s] : 0.; }
+    int t1 = 0, t2 = 0;
+    if (CHM_GW_TOUCH) {
+      const int ts = nq0 + sl * 16;
+      if (ts < nq1) { t1 = __builtin_nontemporal_load(reinterpret_cast<const int*>(wz + ts)); t2 = __builtin_nontemporal_load(reinterpret_cast<const int*>(ww + ts)); }
+    }
+    kde_sub_item<SW, NR, BINS, DUMP, (IPW <= 2)>(L, params, Q, es, b, e, p, pp, live, poisoned, s0, s1, zr, wr, 0., nullptr, nullptr, nullptr, nit);
+    if (CHM_GW_TOUCH) asm volatile("" :: "v"(t1), "v"(t2));
   };
-  run(blockIdx.y, pA, ppA, a0, a1, true);
-  run(blockIdx.y + H, pB, ppB, b0, b1, false);
-  if (IPW > 2) { run(blockIdx.y + 2 * H, pC, ppC, c0, c1, false); run(blockIdx.y + 3 * H, pD, ppD, d0, d1, false); }
+  run(blockIdx.y, pA, ppA, a0, a1, true, b0, b1);
+  run(blockIdx.y + H, pB, ppB, b0, b1, false, c0, c1);
+  if (IPW > 2) { run(blockIdx.y + 2 * H, pC, ppC, c0, c1, false, d0, d1); run(blockIdx.y + 3 * H, pD, ppD, d0, d1, false); }
 }
 
 // ------------------------------------------------------------------------------------------------------
