@@ -18,7 +18,11 @@ launcher only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT; the ranks m
 (a Unix-domain socket) for the RCCL unique id, the barriers and the max-over-ranks of the wall time.
 
 Roofline bookkeeping: the two kernels that make up ~90 % of a step -- the sample stage ``k_samples`` and
-the marginalized GW kernel ``k_kde_marg_sub2`` -- are bound by VALU ISSUE.  Each is priced with the issue costs measured on the card
+the marginalized GW kernel ``k_kde_marg_sub2`` -- are bound by VALU ISSUE.  [r4] The headline ``roofline.frac`` is the USEFUL fraction: the
+issue cycles of the launch's fp64 add / mul / fma instructions (PMC class counters x 4 cycles) over the cycles 1024 SIMDs offer at 2.4 GHz
+during the launch -- moves, selects, lane reads, integer and address arithmetic do not count as achieved work; ``issue_busy_frac`` (every
+VALU instruction at its issue cost) says how full the issue ports were, ``min_inst`` what the kernel would need at the least per unit of
+work and how far above that it is.  Each kernel is priced with the issue costs measured on the card
 (scripts/issue_cost.hip -> profiles/r03/issue_cost.txt: 2 cycles per wave64 instruction for a few simple 32-bit opcodes, 16 for fp64
 reciprocal / square root, 8 for fp32 transcendentals, 4 for EVERYTHING else -- fp64 arithmetic, v_mov_b64, v_cndmask, DPP moves,
 v_readlane, 64-bit integer operations alike): busy cycles = PMC instruction counts of one launch (committed passes of this very command,
@@ -107,7 +111,9 @@ def load_pmc(keys, sha=None):
       continue
     w = j.get('workload')
     if isinstance(w, dict) and all(w.get(k) == v for k, v in keys.items()):
-      best = (os.path.relpath(f, ROOT), j, bool(sha) and j.get('code_object_sha256') == sha)
+      fresh = bool(sha) and j.get('code_object_sha256') == sha
+      if best is None or fresh or not best[2]:               # a file collected from the loaded binary wins over a newer one that was not
+        best = (os.path.relpath(f, ROOT), j, fresh)
   return best
 
 
@@ -126,8 +132,19 @@ def quartiles(x):
   return float(np.median(x)), float(np.percentile(x, 25)), float(np.percentile(x, 75))
 
 
-def kernel_roofline(label, prefix, ms, unique_bytes, pmc):
-  """One kernel against its two ceilings.  ms: live HIP-event duration of one launch."""
+# What a kernel needs AT THE LEAST per unit of work, in wave64 VALU instructions per 64 units (one per lane) -- the floor `achieved / minimal`
+# is quoted against ("Minimal instruction counts", derives each figure):
+#   sample stage, per sample: z(dL) from the direct-index table 14, 1/(1+z) and the two source masses 9, log(1+z) 10, four exps of the mass
+#     model at 13 + their arguments 12, the cdf interpolant 10, smoothing windows 14, one quotient 8, prior + four statistics 9, stores 2 = 140
+#   GW kernel, per PAIR of pixels (one wave): 5.1 rounds of 32 samples x 13 (bin index + atomic) = 66, prefix sums of 200 bins x 3 moments
+#     (7 bins per lane x 5 + four 5-level scans x 3) = 95, bandwidth and node constants 50, 4.3 passes x (2 points x 2 nodes x 12 + interpolation
+#     and integrand 2 x 11 + loop 6) = 327, final scans and stores 32 = 570
+#   selection kernel, per injection: the sample stage's 140 minus stores and statistics (11) + E(z), the rate powers and the Jacobian 95 = 224
+MIN_INST = {'k_samples': (140., 'sample'), 'k_kde_marg_sub2': (570., 'pair of pixels'), 'k_selection': (224., 'injection')}
+
+
+def kernel_roofline(label, prefix, ms, unique_bytes, pmc, units=None):
+  """One kernel against its ceilings.  ms: live HIP-event duration of one launch; units: units of work per launch in waves (MIN_INST)."""
   k = pmc_kernel(pmc, prefix)
   fresh = bool(pmc and pmc[2])
   sec = ms * 1e-3
@@ -154,8 +171,14 @@ def kernel_roofline(label, prefix, ms, unique_bytes, pmc):
                   "static_hot_loop": {kk: st.get(kk) for kk in ('valu_total', 'f64', 'f64_amf', 'f64_trans', 'fast', 'mov', 'cndmask', 'lane', 'valu', 'salu', 'lds', 'vmem')} if st else None,
                   "fp64_add_mul_fma_share_pmc": n_amf / insts if n_amf else None,
                   "valu_busy_Tcycle_s": cycles / sec / 1e12, "valu_busy_frac": cycles / sec / 1e12 / ISSUE_PEAK_TCYC,
+                  # [r4] what the kernel ACHIEVES: issue cycles of its fp64 add / mul / fma instructions (4 each) over the cycles on offer
+                  "useful_Tcycle_s": CYC_VALU * n_amf / sec / 1e12 if n_amf else None,
+                  "useful_frac": CYC_VALU * n_amf / sec / 1e12 / ISSUE_PEAK_TCYC if n_amf else None,
                   "fp64_TFLOPs_real": flops * 64 / sec / 1e12 if flops else None,
                   "fp64_frac_of_78.6_TFLOPs": flops * 64 / sec / 1e12 / FP64_PEAK_TFLOPS if flops else None})
+      mi = next((v for kk, v in MIN_INST.items() if prefix.startswith(kk)), None)
+      if mi and units:
+        out["min_inst"] = {"per_unit_minimal": mi[0], "unit": mi[1], "per_unit_achieved": insts / units, "achieved_over_minimal": insts / units / mi[0]}
       if k.get('GRBM_GUI_ACTIVE') and k.get('profiled_ms'):
         clk = k['GRBM_GUI_ACTIVE'] / 8 / (k['profiled_ms'] * 1e-3)         # 8 XCDs count the launch's cycles
         out["clock_GHz_under_profile"] = clk / 1e9
@@ -182,7 +205,10 @@ def main():
   ap.add_argument('--no-single-call', action='store_true', help='skip the scalar one-draw call timing (runs after the timed region)')
   ap.add_argument('--single-calls', type=int, default=40, help='scalar calls timed for single_call_ms (median + IQR)')
   ap.add_argument('--no-graph', action='store_true', help='no HIP-graph replay of few-draw calls (keeps the per-kernel HIP-event timings for --nbatch <= 8)')
-  ap.add_argument('--host-comm', action='store_true', help='reduce the partial sums through the host sockets instead of RCCL')
+  ap.add_argument('--serial', action='store_true', help='every kernel of a call on one stream (CHM_OPT_SERIAL; per-kernel durations under a profiler)')
+  ap.add_argument('--groups', type=int, default=0, help='event groups alternating between two streams (CHM_OPT_GROUPS; 0 = automatic, 1 = one group)')
+  ap.add_argument('--fused', type=int, default=0, help='fused event kernel (CHM_OPT_FUSED): 0 never, 1 calls of <= 8 draws, 2 every call')
+  ap.add_argument('--host-comm', action='store_true', help='reduce the partial sums through the host sockets instead of RCCL (a rehearsal: the line then says so; never a fallback)')
   ap.add_argument('--force-comm', action='store_true', help='build the rendezvous and the RCCL communicator even for one rank (rehearses the N > 1 path)')
   ap.add_argument('--inflight', type=int, default=1, help='evaluations in flight per rank: 2 = two lanes (hyperlikelihood.lane) driven by two host threads, the steps alternate between them')
   ap.add_argument('--cpu-events', type=int, default=1000, help='events of the workload the CPU baseline evaluates (1000 = all of C3)')
@@ -202,10 +228,7 @@ def main():
 
   # few-draw calls are replayed from a HIP graph, which carries no timing events: the timed loop keeps its per-kernel timings (its calls
   # stay eager when nbatch <= 8), the scalar-call latency is measured on the graph path unless --no-graph
-  if args.no_graph:
-    os.environ['CHM_GRAPH_MAX_NB'] = '0'
-  elif 1 < args.nbatch <= 8:
-    os.environ['CHM_GRAPH_MAX_NB'] = '1'
+  graph_max_nb = 0 if args.no_graph else (1 if 1 < args.nbatch <= 8 else None)
   import chimera_amd as CH
   from chimera_amd import synth, _lib
   from chimera_amd.catalog import dVdz_completeness, pixelated_catalog
@@ -235,15 +258,22 @@ def main():
     except Exception as e:                                                        # noqa: BLE001 -- any failure -> host fallback
       err = e
     nfail = int(rdzv.allreduce_sum(np.array([0. if comm is not None else 1.]))[0])    # every rank must take the same branch
-    if nfail > 0:
+    nccl_count = None
+    if nfail > 0 and not args.host_comm:
+      # [r4] no silent fallback: a multi-GPU `value` printed by this script means RCCL carried the all-reduce.  A rank whose communicator
+      # does not come up ends the job with a non-zero exit code on every rank (the host-socket path is a rehearsal one asks for: --host-comm)
+      if err is not None:
+        print(f"[bench] rank {rank}: RCCL communicator failed: {err}", file=sys.stderr)
       if comm is not None:
         comm.close()
-      if err is not None:
-        print(f"[bench] rank {rank}: RCCL communicator failed ({err}); partial sums go through the host sockets", file=sys.stderr)
+      rdzv.barrier()
+      rdzv.close()
+      raise SystemExit(f"bench.py: RCCL communicator unavailable on {nfail} of {world} rank(s); no line is printed (use --host-comm to rehearse over the host sockets)")
+    if args.host_comm:
       comm = HostComm(world, rank, device, rendezvous=rdzv)
-      comm_kind = "HOST-socket all-reduce of 3*nbatch doubles (RCCL unavailable)" if not args.host_comm else "host-socket all-reduce (--host-comm)"
+      comm_kind = "host-socket all-reduce (--host-comm: a rehearsal, not a scaling measurement)"
     else:
-      nr = L.chm_comm_nranks(comm.handle)
+      nccl_count = nr = L.chm_comm_nranks(comm.handle)
       assert nr == world, (nr, world)
       comm_kind = f"RCCL all-reduce of 3*nbatch doubles inside chm_eval, ncclCommCount={nr}"
   mg = args.config == 'C5'                      # BASELINE.json configs[4]: modified GW propagation (Xi0, n)
@@ -270,6 +300,15 @@ def main():
   t0 = time.time()
   like._handle(); sel._handle()
   t_upload = time.time() - t0
+  # evaluation options of the handles (include/chimera_hip.h: CHM_OPT_*; the library reads no environment variable)
+  if args.serial:
+    like.set_option('serial', 1)
+  if args.groups:
+    like.set_option('groups', args.groups)
+  if args.fused:
+    like.set_option('fused', args.fused)
+  if graph_max_nb is not None:
+    like.set_option('graph_max_nb', graph_max_nb)
   nb = args.nbatch
   H0s = np.linspace(55., 95., 4099)          # a different H0 for every draw of every step
   Xi0s = np.linspace(0.6, 3.0, 4099)
@@ -318,11 +357,21 @@ def main():
       kt += like.last_timing()
   else:
     from collections import deque
+    # [r4] step k carries ticket k on every rank: the lanes' all-reduces (one RCCL communicator per lane, one host thread per lane) are handed
+    # to the device in step order everywhere (chm_comm_set_ticket; the order two host threads reach ncclAllReduce in is otherwise free)
+    ticketed = comm is not None and hasattr(comm, 'set_ticket')
+    if ticketed:
+      Comm.reset_tickets(0)
+
+    def run_step(ln, k):
+      if ticketed:
+        ln.comm.set_ticket(k)
+      return ln.batch(draws[args.warmup + k])
     pending = deque()
     for k in range(args.steps):
       if len(pending) == args.inflight:
         vals.append(pending.popleft().result())
-      pending.append(pool.submit(lanes[k % args.inflight].batch, draws[args.warmup + k]))
+      pending.append(pool.submit(run_step, lanes[k % args.inflight], k))
     while pending:
       vals.append(pending.popleft().result())
     for ln in lanes:
@@ -334,8 +383,7 @@ def main():
   # HIP-event span is not its duration) -- outside the timed region, same draws
   kt_timed_eval = kt[0] / max(args.steps, 1)
   if pool is None and world == 1 and nb > 8:             # (calls of few draws are a single chain anyway)
-    prev_groups = os.environ.get('CHM_GROUPS')
-    os.environ['CHM_GROUPS'] = '1'
+    like.set_option('groups', 1)
     kt = np.zeros(8)
     ntot = max(4, min(args.steps, 24))               # as sustained as the timed region (the chip clocks higher in short bursts): the last half counts
     nser = 0
@@ -343,10 +391,7 @@ def main():
       like.batch(draws[args.warmup + (k % max(args.steps, 1))])
       if k >= ntot // 2:
         kt += like.last_timing(); nser += 1
-    if prev_groups is None:
-      del os.environ['CHM_GROUPS']
-    else:
-      os.environ['CHM_GROUPS'] = prev_groups
+    like.set_option('groups', args.groups)
     kt *= max(args.steps, 1) / nser
     sync()
   dt_rank = dt
@@ -363,7 +408,8 @@ def main():
         ta = time.perf_counter()
         comm.allreduce_sum(x)
         ar.append(1e6 * (time.perf_counter() - ta))
-    multi_info = {"rank_ms_per_step": {"max": 1e3 * dt / max(args.steps, 1), "min": 1e3 * dt_min / max(args.steps, 1)},
+    multi_info = {"collective": "host sockets (--host-comm rehearsal)" if args.host_comm else "RCCL", "ncclCommCount": nccl_count, "world": world,
+                  "rank_ms_per_step": {"max": 1e3 * dt / max(args.steps, 1), "min": 1e3 * dt_min / max(args.steps, 1)},
                   "allreduce_us": {"median": float(np.median(ar[5:])), "calls": len(ar) - 5, "doubles": 3 * nb,
                                    "note": "host call to return, incl. H2D / D2H of the buffer: an upper bound on what the in-stream collective adds"} if len(ar) > 5 else None,
                   "inflight": args.inflight}
@@ -381,7 +427,10 @@ def main():
       ts.append(1e3 * (time.perf_counter() - ta))
     sync()
     med, q1, q3 = quartiles(ts)
-    single = {"median_ms": med, "q25_ms": q1, "q75_ms": q3, "calls": len(ts), "evals_per_s": 1e3 / med}
+    b_alg = algorithmic_bytes(E, S, P, Z, I, 200, pixelated, kind == 'full')
+    single = {"median_ms": med, "q25_ms": q1, "q75_ms": q3, "calls": len(ts), "evals_per_s": 1e3 / med,
+              # [r4] the whole call against the HBM roofline: SURVEY 8(d)'s algorithmic bytes of one evaluation over the call's wall time
+              "algorithmic_bytes": b_alg, "hbm_GBs": b_alg / (med * 1e-3) / 1e9, "hbm_frac": b_alg / (med * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
   if rank == 0:
     evals = args.steps * nb
@@ -392,7 +441,7 @@ def main():
     kernels = []
     if kind == 'marginalized':
       kernels.append(kernel_roofline("marginalized GW kernel (histogram + KDE + interp + integrand + trapz)", "k_kde_marg_sub2", kt[3],
-                                     gw_kernel_unique_bytes(El, S, P, Z, nb), pmc))
+                                     gw_kernel_unique_bytes(El, S, P, Z, nb), pmc, units=El * P / 2. * nb))
     full_pairs = None
     if kind == 'full':
       kernels.append(kernel_roofline("3-D Gaussian KDE + integrand (sample-stationary kernel; the general kernel's share of the stage is its empty blocks)", "k_full_kde_chain", kt[3], El * S * 32 * nb + El * P * Z * 8, pmc))
@@ -412,7 +461,7 @@ def main():
       kf.update({"pairs_per_launch": full_pairs, "Gpairs_s": full_pairs / sec / 1e9 if sec > 0 else None,
                  "peak_Gpairs_s": pk, "pair_frac": full_pairs / sec / 1e9 / pk if sec > 0 else None})
     kernels.append(kernel_roofline("sample stage (z(dL), source-frame masses, population weights, event statistics)", "k_samples", kt[2],
-                                   sample_kernel_unique_bytes(El, S, nb), pmc))
+                                   sample_kernel_unique_bytes(El, S, nb), pmc, units=El * S * nb / 64.))
     # the selection kernel runs on its own stream beside the event kernels (its span there is not a kernel duration): timed standalone
     # here, after the timed region, as the selection-only call chm_eval(NULL, sel, ...) of the same draws
     sel_ms = None
@@ -431,15 +480,17 @@ def main():
       if acc:
         sel_ms = float(np.median(acc))
         kernels.append(kernel_roofline("selection function (dN/dtheta per injection, two sums); standalone selection-only call", "k_selection", sel_ms,
-                                       I * 48 + nb * (2 * 1500 + 2 * 1000) * 8, pmc))
+                                       I * 48 + nb * (2 * 1500 + 2 * 1000) * 8, pmc, units=I * nb / 64.))
     dom = max(kernels, key=lambda k_: k_["kernel_ms"] or 0.) if kind != 'full' else kernels[0]
     path_bytes = algorithmic_bytes(E, S, P, Z, I, 200, pixelated, kind == 'full')
     med, q1, q3 = quartiles(step_s) if step_s else (None, None, None)
     roof = {"bound": "valu-issue", "kernel": dom["kernel"],
-            "achieved": dom.get("valu_busy_Tcycle_s") if kind != 'full' else dom.get("Gpairs_s"),
-            "peak": ISSUE_PEAK_TCYC if kind != 'full' else dom.get("peak_Gpairs_s"), "unit": "Tcycle/s (VALU issue cycles of 1024 SIMDs)" if kind != 'full' else "Gpair/s",
-            "frac": dom.get("valu_busy_frac") if kind != 'full' else dom.get("pair_frac"),
-            "frac_at_held_clock": dom.get("valu_busy_frac_at_held_clock"),
+            "achieved": dom.get("useful_Tcycle_s") if kind != 'full' else dom.get("Gpairs_s"),
+            "peak": ISSUE_PEAK_TCYC if kind != 'full' else dom.get("peak_Gpairs_s"),
+            "unit": "Tcycle/s (issue cycles of fp64 add / mul / fma instructions; peak: the VALU issue cycles of 1024 SIMDs at 2.4 GHz)" if kind != 'full' else "Gpair/s",
+            "frac": dom.get("useful_frac") if kind != 'full' else dom.get("pair_frac"),
+            "useful_frac": dom.get("useful_frac"), "issue_busy_frac": dom.get("valu_busy_frac"),
+            "issue_busy_frac_at_held_clock": dom.get("valu_busy_frac_at_held_clock"), "min_inst": dom.get("min_inst"),
             "fp64_TFLOPs_real": dom.get("fp64_TFLOPs_real"), "fp64_peak_TFLOPs": FP64_PEAK_TFLOPS,
             "traffic": dom.get("traffic_bytes_per_launch"),
             "traffic_source": (pmc[0] + " (separate rocprofv3 --pmc passes of this command)") if pmc else None,
@@ -448,14 +499,15 @@ def main():
             "hbm": {"unique_bytes_per_launch": dom["unique_bytes_per_launch"], "achieved": dom["hbm_unique_GBs"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": dom["hbm_unique_frac"], "traffic_frac": dom.get("hbm_traffic_frac")},
             "kernels": kernels,
-            "note": "both dominant kernels are bound by VALU issue: achieved = issue cycles of one launch -- PMC instruction counts of the committed "
-                    "passes of this command priced with the costs measured on the card (profiles/r03/issue_cost.txt: 4 cycles per wave64 instruction "
-                    "for everything but a few simple 32-bit opcodes at 2, fp64 rcp/sqrt at 16) -- / the launch's LIVE HIP-event duration; peak = 1024 "
-                    "SIMDs x 2.4 GHz; frac_at_held_clock uses the clock under the profile.  fp64_TFLOPs_real counts FMA = 2, add / mul = 1 (PMC).  "
-                    "No fraction is printed when the PMC file was collected from another code object than the one loaded.  hbm.* is the same launch "
-                    "against 8 TB/s: unique bytes (shared inputs once, per-draw arrays x nbatch) and PMC fabric traffic",
+            "note": "both dominant kernels are bound by VALU issue.  frac = useful_frac = issue cycles of the launch's fp64 add / mul / fma instructions "
+                    "(PMC class counters of the committed passes of this command x 4 cycles, profiles/r03/issue_cost.txt) / (1024 SIMDs x 2.4 GHz x the "
+                    "launch's LIVE HIP-event duration): what the kernel achieves.  issue_busy_frac prices EVERY VALU instruction at its measured issue "
+                    "cost (4 cycles; a few simple 32-bit opcodes 2, fp64 rcp/sqrt 16) -- how full the issue ports are, moves and selects included; "
+                    "..._at_held_clock uses the clock under the profile.  min_inst: instructions per unit of work against the stated minimum.  "
+                    "fp64_TFLOPs_real counts FMA = 2, add / mul = 1 (PMC).  No fraction is printed when the PMC file was collected from another code "
+                    "object than the one loaded.  hbm.* is the same launch against 8 TB/s: unique bytes (shared inputs once, per-draw arrays x nbatch) "
+                    "and PMC fabric traffic; the call-level HBM fraction of the scalar call is single_call.hbm_frac",
             "path_bytes_per_eval": path_bytes,
-            "path_frac": path_bytes * nb / (kt[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[0] > 0 else None,
             "stage_ms": {"note": "per-kernel times from steps with the event kernels on one lane (CHM_GROUPS=1) after the timed region; "
                                  "eval_timed = HIP-event time of a step inside the timed region (event groups on two lanes)",
                          "eval_timed": kt_timed_eval, "eval": kt[0], "tables": kt[1], "samples": kt[2], "kde_integrate": kt[3],

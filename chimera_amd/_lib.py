@@ -72,7 +72,14 @@ SYMBOLS = ['chm_version', 'chm_device_count', 'chm_last_error', 'chm_like_create
            'chm_comm_unique_id', 'chm_comm_init_rank', 'chm_comm_destroy', 'chm_comm_allreduce_sum', 'chm_comm_nranks',
            'chm_device_synchronize',
            'chm_last_timing', 'chm_like_full_general_pixels', 'chm_pcat_compute', 'chm_kde2d_pixels',
-           'chm_kde1d', 'chm_binning1d', 'chm_gkde_nd', 'chm_trapz', 'chm_cumtrapz']
+           'chm_kde1d', 'chm_binning1d', 'chm_gkde_nd', 'chm_trapz', 'chm_cumtrapz',
+           'chm_like_set_option', 'chm_sel_set_option', 'chm_diag_build', 'chm_comm_set_ticket', 'chm_comm_ticket_reset']
+
+# options of a handle (include/chimera_hip.h: CHM_OPT_*); ids >= 100 need a library built with -DCHM_DIAG
+OPTION = {'serial': 1, 'groups': 2, 'fused': 3, 'timing': 4, 'graph_max_nb': 5, 'spin_wait': 6,
+          'diag_full_chain': 100, 'diag_no_dense_node': 101, 'diag_marg_generic': 102, 'diag_samples_generic': 103,
+          'diag_selection_generic': 104, 'diag_no_grid_prep': 105, 'diag_zf_full': 106, 'diag_kde_ipw': 107, 'diag_samp_cpb': 108,
+          'diag_self_blocks': 109, 'diag_few_nb': 110, 'diag_no_zero_copy': 111, 'diag_no_zf_sel': 112, 'diag_host_prof': 113}
 
 _lib = None
 
@@ -116,6 +123,11 @@ def lib():
   L.chm_gkde_nd.argtypes = [c_dp, c_dp, i32, i64, c_dp, i64, i32, f64, c_dp, i32]
   L.chm_trapz.argtypes = [c_dp, c_dp, i64, i32, i32, c_dp, i32]
   L.chm_cumtrapz.argtypes = [c_dp, c_dp, i32, c_dp, i32]
+  L.chm_like_set_option.argtypes = [vp, i32, i64]
+  L.chm_sel_set_option.argtypes = [vp, i32, i64]
+  L.chm_diag_build.argtypes = []
+  L.chm_comm_set_ticket.argtypes = [vp, i64]
+  L.chm_comm_ticket_reset.argtypes = [i64]
   for name in SYMBOLS:
     if name not in ('chm_version', 'chm_last_error'):
       getattr(L, name).restype = C.c_int

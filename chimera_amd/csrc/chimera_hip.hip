@@ -33,6 +33,88 @@ extern "C" const char* chm_last_error(void) { return g_err.c_str(); }
 extern "C" int chm_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
 // ------------------------------------------------------------------------------------------------------
+// evaluation options of a handle (chm_like_set_option / chm_sel_set_option, include/chimera_hip.h)
+// ------------------------------------------------------------------------------------------------------
+// The release library reads NO environment variable: what a call computes and how it is scheduled depends on the handle's options alone.
+// The first group is part of the product; the second group (other kernels for the same quantity, launch geometry, switched-off safeguards)
+// exists for same-box A/B runs and for the tests that compare code paths -- set_option refuses it unless the library was built with -DCHM_DIAG
+// (scripts/build_variant.sh diag -DCHM_DIAG), and only such a build takes its initial values from CHM_* environment variables, once, when
+// a handle is created.
+struct Opts {
+  int serial = 0;            // 1: every kernel of a call on one stream
+  int groups = 0;            // event groups alternating between two streams (0: automatic; 1: one group)
+  int fused = 0;             // fused event kernel (chm_fused.h): 0 never, 1 few-draw calls, 2 every call
+  int timing = 1;            // 0: no timing events in the streams; 1: default set; 2: per-kernel events also under a communicator / with event groups
+  int graph_max_nb = 8;      // calls of at most this many draws are replayed from a HIP graph (0: never)
+  int spin_wait = 1;         // few-draw calls poll the stream for completion instead of sleeping on an interrupt (the wake-up is part of their latency)
+  // ---- diagnostics (-DCHM_DIAG builds only)
+  int full_chain = 1;        // full mode: 0 = the general kernel alone
+  int no_dense = 0;          // standard GW kernel without the dense redo (shows the limit of the prefix-sum form: WRONG results for extreme weights)
+  int marg_generic = 0, samples_generic = 0, selection_generic = 0, no_grid_prep = 0, zf_full = 0;
+  int kde_ipw = 0, samp_cpb = 0, self_blocks = 8192, few_nb = 8, no_zero_copy = 0, no_zf_sel = 0, host_prof = 0;
+};
+#ifdef CHM_DIAG
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static bool env_set(const char* name) { return getenv(name) != nullptr; }
+#endif
+static void opts_init(Opts& o) {
+#ifdef CHM_DIAG
+  o.serial = env_set("CHM_SERIAL"); o.groups = env_int("CHM_GROUPS", 0); o.fused = env_int("CHM_FUSED", 0);
+  o.timing = env_set("CHM_NO_TIMING") ? 0 : (env_set("CHM_TIMING_ALL") ? 2 : 1);
+  o.graph_max_nb = env_int("CHM_GRAPH_MAX_NB", 8); o.spin_wait = env_set("CHM_SYNC_BLOCK") ? 0 : 1;
+  o.full_chain = env_int("CHM_FULL_CHAIN", 1); o.no_dense = env_set("CHM_NO_DENSE_NODE");
+  o.marg_generic = env_set("CHM_MARG_GENERIC"); o.samples_generic = env_set("CHM_SAMPLES_GENERIC"); o.selection_generic = env_set("CHM_SELECTION_GENERIC");
+  o.no_grid_prep = env_set("CHM_NO_GRID_PREP"); o.zf_full = env_set("CHM_ZF_FULL"); o.kde_ipw = env_int("CHM_KDE_IPW", 0);
+  o.samp_cpb = env_int("CHM_SAMP_CPB", 0); o.self_blocks = env_int("CHM_SELF_BLOCKS", 8192); o.few_nb = env_int("CHM_FEW_NB", 8);
+  o.no_zero_copy = env_set("CHM_NO_ZERO_COPY"); o.no_zf_sel = env_set("CHM_NO_ZF_SEL"); o.host_prof = env_set("CHM_HOST_PROF");
+#else
+  (void)o;
+#endif
+}
+static int opts_set(Opts& o, int32_t option, int64_t value) {
+  const int v = (int)value;
+  switch (option) {
+    case CHM_OPT_SERIAL: o.serial = v != 0; return CHM_OK;
+    case CHM_OPT_GROUPS: if (v < 0 || v > 16) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_GROUPS must be in [0, 16]"); o.groups = v; return CHM_OK;
+    case CHM_OPT_FUSED: if (v < 0 || v > 2) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_FUSED must be 0, 1 or 2"); o.fused = v; return CHM_OK;
+    case CHM_OPT_TIMING: if (v < 0 || v > 2) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_TIMING must be 0, 1 or 2"); o.timing = v; return CHM_OK;
+    case CHM_OPT_GRAPH_MAX_NB: if (v < 0) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_GRAPH_MAX_NB must be >= 0"); o.graph_max_nb = v; return CHM_OK;
+    case CHM_OPT_SPIN_WAIT: o.spin_wait = v != 0; return CHM_OK;
+    default: break;
+  }
+#ifdef CHM_DIAG
+  switch (option) {
+    case CHM_OPT_DIAG_FULL_CHAIN: o.full_chain = v != 0; return CHM_OK;
+    case CHM_OPT_DIAG_NO_DENSE_NODE: o.no_dense = v != 0; return CHM_OK;
+    case CHM_OPT_DIAG_MARG_GENERIC: o.marg_generic = v != 0; return CHM_OK;
+    case CHM_OPT_DIAG_SAMPLES_GENERIC: o.samples_generic = v != 0; return CHM_OK;
+    case CHM_OPT_DIAG_SELECTION_GENERIC: o.selection_generic = v != 0; return CHM_OK;
+    case CHM_OPT_DIAG_NO_GRID_PREP: o.no_grid_prep = v != 0; return CHM_OK;
+    case CHM_OPT_DIAG_ZF_FULL: o.zf_full = v != 0; return CHM_OK;
+    case CHM_OPT_DIAG_KDE_IPW: o.kde_ipw = v; return CHM_OK;
+    case CHM_OPT_DIAG_SAMP_CPB: o.samp_cpb = v; return CHM_OK;
+    case CHM_OPT_DIAG_SELF_BLOCKS: o.self_blocks = v > 0 ? v : 8192; return CHM_OK;
+    case CHM_OPT_DIAG_FEW_NB: o.few_nb = v; return CHM_OK;
+    case CHM_OPT_DIAG_NO_ZERO_COPY: o.no_zero_copy = v != 0; return CHM_OK;
+    case CHM_OPT_DIAG_NO_ZF_SEL: o.no_zf_sel = v != 0; return CHM_OK;
+    case CHM_OPT_DIAG_HOST_PROF: o.host_prof = v != 0; return CHM_OK;
+    default: break;
+  }
+#else
+  if (option >= CHM_OPT_DIAG_FULL_CHAIN && option <= CHM_OPT_DIAG_HOST_PROF)
+    return fail(CHM_E_ARG, "chm_*_set_option: diagnostic option -- this library was built without -DCHM_DIAG");
+#endif
+  return fail(CHM_E_ARG, "chm_*_set_option: unknown option");
+}
+extern "C" int chm_diag_build(void) {
+#ifdef CHM_DIAG
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------
 // per-device evaluation context: stream, per-draw parameter block + tables, staging buffers
 // ------------------------------------------------------------------------------------------------------
 struct Ctx {
@@ -67,10 +149,7 @@ struct Ctx {
 
 static int ctx_init(Ctx& c, int device) {
   c.device = device;
-  // hipStreamSynchronize spins instead of sleeping on an interrupt: the scalar call waits ~0.17 ms per evaluation, the wake-up is part of
-  // its latency (CHM_SYNC_BLOCK=1 keeps the runtime's default).  Must precede the device's first use; later calls fail harmlessly.
-  static const bool spin = getenv("CHM_SYNC_BLOCK") == nullptr;
-  if (spin) { (void)hipSetDevice(device); (void)hipSetDeviceFlags(hipDeviceScheduleSpin); (void)hipGetLastError(); }
+  // (no process-wide device flags: few-draw calls that want to spin for their result poll their own stream, wait_stream below)
   HIPCHK(hipSetDevice(device));
   HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
@@ -215,6 +294,7 @@ struct OwnedArrays {
 };
 struct chm_like {
   Ctx ctx;
+  Opts opts;
   LikeDev L;
   std::shared_ptr<OwnedArrays> owned_sp = std::make_shared<OwnedArrays>();
   int nb_ws = 0;
@@ -236,6 +316,7 @@ struct chm_like {
 };
 struct chm_sel {
   Ctx ctx;
+  Opts opts;
   SelDev S;
   std::shared_ptr<OwnedArrays> owned_sp = std::make_shared<OwnedArrays>();
   int nb_ws = 0;
@@ -250,7 +331,35 @@ struct chm_comm {
   int nranks = 1, rank = 0, device = 0;
   hipStream_t stream = nullptr;
   double* d_buf = nullptr; int cap = 0;
+  long long ticket = -1;               // >= 0: the next chm_eval on this communicator enqueues its collective in ticket order (chm_comm_set_ticket)
 };
+
+// Collective sequencer of the process.  Several evaluation lanes of one rank -- each with its own communicator, each driven by its own host
+// thread -- must hand their collectives to the device in the SAME order on every rank: the streams of the lanes share a handful of
+// hardware queues, a queue runs its kernels in submission order, and an RCCL kernel spins until its peers on the other ranks run; rank A
+// queueing lane 0's all-reduce in front of lane 1's while rank B queues them the other way round can leave each waiting for a kernel that sits
+// behind the other.  The caller numbers the calls (chm_comm_set_ticket: step k of the job carries ticket k on every rank); a ticketed call
+// enqueues its all-reduce only when every lower ticket has enqueued its own.
+#include <mutex>
+#include <condition_variable>
+static struct CollSeq { std::mutex m; std::condition_variable cv; long long next = 0; } g_seq;
+struct TicketTurn {
+  chm_comm* c; bool held = false;
+  explicit TicketTurn(chm_comm* c_) : c(c_ && c_->ticket >= 0 ? c_ : nullptr) {}
+  void acquire() { if (c && !held) { std::unique_lock<std::mutex> lk(g_seq.m); g_seq.cv.wait(lk, [&] { return g_seq.next >= c->ticket; }); held = true; } }
+  void release() { if (c && held) { { std::lock_guard<std::mutex> lk(g_seq.m); if (g_seq.next <= c->ticket) g_seq.next = c->ticket + 1; } c->ticket = -1; held = false; c = nullptr; g_seq.cv.notify_all(); } }
+  ~TicketTurn() { if (c) { acquire(); release(); } }      // a call that failed before its collective still passes the turn on
+};
+extern "C" int chm_comm_set_ticket(chm_comm* c, int64_t ticket) {
+  if (!c) return fail(CHM_E_ARG, "chm_comm_set_ticket: null communicator");
+  c->ticket = (long long)ticket;
+  return CHM_OK;
+}
+extern "C" int chm_comm_ticket_reset(int64_t next) {
+  { std::lock_guard<std::mutex> lk(g_seq.m); g_seq.next = (long long)next; }
+  g_seq.cv.notify_all();
+  return CHM_OK;
+}
 
 template <class T, class Own>
 static int upload(Own& owned, const T* host, size_t n, const T** dev, hipStream_t s) {
@@ -305,6 +414,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
   if (d->device < 0 || d->device >= ndev) return fail(CHM_E_HIP, "chm_like_create: no such HIP device (is a GPU visible?)");
 
   chm_like* h = new chm_like();
+  opts_init(h->opts);
   int rc = ctx_init(h->ctx, d->device);
   if (rc) { delete h; return rc; }
   h->owned_sp->device = d->device;
@@ -513,6 +623,7 @@ extern "C" int chm_like_clone(const chm_like* src, chm_like** out) {
   if (!src || !out) return fail(CHM_E_ARG, "chm_like_clone: null argument");
   *out = nullptr;
   chm_like* h = new chm_like();
+  h->opts = src->opts;
   int rc = ctx_init(h->ctx, src->ctx.device);
   if (rc) { delete h; return rc; }
   h->owned_sp = src->owned_sp;
@@ -572,6 +683,7 @@ extern "C" int chm_sel_create(const chm_sel_desc* d, chm_sel** out) {
   int ndev = chm_device_count();
   if (d->device < 0 || d->device >= ndev) return fail(CHM_E_HIP, "chm_sel_create: no such HIP device (is a GPU visible?)");
   chm_sel* h = new chm_sel();
+  opts_init(h->opts);
   int rc = ctx_init(h->ctx, d->device);
   if (rc) { delete h; return rc; }
   h->owned_sp->device = d->device;
@@ -628,6 +740,7 @@ extern "C" int chm_sel_clone(const chm_sel* src, chm_sel** out) {
   if (!src || !out) return fail(CHM_E_ARG, "chm_sel_clone: null argument");
   *out = nullptr;
   chm_sel* h = new chm_sel();
+  h->opts = src->opts;
   int rc = ctx_init(h->ctx, src->ctx.device);
   if (rc) { delete h; return rc; }
   h->owned_sp = src->owned_sp;
@@ -636,6 +749,15 @@ extern "C" int chm_sel_clone(const chm_sel* src, chm_sel** out) {
   h->lut = src->lut; h->fast_ok = src->fast_ok; h->dl_gmin = src->dl_gmin; h->dl_gmax = src->dl_gmax;
   *out = h;
   return CHM_OK;
+}
+
+extern "C" int chm_like_set_option(chm_like* h, int32_t option, int64_t value) {
+  if (!h) return fail(CHM_E_ARG, "chm_like_set_option: null handle");
+  return opts_set(h->opts, option, value);
+}
+extern "C" int chm_sel_set_option(chm_sel* h, int32_t option, int64_t value) {
+  if (!h) return fail(CHM_E_ARG, "chm_sel_set_option: null handle");
+  return opts_set(h->opts, option, value);
 }
 
 static int sel_ensure_ws(chm_sel* h, int nb) {
@@ -678,8 +800,15 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
 // key, parameter packing), inside hipGraphLaunch, inside hipStreamSynchronize
 #include <chrono>
 #include <algorithm>
+// Completion of a call: few-draw calls (the reference-shaped scalar call waits ~0.15 ms per evaluation) poll their own stream -- the default
+// wait sleeps on an interrupt whose wake-up is part of the call's latency.  Per call and per handle: no process-wide device flag.
+static hipError_t wait_stream(hipStream_t s, bool spin) {
+  if (spin) { hipError_t e; while ((e = hipStreamQuery(s)) == hipErrorNotReady) {} return e; }
+  return hipStreamSynchronize(s);
+}
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-static bool host_prof_on() { static const bool on = getenv("CHM_HOST_PROF") != nullptr; return on; }
+static thread_local bool g_host_prof = false;               // (CHM_OPT_DIAG_HOST_PROF of the handle being evaluated)
+static bool host_prof_on() { return g_host_prof; }
 static struct HostProf { std::vector<double> pre, launch, sync;
   static double med(std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
   ~HostProf() { if (!pre.empty()) fprintf(stderr, "[chm host prof] %zu replayed calls: before launch %.1f us, hipGraphLaunch %.1f us, hipStreamSynchronize %.1f us (medians)\n",
@@ -700,10 +829,13 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   if ((!like && !sel) || !params || !out || nb <= 0) return fail(CHM_E_ARG, "chm_eval: need a handle, params, out and nb > 0");
   if (like && sel && like->ctx.device != sel->ctx.device) return fail(CHM_E_ARG, "chm_eval: like and sel live on different devices");
   Ctx& c = like ? like->ctx : sel->ctx;
+  const Opts& o = like ? like->opts : sel->opts;             // the options of the call: the event handle's when there is one
+  g_host_prof = o.host_prof != 0;
   const double hp0 = host_prof_on() ? now_us() : 0.;
   if (comm && comm->device != c.device) return fail(CHM_E_ARG, "chm_eval: comm lives on a different device");
+  TicketTurn turn(comm);                                      // (ticketed calls: the collective is enqueued in ticket order, see CollSeq)
   HIPCHK(hipSetDevice(c.device));
-  const bool serial = getenv("CHM_SERIAL") != nullptr;            // diagnostics: everything on one stream (read per call: bench.py times the kernels on their own after its timed region)
+  const bool serial = o.serial != 0;                        // everything on one stream (bench.py times the kernels on their own after its timed region)
   hipStream_t sA = c.stream, sB = serial ? c.stream : c.stream2, sC = serial ? c.stream : c.stream3;      // (all three = sA for fused few-draw calls, below)
   const bool want_dump = like && out->p_gw != nullptr;
   int rc;
@@ -737,13 +869,13 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       rc = tab_upload(&td.jac_i, tab->jac_inj, NI, sA); if (rc) return rc;
     }
   }
-  static const bool timing_env = getenv("CHM_NO_TIMING") == nullptr;  // CHM_NO_TIMING=1: no timing events in the streams (chm_last_timing returns zeros)
+  const bool timing_env = o.timing > 0;                       // CHM_OPT_TIMING 0: no timing events in the streams (chm_last_timing returns zeros)
   // Few draws per call (the reference's scalar call): the launch sequence is replayed from a HIP graph -- no timing events, no
   // per-event outputs, no caller tables.  A configuration runs eagerly the first time it is seen (function attributes, workspaces), is
   // captured the second time and replayed afterwards.  [r3] With a communicator the graph ends at the rank's partial sums; the RCCL
   // all-reduce and k_combine follow it on the same stream (the 8-GPU job keeps the replayed path of the scalar call).
-  static const int graph_max_nb = getenv("CHM_GRAPH_MAX_NB") ? atoi(getenv("CHM_GRAPH_MAX_NB")) : 8;
-  static const bool zc_env = getenv("CHM_NO_ZERO_COPY") == nullptr;
+  const int graph_max_nb = o.graph_max_nb;
+  const bool zc_env = !o.no_zero_copy;
   const bool zero_copy = zc_env && nb <= 8;               // parameters read from / results written to pinned host memory by the kernels themselves
   const bool graph_ok = nb <= graph_max_nb && !tab && !want_dump && !out->log_like_evs && !out->numlike_evs;
   int Tc_host = 0, Tm_host = 0;
@@ -759,7 +891,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   // range (entries per octave of the reference's logspace z grid, cosmo.py:43-46, with a margin; a draw whose slice does not fit
   // takes the general searches inside the same kernel)
   LutDesc lutA = {};
-  bool use_fast = like && like->fast_ok && !td.pm_s && !getenv("CHM_SAMPLES_GENERIC");
+  bool use_fast = like && like->fast_ok && !td.pm_s && !o.samples_generic;
   size_t lds_fast = 0;
   if (use_fast) {
     int Tc_call = 0, Tm_call = 0;
@@ -784,19 +916,18 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     }
   }
   // k_marg_fused (chm_fused.h): the standard marginalized configuration in ONE kernel per (event, draw) -- few-draw calls by default
-  // (CHM_FUSED=1: few-draw calls, 2: calls of any size; read per call; default off).  LDS per block: P histograms of num_bins + 1 doubles, the overlay region
+  // (CHM_OPT_FUSED 1: few-draw calls, 2: calls of any size; default off).  LDS per block: P histograms of num_bins + 1 doubles, the overlay region
   // (the draw's mass tables + the widest event's slice of the distance tables + NW - 1 boundary rows | 4 NW prefix arrays) and ~2 KB.
   FusedDesc FDc = {};
   size_t lds_fused = 0;
   const int fused_nw = 4;
   bool use_fused = false;
   {
-    const char* fe = getenv("CHM_FUSED");
-    const int fmode = fe ? atoi(fe) : 0;                    // off by default: measured slower than the separate kernels at every call size (profiles/r04/ab_fused_event_kernel.txt)
-    static const int few_nb_f = getenv("CHM_FEW_NB") ? atoi(getenv("CHM_FEW_NB")) : 8;
+    const int fmode = o.fused;                              // off by default: measured slower than the separate kernels at every call size (profiles/r04/ab_fused_event_kernel.txt)
+    const int few_nb_f = o.few_nb;
     if (like && like->fused_ok && use_fast && !tab && !want_dump && fmode > 0 && (nb <= few_nb_f || fmode >= 2) && !serial &&
         like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && like->L.num_bins == 200 &&
-        !getenv("CHM_MARG_GENERIC") && !getenv("CHM_ZF_FULL")) {
+        !o.marg_generic && !o.zf_full) {
       int Tc_call = 0, Tm_call = 0;
       double zmax_min = INFINITY;
       for (int b = 0; b < nb; b++) {
@@ -829,7 +960,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   }
   // k_selection_fast: built-in models of an FLRW draw (cosmo_model 0), the same mass model for every draw; table slice capacity as above
   LutDesc lutB = {};
-  bool sel_fast = sel && sel->fast_ok && !td.pm_i && !td.rate_i && !td.bkg_i && !td.jac_i && !td.zt && !getenv("CHM_SELECTION_GENERIC");
+  bool sel_fast = sel && sel->fast_ok && !td.pm_i && !td.rate_i && !td.bkg_i && !td.jac_i && !td.zt && !o.selection_generic;
   size_t lds_sel = 0;
   if (sel_fast) {
     int Tc_call = 0, Tm_call = 0;
@@ -856,18 +987,18 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   // Few draws per call (the scalar call), standard marginalized configuration, fast selection kernel: the per-z factors, the event
   // statistics and the selection sums share ONE launch (k_zf_sel) and the whole call runs on one stream -- the captured graph is a plain
   // chain (hipGraphLaunch 10 instead of 39 us) and the selection kernel hides behind the per-z factors.
-  static const int few_nb = getenv("CHM_FEW_NB") ? atoi(getenv("CHM_FEW_NB")) : 8;
-  static const bool fuse_env = getenv("CHM_NO_ZF_SEL") == nullptr;
+  const int few_nb = o.few_nb;
+  const bool fuse_env = !o.no_zf_sel;
   const size_t lds_zfac_call = sizeof(double) * (size_t)2 * c.TcMax;
   const bool fuse_sel = fuse_env && !use_fused && !serial && like && sel && sel_fast && nb <= few_nb && !td.rate_g && !td.bkg_g && !td.jac_g &&
-                        like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && !getenv("CHM_MARG_GENERIC") && !getenv("CHM_ZF_FULL") &&
-                        !(getenv("CHM_GROUPS") && atoi(getenv("CHM_GROUPS")) > 1) && lds_zfac_call <= 64 * 1024 && like->L.E <= 65535;
+                        like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && !o.marg_generic && !o.zf_full &&
+                        !(o.groups > 1) && lds_zfac_call <= 64 * 1024 && like->L.E <= 65535;
   const bool one_stream = serial || fuse_sel;
   if (fuse_sel) { sB = sA; sC = sA; }
   // draw-independent brackets of the event grids on the z table: usable when every draw of the call has one (z_max, z_grid_res) and the
   // cosmology is built in; (re)made by k_grid_prep after k_tables when that pair changes
   bool zg_use = false, zg_make = false;
-  if (like && !td.zt && !getenv("CHM_NO_GRID_PREP")) {
+  if (like && !td.zt && !o.no_grid_prep) {
     zg_use = true;
     for (int b = 1; b < nb; b++) if (params[b].z_max != params[0].z_max || params[b].z_grid_res != params[0].z_grid_res) zg_use = false;
     if (zg_use && (like->zg_zmax != params[0].z_max || like->zg_Tc != params[0].z_grid_res)) zg_make = true;
@@ -885,7 +1016,9 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       const double hp1 = host_prof_on() ? now_us() : 0.;
       HIPCHK(hipGraphLaunch(c.gexec, sA));
       if (comm) {                                             // the graph ends at the rank's partials: all-reduce + combination behind it
+        turn.acquire();
         NCCLCHK(ncclAllReduce(c.d_partials, c.d_partials, (size_t)nb * 3, ncclDouble, ncclSum, comm->comm, sA));
+        turn.release();
         hipLaunchKernelGGL(k_combine, dim3((nb + 63) / 64), dim3(64), 0, sA, nb, (const DevParams*)c.d_params, (const double*)c.d_partials,
                            comm ? (double)E_total : (like ? (double)like->L.E : 0.), sel ? sel->S.N_inj : 1., sel ? sel->S.N_eff : 0.,
                            sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, zero_copy ? c.h_out : c.d_out3);
@@ -893,7 +1026,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         if (!zero_copy) HIPCHK(hipMemcpyAsync(c.h_out, c.d_out3, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
       }
       const double hp2 = host_prof_on() ? now_us() : 0.;
-      HIPCHK(hipStreamSynchronize(sA));
+      HIPCHK(wait_stream(sA, o.spin_wait != 0));
       if (host_prof_on()) { const double hp3 = now_us(); g_hp.pre.push_back(hp1 - hp0); g_hp.launch.push_back(hp2 - hp1); g_hp.sync.push_back(hp3 - hp2); }
       for (int b = 0; b < nb; b++) {
         if (out->log_hyper) out->log_hyper[b] = c.h_out[b * 3];
@@ -913,11 +1046,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   const bool timing = timing_env && !capturing;
   // with a communicator (multi-GPU shards: short calls) only the whole evaluation and the GW kernel are timed: each event record
   // costs ~3 us of stream time (measured: 35 us per call for the full set); CHM_TIMING_ALL=1 keeps the full set (diagnosing a multi-GPU line)
-  static const bool timing_all_env = getenv("CHM_TIMING_ALL") != nullptr;
+  const bool timing_all_env = o.timing >= 2;
   // (per-kernel events only for calls whose kernels follow each other on one lane: with event groups on two streams the spans overlap and
   //  the 4 records per group would cost more stream time than they inform -- bench.py times the kernels in a CHM_GROUPS=1 pass)
-  const char* eg0 = getenv("CHM_GROUPS");
-  const bool grouped = like && nb > few_nb && !(eg0 && atoi(eg0) == 1) && !serial && like->L.E >= 500;
+  const bool grouped = like && nb > few_nb && o.groups != 1 && !serial && like->L.E >= 500;
   const bool timing_all = timing && ((!comm && !grouped) || timing_all_env);
   // an error inside a capture must end it before returning
   struct CaptureGuard { hipStream_t s; bool* on; ~CaptureGuard() { if (*on) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); } } } cguard{sA, &capturing};
@@ -954,8 +1086,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     // are VALU-issue bound at ~80 % of the slots with the chip to themselves; side by side they fill each other's stalls: 9.74 -> 9.43 ms per
     // 128-draw step at C3 with 4 - 8 groups (profiles/r03/ab_event_groups_and_lanes.txt; 12 / 16 groups: 9.6).  One group per 250 events, at
     // most 8; CHM_GROUPS=n overrides (1: one group).  Few-draw calls stay a single chain (one_stream).
-    const char* eg = getenv("CHM_GROUPS");
-    const int env_groups = eg ? atoi(eg) : 0;
+    const int env_groups = o.groups;
     ngroups = env_groups > 0 ? env_groups : (nb > few_nb ? (L0.E / 250 < 1 ? 1 : (L0.E / 250 > 8 ? 8 : L0.E / 250)) : 1);
     if (ngroups > 16) ngroups = 16;
     if (ngroups > L0.E) ngroups = L0.E;
@@ -967,7 +1098,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       LikeDev L = like->L;
       L.tab_pm = td.pm_s; L.tab_rate = td.rate_g; L.tab_bkg = td.bkg_g; L.tab_jac = td.jac_g;
       if (zg_use) { L.zg_i = like->d_zg_i; L.zg_t = like->d_zg_t; L.zg_lz = like->d_zg_lz; }
-      L.no_dense = getenv("CHM_NO_DENSE_NODE") ? 1 : 0;     // diagnostics: no dense-sum fallback in the standard GW kernel
+      L.no_dense = o.no_dense ? 1 : 0;                      // diagnostics (-DCHM_DIAG): no dense-sum fallback in the standard GW kernel
       if (!want_dump) L.p_gw_dump = nullptr;
       const int eb = (int)((long long)L0.E * g / ngroups), ee = (int)((long long)L0.E * (g + 1) / ngroups);
       L.e_off = eb; L.E_cnt = ee - eb; L.nb = nb;
@@ -990,10 +1121,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         ev_from_fixup = true;
         continue;
       }
-      const bool zf_ranged = (L.mode == CHM_MODE_MARG || L.mode == CHM_MODE_1D || L.mode == CHM_MODE_APPROX) && !getenv("CHM_ZF_FULL");
+      const bool zf_ranged = (L.mode == CHM_MODE_MARG || L.mode == CHM_MODE_1D || L.mode == CHM_MODE_APPROX) && !o.zf_full;
       // standard configuration (binning, cut_grid set) -> k_kde_marg_sub<32>, two pixels per wave (16 lanes per pixel measured
       // 30 % slower: 19 KB of LDS per wave halve the occupancy); anything else, or CHM_MARG_GENERIC=1, -> the general kernel
-      const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && (L.Z & 1) == 0 && !getenv("CHM_MARG_GENERIC");
+      const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && (L.Z & 1) == 0 && !o.marg_generic;
       const int zf_mode = !zf_ranged ? 0 : (L.mode == CHM_MODE_MARG ? 1 : 2);
       hipStream_t sz = (one_stream || zf_ranged) ? sg : ((g & 1) ? sA : sB);
       // ~2048 blocks in all: each stages the draw's (zt, It) tables in LDS once and walks over E_cnt / gridDim.x events
@@ -1032,7 +1163,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       // four chunks per block amortise the staging while leaving enough blocks for dynamic balance (1 / 2 / 4 / 8 / 16 chunks per
       // block at C3 / 128 draws, barrier-free chunk loop: 5.89 / 5.70 / 5.61 / 5.67 / 5.78 ms), fewer when few draws leave fewer
       // than ~2048 blocks
-      static const int cpb_env = getenv("CHM_SAMP_CPB") ? atoi(getenv("CHM_SAMP_CPB")) : 0;
+      const int cpb_env = o.samp_cpb;
       int cpb = cpb_env > 0 ? cpb_env : 4;
       if (cpb_env <= 0) {
         long long want = (long long)nchunk * nb / 2048;
@@ -1069,7 +1200,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         // [r3] sample-stationary kernel first; the pixels it cannot do (non-uniform stretch of the grid, very coarse grid, > 4096 samples) are
         // flagged in full_todo and done by the general kernel, whose other blocks return at once.  CHM_FULL_CHAIN=0: general kernel only.
-        const bool full_chain = !(getenv("CHM_FULL_CHAIN") && atoi(getenv("CHM_FULL_CHAIN")) == 0);      // (read per call: tests compare the two)
+        const bool full_chain = o.full_chain != 0;         // (CHM_OPT_DIAG_FULL_CHAIN 0: the general kernel alone; tests compare the two)
         if (full_chain) {
           hipLaunchKernelGGL(k_full_prep, dim3(L.E_cnt, nb), dim3(256), 0, sg, L); HIPCHK(hipGetLastError());
           hipLaunchKernelGGL(k_full_kde_chain, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp, L.full_todo); HIPCHK(hipGetLastError());
@@ -1086,7 +1217,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
           // several pixel groups (pairs of pixels) of the same (event, draw) per wave, one after the other: event statistics and segment
           // offsets once (four items per wave: 5.45 ms at C3 / 128 draws, two: 5.51, one: 5.66)
           const int PG2 = (Pd + 1) / 2;
-          static const int ipw_env = getenv("CHM_KDE_IPW") ? atoi(getenv("CHM_KDE_IPW")) : 0;       // diagnostics: 2 or 4 items per wave
+          const int ipw_env = o.kde_ipw;                    // diagnostics: 2 or 4 items per wave
           // (few draws per call: two items per wave -- twice the waves, half the serial chain of each: 0.238 -> 0.229 ms for the scalar call at C3)
           const int ipw = ipw_env == 2 || ipw_env == 4 ? ipw_env : ((PG2 >= 4 && nb > 8) ? 4 : 2);
           const size_t lds_sub = sizeof(double) * (3 * N + 3) * 2;
@@ -1131,7 +1262,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
 #define LAUNCH_SELF(M) do { allow_lds(k_selection_fast<M>, lds_sel); \
         hipLaunchKernelGGL((k_selection_fast<M>), dim3(gx, nb), dim3(256), lds_sel, sC, S, lutB, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm); } while (0)
       // every block stages the draw's table slice (tens of KB): ~8192 blocks in all, each walking over several tiles of injections
-      static const int self_blocks = getenv("CHM_SELF_BLOCKS") ? atoi(getenv("CHM_SELF_BLOCKS")) : 8192;
+      const int self_blocks = (sel ? sel->opts.self_blocks : 8192) > 0 ? (sel ? sel->opts.self_blocks : 8192) : 8192;
       int gx = self_blocks / nb;
       gx = gx < 1 ? 1 : (gx > S.nblocks ? S.nblocks : gx);
       const int mm = params[0].mass_model;
@@ -1195,7 +1326,9 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   };
   if (multi) {
     if (capturing) { rc = end_capture(); if (rc) return rc; }      // the collective stays outside the graph
+    turn.acquire();
     NCCLCHK(ncclAllReduce(c.d_partials, c.d_partials, (size_t)nb * 3, ncclDouble, ncclSum, comm->comm, sA));
+    turn.release();
     hipLaunchKernelGGL(k_combine, dim3((nb + 63) / 64), dim3(64), 0, sA, nb, dp, (const double*)c.d_partials, Etot,
                        sel ? sel->S.N_inj : 1., sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, out3);
     HIPCHK(hipGetLastError());
@@ -1210,7 +1343,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     HIPCHK(hipMemcpyAsync(out->p_gw, src, sizeof(double) * nb * El * Pd * like->L.Z, hipMemcpyDeviceToHost, sA));
   }
   if (capturing) { rc = end_capture(); if (rc) return rc; }
-  HIPCHK(hipStreamSynchronize(sA));
+  HIPCHK(wait_stream(sA, o.spin_wait != 0 && nb <= few_nb));
   for (int b = 0; b < nb; b++) {
     if (out->log_hyper) out->log_hyper[b] = c.h_out[b * 3];
     if (out->log_num) out->log_num[b] = c.h_out[b * 3 + 1];

@@ -92,6 +92,7 @@ class hyperlikelihood(object):
     else:
       self._e0, self._e1 = 0, self.nevents
     self._handles = {}
+    self._options = {}
     from .population.plugins import population_plugins
     self._plugins = population_plugins(self.population)        # (mass, rate, completeness) evaluated on the host?
     if any(self._plugins):
@@ -160,7 +161,22 @@ class hyperlikelihood(object):
     h = C.c_void_p()
     _lib.check(_lib.lib().chm_like_create(C.byref(d), C.byref(h)))
     self._handles[mode] = (h, None)
+    for name, value in self._options.items():
+      _lib.check(_lib.lib().chm_like_set_option(h, _lib.OPTION[name], int(value)))
     return h
+
+  def set_option(self, name, value):
+    """Evaluation option of this object's device handles (include/chimera_hip.h, ``CHM_OPT_*``; names: ``_lib.OPTION``), e.g.
+    ``set_option('groups', 1)``, ``set_option('fused', 1)``.  Also handed to the selection function, whose handle takes part in the
+    same calls.  ``diag_*`` options need a library built with ``-DCHM_DIAG`` (``ValueError`` otherwise).  Returns ``self``."""
+    if name not in _lib.OPTION:
+      raise ValueError(f"hyperlikelihood.set_option: unknown option {name!r} (known: {sorted(_lib.OPTION)})")
+    for h, _ in self._handles.values():
+      _lib.check(_lib.lib().chm_like_set_option(h, _lib.OPTION[name], int(value)))
+    self._options = dict(self._options, **{name: int(value)})
+    if self.selection_function is not None and hasattr(self.selection_function, 'set_option'):
+      self.selection_function.set_option(name, value)
+    return self
 
   def close(self):
     for h, _ in self._handles.values():
@@ -180,6 +196,7 @@ class hyperlikelihood(object):
     self._handle()
     new = copy.copy(self)
     new._handles = {}
+    new._options = dict(self._options)
     new.comm = comm
     for mode, (h, _) in self._handles.items():
       h2 = C.c_void_p()

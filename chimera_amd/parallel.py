@@ -221,6 +221,16 @@ class Comm(object):
     _lib.check(_lib.lib().chm_comm_allreduce_sum(self._h, _lib.dptr(x), x.size))
     return x
 
+  def set_ticket(self, ticket):
+    """The next evaluation on this communicator enqueues its all-reduce in ticket order (``chm_comm_set_ticket``): several lanes per rank,
+    each with its own communicator and host thread, number their steps identically on every rank so that the collectives reach the devices
+    in one order everywhere."""
+    _lib.check(_lib.lib().chm_comm_set_ticket(self._h, int(ticket)))
+
+  @staticmethod
+  def reset_tickets(next_ticket=0):
+    _lib.check(_lib.lib().chm_comm_ticket_reset(int(next_ticket)))
+
   def close(self):
     if self._h:
       _lib.lib().chm_comm_destroy(self._h)

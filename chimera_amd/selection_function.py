@@ -19,6 +19,7 @@ class selection_function(object):
     self.comm = comm
     self.device = (comm.device if comm is not None else _lib.default_device()) if device is None else device
     self._h = None
+    self._options = {}
 
   # -- device handle -----------------------------------------------------------------------------------
   def _handle(self):
@@ -42,7 +43,18 @@ class selection_function(object):
     h = C.c_void_p()
     _lib.check(_lib.lib().chm_sel_create(C.byref(d), C.byref(h)))
     self._h = h
+    for name, value in self._options.items():
+      _lib.check(_lib.lib().chm_sel_set_option(h, _lib.OPTION[name], int(value)))
     return h
+
+  def set_option(self, name, value):
+    """Evaluation option of the device handle (``CHM_OPT_*``, see ``hyperlikelihood.set_option``).  Returns ``self``."""
+    if name not in _lib.OPTION:
+      raise ValueError(f"selection_function.set_option: unknown option {name!r}")
+    if self._h is not None:
+      _lib.check(_lib.lib().chm_sel_set_option(self._h, _lib.OPTION[name], int(value)))
+    self._options = dict(self._options, **{name: int(value)})
+    return self
 
   def close(self):
     if self._h is not None:
@@ -57,6 +69,7 @@ class selection_function(object):
     h = self._handle()
     new = copy.copy(self)
     new.comm = comm
+    new._options = dict(self._options)
     new._h = C.c_void_p()
     _lib.check(_lib.lib().chm_sel_clone(h, C.byref(new._h)))
     return new

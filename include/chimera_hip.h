@@ -258,6 +258,12 @@ int chm_comm_allreduce_sum(chm_comm* c, double* buf, int32_t n);
 /* number of ranks RCCL reports for the communicator (ncclCommCount); 0 for a NULL / dead handle.  The sharded job checks it
  * against the launcher's WORLD_SIZE (the partition of CHIMERA/parallel.py:68-73,94-99 assumes every rank is present).   */
 int chm_comm_nranks(chm_comm* c);
+/* Several evaluation lanes per rank (chm_like_clone), each with a communicator of its own and a host thread of its own: collectives must reach
+ * the device in the same order on every rank.  chm_comm_set_ticket(c, t) makes the NEXT chm_eval on c enqueue its all-reduce only after the
+ * calls carrying tickets < t (on any communicator of this process) have enqueued theirs; the job numbers its steps identically on every rank
+ * (step k: ticket k).  chm_comm_ticket_reset(n): the next ticket to be served.  Calls without a ticket are not sequenced.                   */
+int chm_comm_set_ticket(chm_comm* c, int64_t ticket);
+int chm_comm_ticket_reset(int64_t next);
 /* hipDeviceSynchronize on `device`: the barrier bracket of a timed region (chm_eval itself returns after its stream drained). */
 int chm_device_synchronize(int32_t device);
 
@@ -270,6 +276,31 @@ int chm_last_timing(chm_like* like, chm_sel* sel, double ms[8]);
  * uniform, a grid step of more than 15/32 kernel widths, more than 1024 grid points inside the mask).  Both
  * kernels compute the same sums; the tests use the count to know which one they are looking at.                                          */
 int chm_like_full_general_pixels(chm_like* like, int32_t nb, int64_t* count);
+
+/* Evaluation options of a handle (a clone starts with its source's).  The reference steers its evaluation through constructor arguments of
+ * the jitted object alone (CHIMERA/likelihood.py:48-62 are jit-static); this library likewise reads NO environment variable -- what a call
+ * computes, and on which streams, follows from the handle.  A call that carries both handles uses the options of `like`.
+ *   CHM_OPT_SERIAL        1: every kernel of a call on one stream (per-kernel timings without overlap)
+ *   CHM_OPT_GROUPS        event groups alternating between two streams: 0 automatic (one per 250 events, at most 8, for calls of more than
+ *                         8 draws), 1 one group, n <= 16
+ *   CHM_OPT_FUSED         the fused event kernel (one block per (event, draw): samples, statistics, histograms, KDE, integrand; results equal
+ *                         to the separate kernels' to rounding, ~1e-15 per event): 0 never (default), 1 calls of <= 8 draws, 2 every call
+ *   CHM_OPT_TIMING        0 no timing events in the streams, 1 default, 2 per-kernel events also under a communicator / with event groups
+ *   CHM_OPT_GRAPH_MAX_NB  calls of at most this many draws without per-event outputs are replayed from a HIP graph (default 8; 0: never)
+ *   CHM_OPT_SPIN_WAIT     1 (default): calls of <= 8 draws poll their stream for completion instead of sleeping on an interrupt
+ * Options >= 100 select other kernels for the same quantity, launch geometries or switch a safeguard off (CHM_OPT_DIAG_NO_DENSE_NODE gives
+ * WRONG results for weights spanning many decades): they exist for same-box A/B runs and for the tests that compare code paths, and are
+ * refused (CHM_E_ARG) unless the library was built with -DCHM_DIAG -- chm_diag_build() tells which build is loaded.                      */
+enum {
+  CHM_OPT_SERIAL = 1, CHM_OPT_GROUPS = 2, CHM_OPT_FUSED = 3, CHM_OPT_TIMING = 4, CHM_OPT_GRAPH_MAX_NB = 5, CHM_OPT_SPIN_WAIT = 6,
+  CHM_OPT_DIAG_FULL_CHAIN = 100, CHM_OPT_DIAG_NO_DENSE_NODE = 101, CHM_OPT_DIAG_MARG_GENERIC = 102, CHM_OPT_DIAG_SAMPLES_GENERIC = 103,
+  CHM_OPT_DIAG_SELECTION_GENERIC = 104, CHM_OPT_DIAG_NO_GRID_PREP = 105, CHM_OPT_DIAG_ZF_FULL = 106, CHM_OPT_DIAG_KDE_IPW = 107,
+  CHM_OPT_DIAG_SAMP_CPB = 108, CHM_OPT_DIAG_SELF_BLOCKS = 109, CHM_OPT_DIAG_FEW_NB = 110, CHM_OPT_DIAG_NO_ZERO_COPY = 111,
+  CHM_OPT_DIAG_NO_ZF_SEL = 112, CHM_OPT_DIAG_HOST_PROF = 113
+};
+int chm_like_set_option(chm_like* like, int32_t option, int64_t value);
+int chm_sel_set_option(chm_sel* sel, int32_t option, int64_t value);
+int chm_diag_build(void);                                   /* 1: built with -DCHM_DIAG (diagnostic options, CHM_* environment defaults) */
 
 #ifdef __cplusplus
 }

@@ -230,7 +230,7 @@ def test_sharded_partials_add_up(cfg_pix, kind):
 def test_event_groups_on_two_streams_give_the_one_lane_values(kind):
   """[r3] Shards of >= 500 events are evaluated in event groups that alternate between two streams when a call carries more than 8 draws
   (the sample stage of one group beside the GW kernel of the previous one).  The values must be those of the same call with one group
-  (CHM_GROUPS=1, read per call), bit for bit -- every event's log-likelihood and the hyper-likelihood -- and agree with the C restatement."""
+  (set_option('groups', 1)), bit for bit -- every event's log-likelihood and the hyper-likelihood -- and agree with the C restatement."""
   from oracle import oracle_c as OC
   pix = kind is not None
   cfg, ev, inj = H.small_config(E=640, S=96, P=3, Z=40 if kind != 'full' else 400, I=4000, seed=31, ragged=True, pixelated=pix)
@@ -238,11 +238,9 @@ def test_event_groups_on_two_streams_give_the_one_lane_values(kind):
   lams = [dict(H0=float(h)) for h in np.linspace(62., 78., 11)]
   pops = [like.population.update(**l) for l in lams]
   grouped = like._eval(pops, want=('log_like_evs',))
-  os.environ['CHM_GROUPS'] = '1'
-  try:
-    one = like._eval(pops, want=('log_like_evs',))
-  finally:
-    del os.environ['CHM_GROUPS']
+  like.set_option('groups', 1)
+  one = like._eval(pops, want=('log_like_evs',))
+  like.set_option('groups', 0)
   np.testing.assert_array_equal(grouped['log_like_evs'], one['log_like_evs'])
   np.testing.assert_array_equal(grouped['log_hyper'], one['log_hyper'])
   np.testing.assert_array_equal(like.batch(lams), one['log_hyper'])
@@ -260,7 +258,8 @@ def test_full_mode_sample_stationary_and_general_kernels(case):
   start at a later chunk -- the 'waiting' path -- and leave the 37-width window again); a grid jittered by 1e-7 of its step (not uniform:
   general kernel); 4500 samples per event (more than a thread block keeps in registers: walked in two sets); a 60-point grid with narrow kernels
   (a chunk spans > 15 widths: general kernel, one exp per pair); a 5000-point grid (> 1024 points inside the mask: general kernel).  Every case against the NumPy oracle (all pairs, one exp each) to the stated
-  1e-9, with the kernel that ran checked through chm_like_full_general_pixels, and the two kernels against each other."""
+  1e-9, with the kernel that ran checked through chm_like_full_general_pixels (the two kernels against each other: tests/test_zz_variant_builds.py,
+  which needs the diagnostic build of the library)."""
   kw = dict(E=3, S=700, P=3, Z=900, I=1500, seed=41)
   like_kw = {}
   if case == 'narrow_kernels':
@@ -281,34 +280,13 @@ def test_full_mode_sample_stationary_and_general_kernels(case):
   like_p, _, _ = H.build_product(ev, inj, kind='full', like_kw=like_kw)
   lam = dict(H0=69.)
   _compare(like_p, like_o, lam, cfg['E'])
-  res = like_p._eval([like_p.population.update(**lam)], want=('log_like_evs',))
+  like_p._eval([like_p.population.update(**lam)], want=('log_like_evs',))
   general = like_p.full_general_pixels(1)
   npix = int(np.sum(ev['neff_pixels']))
   if case in ('wide_kernels', 'narrow_kernels', 'many_samples'):
     assert general == 0, (case, general, npix)
   else:
     assert general == npix, (case, general, npix)
-  os.environ['CHM_FULL_CHAIN'] = '0'
-  try:
-    ref = like_p._eval([like_p.population.update(**lam)], want=('log_like_evs',))      # general kernel only
-  finally:
-    del os.environ['CHM_FULL_CHAIN']
-  H.assert_loglike_close(res['log_like_evs'][0], ref['log_like_evs'][0], rtol=1e-11, atol=1e-11)
-
-
-def test_k_tables_runs_with_a_private_segment_at_1024_threads():
-  """[r3] Round 2 held k_tables to zero scratch after builds that spilled two registers at 1024 threads per block died with
-  HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION.  Builds of the kernel that DO use scratch (64 B per lane, forced) -- the short-table variant
-  at 1024 threads beside 33 KB static + dynamic LDS, the long-table variant at 512 and at 1024 threads -- run and reproduce the default
-  build's tables and likelihoods (scripts/probe_tables_scratch.py, each variant in its own process): the private segment at that block
-  size is not the cause."""
-  import subprocess, sys
-  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-  for name, flags in (('ts512', ['-DCHM_TABLES_FORCE_SCRATCH=6']), ('ts1024', ['-DCHM_TABLES_LONG_NT=1024', '-DCHM_TABLES_FORCE_SCRATCH=6'])):
-    subprocess.check_call(['bash', os.path.join(root, 'scripts', 'build_variant.sh'), name] + flags, cwd=root)
-  p = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'probe_tables_scratch.py')], cwd=root, capture_output=True, text=True, timeout=600)
-  assert p.returncode == 0, p.stdout + p.stderr
-  assert 'ts512: rc 0' in p.stdout and 'ts1024: rc 0' in p.stdout, p.stdout
 
 
 def test_rccl_single_rank_communicator(cfg_pix):
@@ -866,9 +844,9 @@ def _decades_case():
 def test_standard_marginalized_kernel_takes_the_dense_sum_where_the_prefix_differences_are_rounding():
   """The production GW kernel (binning, cut_grid set, marginalized: kde_sub_item) on weights spanning 60 decades: nodes whose bins in
   reach hold < 1e-4 of the weight below them take the reference's dense kernel sum (math.py:77-81) over the pixel's samples, so
-  log L_i (-41 ... -49 here) agrees with the oracle to the stated tolerance; with the fallback switched off (CHM_NO_DENSE_NODE=1,
-  diagnostics) the same events come out wrong, i.e. the case does exercise the limit of the prefix-sum form."""
-  import os
+  log L_i (-41 ... -49 here) agrees with the oracle to the stated tolerance.  (That the same events come out wrong with the fallback
+  switched off -- i.e. that the case does exercise the limit of the prefix-sum form -- is checked on the diagnostic build of the library,
+  tests/test_zz_variant_builds.py: the release library has no such switch.)"""
   cfg, ev, inj = _decades_case()
   like_o, _, _ = H.build_oracle(ev, inj)
   with np.errstate(all='ignore'):
@@ -877,15 +855,12 @@ def test_standard_marginalized_kernel_takes_the_dense_sum_where_the_prefix_diffe
   like_p, _, _ = H.build_product(ev, inj)
   rp = like_p.compute_all(H0=70.)
   H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
+  like_p.set_option('fused', 2)                              # the fused event kernel applies the same bound and redo (chm_fused.h)
+  rf = like_p.compute_all(H0=70.)
+  H.assert_loglike_close(rf[0], ro[0], rtol=RTOL_L, atol=1e-9)
+  with pytest.raises(ValueError):                             # the release library refuses the diagnostic switch
+    like_p.set_option('diag_no_dense_node', 1)
   like_p.close()
-  os.environ['CHM_NO_DENSE_NODE'] = '1'
-  try:
-    like_q, _, _ = H.build_product(ev, inj)
-    rq = like_q.compute_all(H0=70.)
-    like_q.close()
-  finally:
-    del os.environ['CHM_NO_DENSE_NODE']
-  assert np.max(np.abs(rq[0] - ro[0])) > 1e-3                 # the prefix differences alone lose these events
 
 
 def test_nan_tail_of_the_distance_table_and_the_scan_search():
