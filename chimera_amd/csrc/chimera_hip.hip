@@ -125,6 +125,8 @@ struct Ctx {
   DevParams* h_params = nullptr;       // pinned
   double *zt = nullptr, *It = nullptr, *dLt = nullptr, *mg = nullptr, *cdf = nullptr, *tmp = nullptr;
   double* rec = nullptr;               // (nb, TcMax, 4) node records of the fast sample stage (k_tables)
+  double *zt_c = nullptr, *lz_c = nullptr;   // (TcMax) z_grid_interp and log(1 + z) of its nodes for (zc_zmax, zc_Tc): draw-independent (k_znodes)
+  double zc_zmax = -1.; int zc_Tc = 0;
   double* d_evpart = nullptr;          // (nb, nblk_ev) block sums of log L_i
   int evpart_cap = 0;
   double* d_partials = nullptr;        // (nb,3)
@@ -165,6 +167,7 @@ static int ctx_init(Ctx& c, int device) {
 static void ctx_free_tables(Ctx& c) {
   (void)hipFree(c.d_params); (void)hipHostFree(c.h_params);
   (void)hipFree(c.zt); (void)hipFree(c.It); (void)hipFree(c.dLt); (void)hipFree(c.mg); (void)hipFree(c.cdf); (void)hipFree(c.tmp); (void)hipFree(c.rec); c.rec = nullptr;
+  (void)hipFree(c.zt_c); (void)hipFree(c.lz_c); c.zt_c = c.lz_c = nullptr; c.zc_zmax = -1.; c.zc_Tc = 0;
   (void)hipFree(c.d_partials); (void)hipFree(c.d_out3); (void)hipHostFree(c.h_out); (void)hipFree(c.d_evpart);
   c.d_evpart = nullptr; c.evpart_cap = 0;
   c.d_params = nullptr; c.h_params = nullptr; c.zt = c.It = c.dLt = c.mg = c.cdf = c.tmp = nullptr;
@@ -203,6 +206,8 @@ static int ctx_ensure(Ctx& c, int nb, int Tc, int Tm) {
   HIPCHK(hipMalloc(&c.cdf, sizeof(double) * nbn * Tmn));
   HIPCHK(hipMalloc(&c.tmp, sizeof(double) * nbn * ((size_t)Tcn + Tmn)));
   HIPCHK(hipMalloc(&c.rec, sizeof(double) * nbn * (size_t)Tcn * 4));
+  HIPCHK(hipMalloc(&c.zt_c, sizeof(double) * Tcn));
+  HIPCHK(hipMalloc(&c.lz_c, sizeof(double) * Tcn));
   HIPCHK(hipMalloc(&c.d_partials, sizeof(double) * nbn * 3));
   HIPCHK(hipMalloc(&c.d_out3, sizeof(double) * nbn * 3));
   HIPCHK(hipHostMalloc(&c.h_out, sizeof(double) * nbn * 6));
@@ -259,7 +264,8 @@ static int ctx_tables_host(Ctx& c, const chm_params* params, int nb, const doubl
 // zero_copy (few draws per call -- the scalar call): k_tables reads the pinned host copy of the parameters itself instead of a copy
 // node in front of it (one graph node and ~8 us of stream time less)
 static int ctx_tables_enqueue(Ctx& c, int nb, int Tc, int Tm, LutDesc lutA = LutDesc{}, LutDesc lutB = LutDesc{},
-                              const double* tab_zt = nullptr, const double* tab_dLt = nullptr, bool zero_copy = false) {
+                              const double* tab_zt = nullptr, const double* tab_dLt = nullptr, bool zero_copy = false, bool znodes = false) {
+  const double* ztc = znodes ? c.zt_c : nullptr; const double* lzc = znodes ? c.lz_c : nullptr;
   const size_t tl = sizeof(double) * 3 * (size_t)(Tc > Tm ? Tc : Tm);
   if (tl > 112 * 1024) zero_copy = false;                   // the long-table variant of k_tables keeps the copy node
   const DevParams* hsrc = zero_copy ? c.h_params : nullptr;
@@ -267,9 +273,9 @@ static int ctx_tables_enqueue(Ctx& c, int nb, int Tc, int Tm, LutDesc lutA = Lut
   if (tl <= 112 * 1024) {                                   // + 33 KB of static LDS (build_lut scratch, parameter block)
     static size_t tl_allowed = 0;                             // the kernel also holds 33 KB of static LDS: ask as soon as the sum passes 48 KB
     if (tl > 14 * 1024 && tl > tl_allowed) { (void)hipFuncSetAttribute((const void*)k_tables<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl); tl_allowed = tl; }
-    hipLaunchKernelGGL(k_tables<true>, dim3(nb, 2), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt, hsrc);
+    hipLaunchKernelGGL(k_tables<true>, dim3(nb, 3), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt, hsrc, ztc, lzc);
   } else {
-    hipLaunchKernelGGL(k_tables<false>, dim3(nb, 2), dim3(CHM_TABLES_LONG_NT), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt, hsrc);
+    hipLaunchKernelGGL(k_tables<false>, dim3(nb, 2), dim3(CHM_TABLES_LONG_NT), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt, hsrc, ztc, lzc);
   }
   HIPCHK(hipGetLastError());
   return CHM_OK;
@@ -1003,6 +1009,12 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     for (int b = 1; b < nb; b++) if (params[b].z_max != params[0].z_max || params[b].z_grid_res != params[0].z_grid_res) zg_use = false;
     if (zg_use && (like->zg_zmax != params[0].z_max || like->zg_Tc != params[0].z_grid_res)) zg_make = true;
   }
+  // [r4] the nodes of z_grid_interp and their log(1 + z) depend on (z_max, z_grid_res) alone: formed once by k_znodes, read by k_tables while every
+  // draw of a call has the pair they were made for (an H0 scan, a chain); re-made when the pair changes
+  bool zc_use = !td.zt, zc_make = false;
+  for (int b = 1; b < nb && zc_use; b++) if (params[b].z_max != params[0].z_max || params[b].z_grid_res != params[0].z_grid_res) zc_use = false;
+  if (zc_use && !(params[0].z_max > 0.)) zc_use = false;
+  if (zc_use && (c.zc_zmax != params[0].z_max || c.zc_Tc != params[0].z_grid_res)) zc_make = true;
   // ---- graph bookkeeping: the key lists everything the captured launch arguments depend on
   std::vector<long long> key;
   bool capturing = false;
@@ -1011,7 +1023,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
             Tc_host, Tm_host, use_fast, lutA.key0, lutA.nk, lutA.cap, (long long)lds_fast, params[0].mass_model, out->partials != nullptr,
             sel_fast, lutB.key0, lutB.nk, lutB.cap, (long long)lds_sel, (long long)(intptr_t)lutB.lut, fuse_sel,
             (long long)(intptr_t)c.d_evpart, (long long)(intptr_t)(like ? like->L.ws_z : nullptr), (long long)(intptr_t)(sel ? sel->S.partial : nullptr),
-            zg_use, zg_make, (long long)(intptr_t)comm, use_fused, (long long)lds_fused, FDc.cap_rec, FDc.cap_keys, FDc.cap_m };
+            zg_use, zg_make, (long long)(intptr_t)comm, use_fused, (long long)lds_fused, FDc.cap_rec, FDc.cap_keys, FDc.cap_m, zc_use, zc_make };
     if (c.gexec && key == c.gkey) {                           // replay
       const double hp1 = host_prof_on() ? now_us() : 0.;
       HIPCHK(hipGraphLaunch(c.gexec, sA));
@@ -1054,7 +1066,12 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   // an error inside a capture must end it before returning
   struct CaptureGuard { hipStream_t s; bool* on; ~CaptureGuard() { if (*on) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); } } } cguard{sA, &capturing};
   if (timing) HIPCHK(hipEventRecord(c.ev[0], sA));
-  rc = ctx_tables_enqueue(c, nb, Tc_host, Tm_host, use_fast ? lutA : LutDesc{}, sel_fast ? lutB : LutDesc{}, td.zt, td.dLt, zero_copy); if (rc) return rc;
+  if (zc_make) {
+    hipLaunchKernelGGL(k_znodes, dim3((params[0].z_grid_res + 255) / 256), dim3(256), 0, sA, params[0].z_max, params[0].z_grid_res, c.zt_c, c.lz_c);
+    HIPCHK(hipGetLastError());
+    c.zc_zmax = params[0].z_max; c.zc_Tc = params[0].z_grid_res;
+  }
+  rc = ctx_tables_enqueue(c, nb, Tc_host, Tm_host, use_fast ? lutA : LutDesc{}, sel_fast ? lutB : LutDesc{}, td.zt, td.dLt, zero_copy, zc_use); if (rc) return rc;
   if (zg_make) {                                            // the table of draw 0 stands for all of them
     const size_t n = (size_t)like->L.E * like->L.Z;
     hipLaunchKernelGGL(k_grid_prep, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, sA, like->L.E, like->L.Z, like->L.z_grids,

@@ -179,13 +179,23 @@ DEVFN double lut_key_floor(int key) { return __hiloint2double(key << LUT_SHIFT, 
 #ifdef CHM_TABLES_PROF
 #define TS_INIT long long ts_[9]; int ts_n = 0
 #define TS(i) do { __syncthreads(); ts_[ts_n++] = wall_clock64(); } while (0)
-#define TS_PRINT do { if (t == 0 && b == 0) printf("[k_tables phases, x10 ns] nodes+1/E %lld | cumtrapz %lld | dL %lld | flags + index tables + records + fR %lld\n", \
-  ts_[1] - ts_[0], ts_[2] - ts_[1], ts_[3] - ts_[2], ts_[4] - ts_[3]); } while (0)
+#define TS_PRINT do { if (t == 0 && b == 0) printf("[k_tables phases, x10 ns] parameter block %lld | nodes+1/E %lld | cumtrapz %lld | dL %lld | flags + index tables + records + fR %lld\n", \
+  ts_[0] - ts_k0, ts_[1] - ts_[0], ts_[2] - ts_[1], ts_[3] - ts_[2], ts_[4] - ts_[3]); } while (0)
+#define TS_PRINT_M do { if (t == 0 && b == 0) printf("[k_tables mass block, x10 ns] parameter block %lld | constants (thread 0) %lld | nodes + secondary %lld | cumtrapz %lld | primary %lld | norm %lld\n", \
+  ts_[0] - ts_k0, ts_[1] - ts_[0], ts_[2] - ts_[1], ts_[3] - ts_[2], ts_[4] - ts_[3], ts_[5] - ts_[4]); } while (0)
 #else
 #define TS_INIT
 #define TS(i)
 #define TS_PRINT
+#define TS_PRINT_M
 #endif
+// node i of z_grid_interp = [0] U logspace(-10, log10 z_max, Tc - 1) (cosmo.py:43-46), lzmax = log10(z_max)
+DEVFN double znode_at(double lzmax, int Tc, int i) { return i == 0 ? 0. : chm_pow10(jnp_linspace_at(-10., lzmax, Tc - 1, i - 1)); }
+// k_znodes: the nodes and their log(1 + z) for one (z_max, Tc) -- what k_tables otherwise re-forms for every draw of every call
+__global__ void __launch_bounds__(256) k_znodes(double z_max, int Tc, double* zt_c, double* lz_c) {
+  const double lzmax = log10(z_max);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < Tc; i += gridDim.x * 256) { const double z = znode_at(lzmax, Tc, i); zt_c[i] = z; lz_c[i] = log1p(z); }
+}
 // (the long-table variant, LDS_ARR = false, runs 512-thread blocks: at 1024 threads it sits at the 128-register limit and any spill there
 //  has ended in a memory-aperture fault on the MI355X boxes, see tests/test_abi_and_host.py)
 #ifndef CHM_TABLES_LONG_NT
@@ -194,8 +204,12 @@ DEVFN double lut_key_floor(int key) { return __hiloint2double(key << LUT_SHIFT, 
 template <bool LDS_ARR>
 __global__ void __launch_bounds__(LDS_ARR ? 1024 : CHM_TABLES_LONG_NT) k_tables(DevParams* params, double* zt_all, double* It_all,
                                                   double* dLt_all, double* mg_all, double* cdf_all, double* tmp_all, int TcMax, int TmMax,
-                                                  LutDesc lutA, LutDesc lutB, double* rec_all, const double* tab_zt, const double* tab_dLt, const DevParams* hsrc) {
+                                                  LutDesc lutA, LutDesc lutB, double* rec_all, const double* tab_zt, const double* tab_dLt, const DevParams* hsrc,
+                                                  const double* zt_c, const double* lz_c) {
   extern __shared__ double larr[];
+#ifdef CHM_TABLES_PROF
+  const long long ts_k0 = wall_clock64();
+#endif
   __shared__ double sh[32];
   __shared__ int lut_ks[LUT_MAXKEYS + 1];           // searchsorted answer of every key of the direct-index tables
   __shared__ int s_int[8];                          // [0] first non-finite node of the integral, [1], [2] widest key of table A / B, [3], [4] brackets of the completeness limits
@@ -234,11 +248,17 @@ __global__ void __launch_bounds__(LDS_ARR ? 1024 : CHM_TABLES_LONG_NT) k_tables(
   double* g_cdf = cdf_all + (size_t)b * TmMax;
   double* g_tmp = tmp_all + (size_t)b * (TcMax + TmMax) + (blockIdx.y == 0 ? 0 : TcMax);
 
-  if (blockIdx.y == 0) {
+  // [r4] LDS_ARR launches run TWO cosmology blocks per draw (grid (nb, 3)): both form the z nodes, the running integral and the dL table in their
+  // own LDS (the same bits); block 0 (doA) stores them and goes on to what the sample stage waits for -- its direct-index table and the
+  // node records --, block 2 (doB) to the rest: the per-draw flags, the injections' index table, fR.  One block did all of it in 17 us, 8 of them
+  // in this tail (1024 threads on one CU are bound by instruction issue, 255 CUs stand idle).  Grid (nb, 2): block 0 does both (doA = doB).
+  const bool split = LDS_ARR && gridDim.y == 3;
+  const bool doA = blockIdx.y == 0, doB = split ? blockIdx.y == 2 : true;
+  if (blockIdx.y != 1) {
     double* zt = LDS_ARR ? larr : g_zt;
     double* tmp = LDS_ARR ? larr + Tc : g_tmp;
     double* It = LDS_ARR ? larr + 2 * Tc : g_It;
-    if (t == 0) {                                   // rate constants (used by later kernels only)
+    if (t == 0 && doA) {                            // rate constants (used by later kernels only)
       double g = P.r[0], k = P.r[1], zp = P.r[2], zmax = P.r[3];
       Pg.md_norm = 1. + pow(1. + zp, -g - k);                             // rate.py:114
       Pg.tpl_rate_norm = (pow(1. + zmax, g + 1.) - 1.) / (g + 1.);        // rate.py:105
@@ -248,9 +268,14 @@ __global__ void __launch_bounds__(LDS_ARR ? 1024 : CHM_TABLES_LONG_NT) k_tables(
     const double lzmax = log10(P.z_max);
     for (int i = t; i < Tc; i += nt) {
       // plug-in cosmology (chm_tab): the caller's z_grid_interp; 1/E is not needed (the Jacobian and p_bkg come tabulated too)
-      double z = tab_zt ? tab_zt[(size_t)b * Tc + i] : (i == 0 ? 0. : chm_pow10(jnp_linspace_at(-10., lzmax, Tc - 1, i - 1)));
+      // [r4] zt_c: the nodes of this (z_max, Tc) as k_znodes formed them for an earlier call (the same expression: the same bits) -- the grid
+      // depends on nothing else, and an H0 scan or a chain changes neither
+      double z = tab_zt ? tab_zt[(size_t)b * Tc + i] : (zt_c ? zt_c[i] : znode_at(lzmax, Tc, i));
       zt[i] = z;
-      tmp[i] = tab_zt ? 0. : 1. / E_at_z(P, z);
+      // (a cosmological constant -- w0 = -1, wa = 0 -- needs neither w(z)'s quotient nor the power: the same sum with de = 1, the same bits)
+      const double zp1 = 1. + z, z2 = zp1 * zp1;
+      const double Ez = de_needs_log(P) ? E_at_z(P, z) : sqrt(P.Om0 * (z2 * zp1) + P.Or0 * (z2 * z2) + P.Ok0 * z2 + P.Ode0 * 1.);
+      tmp[i] = tab_zt ? 0. : 1. / Ez;
     }
     if (LDS_ARR) __syncthreads(); else gsync();
     TS(1);
@@ -268,9 +293,9 @@ __global__ void __launch_bounds__(LDS_ARR ? 1024 : CHM_TABLES_LONG_NT) k_tables(
       if (i == Tc - 1) { double dx = zt[i] - zt[i - 1]; ii = It[i - 1] + (dx / dx) * (It[i] - It[i - 1]); }
       else ii = It[i] + (0. / (zt[i + 1] - zt[i])) * (It[i + 1] - It[i]);
       double dl = tab_dLt ? tab_dLt[(size_t)b * Tc + i] : dL_from_dCt(P, dCt_from_dCr(P, P.dH * ii), z);
-      dLt[i] = dl;
+      if (doA) dLt[i] = dl;
       tmp[i] = dl;
-      if (LDS_ARR) { g_zt[i] = z; g_It[i] = It[i]; }
+      if (LDS_ARR && doA) { g_zt[i] = z; g_It[i] = It[i]; }
     }
     if (LDS_ARR) __syncthreads(); else gsync();
     TS(3);
@@ -283,10 +308,10 @@ __global__ void __launch_bounds__(LDS_ARR ? 1024 : CHM_TABLES_LONG_NT) k_tables(
     {
       int bad = 0;
       for (int i = t; i < Tc; i += nt) {
-        if (!(fabs(It[i]) <= 1.7976931348623157e308)) atomicMin(&s_int[0], i);
+        if (doB && !(fabs(It[i]) <= 1.7976931348623157e308)) atomicMin(&s_int[0], i);
         if (i > 0) bad |= ((tmp[i] < tmp[i - 1]) || (tmp[i] != tmp[i])) ? 1 : 0;
       }
-      const int nkA = lutA.nk > 0 ? lutA.nk + 1 : 0, nkB = lutB.nk > 0 ? lutB.nk + 1 : 0;      // entries of each table (keys + 1)
+      const int nkA = (doA && lutA.nk > 0) ? lutA.nk + 1 : 0, nkB = (doB && lutB.nk > 0) ? lutB.nk + 1 : 0;      // entries of each table (keys + 1) this block makes
       int* ksA = lut_ks; int* ksB = lut_ks + nkA;
       auto search = [&](const LutDesc& D, int* ks, int n) {
         unsigned short* lut = D.lut + (size_t)b * n;
@@ -298,28 +323,38 @@ __global__ void __launch_bounds__(LDS_ARR ? 1024 : CHM_TABLES_LONG_NT) k_tables(
       const bool lut_both = nkA + nkB <= LUT_MAXKEYS + 1;         // both tables' answers fit the scratch (else B follows A, below)
       if (nkA) search(lutA, ksA, nkA);
       if (nkB && lut_both) search(lutB, ksB, nkB);
-      if (rec_all) {
+      if (rec_all && doA) {
         double* rec = rec_all + (size_t)b * TcMax * 4;
         for (int i = t; i < Tc; i += nt) {
           const double x0 = tmp[i], f0 = zt[i];
           double sl = 0.;
           if (i + 1 < Tc) { const double dx = tmp[i + 1] - x0; sl = (fabs(dx) <= 4.930380657631324e-32) ? 0. : (zt[i + 1] - f0) / dx; }
-          rec[4 * i] = x0; rec[4 * i + 1] = f0; rec[4 * i + 2] = sl; rec[4 * i + 3] = log1p(f0);
+          rec[4 * i] = x0; rec[4 * i + 1] = f0; rec[4 * i + 2] = sl; rec[4 * i + 3] = lz_c ? lz_c[i] : log1p(f0);
         }
       }
-      for (int i = t + 1; i < Tc; i += nt) {                      // interval (i-1, i): zt[i-1] <= x < zt[i]  (searchsorted right), as block_interp
+      if (doB) for (int i = t + 1; i < Tc; i += nt) {             // interval (i-1, i): zt[i-1] <= x < zt[i]  (searchsorted right), as block_interp
         if (zt[i - 1] <= P.zc0 && (P.zc0 < zt[i] || i == Tc - 1)) s_int[3] = i;
         if (zt[i - 1] <= P.zc1 && (P.zc1 < zt[i] || i == Tc - 1)) s_int[4] = i;
       }
       bad = __syncthreads_or(bad);                                // barrier 1
+#ifdef CHM_TABLES_PROF
+      const long long ts_b1 = wall_clock64();
+#endif
       auto spans = [&](const int* ks, int n, int slot) {
         int lm = 0;
         for (int q = t; q + 1 < n; q += nt) lm = max(lm, ks[q + 1] - ks[q]);
-        if (lm > 0) atomicMax(&s_int[slot], lm);
+        // [r4] one LDS atomic per wave (a thousand threads on one cell took 2.3 of the kernel's 17 us)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) lm = max(lm, __shfl_xor(lm, o, 64));
+        if ((t & 63) == 0 && lm > 0) atomicMax(&s_int[slot], lm);
       };
       if (nkA) spans(ksA, nkA, 1);
       if (nkB && lut_both) spans(ksB, nkB, 2);
       __syncthreads();                                            // barrier 2
+#ifdef CHM_TABLES_PROF
+      const long long ts_b2 = wall_clock64();
+      if (t == 0 && b == 0) printf("[k_tables last phase, x10 ns] searches + records + brackets %lld | spans %lld\n", ts_b1 - ts_[3], ts_b2 - ts_b1);
+#endif
       auto info = [&](const LutDesc& D, const int* ks, int n, int slot) {
         const int first = ks[0], last = ks[n - 1];
         const int i_lo = first > 0 ? first - 1 : 0, i_hi = last + 1 < Tc ? last + 1 : Tc - 1;
@@ -336,14 +371,16 @@ __global__ void __launch_bounds__(LDS_ARR ? 1024 : CHM_TABLES_LONG_NT) k_tables(
         return f;
       };
       if (t == 0) {
-        const int j = s_int[0];
-        Pg.z_bad = j < 0x7fffffff ? zt[j > 0 ? j - 1 : 0] : __builtin_inf();
-        Pg.dl_sorted = bad ? 0. : 1.;
         if (nkA) info(lutA, ksA, nkA, 1);
         if (nkB && lut_both) info(lutB, ksB, nkB, 2);
-        const double v0 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * interp_at(P.zc0, s_int[3])));
-        const double v1 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * interp_at(P.zc1, s_int[4])));
-        Pg.fR = P.fR_given != 0. ? P.fR : v1 - v0;      // a plug-in completeness hands its own fR(cosmo) over (chm_tab.fR)
+        if (doB) {
+          const int j = s_int[0];
+          Pg.z_bad = j < 0x7fffffff ? zt[j > 0 ? j - 1 : 0] : __builtin_inf();
+          Pg.dl_sorted = bad ? 0. : 1.;
+          const double v0 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * interp_at(P.zc0, s_int[3])));
+          const double v1 = Vc_from_dCt(P, dCt_from_dCr(P, P.dH * interp_at(P.zc1, s_int[4])));
+          Pg.fR = P.fR_given != 0. ? P.fR : v1 - v0;    // a plug-in completeness hands its own fR(cosmo) over (chm_tab.fR)
+        }
       }
       if (nkB && !lut_both) {                                     // > 64 octaves of distances in all: the second table on its own
         __syncthreads();
@@ -363,16 +400,26 @@ __global__ void __launch_bounds__(LDS_ARR ? 1024 : CHM_TABLES_LONG_NT) k_tables(
     double* mg = LDS_ARR ? larr : g_mg;
     double* tmp = LDS_ARR ? larr + Tm : g_tmp;
     double* cdf = LDS_ARR ? larr + 2 * Tm : g_cdf;
+    // [r4] the transcendental pieces of the constants by the first lanes of FOUR waves side by side (one thread formed them one after the
+    // other in 3 of the block's 12 us): sh[24..29]; thread 0 assembles them below -- the same calls on the same arguments, the same bits
+    if (P.mass_model == 2) {
+      const double mu = P.m[6], sg = P.m[7], hi = mu + 5. * sg;
+      if (t == 128) sh[24] = erf((hi - mu) / (sg * sqrt(2.)));
+      if (t == 192) sh[25] = erf((P.m[0] - mu) / (sg * sqrt(2.)));
+      if (t == 256) sh[26] = -0.5 * chm_log(2. * CHM_PI) - chm_log(sg);
+    }
+    if (t == 320) { sh[27] = chm_log(P.m[0]); sh[28] = chm_log(P.m[1]); }
+    if (t == 64) { sh[30] = log10(P.m[0]); sh[31] = log10(P.m[1]); }
+    if (t == 0 && P.mass_model == 2) sh[29] = tpl_cdf(-P.m[3], P.m[0], P.m[1]);      // mass.py:301
+    __syncthreads();
     if (t == 0) {                                   // mass-model constants: into the LDS copy (used below) and to global memory
       double m_low = P.m[0], m_high = P.m[1];
       if (P.mass_model == 2) {
         double mu = P.m[6], sg = P.m[7];
-        Ps.plp_plnorm = tpl_cdf(-P.m[3], m_low, m_high);                  // mass.py:301
+        Ps.plp_plnorm = sh[29];
         Ps.tg_hi = mu + 5. * sg;                                          // mass.py:302
-        double max_point = (Ps.tg_hi - mu) / (sg * sqrt(2.));
-        double min_point = (m_low - mu) / (sg * sqrt(2.));
-        Ps.tg_norm = 0.5 * erf(max_point) - 0.5 * erf(min_point);         // mass.py:272-274
-        Ps.g_c0 = -0.5 * chm_log(2. * CHM_PI) - chm_log(sg);                      // mass.py:268
+        Ps.tg_norm = 0.5 * sh[24] - 0.5 * sh[25];                         // mass.py:272-274
+        Ps.g_c0 = sh[26];                                                 // mass.py:268
         Ps.inv_plnorm = 1. / Ps.plp_plnorm; Ps.inv_tg_norm = 1. / Ps.tg_norm; Ps.inv_2s2 = 1. / (2. * (sg * sg));
         Pg.plp_plnorm = Ps.plp_plnorm; Pg.tg_hi = Ps.tg_hi; Pg.tg_norm = Ps.tg_norm; Pg.g_c0 = Ps.g_c0;
         Pg.inv_plnorm = Ps.inv_plnorm; Pg.inv_tg_norm = Ps.inv_tg_norm; Pg.inv_2s2 = Ps.inv_2s2;
@@ -383,30 +430,35 @@ __global__ void __launch_bounds__(LDS_ARR ? 1024 : CHM_TABLES_LONG_NT) k_tables(
         Ps.bpl_pl2 = tpl_notnorm(mb, -P.m[3], mb, m_high);
         Pg.bpl_mbreak = Ps.bpl_mbreak; Pg.bpl_pl1 = Ps.bpl_pl1; Pg.bpl_pl2 = Ps.bpl_pl2;
       }
-      Pg.lmg0 = chm_log(m_low);
-      Pg.inv_dlmg = (double)(P.Tm - 1) / (chm_log(m_high) - chm_log(m_low));
+      Pg.lmg0 = sh[27];
+      Pg.inv_dlmg = (double)(P.Tm - 1) / (sh[28] - sh[27]);
     }
     __syncthreads();
+    TS(1);
     // m_grid = logspace(log10 m_low, log10 m_high, Tm); cdf = cumtrapz(secondary(m_grid; m_high))   mass.py:45-49
-    const double l0 = log10(P.m[0]), l1 = log10(P.m[1]);
+    const double l0 = sh[30], l1 = sh[31];                    // log10(m_low), log10(m_high): formed once by thread 1 above
     for (int i = t; i < Tm; i += nt) {
       double m = i == 0 ? P.mg_first : (i == Tm - 1 ? P.mg_last : chm_pow10(jnp_linspace_at(l0, l1, Tm, i)));   // end nodes: host libm (DevParams)
       mg[i] = m;
       tmp[i] = secondary_notnorm(P, m, P.m[1]);
     }
     if (LDS_ARR) __syncthreads(); else gsync();
+    TS(2);
     block_cumtrapz(tmp, mg, cdf, Tm, sh);
     if (!LDS_ARR) gsync();
+    TS(3);
     // norm_p_m1 = trapz(primary(m_grid), m_grid) = 0.5 * sum(dx * (y1 + y0))             mass.py:50-52
     for (int i = t; i < Tm; i += nt) {
       tmp[i] = primary_notnorm(P, mg[i]);
       if (LDS_ARR) { g_mg[i] = mg[i]; g_cdf[i] = cdf[i]; }
     }
     if (LDS_ARR) __syncthreads(); else gsync();
+    TS(4);
     double acc = 0.;
     for (int k = t; k < Tm - 1; k += nt) acc += (mg[k + 1] - mg[k]) * (tmp[k + 1] + tmp[k]);
     acc = block_reduce<RED_SUM>(acc, sh);
     if (t == 0) { Pg.norm_p_m1 = 0.5 * acc; Pg.inv_norm_p_m1 = 1. / (0.5 * acc); Pg.cdf_last = cdf[Tm - 1]; }
+    TS(5); TS_PRINT_M;
   }
 }
 

@@ -49,7 +49,7 @@ def _vector_length(hyper_lambdas):
 
 class hyperlikelihood(object):
   def __init__(self, theta_gw_det, z_grids, population, selection_function=None, kind_p_gw3d=None, kernel='epan',
-               bw_method=None, cut_grid=2.0, binning=True, num_bins=200, pe_neff=2.0, comm=None, device=None):
+               bw_method=None, cut_grid=2.0, binning=True, num_bins=200, pe_neff=2.0, comm=None, device=None, scheme='data'):
     self.theta_gw_det = theta_gw_det
     self.population = population
     self.z_grids = np.ascontiguousarray(z_grids, dtype=np.float64)
@@ -63,6 +63,18 @@ class hyperlikelihood(object):
     self.pe_neff = pe_neff
     self.comm = comm
     self.device = (comm.device if comm is not None else _lib.default_device()) if device is None else device
+    # Parallel scheme of a likelihood with a communicator (the reference's MPIHyperLike, CHIMERA/parallel.py:13-160):
+    #   'data'    events and injections are sharded, every rank evaluates every draw on its shard, one all-reduce of 3 doubles per draw
+    #             (parallel.py:94-99, 366-376) -- for large catalogues;
+    #   'params'  every rank holds ALL events and injections and evaluates its own chunk of the DRAWS of a batch; the values are gathered
+    #             (parallel.py:258-278: zeros(nparams), own slice set, allreduce SUM) -- for catalogues too small to shard (a 12-event shard
+    #             is pure launch latency) under a vectorised sampler.
+    if scheme not in ('data', 'params'):
+      raise ValueError("hyperlikelihood: scheme must be 'data' or 'params'")
+    self.scheme = scheme
+    if scheme == 'params' and selection_function is not None and getattr(selection_function, 'comm', None) is not None \
+       and selection_function.comm.nranks > 1:
+      raise ValueError("hyperlikelihood: scheme='params' replicates the data -- build the selection function without a communicator")
 
     self.pixelated = True if self.theta_gw_det.pixels_opt_nsides is not None else False     # likelihood.py:79
     self.nevents = len(self.theta_gw_det.dL)
@@ -87,7 +99,7 @@ class hyperlikelihood(object):
       self._mode = self.kind_p_gw3d
     else:
       self._mode = '1d'
-    if comm is not None and comm.nranks > 1:
+    if comm is not None and comm.nranks > 1 and scheme == 'data':
       self._e0, self._e1 = chunk_bounds(self.nevents, comm.nranks, comm.rank)
     else:
       self._e0, self._e1 = 0, self.nevents
@@ -248,7 +260,7 @@ class hyperlikelihood(object):
     if 'partials' in want:
       res['partials'] = np.empty((nb, 3)); out.partials = _lib.dptr(res['partials'])
     sel = self.selection_function._handle() if (with_sel and self.selection_function is not None) else None
-    comm = self.comm if collective else None
+    comm = self.comm if (collective and self.scheme == 'data') else None      # 'params': replicas, nothing to reduce inside a call
     comm_h = getattr(comm, 'handle', None) if comm is not None else None                 # RCCL all-reduce inside chm_eval
     host_reduce = (comm is not None and comm_h is None and comm.nranks > 1 and hasattr(comm, 'allreduce_sum'))
     if host_reduce and 'partials' not in res:               # HostComm: the partial sums are reduced and combined on the host
@@ -385,8 +397,24 @@ class hyperlikelihood(object):
   def batch(self, list_of_hyper_lambdas):
     """log-hyperlikelihood of several draws in one launch sequence: array of len(list)."""
     lams = list(list_of_hyper_lambdas)
+    if self.scheme == 'params' and self.comm is not None and self.comm.nranks > 1:
+      return self._batch_over_params(lams)
+    return self._batch_local(lams)
+
+  def _batch_local(self, lams):
     m = max(1, int(self.max_draws_per_call))
     pack = (lambda ls: [self.population.update(**l) for l in ls]) if any(self._plugins) else self._params_array
     if len(lams) <= m:
       return self._eval(pack(lams))['log_hyper']
     return np.concatenate([self._eval(pack(lams[i:i + m]))['log_hyper'] for i in range(0, len(lams), m)])
+
+  def _batch_over_params(self, lams):
+    """The reference's 'params' scheme (CHIMERA/parallel.py:258-278): rank r evaluates the draws [r c, min((r + 1) c, n)), c = ceil(n / R), on
+    its full copy of the data; every rank then holds all n values (own slice in a vector of zeros, summed over the ranks)."""
+    n, R, r = len(lams), self.comm.nranks, self.comm.rank
+    per = (n + R - 1) // R
+    i0, i1 = min(r * per, n), min((r + 1) * per, n)
+    out = np.zeros(n)
+    if i0 < i1:
+      out[i0:i1] = self._batch_local(lams[i0:i1])
+    return np.asarray(self.comm.allreduce_sum(out)).reshape(n)

@@ -384,6 +384,40 @@ def test_two_ranks_share_one_gpu_through_the_host_communicator(tmp_path):
     np.testing.assert_allclose(r0[k], ref, rtol=1e-12)
 
 
+def _params_worker(rank, world, addr, outdir):
+  import os, sys
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  import chimera_amd as CH
+  from chimera_amd.parallel import HostComm, Rendezvous
+  from tests import helpers as HH
+  rd = Rendezvous(world, rank, address=addr, timeout=120.)
+  cfg, ev, inj = HH.small_config(E=9, S=300, P=4, Z=60, I=3001, seed=41, ragged=True)
+  comm = HostComm(world, rank, device=0, rendezvous=rd)
+  like0, pop, sel = HH.build_product(ev, inj)                # replicas: the selection function carries no communicator
+  like = CH.hyperlikelihood(like0.theta_gw_det, ev['z_grids'], pop, sel, kind_p_gw3d='marginalized', comm=comm, scheme='params')
+  lams = [dict(H0=float(h)) for h in np.linspace(62., 79., 5)]
+  out = np.concatenate([like.batch(lams), [like(H0=70.5)], like(H0=np.array([66., 67., 68.]))])
+  np.save(os.path.join(outdir, f'rank{rank}.npy'), out)
+  like.close(); sel.close()
+  rd.barrier()
+  rd.close()
+
+
+@pytest.mark.timeout(300)
+def test_params_scheme_two_replicas_share_one_gpu(tmp_path):
+  """[r4] scheme='params' (CHIMERA/parallel.py:258-278) end to end on the device: two processes, each with ALL events and injections on GPU 0,
+  evaluate their own chunk of the draws of a batch and gather the values over the host communicator -- every rank the single-process values,
+  bit for bit (each value is computed by exactly one rank)."""
+  _spawn(_params_worker, 2, (str(tmp_path / 'rdzv.sock'), str(tmp_path)))
+  r0, r1 = np.load(tmp_path / 'rank0.npy'), np.load(tmp_path / 'rank1.npy')
+  np.testing.assert_array_equal(r0, r1)
+  cfg, ev, inj = H.small_config(E=9, S=300, P=4, Z=60, I=3001, seed=41, ragged=True)
+  like, _, _ = H.build_product(ev, inj)
+  lams = [dict(H0=float(h)) for h in np.linspace(62., 79., 5)]
+  ref = np.concatenate([like.batch(lams), [like(H0=70.5)], like(H0=np.array([66., 67., 68.]))])
+  np.testing.assert_array_equal(r0, ref)
+
+
 def _rccl_worker(rank, world, addr, outdir):
   import os, sys
   sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

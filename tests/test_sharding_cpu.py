@@ -160,3 +160,77 @@ def test_default_rendezvous_address_is_per_launcher():
     assert parallel.default_address() == ('node7', 4242)
   finally:
     os.environ.clear(); os.environ.update(old)
+
+# ----------------------------------------------------------------------------------------------------------
+# the 'params' scheme (CHIMERA/parallel.py:258-278): replicas, the draws of a batch split over the ranks, values gathered
+# ----------------------------------------------------------------------------------------------------------
+def _params_worker(rank, world, addr, outdir):
+  sys.path.insert(0, ROOT)
+  import chimera_amd as CH
+  from chimera_amd.parallel import Rendezvous, HostComm
+  from tests import helpers as H
+  rd = Rendezvous(world, rank, address=addr, timeout=60.)
+  comm = HostComm(world, rank, device=0, rendezvous=rd)
+  cfg, ev, inj = H.small_config(E=5, S=64, P=3, Z=24, I=301, seed=19, ragged=True)
+  like_o, _, _ = H.build_oracle(ev, inj)
+  like, pop, sel = H.build_product(ev, inj)                   # (constructing the product object needs no GPU; its evaluator is replaced below)
+  like = CH.hyperlikelihood(like.theta_gw_det, ev['z_grids'], pop, sel, kind_p_gw3d='marginalized', comm=comm, scheme='params')
+  assert (like._e0, like._e1) == (0, cfg['E'])               # replicas: every rank holds every event
+  calls = []
+
+  def local(lams):                                            # the per-rank evaluator: the oracle here, the HIP library on the GPU
+    calls.append(len(lams))
+    return np.array([like_o(**l) for l in lams])
+  like._batch_local = local
+  lams = [dict(H0=float(h)) for h in np.linspace(60., 80., 7)]
+  got = like.batch(lams)
+  one = like(H0=71.)                                          # a scalar call: rank 0 evaluates, every rank receives
+  np.savez(os.path.join(outdir, f'rank{rank}.npz'), got=got, one=one, calls=np.array(calls))
+  rd.barrier()
+  comm.close()
+  rd.close()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('world', [2, 3])
+def test_params_scheme_splits_the_draws_and_gathers_the_values(tmp_path, world):
+  """scheme='params': rank r evaluates the draws [r c, min((r + 1) c, n)), c = ceil(n / R) (parallel.py:262-264), and every rank ends up with
+  all n values -- equal on every rank to the last bit and equal to the single-process values."""
+  import multiprocessing as mp
+  ctx = mp.get_context('spawn')
+  addr = str(tmp_path / 'rdzv.sock')
+  procs = [ctx.Process(target=_params_worker, args=(r, world, addr, str(tmp_path))) for r in range(world)]
+  for p in procs:
+    p.start()
+  for p in procs:
+    p.join(200)
+    assert p.exitcode == 0
+  sys.path.insert(0, ROOT)
+  from tests import helpers as H
+  cfg, ev, inj = H.small_config(E=5, S=64, P=3, Z=24, I=301, seed=19, ragged=True)
+  like_o, _, _ = H.build_oracle(ev, inj)
+  want = np.array([like_o(H0=float(h)) for h in np.linspace(60., 80., 7)])
+  recs = [np.load(tmp_path / f'rank{r}.npz') for r in range(world)]
+  per = -(-7 // world)
+  for r, rec in enumerate(recs):
+    np.testing.assert_array_equal(rec['got'], recs[0]['got'])
+    np.testing.assert_array_equal(rec['got'], want)
+    assert float(rec['one']) == like_o(H0=71.)
+    n_own = max(0, min((r + 1) * per, 7) - min(r * per, 7))
+    assert list(rec['calls']) == ([n_own] if n_own else []) + ([1] if r == 0 else [])
+
+
+def test_params_scheme_argument_checks():
+  sys.path.insert(0, ROOT)
+  import chimera_amd as CH
+  from tests import helpers as H
+  cfg, ev, inj = H.small_config(E=3, S=32, P=2, Z=16, I=101, seed=2)
+  like, pop, sel = H.build_product(ev, inj)
+  with pytest.raises(ValueError, match="scheme"):
+    CH.hyperlikelihood(like.theta_gw_det, ev['z_grids'], pop, sel, kind_p_gw3d='marginalized', scheme='both')
+
+  class FakeComm:
+    nranks, rank, device, handle = 2, 0, 0, None
+  sel.comm = FakeComm()
+  with pytest.raises(ValueError, match="replicates the data"):
+    CH.hyperlikelihood(like.theta_gw_det, ev['z_grids'], pop, sel, kind_p_gw3d='marginalized', comm=FakeComm(), scheme='params')
