@@ -72,7 +72,7 @@ SYMBOLS = ['chm_version', 'chm_device_count', 'chm_last_error', 'chm_like_create
            'chm_comm_unique_id', 'chm_comm_init_rank', 'chm_comm_destroy', 'chm_comm_allreduce_sum', 'chm_comm_nranks',
            'chm_device_synchronize',
            'chm_last_timing', 'chm_like_full_general_pixels', 'chm_pcat_compute', 'chm_kde2d_pixels',
-           'chm_kde1d', 'chm_binning1d', 'chm_gkde_nd', 'chm_trapz', 'chm_cumtrapz',
+           'chm_kde1d', 'chm_binning1d', 'chm_gkde_nd', 'chm_gkde_nd_log', 'chm_trapz', 'chm_cumtrapz',
            'chm_like_set_option', 'chm_sel_set_option', 'chm_diag_build', 'chm_comm_set_ticket', 'chm_comm_ticket_reset']
 
 # options of a handle (include/chimera_hip.h: CHM_OPT_*); ids >= 100 need a library built with -DCHM_DIAG
@@ -121,6 +121,7 @@ def lib():
   L.chm_kde1d.argtypes = [c_dp, c_dp, i64, c_dp, i64, i32, i32, f64, c_dp, i32]
   L.chm_binning1d.argtypes = [c_dp, c_dp, i64, i32, c_dp, c_dp, i32]
   L.chm_gkde_nd.argtypes = [c_dp, c_dp, i32, i64, c_dp, i64, i32, f64, c_dp, i32]
+  L.chm_gkde_nd_log.argtypes = [c_dp, c_dp, i32, i64, c_dp, i64, i32, f64, c_dp, i32]
   L.chm_trapz.argtypes = [c_dp, c_dp, i64, i32, i32, c_dp, i32]
   L.chm_cumtrapz.argtypes = [c_dp, c_dp, i32, c_dp, i32]
   L.chm_like_set_option.argtypes = [vp, i32, i64]

@@ -1587,8 +1587,8 @@ extern "C" int chm_binning1d(const double* dataset, const double* weights, int64
   return CHM_OK;
 }
 
-extern "C" int chm_gkde_nd(const double* dataset, const double* weights, int32_t d, int64_t N, const double* points, int64_t M,
-                           int32_t bw_method, double bw_scalar, double* out, int32_t device) {
+static int gkde_nd_impl(const double* dataset, const double* weights, int32_t d, int64_t N, const double* points, int64_t M,
+                        int32_t bw_method, double bw_scalar, double* out, int32_t device, bool in_log) {
   if (!dataset || !points || !out || d <= 0 || d > CHM_GKDE_MAXD || N <= 1 || M <= 0 || bw_method < 0 || bw_method > 2)
     return fail(CHM_E_ARG, "chm_gkde_nd: need dataset (d in 1..4, N > 1), points (M > 0), out, bw_method in {0,1,2}");
   MCK(math_device("chm_gkde_nd", device));
@@ -1597,11 +1597,21 @@ extern "C" int chm_gkde_nd(const double* dataset, const double* weights, int32_t
   MCK(sc.up(dataset, (size_t)d * N, &d_x)); MCK(sc.up(weights, weights ? (size_t)N : 0, &d_w)); MCK(sc.up(points, (size_t)d * M, &d_p));
   MCK(sc.alloc(&d_st, 2 + CHM_GKDE_MAXD * CHM_GKDE_MAXD)); MCK(sc.alloc(&d_o, (size_t)M));
   hipLaunchKernelGGL(k_math_gkde_setup, dim3(1), dim3(1024), 0, (hipStream_t)0, d_x, d_w, (int)d, (long long)N, bw_method, bw_scalar, d_st);
-  hipLaunchKernelGGL(k_math_gkde_eval, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)0, d_x, d_w, (int)d, (long long)N, d_p,
-                     (long long)M, (const double*)d_st, d_o);
+  if (in_log) hipLaunchKernelGGL(k_math_gkde_eval<true>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)0, d_x, d_w, (int)d, (long long)N, d_p,
+                                 (long long)M, (const double*)d_st, d_o);
+  else hipLaunchKernelGGL(k_math_gkde_eval<false>, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)0, d_x, d_w, (int)d, (long long)N, d_p,
+                          (long long)M, (const double*)d_st, d_o);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(out, d_o, sizeof(double) * (size_t)M, hipMemcpyDeviceToHost));
   return CHM_OK;
+}
+extern "C" int chm_gkde_nd(const double* dataset, const double* weights, int32_t d, int64_t N, const double* points, int64_t M,
+                           int32_t bw_method, double bw_scalar, double* out, int32_t device) {
+  return gkde_nd_impl(dataset, weights, d, N, points, M, bw_method, bw_scalar, out, device, false);
+}
+extern "C" int chm_gkde_nd_log(const double* dataset, const double* weights, int32_t d, int64_t N, const double* points, int64_t M,
+                               int32_t bw_method, double bw_scalar, double* out, int32_t device) {
+  return gkde_nd_impl(dataset, weights, d, N, points, M, bw_method, bw_scalar, out, device, true);
 }
 
 extern "C" int chm_trapz(const double* y, const double* x, int64_t rows, int32_t n, int32_t x_per_row, double* out, int32_t device) {

@@ -3439,7 +3439,10 @@ __global__ void __launch_bounds__(1024) k_math_gkde_setup(const double* data /* 
   }
 }
 
-// out[i] = sum_j W_j exp(log_norm - 1/2 |x_j L - p_i L|^2) (math.py:133-147); one thread per point, the dataset through LDS tiles
+// out[i] = sum_j W_j exp(log_norm - 1/2 |x_j L - p_i L|^2) (math.py:133-147); one thread per point, the dataset through LDS tiles.
+// LOG (in_log=True, math.py:223-226): out[i] = logsumexp_j(log W_j + log_norm - 1/2 |.|^2), accumulated in the reference's own order by
+// np.logaddexp -- max(a, b) + log1p(exp(-|a - b|)) -- from log_sum = -inf
+template <bool LOG>
 __global__ void __launch_bounds__(256) k_math_gkde_eval(const double* data, const double* wgt, int d, long long N, const double* pts /* (d,M) */,
                                                          long long M, const double* st, double* out) {
   __shared__ double xs[CHM_GKDE_MAXD][256], ws[256];
@@ -3451,19 +3454,24 @@ __global__ void __launch_bounds__(256) k_math_gkde_eval(const double* data, cons
   const double tot = st[0], log_norm = st[1];
   double q[CHM_GKDE_MAXD];
   for (int c = 0; c < d; c++) { double s = 0.; for (int k = 0; k < d; k++) s += (i < M ? pts[(size_t)k * M + i] : 0.) * Ls[k * d + c]; q[c] = s; }      // points.T @ L
-  double acc = 0.;
+  double acc = LOG ? -__builtin_inf() : 0.;
   for (long long j0 = 0; j0 < N; j0 += 256) {
     const int m = (int)((N - j0) < 256 ? (N - j0) : 256);
     __syncthreads();
     if (t < m) {
       for (int c = 0; c < d; c++) { double s = 0.; for (int k = 0; k < d; k++) s += data[(size_t)k * N + j0 + t] * Ls[k * d + c]; xs[c][t] = s; }     // dataset.T @ L
-      ws[t] = (wgt ? wgt[j0 + t] : 1.) / tot;
+      const double W = (wgt ? wgt[j0 + t] : 1.) / tot;
+      ws[t] = LOG ? log(W) : W;
     }
     __syncthreads();
     for (int j = 0; j < m; j++) {
       double r2 = 0.;
       for (int c = 0; c < d; c++) { double dd = xs[c][j] - q[c]; r2 += dd * dd; }
-      acc += ws[j] * exp(log_norm - 0.5 * r2);
+      if (LOG) {
+        const double a = acc, bq = ws[j] + (log_norm - 0.5 * r2);
+        if (a == bq) acc = a + 0.6931471805599453;            // np.logaddexp: equal arguments (also -inf, -inf -> -inf)
+        else { const double mx = a > bq ? a : bq, df = a > bq ? bq - a : a - bq; acc = (df != df) ? a + bq : mx + log1p(exp(df)); }
+      } else acc += ws[j] * exp(log_norm - 0.5 * r2);
     }
   }
   if (i < M) out[i] = acc;

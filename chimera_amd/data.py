@@ -100,17 +100,19 @@ def load_galaxy_catalog(file_path, parameters=['ra_gal', 'dec_gal', 'z_cgal'], u
 
 
 def _process_selection(n, max_n, name):
-  """data.py:218-233."""
+  """What a loader's ``nevents`` / ``nsamples`` / ``ninj`` argument selects (the rules of data.py:218-233): everything for ``None``, the listed
+  indices for an index array, and for a count that many entries drawn without replacement (``np.random.choice``, so that a seeded
+  session picks what the reference picks) in ascending order -- or everything, with a warning, when the count exceeds what is there."""
   if n is None:
     return slice(None)
-  elif isinstance(n, (list, np.ndarray)):
+  if np.ndim(n) > 0:
     return np.asarray(n)
-  elif isinstance(n, (int, np.integer)):
-    if n > max_n:
-      logger.warning(f"Requested more {name} than available. Using all {max_n}.")
-      return slice(None)
+  if isinstance(n, (bool, np.bool_)) or not isinstance(n, (int, np.integer)):
+    raise ValueError(f"Invalid selection for {name}: must be None, list or int")
+  if n <= max_n:
     return np.sort(np.random.choice(max_n, n, replace=False))
-  raise ValueError(f"Invalid selection for {name}: must be None, list or int")
+  logger.warning(f"Requested more {name} than available. Using all {max_n}.")
+  return slice(None)
 
 
 def load_gw_pe_samples(file_ev_pe, parameters=['dL', 'm1det', 'm2det', 'phi', 'theta'], group='posteriors', nevents=None,
@@ -151,28 +153,44 @@ def load_injection_data(file_inj, snr_cut=None, ninj=None, group=None, key_mappi
 theta_pe_pixelated_groups = ['pixels_pe_all_nsides']
 
 
-def _get_threshold(norm_counts, level):
-  """data.py:239-244."""
-  prob_sorted = np.sort(norm_counts)[::-1]
-  prob_sorted_cum = np.cumsum(prob_sorted)
-  idx = np.searchsorted(prob_sorted_cum, level)
-  return prob_sorted[idx]
+def sky_conf_pixels(healpix_pe, sky_conf, nside):
+  """The pixels inside the ``sky_conf`` credible area of EVERY event at once (the per-event rule of data.py:239-260): with p the fraction of
+  an event's samples per pixel, sorted downwards and summed up, the threshold is the fraction at which the running sum first reaches
+  ``sky_conf``; the event keeps every pixel with p >= threshold, in ascending pixel order.
+
+  One ``np.unique`` over the keys ``event * npix + pixel`` of all (event, sample) pairs gives every event's occupied pixels and their counts
+  (the map of 12 nside^2 zeros per event the reference fills is never formed); each event's threshold then comes from its own short
+  stretch of that array.  Returns a list of E index arrays."""
+  pix = np.atleast_2d(np.asarray(healpix_pe, dtype=np.int64))
+  E, S = pix.shape
+  npix = int(angles.nside2npix(nside))
+  keys, counts = np.unique(np.arange(E, dtype=np.int64)[:, None] * npix + pix, return_counts=True)
+  bounds = np.searchsorted(keys, np.arange(E + 1, dtype=np.int64) * npix)
+  out = []
+  for e in range(E):
+    a, b = bounds[e], bounds[e + 1]
+    occupied, frac = keys[a:b] - e * npix, counts[a:b] / S
+    downwards = np.sort(frac)[::-1]
+    first = int(np.searchsorted(np.cumsum(downwards), sky_conf))
+    if first < downwards.size:
+      out.append(occupied[frac >= downwards[first]])
+    else:                                                   # the occupied pixels never reach the level: the threshold falls on an empty pixel (p = 0)
+      out.append(np.arange(npix, dtype=np.int64))
+  return out
 
 
 def compute_sky_conf_event(healpix_pe, sky_conf, nside):
-  """data.py:246-260: pixels whose sample fraction reaches the sky-confidence threshold."""
-  unique, counts = np.unique(healpix_pe, return_counts=True)
-  p = np.zeros(angles.nside2npix(nside))
-  p[unique] = counts / healpix_pe.shape[0]
-  return np.argwhere(p >= _get_threshold(p, sky_conf)).flatten()
+  """data.py:246-260 for one event: pixels whose sample fraction reaches the sky-confidence threshold."""
+  return sky_conf_pixels(np.asarray(healpix_pe)[None, :], sky_conf, nside)[0]
 
 
 def _pad_arr_list(array_list, pad_value):
-  """data.py:406-420 (1-D case)."""
-  max_rows = max(arr.shape[0] for arr in array_list)
-  padded = np.full((len(array_list), max_rows), pad_value, dtype=array_list[0].dtype)
-  for i, arr in enumerate(array_list):
-    padded[i, :arr.shape[0]] = arr
+  """Ragged rows -> one (rows, longest) array, short rows filled with ``pad_value`` (what data.py:406-420 returns for 1-D rows): a boolean
+  mask of the filled cells takes all rows in one assignment."""
+  rows = [np.asarray(a) for a in array_list]
+  lengths = np.array([r.shape[0] for r in rows])
+  padded = np.full((len(rows), int(lengths.max())), pad_value, dtype=rows[0].dtype)
+  padded[np.arange(padded.shape[1])[None, :] < lengths[:, None]] = np.concatenate(rows)
   return padded
 
 
@@ -200,12 +218,11 @@ def pixelize_gw_catalog(theta_gw, nside_list, mean_npixels_event, sky_conf, nest
   for nside in nside_list:
     logger.info(f"Precomputing Healpix pixels (NSIDE={nside}, NEST={nest})")
     pixels_pe_all_nsides[f"nside_{nside}"] = angles.find_pix_RAdec(ra, dec, nside, nest)
-  pixel_count_matrix = np.array([[len(compute_sky_conf_event(pixels_pe_all_nsides[f"nside_{nside}"][e], sky_conf, nside))
-                                  for nside in nside_list] for e in range(num_events)])
+  conf_pixels = {nside: sky_conf_pixels(pixels_pe_all_nsides[f"nside_{nside}"], sky_conf, nside) for nside in nside_list}     # every event at once
+  pixel_count_matrix = np.array([[len(conf_pixels[nside][e]) for nside in nside_list] for e in range(num_events)])
   best = np.argmin(np.abs(pixel_count_matrix - mean_npixels_event), axis=1)
   opt_nsides = np.array(nside_list)[best]
-  event_pixels = [compute_sky_conf_event(pixels_pe_all_nsides[f"nside_{opt_nsides[e]}"][e], sky_conf, opt_nsides[e])
-                  for e in range(num_events)]
+  event_pixels = [conf_pixels[int(opt_nsides[e])][e] for e in range(num_events)]
   # (the reference calls find_ra_dec without `nest`, data.py:311 -- RING centres for NESTED indices; here the ordering is passed on)
   pixel_ra, pixel_dec = zip(*[angles.find_ra_dec(event_pixels[e], nside=opt_nsides[e], nest=nest) for e in range(num_events)])
   pe_samples_pixels = np.zeros(ra.shape, dtype=np.int64)
@@ -258,3 +275,19 @@ def compute_localization_areas(theta, phi, percentile=0.9, unit='deg2'):
     one_sigma = 2 * np.pi * np.abs(np.sin(np.mean(th))) * np.sqrt(s2t * s2p - cov2)
     area[e] = -np.log(1 - percentile / 100) * one_sigma * (180 / np.pi)**2
   return area
+
+
+def compute_localization_volumes(theta, phi, dL, cosmo_min, cosmo_max, percentile=90):
+  """data.py:452-484 -> localisation volume of every event [Gpc^3]: the event's sky area (``compute_localization_areas``, in steradians) times
+  the comoving shell between the redshifts of the lower / upper ``(100 - percentile) / 2`` distance percentiles, the nearer edge under
+  ``cosmo_min`` and the farther one under ``cosmo_max``, per unit solid angle:  A (Vc(z_max; cosmo_max) - Vc(z_min; cosmo_min)) / 4 pi.
+  (The reference body names undefined objects -- ``flrw.z_from_dGW``, ``flrw.V_at_z``, ``cosmo_param_min`` -- and cannot run; this is what it
+  spells out, on ``cosmo.z_from_dGW`` / ``cosmo.Vc_at_z``, which evaluate on the GPU through ``chm_model_eval``.)"""
+  from .population import cosmo as _cosmo
+  dL = np.atleast_2d(np.asarray(dL, dtype=np.float64))
+  steradians = compute_localization_areas(theta, phi, percentile) / (180. / np.pi)**2
+  tail = (100. - percentile) / 2.
+  d_near, d_far = np.percentile(dL, tail, axis=1), np.percentile(dL, 100. - tail, axis=1)
+  v_near = _cosmo.Vc_at_z(cosmo_min, _cosmo.z_from_dGW(cosmo_min, d_near))
+  v_far = _cosmo.Vc_at_z(cosmo_max, _cosmo.z_from_dGW(cosmo_max, d_far))
+  return steradians * (np.asarray(v_far) - np.asarray(v_near)) / (4. * np.pi)

@@ -17,52 +17,43 @@ def _need_h5py(fname):
     raise ImportError(f"{fname}: reading/writing HDF5 needs h5py, which is not installed; use .npz")
 
 
-def save_set(obj, dir_file, attrs=[], datasets=[], groups=[]):
-  """io.py:7-18."""
-  if _is_h5(dir_file):
-    _need_h5py(dir_file)
-    with h5py.File(dir_file, 'w') as f:
-      for a in attrs:
-        f.attrs[a] = getattr(obj, a)
-      for d in datasets:
-        f.create_dataset(d, data=np.asarray(getattr(obj, d)))
-      for g in groups:
-        dg = f.create_group(g)
-        for k, v in getattr(obj, g).items():
-          dg.create_dataset(k, data=v)
-    return
-  out = {}
-  for a in attrs:
-    out['attr/' + a] = np.asarray(getattr(obj, a))
-  for d in datasets:
-    out[d] = np.asarray(getattr(obj, d))
+def _flatten(obj, attrs, datasets, groups):
+  """(attributes, arrays keyed by their path in the file) of a set: ``name`` for a dataset, ``group/key`` for a member of a dict-valued field."""
+  arrays = {d: np.asarray(getattr(obj, d)) for d in datasets}
   for g in groups:
-    for k, v in (getattr(obj, g) or {}).items():
-      out[f'{g}/{k}'] = np.asarray(v)
-  np.savez(dir_file, **out)
+    arrays.update({f'{g}/{k}': np.asarray(v) for k, v in (getattr(obj, g) or {}).items()})
+  return {a: getattr(obj, a) for a in attrs}, arrays
+
+
+def save_set(obj, dir_file, attrs=[], datasets=[], groups=[]):
+  """io.py:7-18: the listed attributes, datasets and dict-valued fields (one HDF5 group each) of ``obj`` in one file.  Both back ends write the
+  same flat (path -> array) map: HDF5 creates the groups from the paths, ``.npz`` keeps the paths as names and the attributes under ``attr/``."""
+  meta, arrays = _flatten(obj, attrs, datasets, groups)
+  if not _is_h5(dir_file):
+    np.savez(dir_file, **{'attr/' + a: np.asarray(v) for a, v in meta.items()}, **arrays)
+    return
+  _need_h5py(dir_file)
+  with h5py.File(dir_file, 'w') as f:
+    f.attrs.update(meta)
+    for g in groups:                                          # (also when the field is empty: readers look the group up)
+      f.require_group(g)
+    for path, value in arrays.items():
+      f[path] = value
 
 
 def load_set(obj, dir_file, attrs=[], datasets=[], groups=[]):
   """io.py:20-41: returns a new object for the immutable theta_* containers, updates mutable objects in place."""
-  new_fields = {}
   if _is_h5(dir_file):
     _need_h5py(dir_file)
     with h5py.File(dir_file, 'r') as f:
-      for a in attrs:
-        new_fields[a] = f.attrs[a]
-      for d in datasets:
-        new_fields[d] = np.array(f[d][:])
-      for g in groups:
-        new_fields[g] = {k: np.array(f[g][k][:]) for k in f[g].keys()}
+      new_fields = {a: f.attrs[a] for a in attrs}
+      new_fields.update({d: f[d][()] for d in datasets})
+      new_fields.update({g: ({k: member[()] for k, member in f[g].items()} if g in f else {}) for g in groups})
   else:
     with np.load(dir_file, allow_pickle=False) as f:
-      for a in attrs:
-        v = f['attr/' + a]
-        new_fields[a] = v[()] if v.ndim == 0 else v
-      for d in datasets:
-        new_fields[d] = f[d]
-      for g in groups:
-        new_fields[g] = {k[len(g) + 1:]: f[k] for k in f.files if k.startswith(g + '/')}
+      new_fields = {a: (f['attr/' + a][()] if f['attr/' + a].ndim == 0 else f['attr/' + a]) for a in attrs}
+      new_fields.update({d: f[d] for d in datasets})
+      new_fields.update({g: {k[len(g) + 1:]: f[k] for k in f.files if k.startswith(g + '/')} for g in groups})
   if hasattr(obj, '_fields') and hasattr(obj, 'update'):
     return obj.update(**new_fields)
   for k, v in new_fields.items():

@@ -76,9 +76,9 @@ def kde1d(dataset, grid, weights=None, kernel='epan', bw_method=None):
 
 def gkde_nd(dataset, evaluation_grid, weights=None, bw_method=None, in_log=False):
   """math.py:95-148 (``jax_gkde_nd``) / 154-229 (``numba_gkde_nd``): n-dimensional weighted Gaussian KDE with covariance
-  whitening ("same as jax.scipy.stats.gaussian_kde").  ``dataset`` (d, N), ``evaluation_grid`` (d, M); d <= 4."""
-  if in_log:
-    raise NotImplementedError("gkde_nd: in_log=True is not provided (the likelihood path uses in_log=False)")
+  whitening ("same as jax.scipy.stats.gaussian_kde").  ``dataset`` (d, N), ``evaluation_grid`` (d, M); d <= 4.
+  ``in_log=True`` (math.py:223-226, the numba kernel): the logarithm of the density, accumulated as the reference does
+  (``np.logaddexp`` over the dataset from -inf) -- finite where the density itself underflows."""
   dataset = np.atleast_2d(np.asarray(dataset, dtype=np.float64))
   d, n = dataset.shape
   points = np.atleast_2d(np.asarray(evaluation_grid, dtype=np.float64))
@@ -107,8 +107,8 @@ def gkde_nd(dataset, evaluation_grid, weights=None, bw_method=None, in_log=False
     raise ValueError("`bw_method` should be 'scott', 'silverman', a scalar")
   ds, pts = _lib.as_f64(dataset), _lib.as_f64(points)
   out = np.empty(m)
-  _lib.check(_lib.lib().chm_gkde_nd(_lib.dptr(ds), _lib.dptr(w), d, n, _lib.dptr(pts), m, code, scalar, _lib.dptr(out),
-                                    _lib.default_device()))
+  fn = _lib.lib().chm_gkde_nd_log if in_log else _lib.lib().chm_gkde_nd
+  _lib.check(fn(_lib.dptr(ds), _lib.dptr(w), d, n, _lib.dptr(pts), m, code, scalar, _lib.dptr(out), _lib.default_device()))
   return out
 
 

@@ -237,6 +237,8 @@ int chm_kde2d_pixels(int32_t E, int32_t S, int32_t P, const double* ra, const do
  *   chm_binning1d  binning1d(dataset, weights, num_bins) -> centres, counts     math.py:32-46
  *   chm_gkde_nd    jax_gkde_nd / numba_gkde_nd(dataset (d,N), points (d,M), weights, bw_method), in_log=False, d <= 4
  *                                                                                math.py:95-148, 154-229
+ *   chm_gkde_nd_log  the same with in_log=True: logsumexp_j(log W_j + log_norm - |.|^2 / 2), np.logaddexp from -inf in dataset order
+ *                                                                                math.py:217-227 (the numba kernel; the JAX branch's in_log raises, Q11)
  *   chm_trapz      trapz(y, x, axis=-1) of `rows` rows of n points; x one row (x_per_row = 0) or one per row   math.py:10-16
  *   chm_cumtrapz   cumtrapz(y, x) of one row                                     math.py:22-26                                  */
 int chm_kde1d(const double* dataset, const double* weights, int64_t N, const double* grid, int64_t G, int32_t kernel,
@@ -245,6 +247,8 @@ int chm_binning1d(const double* dataset, const double* weights, int64_t N, int32
                   int32_t device);
 int chm_gkde_nd(const double* dataset, const double* weights, int32_t d, int64_t N, const double* points, int64_t M,
                 int32_t bw_method, double bw_scalar, double* out, int32_t device);
+int chm_gkde_nd_log(const double* dataset, const double* weights, int32_t d, int64_t N, const double* points, int64_t M,
+                    int32_t bw_method, double bw_scalar, double* out, int32_t device);
 int chm_trapz(const double* y, const double* x, int64_t rows, int32_t n, int32_t x_per_row, double* out, int32_t device);
 int chm_cumtrapz(const double* y, const double* x, int32_t n, double* out, int32_t device);
 

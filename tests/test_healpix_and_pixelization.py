@@ -123,10 +123,26 @@ def test_angle_helpers():
 def test_sky_conf_pixels():
   # 10 samples: pixel 5 holds 6, pixel 7 holds 3, pixel 2 holds 1 (nside = 1 -> 12 pixels)
   hpx = np.array([5] * 6 + [7] * 3 + [2])
-  assert D._get_threshold(np.array([0.6, 0.3, 0.1, 0.]), 0.5) == 0.6
   np.testing.assert_array_equal(D.compute_sky_conf_event(hpx, 0.5, 1), [5])
   np.testing.assert_array_equal(D.compute_sky_conf_event(hpx, 0.8, 1), [5, 7])
   np.testing.assert_array_equal(D.compute_sky_conf_event(hpx, 0.95, 1), [2, 5, 7])
+  # every event at once (sky_conf_pixels) against the per-event rule of data.py:239-260 spelt out on the full map of 12 nside^2 pixels
+  rng = np.random.default_rng(4)
+  for nside in (1, 2, 8):
+    npix = 12 * nside * nside
+    centre = rng.integers(0, npix, size=(7, 1))
+    pix = (centre + rng.geometric(0.3, size=(7, 500)) - 1) % npix
+    for level in (0.5, 0.9, 0.99):
+      got = D.sky_conf_pixels(pix, level, nside)
+      for e in range(7):
+        p = np.bincount(pix[e], minlength=npix) / pix.shape[1]
+        srt = np.sort(p)[::-1]
+        thr = srt[np.searchsorted(np.cumsum(srt), level)]
+        np.testing.assert_array_equal(got[e], np.flatnonzero(p >= thr))
+  # ragged rows -> padded array
+  rows = [np.array([3, 1, 2]), np.array([7]), np.array([5, 6])]
+  np.testing.assert_array_equal(D._pad_arr_list(rows, -100), [[3, 1, 2], [7, -100, -100], [5, 6, -100]])
+  assert D._pad_arr_list([np.array([1.5]), np.array([2.5, 3.5])], -100.).dtype == np.float64
 
 
 def test_loaders_round_trip(tmp_path):

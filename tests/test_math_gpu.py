@@ -51,6 +51,21 @@ def test_gkde_nd(d, bw):
   np.testing.assert_allclose(M.numba_gkde_nd(data, pts), O.gkde_nd(data, pts), rtol=1e-10)             # unweighted
   with pytest.raises(ValueError):
     M.jax_gkde_nd(data, np.zeros((d + 1, 5)))
+  # in_log=True (math.py:223-226): log of the density where it is representable, and finite far out in the tail where the density
+  # itself underflows -- against scipy's logsumexp of the same terms (and gaussian_kde.logpdf)
+  from scipy.special import logsumexp
+  lg = M.gkde_nd(data, pts, weights=w, bw_method=bw, in_log=True)
+  np.testing.assert_allclose(lg, np.log(got), rtol=0, atol=1e-10)
+  far = pts[:, :7] + 60. * np.std(data, axis=1, keepdims=True)
+  lf = M.numba_gkde_nd(data, far, weights=w, bw_method=bw, in_log=True)
+  assert np.all(np.isfinite(lf)) and np.all(lf < -700.) and np.all(M.gkde_nd(data, far, weights=w, bw_method=bw) == 0.)
+  kde = gaussian_kde(data, weights=w, bw_method=bw)
+  np.testing.assert_allclose(lf, kde.logpdf(far), rtol=1e-10)
+  W = w / w.sum()
+  Lc = np.linalg.cholesky(np.linalg.inv(np.atleast_2d(kde.covariance)))
+  dw, fw = data.T @ Lc, far.T @ Lc
+  terms = np.log(W)[None, :] + (np.sum(np.log(np.diag(Lc))) - 0.5 * d * np.log(2 * np.pi)) - 0.5 * np.sum((dw[None, :, :] - fw[:, None, :])**2, axis=2)
+  np.testing.assert_allclose(lf, logsumexp(terms, axis=1), rtol=1e-10)
 
 
 def test_trapz_and_cumtrapz():
@@ -72,3 +87,24 @@ def test_generic_mass_helpers():
   np.testing.assert_allclose(CH.mass.tpl_cdf(-1., 5.1, m), O.tpl_cdf(-1., 5.1, m), rtol=1e-12, atol=1e-14)
   np.testing.assert_allclose(CH.mass.gaussian(m, 34., 3.6), O.gaussian(m, 34., 3.6), rtol=1e-12, atol=1e-300)
   np.testing.assert_allclose(CH.mass.truncated_gaussian(m, 34., 3.6, 5.1, 52.), O.truncated_gaussian(m, 34., 3.6, 5.1, 52.), rtol=1e-12, atol=1e-300)
+
+
+def test_localization_volumes():
+  """data.compute_localization_volumes (CHIMERA/data.py:452-484: the body the reference spells out with undefined names) -- the sky area in
+  steradians times the comoving shell between the 5 % distance under one cosmology and the 95 % distance under another, per unit solid angle --
+  against the same expression on the oracle's z_from_dGW / Vc_at_z."""
+  import chimera_amd as CH
+  from chimera_amd import data as D
+  rng = np.random.default_rng(11)
+  E, S = 4, 3000
+  theta = rng.normal(1.1, 0.03, size=(E, S)) + rng.normal(0., 0.2, size=(E, 1))
+  phi = rng.normal(2.0, 0.05, size=(E, S)) + 0.4 * (theta - theta.mean(axis=1, keepdims=True))
+  dL = rng.lognormal(np.log([[0.8], [1.5], [3.0], [6.0]]), 0.2, size=(E, S))
+  kw_lo, kw_hi = dict(H0=60., Om0=0.3, z_max=5.), dict(H0=80., Om0=0.28, z_max=5.)
+  got = D.compute_localization_volumes(theta, phi, dL, CH.cosmo.flrw(**kw_lo), CH.cosmo.flrw(**kw_hi), percentile=90)
+  ster = D.compute_localization_areas(theta, phi, 90) / (180. / np.pi)**2
+  d5, d95 = np.percentile(dL, 5., axis=1), np.percentile(dL, 95., axis=1)
+  olo, ohi = O.flrw(**kw_lo), O.flrw(**kw_hi)
+  want = ster * (O.Vc_at_z(ohi, O.z_from_dGW(ohi, d95)) - O.Vc_at_z(olo, O.z_from_dGW(olo, d5))) / (4. * np.pi)
+  np.testing.assert_allclose(got, want, rtol=1e-10)
+  assert got.shape == (E,) and np.all(got > 0.) and np.all(np.diff(got) > 0.)       # farther events: larger shells
