@@ -110,7 +110,7 @@ def load_pmc(keys, sha=None):
     except Exception:
       continue
     w = j.get('workload')
-    if isinstance(w, dict) and all(w.get(k) == v for k, v in keys.items()):
+    if isinstance(w, dict) and all(w.get(k, 0 if k == 'fused' else None) == v for k, v in keys.items()):
       fresh = bool(sha) and j.get('code_object_sha256') == sha
       if best is None or fresh or not best[2]:               # a file collected from the loaded binary wins over a newer one that was not
         best = (os.path.relpath(f, ROOT), j, fresh)
@@ -437,9 +437,13 @@ def main():
     value = evals / dt
     El = like._e1 - like._e0
     lib_sha = code_object_sha256(_lib.LIB_PATH)
-    pmc = load_pmc(dict(config=args.config, E=El, P=P, Z=Z, S=S, nbatch=nb, mode=kind or '1d', n_gpus=1), lib_sha) if world == 1 else None
+    pmc = load_pmc(dict(config=args.config, E=El, P=P, Z=Z, S=S, nbatch=nb, mode=kind or '1d', n_gpus=1, fused=args.fused), lib_sha) if world == 1 else None
     kernels = []
-    if kind == 'marginalized':
+    if kind == 'marginalized' and args.fused >= 2:
+      # the fused event kernel does the sample stage, the per-z factors and the GW kernel of every (event, draw) in one launch: its span is kt[3]
+      kernels.append(kernel_roofline("fused event kernel (samples + statistics + histograms + per-z factors + KDE + integrand)", "k_marg_fused", kt[3],
+                                     El * S * 49 + El * P * Z * 8 + El * Z * 8 + nb * ((2 * 1500 + 2 * 1000) * 8 + El * Z * 16), pmc))
+    elif kind == 'marginalized':
       kernels.append(kernel_roofline("marginalized GW kernel (histogram + KDE + interp + integrand + trapz)", "k_kde_marg_sub2", kt[3],
                                      gw_kernel_unique_bytes(El, S, P, Z, nb), pmc, units=El * P / 2. * nb))
     full_pairs = None
@@ -519,7 +523,7 @@ def main():
       "dtype": "f64", "data": "synthetic (seed 20250926; chimera_amd/synth.py)",
       "config": {"workload": f"{args.config}: {E} events x {P} pixels x {Z} z-bins, {S} samples/event, {I} detected injections, "
                              f"PLP + Madau-Dickinson + {'modified-GW-propagation (Xi0, n) flat-LCDM' if mg else 'flat-LCDM'}, {kind or '1d'}, binning 200, cut_grid 2",
-                 "E": E, "P": P, "Z": Z, "S": S, "I": I, "kind_p_gw3d": kind, "nbatch": nb, "inflight": args.inflight,
+                 "E": E, "P": P, "Z": Z, "S": S, "I": I, "kind_p_gw3d": kind, "nbatch": nb, "inflight": args.inflight, "fused": args.fused, "groups": args.groups, "serial": bool(args.serial),
                  "parallelism": f"events+injections sharded over {world} GPU(s)" + (f"; {comm_kind}" if comm_kind else ""),
                  "cells_per_s": value * E * max(P, 1) * Z},
       "step_ms": {"median": 1e3 * med, "q25": 1e3 * q1, "q75": 1e3 * q3, "n": len(step_s)} if step_s else None,

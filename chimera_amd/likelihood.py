@@ -194,6 +194,7 @@ class hyperlikelihood(object):
     for h, _ in self._handles.values():
       _lib.lib().chm_like_destroy(h)
     self._handles = {}
+    self._scalar_state = None
 
   def lane(self, comm=None):
     """A second evaluation lane on the data this object already holds in HBM (``chm_like_clone``; the selection function gets a
@@ -208,6 +209,7 @@ class hyperlikelihood(object):
     self._handle()
     new = copy.copy(self)
     new._handles = {}
+    new._scalar_state = None
     new._options = dict(self._options)
     new.comm = comm
     for mode, (h, _) in self._handles.items():
@@ -327,9 +329,46 @@ class hyperlikelihood(object):
     CHIMERA/utils/emcee_utils.py:54-64) evaluate every draw in one launch sequence and return an array."""
     n = _vector_length(hyper_lambdas)
     if n is None:
-      return self.batch([hyper_lambdas])[0]
+      return self._scalar_call(hyper_lambdas)
     lams = [{k: (np.asarray(v).reshape(-1)[i] if np.ndim(v) > 0 else v) for k, v in hyper_lambdas.items()} for i in range(n)]
     return self.batch(lams)
+
+  def _scalar_call(self, lam):
+    """One draw, nothing but the value wanted -- the reference's ``like(**lambda)``.  The call is ~0.18 ms of which the device needs ~0.15: the
+    host side keeps its parameter block, output block and handles between calls and only patches the hyper-parameters in (what
+    ``batch([lam])[0]`` does through freshly made arrays; same ``chm_eval``, same value)."""
+    st = getattr(self, '_scalar_state', None)
+    sf = self.selection_function
+    if st is None or st[0] is not self._handles.get(self._mode, (None,))[0] or st[4] is not (sf._h if sf is not None else None):
+      comm = self.comm if self.scheme == 'data' else None
+      comm_h = getattr(comm, 'handle', None) if comm is not None else None
+      plain = not any(self._plugins) and not (comm is not None and comm_h is None and comm.nranks > 1) \
+        and not (self.scheme == 'params' and self.comm is not None and self.comm.nranks > 1)
+      if not plain:
+        return self.batch([lam])[0]
+      h = self._handle()
+      self._params_array([{}])                                 # (forms the slot table and the base parameter block)
+      arr = (_lib.chm_params * 1)()
+      res = np.empty(3)
+      out = _lib.chm_out()
+      out.log_hyper, out.log_num, out.N_exp = (C.cast(C.c_void_p(res.ctypes.data + 8 * i), _lib.c_dp) for i in range(3))
+      sel = self.selection_function._handle() if self.selection_function is not None else None
+      st = self._scalar_state = (h, arr, res, out, sel, comm_h, C.byref(arr), C.byref(self._base_params), C.sizeof(_lib.chm_params), C.byref(out),
+                                 _lib.lib().chm_eval)
+    h, arr, res, out, sel, comm_h, parr, pbase, sz, pout, chm_eval = st
+    C.memmove(parr, pbase, sz)
+    p = arr[0]
+    slots = self._slots
+    for k, v in lam.items():
+      for field, idx, is_int in slots.get(k, ()):
+        if idx is None:
+          setattr(p, field, int(v) if is_int else float(v))
+        else:
+          getattr(p, field)[idx] = float(v)
+    rc = chm_eval(h, sel, comm_h, arr, 1, self.nevents, pout)
+    if rc:
+      _lib.check(rc)
+    return res[0]
 
   def __call__(self, **hyper_lambdas):
     """likelihood.py:318-320."""

@@ -5,7 +5,7 @@
 
 Writes under gpurun_out/profiles_<round>/ (copy what is to be judged into profiles/<round>/):
   kernel_stats<tag>.csv          rocprofv3 --kernel-trace --stats summary of `python3 bench.py <args>` (default streams)
-  kernel_stats_serial<tag>.csv   the same with CHM_SERIAL=1 (every kernel on one stream: standalone durations)
+  kernel_stats_serial<tag>.csv   the same with `--serial --groups 1` (every kernel on one stream: standalone durations)
   pmc_per_launch<tag>.json       per kernel, per launch: PMC counters from SEPARATE rocprofv3 --pmc passes (counters only, no
                                  tracing flags besides --kernel-trace), the kernel's average duration in those passes, and the
                                  workload keys bench.py matches against
@@ -66,9 +66,8 @@ def main():
   if not skip_trace:
     for serial in (False, True):
       d = os.path.join(out, 'trace_serial' if serial else 'trace')
-      e = dict(env, CHM_SERIAL='1', CHM_GROUPS='1') if serial else env
-      rc = run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--'] + quick,
-               os.path.join(out, f"trace{'_serial' if serial else ''}{tag}.log"), env=e)
+      rc = run(['rocprofv3', '--kernel-trace', '--stats', '--output-format', 'csv', '-d', d, '--'] + quick + (['--serial', '--groups', '1'] if serial else []),
+               os.path.join(out, f"trace{'_serial' if serial else ''}{tag}.log"), env=env)
       print('kernel-trace', 'serial' if serial else 'default', 'rc', rc, flush=True)
       for f in glob.glob(os.path.join(d, '*', '*kernel_stats.csv')):
         shutil.copy(f, os.path.join(out, f"kernel_stats{'_serial' if serial else ''}{tag}.csv"))
@@ -79,10 +78,10 @@ def main():
     if only is not None and pi not in only:
       continue
     d = os.path.join(out, f'pmc{pi}')
-    # CHM_GROUPS=1: one launch of every kernel per step covers the whole workload (the default splits large shards into event groups on two
+    # --groups 1: one launch of every kernel per step covers the whole workload (the default splits large shards into event groups on two
     # streams) -- the launch the roofline block of bench.py times after its timed region
     rc = run(['rocprofv3', '--kernel-trace', '--pmc'] + counters.split() + ['--output-format', 'csv', '-d', d, '--'] + quick +
-             ['--steps', '3', '--warmup', '1'], os.path.join(out, f'pmc{pi}{tag}.log'), env=dict(env, CHM_GROUPS='1'))
+             ['--steps', '3', '--warmup', '1', '--groups', '1'], os.path.join(out, f'pmc{pi}{tag}.log'), env=env)
     print('pmc pass', pi, counters, 'rc', rc, flush=True)
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(os.path.join(d, '*', '*counter_collection.csv')):
@@ -108,7 +107,7 @@ def main():
   line = [l for l in probe.stdout.strip().split('\n') if l.startswith('{')]
   cfg = json.loads(line[-1])['config'] if line else {}
   wl = {"config": (bench_args[bench_args.index('--config') + 1] if '--config' in bench_args else 'C3'), "E": cfg.get('E'), "P": cfg.get('P'),
-        "Z": cfg.get('Z'), "S": cfg.get('S'), "nbatch": cfg.get('nbatch'), "mode": cfg.get('kind_p_gw3d') or '1d', "n_gpus": 1}
+        "Z": cfg.get('Z'), "S": cfg.get('S'), "nbatch": cfg.get('nbatch'), "mode": cfg.get('kind_p_gw3d') or '1d', "n_gpus": 1, "fused": cfg.get('fused', 0)}
   # [r3] tie the counters to the binary they were collected from, and keep the static instruction mix of its hot loops beside them
   sys.path.insert(0, os.path.join(ROOT, 'scripts'))
   import isa_mix
@@ -139,7 +138,7 @@ def main():
     b = json.loads(open(os.path.join(out, f'bench{tag}.json')).read().strip().split('\n')[-1])
     print('value', b['value'], 'ms/step', b['ms_per_step'], 'single', b.get('single_call_ms'))
     for k in b['roofline']['kernels']:
-      print({x: k.get(x) for x in ('kernel', 'kernel_ms', 'valu_busy_frac', 'valu_busy_frac_at_held_clock', 'fp64_TFLOPs_real', 'cycles_per_valu_inst', 'hbm_unique_frac', 'hbm_traffic_frac', 'clock_GHz_under_profile')})
+      print({x: k.get(x) for x in ('kernel', 'kernel_ms', 'useful_frac', 'valu_busy_frac', 'valu_busy_frac_at_held_clock', 'fp64_TFLOPs_real', 'cycles_per_valu_inst', 'hbm_unique_frac', 'hbm_traffic_frac', 'clock_GHz_under_profile')})
   except Exception as e:                                             # noqa: BLE001
     print('bench line not parsed:', e)
   for k, v in kernels.items():

@@ -54,9 +54,12 @@ def test_gkde_nd(d, bw):
   # in_log=True (math.py:223-226): log of the density where it is representable, and finite far out in the tail where the density
   # itself underflows -- against scipy's logsumexp of the same terms (and gaussian_kde.logpdf)
   from scipy.special import logsumexp
-  lg = M.gkde_nd(data, pts, weights=w, bw_method=bw, in_log=True)
-  np.testing.assert_allclose(lg, np.log(got), rtol=0, atol=1e-10)
-  far = pts[:, :7] + 60. * np.std(data, axis=1, keepdims=True)
+  near = data[:, ::3] + 0.2 * (A @ rng.normal(size=(d, 300)))                                        # points inside the cloud (in its own geometry)
+  dens = M.gkde_nd(data, near, weights=w, bw_method=bw)
+  assert np.all(dens > 1e-30)
+  np.testing.assert_allclose(M.gkde_nd(data, near, weights=w, bw_method=bw, in_log=True), np.log(dens), rtol=0, atol=1e-10)
+  assert np.all(np.isfinite(M.gkde_nd(data, pts, weights=w, bw_method=bw, in_log=True)))
+  far = near[:, :7] + 60. * np.std(data, axis=1, keepdims=True)
   lf = M.numba_gkde_nd(data, far, weights=w, bw_method=bw, in_log=True)
   assert np.all(np.isfinite(lf)) and np.all(lf < -700.) and np.all(M.gkde_nd(data, far, weights=w, bw_method=bw) == 0.)
   kde = gaussian_kde(data, weights=w, bw_method=bw)
