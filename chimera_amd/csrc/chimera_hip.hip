@@ -52,6 +52,7 @@ struct Opts {
   int no_dense = 0;          // standard GW kernel without the dense redo (shows the limit of the prefix-sum form: WRONG results for extreme weights)
   int marg_generic = 0, samples_generic = 0, selection_generic = 0, no_grid_prep = 0, zf_full = 0;
   int kde_ipw = 0, samp_cpb = 0, self_blocks = 8192, few_nb = 8, no_zero_copy = 0, no_zf_sel = 0, host_prof = 0;
+  int fused_nw = 0;          // 16: few-draw calls of the fused event kernel with 16 waves per block (-DCHM_FUSED_NW16 builds; A/B)
 };
 #ifdef CHM_DIAG
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
@@ -67,6 +68,7 @@ static void opts_init(Opts& o) {
   o.no_grid_prep = env_set("CHM_NO_GRID_PREP"); o.zf_full = env_set("CHM_ZF_FULL"); o.kde_ipw = env_int("CHM_KDE_IPW", 0);
   o.samp_cpb = env_int("CHM_SAMP_CPB", 0); o.self_blocks = env_int("CHM_SELF_BLOCKS", 8192); o.few_nb = env_int("CHM_FEW_NB", 8);
   o.no_zero_copy = env_set("CHM_NO_ZERO_COPY"); o.no_zf_sel = env_set("CHM_NO_ZF_SEL"); o.host_prof = env_set("CHM_HOST_PROF");
+  o.fused_nw = env_int("CHM_FUSED_NW", 0);
 #else
   (void)o;
 #endif
@@ -98,10 +100,11 @@ static int opts_set(Opts& o, int32_t option, int64_t value) {
     case CHM_OPT_DIAG_NO_ZERO_COPY: o.no_zero_copy = v != 0; return CHM_OK;
     case CHM_OPT_DIAG_NO_ZF_SEL: o.no_zf_sel = v != 0; return CHM_OK;
     case CHM_OPT_DIAG_HOST_PROF: o.host_prof = v != 0; return CHM_OK;
+    case CHM_OPT_DIAG_FUSED_NW: o.fused_nw = v; return CHM_OK;
     default: break;
   }
 #else
-  if (option >= CHM_OPT_DIAG_FULL_CHAIN && option <= CHM_OPT_DIAG_HOST_PROF)
+  if (option >= CHM_OPT_DIAG_FULL_CHAIN && option <= CHM_OPT_DIAG_FUSED_NW)
     return fail(CHM_E_ARG, "chm_*_set_option: diagnostic option -- this library was built without -DCHM_DIAG");
 #endif
   return fail(CHM_E_ARG, "chm_*_set_option: unknown option");
@@ -926,7 +929,14 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   // (the draw's mass tables + the widest event's slice of the distance tables + NW - 1 boundary rows | 4 NW prefix arrays) and ~2 KB.
   FusedDesc FDc = {};
   size_t lds_fused = 0;
+  // 4 waves per block, two blocks per CU.  (16 waves per block -- one block per CU, 154 KB of LDS with all 32 pixels' prefix arrays at once, 128
+  // VGPRs -- was measured for few-draw calls: 54 spilled registers, 0.294 against 0.219 ms per scalar call; profiles/r04/ab_fused_event_kernel.txt.
+  // -DCHM_FUSED_NW16 + CHM_OPT_DIAG_FUSED_NW 16 bring it back for A/B runs.)
+#ifdef CHM_FUSED_NW16
+  const int fused_nw = (nb <= o.few_nb && o.fused_nw == 16) ? 16 : 4;
+#else
   const int fused_nw = 4;
+#endif
   bool use_fused = false;
   {
     const int fmode = o.fused;                              // off by default: measured slower than the separate kernels at every call size (profiles/r04/ab_fused_event_kernel.txt)
@@ -1023,7 +1033,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
             Tc_host, Tm_host, use_fast, lutA.key0, lutA.nk, lutA.cap, (long long)lds_fast, params[0].mass_model, out->partials != nullptr,
             sel_fast, lutB.key0, lutB.nk, lutB.cap, (long long)lds_sel, (long long)(intptr_t)lutB.lut, fuse_sel,
             (long long)(intptr_t)c.d_evpart, (long long)(intptr_t)(like ? like->L.ws_z : nullptr), (long long)(intptr_t)(sel ? sel->S.partial : nullptr),
-            zg_use, zg_make, (long long)(intptr_t)comm, use_fused, (long long)lds_fused, FDc.cap_rec, FDc.cap_keys, FDc.cap_m, zc_use, zc_make };
+            zg_use, zg_make, (long long)(intptr_t)comm, use_fused, fused_nw, (long long)lds_fused, FDc.cap_rec, FDc.cap_keys, FDc.cap_m, zc_use, zc_make };
     if (c.gexec && key == c.gkey) {                           // replay
       const double hp1 = host_prof_on() ? now_us() : 0.;
       HIPCHK(hipGraphLaunch(c.gexec, sA));
@@ -1126,9 +1136,13 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         L.ev_publish = 1;
         if (timing_all) { HIPCHK(hipEventRecord(c.evg[4 * g], sg)); HIPCHK(hipEventRecord(c.evg[4 * g + 1], sg)); }
         if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
-#define LAUNCH_FUSED_(M, NTL) do { allow_lds((k_marg_fused<M, 4, 200, NTL>), lds_fused); \
-          hipLaunchKernelGGL((k_marg_fused<M, 4, 200, NTL>), dim3((unsigned)L.E_cnt * nb), dim3(256), lds_fused, sg, L, Fq, FDc, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, c.rec, c.TcMax, c.TmMax); } while (0)
-#define LAUNCH_FUSED(M) do { if (nb <= few_nb) LAUNCH_FUSED_(M, true); else LAUNCH_FUSED_(M, false); } while (0)
+#define LAUNCH_FUSED_(M, NWV, NTL) do { allow_lds((k_marg_fused<M, NWV, 200, NTL>), lds_fused); \
+          hipLaunchKernelGGL((k_marg_fused<M, NWV, 200, NTL>), dim3((unsigned)L.E_cnt * nb), dim3(64 * NWV), lds_fused, sg, L, Fq, FDc, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, c.rec, c.TcMax, c.TmMax); } while (0)
+#ifdef CHM_FUSED_NW16
+#define LAUNCH_FUSED(M) do { if (nb <= few_nb) { if (fused_nw == 16) LAUNCH_FUSED_(M, 16, true); else LAUNCH_FUSED_(M, 4, true); } else LAUNCH_FUSED_(M, 4, false); } while (0)
+#else
+#define LAUNCH_FUSED(M) do { if (nb <= few_nb) LAUNCH_FUSED_(M, 4, true); else LAUNCH_FUSED_(M, 4, false); } while (0)
+#endif
         const int mm = params[0].mass_model;
         if (mm == 0) LAUNCH_FUSED(0); else if (mm == 1) LAUNCH_FUSED(1); else LAUNCH_FUSED(2);
 #undef LAUNCH_FUSED

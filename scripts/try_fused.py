@@ -15,7 +15,7 @@ from tests import helpers as H
 def both(like, lams):
   out = {}
   for mode in ('0', '2'):
-    os.environ['CHM_FUSED'] = mode
+    like.set_option('fused', int(mode))
     out[mode] = like._eval(like._params_array(lams), want=('log_like_evs',))
   return out
 
@@ -33,7 +33,7 @@ def check(name, E, S, P, Z, seed, ragged=True, models=None, draws=(60., 70., 85.
   d = np.max(np.abs(a['log_like_evs'][fin] - f['log_like_evs'][fin])) if fin.any() else 0.
   dh = np.max(np.abs(a['log_hyper'] - f['log_hyper']))
   # scalar calls go through the few-draw instantiation
-  os.environ['CHM_FUSED'] = '1'
+  like_p.set_option('fused', 1)
   sc = np.array([like_p(**l) for l in lams])
   ds = np.max(np.abs(sc - f['log_hyper']))
   print(f"{name}: E={E} S={S} P={P} Z={Z}: fused vs oracle ok; |fused - separate| per event {d:.2e}, log_hyper {dh:.2e}; scalar vs batch {ds:.2e}")
@@ -59,7 +59,7 @@ def main():
   for nbatch in (1, 128):
     lams = [dict(H0=60. + 20. * i / max(nbatch - 1, 1)) for i in range(nbatch)]
     for mode in ('0', '2'):
-      os.environ['CHM_FUSED'] = mode
+      like.set_option('fused', int(mode))
       for _ in range(4):
         r = like.batch(lams)
       t0 = time.perf_counter()
