@@ -1,18 +1,14 @@
 #!/bin/bash
-# Round-4 profile set in one gpurun call (writes gpurun_out/profiles_r04/, copy to profiles/r04/):
-#   C3 default command: kernel stats (default + one stream), PMC passes incl. the VALU-class counters, bench line;  C3 nbatch=1 (the scalar call):
-#   PMC + kernel stats;  the FUSED event kernel (--fused 2) at 128 draws and at one draw per call: kernel stats + traffic / instruction counters;
-#   full mode: kernel stats + bench line;  C4;  bench lines of C1, C2, C5, approximate;  scalar-call timeline
+# Round-4 profile set, part 2 of 2: full mode (kernel stats + bench line);  C4;  bench lines of C1, C2, C5, approximate;  scalar-call timeline
 export CHIMERA_NO_REBUILD=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/profiles_r04; mkdir -p $O
-python3 scripts/collect_profiles.py r04 > $O/collect_C3.log 2>&1; tail -14 $O/collect_C3.log
+python3 scripts/collect_profiles.py r04 --tag full --passes 0,1,3,5 -- --mode full --nbatch 4 --steps 10 --warmup 3 > $O/collect_full.log 2>&1; tail -6 $O/collect_full.log
 python3 scripts/collect_profiles.py r04 --tag C4 --passes 0,1,3,5 -- --config C4 > $O/collect_C4.log 2>&1; tail -4 $O/collect_C4.log
 for c in C1 C2; do timeout -k 10 300 python3 bench.py --config $c > $O/bench_$c.json 2> $O/bench_$c.err; done
 timeout -k 10 600 python3 bench.py --config C5 --nbatch 16 --steps 10 --warmup 2 --cpu-evals 3 > $O/bench_C5.json 2> $O/bench_C5.err
 timeout -k 10 300 python3 bench.py --mode approximate > $O/bench_approximate.json 2> $O/bench_approximate.err
 python3 scripts/timeline_scalar.py $O/timeline_scalar_call.txt > /dev/null 2>&1
-for f in $O/bench_C1.json $O/bench_C2.json $O/bench_C4.json $O/bench_C5.json $O/bench_approximate.json $O/bench_full.json $O/bench_fused.json $O/bench_fused_nbatch1.json; do python3 -c "
+for f in $O/bench_C1.json $O/bench_C2.json $O/bench_C4.json $O/bench_C5.json $O/bench_approximate.json $O/bench_full.json; do python3 -c "
 import json,sys; j=json.loads(open('$f').read().strip().split('\n')[-1]); print('$f', round(j['value'],1), 'evals/s', round(j['ms_per_step'],3), 'ms/step single', j['single_call_ms'], 'cpu', j.get('cpu_baseline',{}).get('value'), 'parity', (j.get('parity_full_size') or {}).get('abs_diff'))"; done
 cat $O/timeline_scalar_call.txt
-
