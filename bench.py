@@ -464,8 +464,9 @@ def main():
       pk = N_SIMD * CLK_HZ / CYC_VALU / 1e9 * 64 / 1.25
       kf.update({"pairs_per_launch": full_pairs, "Gpairs_s": full_pairs / sec / 1e9 if sec > 0 else None,
                  "peak_Gpairs_s": pk, "pair_frac": full_pairs / sec / 1e9 / pk if sec > 0 else None})
-    kernels.append(kernel_roofline("sample stage (z(dL), source-frame masses, population weights, event statistics)", "k_samples", kt[2],
-                                   sample_kernel_unique_bytes(El, S, nb), pmc, units=El * S * nb / 64.))
+    if not (kind == 'marginalized' and args.fused >= 2):        # (the fused event kernel has no sample stage of its own)
+      kernels.append(kernel_roofline("sample stage (z(dL), source-frame masses, population weights, event statistics)", "k_samples", kt[2],
+                                     sample_kernel_unique_bytes(El, S, nb), pmc, units=El * S * nb / 64.))
     # the selection kernel runs on its own stream beside the event kernels (its span there is not a kernel duration): timed standalone
     # here, after the timed region, as the selection-only call chm_eval(NULL, sel, ...) of the same draws
     sel_ms = None

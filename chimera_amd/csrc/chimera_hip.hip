@@ -941,7 +941,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   {
     const int fmode = o.fused;                              // off by default: measured slower than the separate kernels at every call size (profiles/r04/ab_fused_event_kernel.txt)
     const int few_nb_f = o.few_nb;
-    if (like && like->fused_ok && use_fast && !tab && !want_dump && fmode > 0 && (nb <= few_nb_f || fmode >= 2) && !serial &&
+    if (like && like->fused_ok && use_fast && !tab && !want_dump && fmode > 0 && (nb <= few_nb_f || fmode >= 2) &&
         like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && like->L.num_bins == 200 &&
         !o.marg_generic && !o.zf_full) {
       int Tc_call = 0, Tm_call = 0;

@@ -54,8 +54,8 @@ def kernel_table(rnd):
   units = {'k_kde_marg_sub2': ('pair of pixels', E * P / 2 * nb), 'k_samples_fast': ('sample', E * S * nb / 64.), 'k_selection_fast': ('injection', I * nb / 64.),
            'k_zfactors': (None, None), 'k_marg_fixup': (None, None), 'k_event_stats': (None, None), 'k_tables': (None, None), 'k_reduce_final': (None, None)}
   rk = {k['kernel'].split('<')[0]: k for k in b['roofline']['kernels']}
-  rows = ['| Kernel | ms per 128 draws (one lane, rocprofv3 average) | µs at 1 draw | VALU wave-instructions per launch (PMC) | per unit | issue cycles / instruction | VALU busy at 2.4 GHz / at the held clock | real fp64 TFLOP/s |',
-          '|---|---|---|---|---|---|---|---|']
+  rows = ['| Kernel | ms per 128 draws (one lane, rocprofv3 average) | µs at 1 draw | VALU wave-instructions per launch (PMC) | per unit | issue cycles / instruction | useful (fp64 add / mul / fma) | VALU busy at 2.4 GHz / at the held clock | real fp64 TFLOP/s |',
+          '|---|---|---|---|---|---|---|---|---|']
   for pref in ('k_tables', 'k_samples_fast', 'k_event_stats', 'k_zfactors', 'k_kde_marg_sub2', 'k_marg_fixup', 'k_selection_fast', 'k_reduce_final'):
     n, v = find(ks, pref)
     n1, v1 = find(k1, pref if pref != 'k_zfactors' else 'k_zf')
@@ -65,10 +65,11 @@ def kernel_table(rnd):
     insts = pk.get('SQ_INSTS_VALU') if pk else None
     unit, cnt = units[pref]
     r = rk.get(pref)
-    rows.append('| `%s` | %s | %s | %s | %s | %s | %s | %s |' % (
+    rows.append('| `%s` | %s | %s | %s | %s | %s | %s | %s | %s |' % (
       n or pref, '%.3f' % (v[0] * 1e-3) if v else '—', '%.1f' % v1[0] if v1 else '—',
       '%.4g' % insts if insts else '—', ('%.0f per %s' % (insts / cnt, unit)) if insts and cnt else '—',
       '%.2f' % r['cycles_per_valu_inst'] if r and r.get('cycles_per_valu_inst') else '—',
+      '%.3f' % r['useful_frac'] if r and r.get('useful_frac') else '—',
       ('%.2f / %.2f' % (r['valu_busy_frac'], r['valu_busy_frac_at_held_clock'])) if r and r.get('valu_busy_frac_at_held_clock') else '—',
       '%.1f' % r['fp64_TFLOPs_real'] if r and r.get('fp64_TFLOPs_real') else '—'))
   sha = p.get('code_object_sha256', '?')[:16] if p else '?'
@@ -96,13 +97,29 @@ def headline(rnd):
   pf = b.get('parity_full_size')
   if pf:
     out.append('| Full-size parity inside the bench run | `log_hyper(H0=67)`: HIP %.13f, C port %.13f (abs diff %.1e; tolerance %.0e) | `parity_full_size` |' % (pf['log_hyper_hip'], pf['log_hyper_cpu_port'], pf['abs_diff'], pf['tolerance']))
-  out.append('| `roofline` of the driver line | bound **%s**, kernel `%s`: achieved %.3f of %.4f Tcycle/s = **frac %.3f** (%.3f at the %.2f GHz held); real fp64 %.1f of 78.6 TFLOP/s; HBM: unique bytes %.2f GB per launch = %.2f of 8 TB/s, PMC traffic %.2f GB = %.2f | `bench.json: roofline` |'
-             % (r['bound'], r['kernel'], r['achieved'], r['peak'], r['frac'], r['frac_at_held_clock'] or 0., [k for k in r['kernels'] if k['kernel'] == r['kernel']][0].get('clock_GHz_under_profile') or 0.,
-                r['fp64_TFLOPs_real'] or 0., r['hbm']['unique_bytes_per_launch'] / 1e9, r['hbm']['frac'], (r['traffic'] or 0) / 1e9, r['hbm']['traffic_frac'] or 0.))
+  dk = [k for k in r['kernels'] if k['kernel'] == r['kernel']][0]
+  if 'issue_busy_frac' in r:                               # round 4 on: frac = the USEFUL fraction (fp64 add / mul / fma issue cycles), the busy fraction beside it
+    mi = r.get('min_inst') or {}
+    out.append('| `roofline` of the driver line | bound **%s**, kernel `%s`: **frac %.3f** = issue cycles of its fp64 add / mul / fma instructions, %.3f of %.4f Tcycle/s (useful work); '
+               'issue ports busy with ANY VALU instruction %.3f (%.3f at the %.2f GHz held); %.0f VALU instructions per %s against a stated minimum of %.0f (x %.2f); real fp64 %.1f of 78.6 TFLOP/s; '
+               'HBM: unique bytes %.2f GB per launch = %.2f of 8 TB/s, PMC traffic %.2f GB = %.2f | `bench.json: roofline` |'
+               % (r['bound'], r['kernel'], r['frac'] or 0., r['achieved'] or 0., r['peak'], r['issue_busy_frac'] or 0., r.get('issue_busy_frac_at_held_clock') or 0., dk.get('clock_GHz_under_profile') or 0.,
+                  mi.get('per_unit_achieved') or 0., mi.get('unit') or 'unit', mi.get('per_unit_minimal') or 0., mi.get('achieved_over_minimal') or 0.,
+                  r['fp64_TFLOPs_real'] or 0., r['hbm']['unique_bytes_per_launch'] / 1e9, r['hbm']['frac'], (r['traffic'] or 0) / 1e9, r['hbm']['traffic_frac'] or 0.))
+    if s.get('hbm_frac') is not None:
+      out.append('| Scalar call against the HBM roofline (call level) | %.1f MB of algorithmic bytes in %.4f ms = %.2f TB/s = **%.3f of 8 TB/s** | `single_call.hbm_frac` |'
+                 % (s['algorithmic_bytes'] / 1e6, s['median_ms'], s['hbm_GBs'] / 1e3, s['hbm_frac']))
+  else:
+    out.append('| `roofline` of the driver line | bound **%s**, kernel `%s`: achieved %.3f of %.4f Tcycle/s = **frac %.3f** (%.3f at the %.2f GHz held); real fp64 %.1f of 78.6 TFLOP/s; HBM: unique bytes %.2f GB per launch = %.2f of 8 TB/s, PMC traffic %.2f GB = %.2f | `bench.json: roofline` |'
+               % (r['bound'], r['kernel'], r['achieved'], r['peak'], r['frac'], r['frac_at_held_clock'] or 0., dk.get('clock_GHz_under_profile') or 0.,
+                  r['fp64_TFLOPs_real'] or 0., r['hbm']['unique_bytes_per_launch'] / 1e9, r['hbm']['frac'], (r['traffic'] or 0) / 1e9, r['hbm']['traffic_frac'] or 0.))
   for k in r['kernels'][1:]:
     if k.get('valu_busy_frac'):
-      out.append('| `%s` | %.3f ms per launch; %.4g VALU instructions x %.2f cycles -> busy %.2f at 2.4 GHz, %.2f at the %.2f GHz held; real fp64 %.1f TFLOP/s; PMC traffic %.2f GB -> %.2f of 8 TB/s | `roofline.kernels` |'
-                 % (k['kernel'], k['kernel_ms'], k['valu_inst_per_launch'], k['cycles_per_valu_inst'], k['valu_busy_frac'], k.get('valu_busy_frac_at_held_clock') or 0., k.get('clock_GHz_under_profile') or 0.,
+      mi = k.get('min_inst') or {}
+      out.append('| `%s` | %.3f ms per launch; useful (fp64 add / mul / fma) %s; %.4g VALU instructions x %.2f cycles -> busy %.2f at 2.4 GHz, %.2f at the %.2f GHz held%s; real fp64 %.1f TFLOP/s; PMC traffic %.2f GB -> %.2f of 8 TB/s | `roofline.kernels` |'
+                 % (k['kernel'], k['kernel_ms'], ('**%.3f**' % k['useful_frac']) if k.get('useful_frac') else '—', k['valu_inst_per_launch'], k['cycles_per_valu_inst'], k['valu_busy_frac'],
+                    k.get('valu_busy_frac_at_held_clock') or 0., k.get('clock_GHz_under_profile') or 0.,
+                    ('; %.0f instructions per %s, minimum %.0f (x %.2f)' % (mi['per_unit_achieved'], mi['unit'], mi['per_unit_minimal'], mi['achieved_over_minimal'])) if mi else '',
                     k.get('fp64_TFLOPs_real') or 0., (k.get('traffic_bytes_per_launch') or 0) / 1e9, k.get('hbm_traffic_frac') or 0.))
   if b1:
     for k in b1['roofline']['kernels']:
@@ -118,6 +135,12 @@ def headline(rnd):
         k = x['roofline']['kernels'][0]
         extra = '; `%s` %.2f ms per launch = %.2f Tpair/s = %.3f of the power-sum ceiling' % (k['kernel'], k['kernel_ms'], k['Gpairs_s'] / 1e3, k['pair_frac'])
       out.append('| %s | %.0f evals/s (%.3f ms per step; scalar call %.3f ms)%s | `bench%s.json` |' % (label, x['value'], x['ms_per_step'], x.get('single_call_ms') or 0., extra, tag))
+  for tag, label in (('_fused', 'FUSED event kernel (`--fused 2`: off by default), 128 draws per call'), ('_fused_nbatch1', 'FUSED event kernel, one draw per call')):
+    x = bench(rnd, tag)
+    if x:
+      k = x['roofline']['kernels'][0]
+      out.append('| %s | %.0f evals/s (%.3f ms per step; scalar call %.3f ms); `%s` %.3f ms per launch, PMC traffic %.2f GB per launch | `bench%s.json`, `ab_fused_event_kernel.txt` |'
+                 % (label, x['value'], x['ms_per_step'], x.get('single_call_ms') or 0., k['kernel'], k['kernel_ms'], (k.get('traffic_bytes_per_launch') or 0) / 1e9, tag))
   out.append('| One-time hand-over of the host arrays | %.2f s; not part of `value` | `bench.json: setup_s.upload_once` |' % b['setup_s']['upload_once'])
   return '\n'.join(out)
 
