@@ -1993,8 +1993,16 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
         } else
 #endif
         {
-          if (in0) pg0 = single(z0);
-          if (in1) pg1 = single(z1);
+#ifndef CHM_GW_BOTH
+#define CHM_GW_BOTH 0
+#endif
+          // PRE (the fused event kernel: two waves per SIMD, 256 VGPRs on offer): both points of the lane in ONE basic block -- their four node
+          // evaluations are independent chains the scheduler can interleave; a lane with one point outside the support computes it for nothing
+          if (PRE && CHM_GW_BOTH) { const double f0 = single(z0), f1 = single(z1); pg0 = in0 ? f0 : 0.; pg1 = in1 ? f1 : 0.; }
+          else {
+            if (in0) pg0 = single(z0);
+            if (in1) pg1 = single(z1);
+          }
         }
       }
       integrand(k, pg0, q.pc.x, q.bk.x, q.a.x);

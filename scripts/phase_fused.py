@@ -20,7 +20,7 @@ def main():
   like, _, _ = H.build_product(ev, inj)
   L = _lib.lib()
   out = (C.c_double * 8)()
-  os.environ['CHM_FUSED'] = '2'
+  like.set_option("fused", 2)
   for nbatch in [int(a) for a in sys.argv[1:]] or [1, 128]:
     lams = [dict(H0=60. + 20. * i / max(nbatch - 1, 1)) for i in range(nbatch)]
     for _ in range(3):
