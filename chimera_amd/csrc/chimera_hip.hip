@@ -835,6 +835,7 @@ extern "C" int chm_eval_tabulated(chm_like* like, chm_sel* sel, chm_comm* comm, 
 
 static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_params* params, int32_t nb,
                      int64_t E_total, const chm_tab* tab, chm_out* out) {
+  TicketTurn turn(comm);                                      // (ticketed calls: the collective is enqueued in ticket order, see CollSeq; every exit passes the turn on)
   if ((!like && !sel) || !params || !out || nb <= 0) return fail(CHM_E_ARG, "chm_eval: need a handle, params, out and nb > 0");
   if (like && sel && like->ctx.device != sel->ctx.device) return fail(CHM_E_ARG, "chm_eval: like and sel live on different devices");
   Ctx& c = like ? like->ctx : sel->ctx;
@@ -842,7 +843,6 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   g_host_prof = o.host_prof != 0;
   const double hp0 = host_prof_on() ? now_us() : 0.;
   if (comm && comm->device != c.device) return fail(CHM_E_ARG, "chm_eval: comm lives on a different device");
-  TicketTurn turn(comm);                                      // (ticketed calls: the collective is enqueued in ticket order, see CollSeq)
   HIPCHK(hipSetDevice(c.device));
   const bool serial = o.serial != 0;                        // everything on one stream (bench.py times the kernels on their own after its timed region)
   hipStream_t sA = c.stream, sB = serial ? c.stream : c.stream2, sC = serial ? c.stream : c.stream3;      // (all three = sA for fused few-draw calls, below)

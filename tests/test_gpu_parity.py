@@ -339,6 +339,82 @@ def test_two_evaluations_in_flight_on_lanes_of_one_handle(cfg_pix):
   lane.selection_function.close(); lane.close()
 
 
+def test_options_select_streams_and_launch_paths_not_results(cfg_pix):
+  """[r4] chm_like_set_option: one stream / one event group / no graph replay / no timing events / no spinning wait are choices of scheduling --
+  every combination returns the default's values bit for bit (scalar calls, batches beyond the few-draw limit, per-event outputs); unknown
+  options and out-of-range values raise ValueError; a clone starts with its source's options."""
+  cfg, ev, inj = cfg_pix
+  like, _, _ = H.build_product(ev, inj)
+  hs = np.linspace(61., 79., 11)
+  lams = [dict(H0=float(h)) for h in hs]
+  want_b = like.batch(lams)
+  want_s = np.array([like(H0=float(h)) for h in hs[:4]])
+  want_e = like.compute_all(H0=70.)[0]
+  for name, value, back in (('serial', 1, 0), ('groups', 1, 0), ('groups', 3, 0), ('graph_max_nb', 0, 8), ('timing', 0, 1), ('timing', 2, 1), ('spin_wait', 0, 1)):
+    like.set_option(name, value)
+    np.testing.assert_array_equal(like.batch(lams), want_b, err_msg=name)
+    np.testing.assert_array_equal(np.array([like(H0=float(h)) for h in hs[:4]]), want_s, err_msg=name)
+    np.testing.assert_array_equal(like.compute_all(H0=70.)[0], want_e, err_msg=name)
+    like.set_option(name, back)
+  assert like.last_timing()[0] > 0.
+  like.set_option('timing', 0); like.batch(lams)
+  assert np.all(like.last_timing()[:7] == 0.)
+  like.set_option('timing', 1)
+  with pytest.raises(ValueError):
+    like.set_option('no_such_option', 1)
+  with pytest.raises(ValueError):
+    like.set_option('groups', 99)
+  with pytest.raises(ValueError):
+    like.set_option('fused', 7)
+  like.set_option('serial', 1)
+  lane = like.lane()
+  assert lane._options == like._options and lane._options['serial'] == 1
+  np.testing.assert_array_equal(lane.batch(lams), want_b)
+  lane.selection_function.close(); lane.close()
+  like.close()
+
+
+def test_ticketed_collectives_of_two_lanes_keep_their_order(cfg_pix):
+  """[r4] Two evaluation lanes, each with a (one-rank) RCCL communicator of its own and a host thread of its own: chm_comm_set_ticket makes the lanes
+  hand their all-reduces to the device in ticket order.  The thread holding the HIGHER ticket is started first and must wait for the lower one;
+  values equal the communicator-free ones bit for bit; a call that fails before its collective passes the turn on instead of blocking the next."""
+  import threading, time
+  from chimera_amd.parallel import Comm
+  cfg, ev, inj = cfg_pix
+  ref, _, _ = H.build_product(ev, inj)
+  c0, c1 = Comm(1, 0, device=0), Comm(1, 0, device=0)
+  like, _, _ = H.build_product(ev, inj, comm=c0)
+  lane = like.lane(comm=c1)
+  hs = np.linspace(62., 78., 8)
+  lams = [dict(H0=float(h)) for h in hs]
+  want = ref.batch(lams)
+  Comm.reset_tickets(0)
+  order, res = [], {}
+
+  def run(ln, comm, ticket, delay):
+    time.sleep(delay)
+    comm.set_ticket(ticket)
+    res[ticket] = ln.batch(lams)
+    order.append(ticket)
+  for rep in range(3):
+    ta = threading.Thread(target=run, args=(lane, c1, 2 * rep + 1, 0.))          # the later ticket starts first ...
+    tb = threading.Thread(target=run, args=(like, c0, 2 * rep, 0.15))            # ... and waits for the earlier one
+    ta.start(); tb.start(); ta.join(60); tb.join(60)
+    assert not ta.is_alive() and not tb.is_alive()
+    assert order[-2:] == [2 * rep, 2 * rep + 1], order
+    np.testing.assert_array_equal(res[2 * rep], want); np.testing.assert_array_equal(res[2 * rep + 1], want)
+  # a ticketed call that fails in its argument checks (nb = 0 is refused) still passes the turn on
+  from chimera_amd import _lib
+  import ctypes as C
+  c0.set_ticket(6)
+  out = _lib.chm_out()
+  assert _lib.lib().chm_eval(like._handle(), None, c0.handle, like._params_array(lams), 0, cfg['E'], C.byref(out)) == _lib.CHM_E_ARG
+  c1.set_ticket(7)
+  np.testing.assert_array_equal(lane.batch(lams), want)                          # (would hang if ticket 6 had been lost)
+  lane.selection_function.close(); lane.close(); like.selection_function.close(); like.close(); ref.close()
+  c0.close(); c1.close()
+
+
 def _hostcomm_worker(rank, world, addr, outdir):
   import os, sys
   sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
