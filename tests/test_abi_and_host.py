@@ -309,6 +309,13 @@ def test_roofline_accounting_of_the_bench():
   r = bench.kernel_roofline('x', 'k_x', 5.0, 1e9, ('f.json', {'kernels': {'k_x<1>': k}, 'static_mix': st}, True))
   assert abs(r['valu_busy_frac'] - 1.0) < 1e-12 and abs(r['fp64_TFLOPs_real'] - bench.FP64_PEAK_TFLOPS) < 1e-9 and abs(r['cycles_per_valu_inst'] - 4.) < 1e-12
   assert abs(r['traffic_bytes_per_launch'] - 3e6 * 1024) < 1 and r['hbm_unique_frac'] == 1e9 / 5e-3 / 1e9 / 8000.
+  assert abs(r['useful_frac'] - 1.0) < 1e-12                      # [r4] every instruction an fp64 FMA: all of the busy cycles are useful ones
+  # [r4] useful_frac counts fp64 add / mul / fma only: the same launch with half of its instructions replaced by moves is as busy and half as useful
+  k2 = dict(k, SQ_INSTS_VALU_FMA_F64=insts / 2, SQ_INSTS_VALU_FLOPS_FP64=insts)
+  r2 = bench.kernel_roofline('x', 'k_kde_marg_sub2', 5.0, 1e9, ('f.json', {'kernels': {'k_kde_marg_sub2<1>': k2}, 'static_mix': {'k_kde_marg_sub2<1>': st['k_x<1>']}}, True), units=insts / 1140.)
+  assert abs(r2['valu_busy_frac'] - 1.0) < 1e-12 and abs(r2['useful_frac'] - 0.5) < 1e-12
+  assert r2['min_inst']['per_unit_minimal'] == 570. and abs(r2['min_inst']['achieved_over_minimal'] - 2.0) < 1e-9 and r2['min_inst']['unit'] == 'pair of pixels'
+  assert '"path_frac"' not in open(os.path.join(ROOT, 'bench.py')).read()      # (round 3 multiplied shared inputs by the draws per call)
   # a quarter of the stream on the 2-cycle opcodes, 1 % fp64 reciprocals: 0.25 * 2 + 0.01 * 16 + 0.74 * 4 cycles per instruction
   st['k_x<1>']['hot_loop'].update(fast=25)
   k.update(SQ_INSTS_VALU_TRANS_F64=0.01 * insts)
