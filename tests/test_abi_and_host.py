@@ -375,6 +375,15 @@ def test_compiler_resource_report_of_the_kernels(lib):
   assert res['k_marg_fused<2, 4, 200, true>']['scratch_bytes_per_lane'] == 0 and res['k_marg_fused<2, 4, 200, true>']['waves_per_simd'] >= 2
 
 
+def test_build_is_reproducible_across_checkout_paths():
+  """[r4] The PMC files under profiles/ are tied to the sha256 of the gfx950 code object, and bench.py prints no roofline fraction for another one.
+  hipcc's default compilation-unit id hashes the source PATH into the names of internal symbols: the library rebuilt on the GPU box (another
+  checkout path) had another sha256 than the one built here.  Both recipes therefore pin the id."""
+  import __graft_entry__ as g
+  assert any(f.startswith('-cuid=') for f in g.HIP_FLAGS)
+  assert '-cuid=' in open(os.path.join(ROOT, 'scripts', 'build_variant.sh')).read()
+
+
 def test_release_library_reads_no_environment_switch(lib):
   """[r4] What a call computes depends on the handle's options alone (chm_like_set_option): the release library contains none of the CHM_*
   switch names the diagnostic build (-DCHM_DIAG) initialises its options from, does not import getenv, and says so (chm_diag_build() == 0)."""

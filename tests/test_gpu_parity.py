@@ -866,6 +866,33 @@ def test_nan_and_out_of_range_samples_behave_like_the_reference(cfg_pix, kind):
   H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
 
 
+@pytest.mark.parametrize('kind', ['marginalized', 'full'])
+def test_nan_hyperparameters_behave_like_the_reference(cfg_pix, kind):
+  """[r4] A NaN hyper-parameter (and an infinite cosmological or mass one) must come out as it does from the reference's arithmetic: NaN
+  weights -> NaN sums -> L_i = NaN -> log L_i in the -inf class, log of the selection bias -inf, total NaN -- or, for a parameter the
+  configured models never read, the unchanged finite answer.  The fast kernels drop NaNs in places (v_min / v_max clamps, saturating
+  conversions) and rely on the NaN having been caught elsewhere: this is the check that it is.  Not covered: INFINITE rate parameters
+  (gamma, kappa, zp = inf), where numpy's power / division reach a finite limit or -inf and the table-driven exponentials give NaN."""
+  cfg, ev, inj = cfg_pix
+  like_o, _, _ = H.build_oracle(ev, inj, kind=kind)
+  like_p, _, _ = H.build_product(ev, inj, kind=kind)
+  cases = [(n, np.nan) for n in ('H0', 'Om0', 'alpha', 'beta', 'ml', 'mh', 'mu_g', 'sigma_g', 'lambda_peak', 'delta_m', 'gamma', 'kappa', 'zp')]
+  cases += [(n, np.inf) for n in ('H0', 'Om0', 'alpha', 'beta', 'mu_g', 'sigma_g', 'lambda_peak', 'delta_m')]
+  seen_nan = seen_finite = 0
+  for name, bad in cases:
+    with np.errstate(all='ignore'):
+      ro, rp = like_o.compute_all(**{name: bad}), like_p.compute_all(**{name: bad})
+    try:
+      H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
+      np.testing.assert_allclose(rp[1], ro[1], rtol=1e-10, atol=0, equal_nan=True)
+      np.testing.assert_allclose(rp[3], ro[3], rtol=1e-10, atol=1e-8, equal_nan=True)
+    except AssertionError as err:
+      raise AssertionError(f'{name} = {bad}\n{err}')
+    seen_nan += bool(np.isnan(ro[3]).all()); seen_finite += bool(np.isfinite(ro[3]).all())
+  assert seen_nan >= 10 and seen_finite >= 2
+  like_p.close()
+
+
 @pytest.mark.parametrize('kind', ['marginalized', 'approximate', 'full', None])
 def test_unphysical_cosmology_behaves_like_the_reference(kind):
   """A strongly closed universe with E(z)^2 < 0 beyond z ~ 2: the distance tables carry NaNs and dL(z) is not monotonic.  The
