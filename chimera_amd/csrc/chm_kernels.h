@@ -1892,6 +1892,9 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
       double a0 = r0, a1 = r1, a2 = r2;
       for (int j = j0; j < j1; j++) { double w = Q0[j], cc = ((double)j + 0.5) * dbin; a1 += w * cc; a2 += w * cc * cc; Q1[j + 1] = -2. * a1; Q2[j + 1] = a2; }
       a0 = r0; for (int j = j0; j < j1; j++) a0 += Q0[j];
+      // the first store below lands in the NEXT lane's first slot (Q0[j1]), whose count that lane has summed in the loops above and will read once
+      // more only for a value it never uses: every lane's reads of the counts are complete here, and stay in front of the stores
+      wave_sync();
       for (int j = j1 - 1; j >= j0; j--) { double w = Q0[j]; Q0[j + 1] = a0; a0 -= w; }
     }
     if (sl == 0) { Q1[0] = 0.; Q2[0] = 0.; }

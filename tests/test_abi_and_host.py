@@ -2,6 +2,7 @@
 the library loads and exports every symbol include/chimera_hip.h declares, the ctypes structures match the C layout,
 argument errors come back as the reference-side exception types, and without a GPU every compute entry fails loudly."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -373,6 +374,28 @@ def test_compiler_resource_report_of_the_kernels(lib):
     assert res[k]['vgpr_spills'] == 0 and res[k]['scratch_bytes_per_lane'] == 0, (k, res[k])
   # the fused event kernel is compiled for two blocks of four waves per CU (256 VGPRs on offer): no scratch
   assert res['k_marg_fused<2, 4, 200, true>']['scratch_bytes_per_lane'] == 0 and res['k_marg_fused<2, 4, 200, true>']['waves_per_simd'] >= 2
+
+
+def test_lds_handovers_sit_between_ordering_points():
+  """[r4] Static check of the wave-private LDS hand-overs: scripts/lds_handover_scan.py compiles the device code to assembly and
+  follows the control flow of every kernel; an LDS store that can be followed by an LDS load (or a load by a store) without a `; wave barrier`
+  (wave_sync()) or `s_barrier` (__syncthreads()) in between is a succession the compiler was free to reorder.  In the kernels that pass data between
+  the lanes of a wave, every such succession must be one that was reviewed (tests/golden/lds_handover_allow.json: the same lane's own slots, or two
+  different arrays); the two production instantiations of the GW kernel must have none."""
+  sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+  import lds_handover_scan as S
+  asm = S.device_asm()
+  allow = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'lds_handover_allow.json')))['allowed']
+  assert not [e for e in allow if e['why'].startswith('REVIEW')]
+  allowed = {(e['kernel'], e['kind'], e['first'], e['second']) for e in allow}
+  keys = S.audit_keys(asm)
+  assert {'k_kde_marg_sub2', 'k_full_kde_chain', 'k_marg_fused', 'k_marg_fixup'} <= set(keys)      # the kernels with wave-level ordering points were found
+  new = [(fam,) + k for fam, ks in keys.items() for k in ks if (fam,) + k not in allowed]
+  assert not new, 'unreviewed LDS store<->load successions without an ordering point:\n' + '\n'.join(map(str, new))
+  res, names = S.scan(asm), None
+  names = S.demangle(list(res))
+  hot = {names[f]: len(t) for f, t in res.items() if names[f].startswith('k_kde_marg_sub2<32') and names[f].endswith('200, false>')}
+  assert len(hot) == 2 and not any(hot.values()), hot
 
 
 def test_build_is_reproducible_across_checkout_paths():
