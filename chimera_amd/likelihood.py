@@ -69,8 +69,13 @@ class hyperlikelihood(object):
     #   'params'  every rank holds ALL events and injections and evaluates its own chunk of the DRAWS of a batch; the values are gathered
     #             (parallel.py:258-278: zeros(nparams), own slice set, allreduce SUM) -- for catalogues too small to shard (a 12-event shard
     #             is pure launch latency) under a vectorised sampler.
-    if scheme not in ('data', 'params'):
-      raise ValueError("hyperlikelihood: scheme must be 'data' or 'params'")
+    #   'both'    the ranks form `ngroups` groups (comm = parallel.split(world, ngroups)): inside a group events and injections are sharded as in
+    #             'data', the groups take consecutive slices of the DRAWS of a batch (parallel.py:132-224, 306-341, 380-406) -- many ranks, a
+    #             catalogue that shards only so far.
+    if scheme not in ('data', 'params', 'both'):
+      raise ValueError("hyperlikelihood: scheme must be 'data', 'params' or 'both'")
+    if scheme == 'both' and not (comm is not None and hasattr(comm, 'world') and hasattr(comm, 'ngroups')):
+      raise ValueError("hyperlikelihood: scheme='both' needs the group communicator of chimera_amd.parallel.split(world, ngroups)")
     self.scheme = scheme
     if scheme == 'params' and selection_function is not None and getattr(selection_function, 'comm', None) is not None \
        and selection_function.comm.nranks > 1:
@@ -99,7 +104,7 @@ class hyperlikelihood(object):
       self._mode = self.kind_p_gw3d
     else:
       self._mode = '1d'
-    if comm is not None and comm.nranks > 1 and scheme == 'data':
+    if comm is not None and comm.nranks > 1 and scheme in ('data', 'both'):
       self._e0, self._e1 = chunk_bounds(self.nevents, comm.nranks, comm.rank)
     else:
       self._e0, self._e1 = 0, self.nevents
@@ -262,7 +267,7 @@ class hyperlikelihood(object):
     if 'partials' in want:
       res['partials'] = np.empty((nb, 3)); out.partials = _lib.dptr(res['partials'])
     sel = self.selection_function._handle() if (with_sel and self.selection_function is not None) else None
-    comm = self.comm if (collective and self.scheme == 'data') else None      # 'params': replicas, nothing to reduce inside a call
+    comm = self.comm if (collective and self.scheme in ('data', 'both')) else None      # 'params': replicas, nothing to reduce inside a call
     comm_h = getattr(comm, 'handle', None) if comm is not None else None                 # RCCL all-reduce inside chm_eval
     host_reduce = (comm is not None and comm_h is None and comm.nranks > 1 and hasattr(comm, 'allreduce_sum'))
     if host_reduce and 'partials' not in res:               # HostComm: the partial sums are reduced and combined on the host
@@ -343,7 +348,7 @@ class hyperlikelihood(object):
       comm = self.comm if self.scheme == 'data' else None
       comm_h = getattr(comm, 'handle', None) if comm is not None else None
       plain = not any(self._plugins) and not (comm is not None and comm_h is None and comm.nranks > 1) \
-        and not (self.scheme == 'params' and self.comm is not None and self.comm.nranks > 1)
+        and not (self.scheme == 'params' and self.comm is not None and self.comm.nranks > 1) and self.scheme != 'both'
       if not plain:
         return self.batch([lam])[0]
       h = self._handle()
@@ -438,6 +443,8 @@ class hyperlikelihood(object):
     lams = list(list_of_hyper_lambdas)
     if self.scheme == 'params' and self.comm is not None and self.comm.nranks > 1:
       return self._batch_over_params(lams)
+    if self.scheme == 'both':
+      return self._batch_over_both(lams)
     return self._batch_local(lams)
 
   def _batch_local(self, lams):
@@ -446,6 +453,21 @@ class hyperlikelihood(object):
     if len(lams) <= m:
       return self._eval(pack(lams))['log_hyper']
     return np.concatenate([self._eval(pack(lams[i:i + m]))['log_hyper'] for i in range(0, len(lams), m)])
+
+  def _batch_over_both(self, lams):
+    """The reference's 'both' scheme (CHIMERA/parallel.py:380-406): group g of the world evaluates its slice of the draws on its sharded copy of
+    the data (the 'data' scheme inside the group: a collective of the group's ranks); the world then assembles all n values -- the first rank
+    of every group puts its group's values into a vector of zeros, the vectors are summed over the world (the reference sums the shards'
+    partial log-likelihoods in the same all-reduce; here a group's values are already complete: k_combine ran behind the group's all-reduce)."""
+    from .parallel import draws_of_group
+    n, grp, world = len(lams), self.comm, self.comm.world
+    i0, i1 = draws_of_group(n, grp.ngroups, grp.group_id)
+    out = np.zeros(n)
+    if i0 < i1:
+      vals = self._batch_local(lams[i0:i1])
+      if grp.rank == 0:
+        out[i0:i1] = vals
+    return np.asarray(world.allreduce_sum(out)).reshape(n)
 
   def _batch_over_params(self, lams):
     """The reference's 'params' scheme (CHIMERA/parallel.py:258-278): rank r evaluates the draws [r c, min((r + 1) c, n)), c = ceil(n / R), on

@@ -289,6 +289,68 @@ def combine_partials(partials, E_total, N_inj, N_eff, scale_free, R0, Tobs, has_
   return log_hyper, log_num, Nexp
 
 
+# ----------------------------------------------------------------------------------------------------------
+# the 'both' scheme: groups of ranks, each group a 'data'-sharded replica that takes its own slice of the draws of a batch
+# ----------------------------------------------------------------------------------------------------------
+def group_layout(nranks, rank, ngroups):
+  """(group id, rank inside the group, size of the group) of ``rank`` when ``nranks`` ranks form ``ngroups`` groups of consecutive ranks, the first
+  ``nranks % ngroups`` groups one rank larger -- the reference's split of MPI processes into parameter batches (CHIMERA/parallel.py:136-156)."""
+  nranks, rank, ngroups = int(nranks), int(rank), int(ngroups)
+  if not (1 <= ngroups <= nranks):
+    raise ValueError("the number of parameter batches must be between 1 and the number of ranks")      # parallel.py:133-134
+  base, rem = divmod(nranks, ngroups)
+  first = 0
+  for g in range(ngroups):
+    size = base + 1 if g < rem else base
+    if first <= rank < first + size:
+      return g, rank - first, size
+    first += size
+  raise ValueError(f"rank {rank} outside a job of {nranks} ranks")
+
+
+def draws_of_group(n, ngroups, group):
+  """[i0, i1): the draws of a batch of ``n`` that parameter batch ``group`` evaluates -- n // ngroups each, the first n % ngroups batches one more
+  (CHIMERA/parallel.py:311-321, 384-394)."""
+  per, rem = divmod(int(n), int(ngroups))
+  i0 = group * per + min(group, rem)
+  return i0, i0 + per + (1 if group < rem else 0)
+
+
+def _group_address(address, group):
+  """where the ranks of one group meet: the job's address with the group number appended (Unix socket) / added to the port (TCP)"""
+  if isinstance(address, str):
+    return f"{address}.g{group}"
+  return (address[0], int(address[1]) + 1 + int(group))
+
+
+def split(world, ngroups, rendezvous=None):
+  """A COLLECTIVE over ``world``: the communicator of this rank's group under the 'both' scheme (the reference's ``comm.Split(color=batch_id,
+  key=rank)``, CHIMERA/parallel.py:149-156).  The result is what the selection function and the likelihood of the group are built on
+  (``selection_function(..., comm=group)``, ``hyperlikelihood(..., comm=group, scheme='both')``): inside a group events and injections are
+  sharded as in the 'data' scheme; the groups share the draws of a batch.  It remembers ``world`` (the values of all draws are assembled over
+  it), ``group_id`` and ``ngroups``.
+
+  RCCL worlds: rank 0 creates one unique id per group; the ids travel over ``rendezvous`` (a temporary one at the job's default address when
+  none is passed).  Host-socket worlds (:class:`HostComm`): every group meets at its own address derived from the world's."""
+  g, r, n = group_layout(world.nranks, world.rank, ngroups)
+  if getattr(world, 'handle', None) is None and hasattr(world, 'rendezvous'):       # HostComm
+    sub = HostComm(n, r, device=world.device, rendezvous=Rendezvous(n, r, address=_group_address(world.rendezvous.address, g)))
+    sub._own = True
+    world.rendezvous.barrier()                                 # every group is connected before anybody goes on
+  else:
+    own = rendezvous is None
+    rdzv = Rendezvous(world.nranks, world.rank) if own else rendezvous
+    try:
+      ids = rdzv.broadcast_bytes(b''.join(new_unique_id() for _ in range(int(ngroups))) if world.rank == 0 else None)
+    finally:
+      if own:
+        rdzv.barrier()
+        rdzv.close()
+    sub = Comm(n, r, device=world.device, unique_id=ids[128 * g:128 * (g + 1)])
+  sub.world, sub.group_id, sub.ngroups = world, g, int(ngroups)
+  return sub
+
+
 def new_unique_id():
   buf = C.create_string_buffer(128)
   _lib.check(_lib.lib().chm_comm_unique_id(buf))

@@ -494,6 +494,61 @@ def test_params_scheme_two_replicas_share_one_gpu(tmp_path):
   np.testing.assert_array_equal(r0, ref)
 
 
+def _both_worker(rank, world, addr, outdir):
+  import os, sys
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  import chimera_amd as CH
+  from chimera_amd.parallel import HostComm, Rendezvous, split
+  from tests import helpers as HH
+  rd = Rendezvous(world, rank, address=addr, timeout=120.)
+  cfg, ev, inj = HH.small_config(E=9, S=300, P=4, Z=60, I=3001, seed=41, ragged=True)
+  wcomm = HostComm(world, rank, device=0, rendezvous=rd)
+  grp = split(wcomm, 2)                                       # two parameter batches of world / 2 ranks
+  like0, pop, sel = HH.build_product(ev, inj, comm=grp)       # events and injections sharded over the GROUP
+  like = CH.hyperlikelihood(like0.theta_gw_det, ev['z_grids'], pop, sel, kind_p_gw3d='marginalized', comm=grp, scheme='both')
+  lams = [dict(H0=float(h)) for h in np.linspace(62., 79., 5)]
+  out = np.concatenate([like.batch(lams), [like(H0=70.5)], like(H0=np.array([66., 67., 68.]))])
+  np.save(os.path.join(outdir, f'rank{rank}.npy'), out)
+  like.close(); like0.close(); sel.close()
+  rd.barrier()
+  grp.close()
+  rd.close()
+
+
+@pytest.mark.timeout(300)
+def test_both_scheme_two_groups_of_two_ranks_share_one_gpu(tmp_path):
+  """[r4] scheme='both' (CHIMERA/parallel.py:132-224, 380-406) end to end on the device: four processes on GPU 0 form two groups of two; a group
+  shards events and injections over its ranks (partial sums reduced over the group's own socket star) and evaluates its slice of the draws;
+  the world assembles the values.  Every rank holds the single-process values (to rounding: the shards' sums are added in another order)."""
+  _spawn(_both_worker, 4, (str(tmp_path / 'rdzv.sock'), str(tmp_path)))
+  rs = [np.load(tmp_path / f'rank{r}.npy') for r in range(4)]
+  for r in rs[1:]:
+    np.testing.assert_array_equal(r, rs[0])
+  cfg, ev, inj = H.small_config(E=9, S=300, P=4, Z=60, I=3001, seed=41, ragged=True)
+  like, _, _ = H.build_product(ev, inj)
+  lams = [dict(H0=float(h)) for h in np.linspace(62., 79., 5)]
+  ref = np.concatenate([like.batch(lams), [like(H0=70.5)], like(H0=np.array([66., 67., 68.]))])
+  np.testing.assert_allclose(rs[0], ref, rtol=1e-12)
+
+
+def test_split_of_a_one_rank_rccl_world_gives_a_working_group_communicator():
+  """[r4] parallel.split on an RCCL world: the group's unique id is created by rank 0 and the group communicator carries the 'both' scheme
+  (one rank = one group here: the collective inside chm_eval runs through RCCL, the assembly over the world too)."""
+  import chimera_amd as CH
+  from chimera_amd.parallel import Comm, split
+  world = Comm(1, 0, device=0)
+  grp = split(world, 1)
+  assert (grp.group_id, grp.ngroups, grp.nranks, grp.rank) == (0, 1, 1, 0) and grp.handle and grp.handle.value != world.handle.value
+  cfg, ev, inj = H.small_config(E=5, S=128, P=3, Z=40, I=1501, seed=9, ragged=True)
+  like0, pop, sel = H.build_product(ev, inj, comm=grp)
+  like = CH.hyperlikelihood(like0.theta_gw_det, ev['z_grids'], pop, sel, kind_p_gw3d='marginalized', comm=grp, scheme='both')
+  ref, _, _ = H.build_product(ev, inj)
+  lams = [dict(H0=float(h)) for h in (64., 70., 77.)]
+  np.testing.assert_array_equal(like.batch(lams), ref.batch(lams))
+  assert like(H0=70.) == ref(H0=70.)
+  like.close(); like0.close(); sel.close(); grp.close(); world.close()
+
+
 def _rccl_worker(rank, world, addr, outdir):
   import os, sys
   sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

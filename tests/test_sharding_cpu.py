@@ -234,3 +234,91 @@ def test_params_scheme_argument_checks():
   sel.comm = FakeComm()
   with pytest.raises(ValueError, match="replicates the data"):
     CH.hyperlikelihood(like.theta_gw_det, ev['z_grids'], pop, sel, kind_p_gw3d='marginalized', comm=FakeComm(), scheme='params')
+
+
+# ----------------------------------------------------------------------------------------------------------
+# the 'both' scheme (CHIMERA/parallel.py:132-224, 306-341, 380-406): groups of ranks; data sharded inside a group, draws split over the groups
+# ----------------------------------------------------------------------------------------------------------
+def test_group_layout_and_draw_slices_follow_the_reference_rule():
+  sys.path.insert(0, ROOT)
+  from chimera_amd.parallel import group_layout, draws_of_group
+  # 8 ranks in 3 parameter batches: sizes 3, 3, 2 (parallel.py:138-141), consecutive ranks (parallel.py:142-147)
+  lay = [group_layout(8, r, 3) for r in range(8)]
+  assert lay == [(0, 0, 3), (0, 1, 3), (0, 2, 3), (1, 0, 3), (1, 1, 3), (1, 2, 3), (2, 0, 2), (2, 1, 2)]
+  assert [group_layout(4, r, 4) for r in range(4)] == [(r, 0, 1) for r in range(4)]
+  assert [group_layout(4, r, 1) for r in range(4)] == [(0, r, 4) for r in range(4)]
+  for bad in (0, 9):
+    with pytest.raises(ValueError):
+      group_layout(8, 0, bad)
+  # 7 draws over 3 batches: 3, 2, 2 (parallel.py:311-321); fewer draws than batches: the last batches get none
+  assert [draws_of_group(7, 3, g) for g in range(3)] == [(0, 3), (3, 5), (5, 7)]
+  assert [draws_of_group(1, 3, g) for g in range(3)] == [(0, 1), (1, 1), (1, 1)]
+  assert [draws_of_group(0, 2, g) for g in range(2)] == [(0, 0), (0, 0)]
+
+
+def _both_worker(rank, world, ngroups, addr, outdir):
+  sys.path.insert(0, ROOT)
+  import chimera_amd as CH
+  from chimera_amd.parallel import Rendezvous, HostComm, split, chunk_bounds, group_layout
+  from tests import helpers as H
+  rd = Rendezvous(world, rank, address=addr, timeout=60.)
+  wcomm = HostComm(world, rank, device=0, rendezvous=rd)
+  grp = split(wcomm, ngroups)
+  g, r, n = group_layout(world, rank, ngroups)
+  assert (grp.group_id, grp.rank, grp.nranks, grp.ngroups) == (g, r, n, ngroups) and grp.world is wcomm
+  cfg, ev, inj = H.small_config(E=7, S=64, P=3, Z=24, I=301, seed=23, ragged=True)
+  like_o, _, sel_o = H.build_oracle(ev, inj)
+  like, pop, sel = H.build_product(ev, inj, comm=grp)         # (no GPU is touched: the per-rank evaluator is replaced below)
+  like = CH.hyperlikelihood(like.theta_gw_det, ev['z_grids'], pop, sel, kind_p_gw3d='marginalized', comm=grp, scheme='both')
+  assert (like._e0, like._e1) == chunk_bounds(cfg['E'], n, r)   # events sharded INSIDE the group
+  i0, i1 = chunk_bounds(cfg['I'], n, r)
+  calls = []
+
+  def local(lams):                                            # the 'data' scheme inside the group, the oracle as the shard evaluator
+    calls.append(len(lams))
+    out = []
+    for lam in lams:
+      part = grp.allreduce_sum(H.shard_partials_oracle(like_o, lam, like._e0, like._e1, i0, i1)) if n > 1 else \
+        H.shard_partials_oracle(like_o, lam, like._e0, like._e1, i0, i1)
+      out.append(H.combine_partials(np.asarray(part), cfg['E'], like_o.population.update(**lam), inj['N_inj'], sel_o.N_eff))
+    return np.array(out)
+  like._batch_local = local
+  lams = [dict(H0=float(h)) for h in np.linspace(60., 80., 7)]
+  got = like.batch(lams)
+  one = like(H0=71.)                                          # a scalar call: group 0 evaluates, every rank receives
+  np.savez(os.path.join(outdir, f'rank{rank}.npz'), got=got, one=one, calls=np.array(calls), group=np.array([g, r, n]))
+  rd.barrier()
+  grp.close()
+  wcomm.close()
+  rd.close()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('world,ngroups', [(4, 2), (5, 2), (3, 3)])
+def test_both_scheme_shards_inside_groups_and_splits_the_draws_over_them(tmp_path, world, ngroups):
+  """scheme='both': the world splits into `ngroups` groups of consecutive ranks (own socket star each), a group evaluates its slice of the draws
+  with events and injections sharded over its ranks, the world assembles the values: every rank holds all n values, equal to the last bit on
+  every rank and equal to the single-process values to rounding (the shards' sums are added in another order)."""
+  import multiprocessing as mp
+  ctx = mp.get_context('spawn')
+  addr = str(tmp_path / 'rdzv.sock')
+  procs = [ctx.Process(target=_both_worker, args=(r, world, ngroups, addr, str(tmp_path))) for r in range(world)]
+  for p in procs:
+    p.start()
+  for p in procs:
+    p.join(200)
+    assert p.exitcode == 0
+  sys.path.insert(0, ROOT)
+  from chimera_amd.parallel import draws_of_group
+  from tests import helpers as H
+  cfg, ev, inj = H.small_config(E=7, S=64, P=3, Z=24, I=301, seed=23, ragged=True)
+  like_o, _, _ = H.build_oracle(ev, inj)
+  want = np.array([like_o(H0=float(h)) for h in np.linspace(60., 80., 7)])
+  recs = [np.load(tmp_path / f'rank{r}.npz') for r in range(world)]
+  for rec in recs:
+    np.testing.assert_array_equal(rec['got'], recs[0]['got'])
+    np.testing.assert_allclose(rec['got'], want, rtol=1e-12)
+    np.testing.assert_allclose(float(rec['one']), like_o(H0=71.), rtol=1e-12)
+    g = int(rec['group'][0])
+    a, b = draws_of_group(7, ngroups, g)
+    assert list(rec['calls']) == ([b - a] if b > a else []) + ([1] if g == 0 else [])
