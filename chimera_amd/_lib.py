@@ -79,7 +79,7 @@ SYMBOLS = ['chm_version', 'chm_device_count', 'chm_last_error', 'chm_like_create
 OPTION = {'serial': 1, 'groups': 2, 'fused': 3, 'timing': 4, 'graph_max_nb': 5, 'spin_wait': 6,
           'diag_full_chain': 100, 'diag_no_dense_node': 101, 'diag_marg_generic': 102, 'diag_samples_generic': 103,
           'diag_selection_generic': 104, 'diag_no_grid_prep': 105, 'diag_zf_full': 106, 'diag_kde_ipw': 107, 'diag_samp_cpb': 108,
-          'diag_self_blocks': 109, 'diag_few_nb': 110, 'diag_no_zero_copy': 111, 'diag_no_zf_sel': 112, 'diag_host_prof': 113, 'diag_fused_nw': 114}
+          'diag_self_blocks': 109, 'diag_few_nb': 110, 'diag_no_zero_copy': 111, 'diag_no_zf_sel': 112, 'diag_host_prof': 113, 'diag_fused_nw': 114, 'diag_poison': 115}
 
 _lib = None
 

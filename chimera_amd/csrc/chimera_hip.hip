@@ -53,6 +53,7 @@ struct Opts {
   int marg_generic = 0, samples_generic = 0, selection_generic = 0, no_grid_prep = 0, zf_full = 0;
   int kde_ipw = 0, samp_cpb = 0, self_blocks = 8192, few_nb = 8, no_zero_copy = 0, no_zf_sel = 0, host_prof = 0;
   int fused_nw = 0;          // 16: few-draw calls of the fused event kernel with 16 waves per block (-DCHM_FUSED_NW16 builds; A/B)
+  long long poison = 0;      // bit mask of the per-call workspaces overwritten with a finite garbage pattern before every evaluation (like_poison_ws)
 };
 #ifdef CHM_DIAG
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
@@ -101,10 +102,11 @@ static int opts_set(Opts& o, int32_t option, int64_t value) {
     case CHM_OPT_DIAG_NO_ZF_SEL: o.no_zf_sel = v != 0; return CHM_OK;
     case CHM_OPT_DIAG_HOST_PROF: o.host_prof = v != 0; return CHM_OK;
     case CHM_OPT_DIAG_FUSED_NW: o.fused_nw = v; return CHM_OK;
+    case CHM_OPT_DIAG_POISON: o.poison = v; return CHM_OK;
     default: break;
   }
 #else
-  if (option >= CHM_OPT_DIAG_FULL_CHAIN && option <= CHM_OPT_DIAG_FUSED_NW)
+  if (option >= CHM_OPT_DIAG_FULL_CHAIN && option <= CHM_OPT_DIAG_POISON)
     return fail(CHM_E_ARG, "chm_*_set_option: diagnostic option -- this library was built without -DCHM_DIAG");
 #endif
   return fail(CHM_E_ARG, "chm_*_set_option: unknown option");
@@ -320,6 +322,7 @@ struct chm_like {
   // widest event in octaves of distance / in keys of the direct-index table (LDS reserved per block)
   FusedDesc FD = {};
   bool fused_ok = false;
+  bool neg_prior = false;    // some pe_prior < 0: negative sample weights -- the standard GW kernel's rounding bound and empty-bin shortcuts assume weights >= 0
   double ev_oct_max = 0.; int ev_nk_max = 0;
   int* d_redo = nullptr;          // (shared with the clones) count of dense redos, diagnostics
 };
@@ -459,7 +462,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
       for (int a = 0; a < 4; a++) {
         const double* in = src[a] + (size_t)(e0 + e) * S;
         double* o = sorted[a].data() + e * S;
-        if (a == 3) { for (size_t k = 0; k < S; k++) o[k] = 1. / in[perm[k]]; }     // the device keeps 1/pe_prior
+        if (a == 3) { for (size_t k = 0; k < S; k++) { o[k] = 1. / in[perm[k]]; if (in[perm[k]] < 0.) { h->neg_prior = true; L.neg_w = 1; } } }     // the device keeps 1/pe_prior
         else { for (size_t k = 0; k < S; k++) o[k] = in[perm[k]]; }
       }
     }
@@ -519,7 +522,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
   } else {
     UP(dL, d->dL, S); UP(m1det, d->m1det, S); UP(m2det, d->m2det, S);
     tmp.resize(E * S);
-    for (size_t k = 0; k < E * S; k++) tmp[k] = 1. / d->pe_prior[(size_t)e0 * S + k];          // the device keeps 1/pe_prior
+    for (size_t k = 0; k < E * S; k++) { tmp[k] = 1. / d->pe_prior[(size_t)e0 * S + k]; if (d->pe_prior[(size_t)e0 * S + k] < 0.) { h->neg_prior = true; L.neg_w = 1; } }          // the device keeps 1/pe_prior
     rc = upload(*h->owned_sp, (const double*)tmp.data(), E * S, &L.pe_prior, s); if (rc) { chm_like_destroy(h); return rc; }
     logs.assign(2, std::vector<double>(E * S));
     for (size_t k = 0; k < E * S; k++) { logs[0][k] = std::log(d->m1det[(size_t)e0 * S + k]); logs[1][k] = std::log(d->m2det[(size_t)e0 * S + k]); }
@@ -641,6 +644,7 @@ extern "C" int chm_like_clone(const chm_like* src, chm_like** out) {
   L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.Aw = L.evstat = L.effg = L.pgw1d = L.like_pix = L.err_pix = L.p_gw_dump = L.ev_li = L.ev_ll = nullptr; L.full_todo = nullptr; L.full_ev = L.full_s = nullptr;
   L.krange = nullptr; L.tab_pm = L.tab_rate = L.tab_bkg = L.tab_jac = nullptr; L.zg_i = nullptr; L.zg_t = L.zg_lz = nullptr;
   h->F = src->F; h->fast_ok = src->fast_ok; h->dl_gmin = src->dl_gmin; h->dl_gmax = src->dl_gmax;
+  h->neg_prior = src->neg_prior;
   h->FD = src->FD; h->fused_ok = src->fused_ok; h->ev_oct_max = src->ev_oct_max; h->ev_nk_max = src->ev_nk_max; h->d_redo = src->d_redo;
   const size_t EZ = (size_t)L.E * L.Z;
   hipError_t e1 = hipMalloc(&h->d_zg_i, sizeof(int) * EZ), e2 = hipMalloc(&h->d_zg_t, sizeof(double) * EZ), e3 = hipMalloc(&h->d_zg_lz, sizeof(double) * EZ);
@@ -680,6 +684,26 @@ static int like_ensure_ws(chm_like* h, int nb, bool dump) {
   h->nb_ws = nb; h->ws_dump = dump;
   return CHM_OK;
 }
+
+#ifdef CHM_DIAG
+// CHM_OPT_DIAG_POISON: the per-call workspaces named by `mask` are filled with the byte 0x3F (doubles of ~4.8e-4: finite, so that the value classes of a
+// result survive) before an evaluation.  Every kernel is supposed to write what a later kernel reads within the same evaluation: a result that
+// changes under a poisoned buffer names a read of stale memory (found that way in round 4: see DESIGN section 11).  Buffers of indices stay untouched.
+static int like_poison_ws(chm_like* h, long long mask, int nb, hipStream_t s) {
+  LikeDev& L = h->L;
+  const size_t E = L.E, S = L.S, Z = L.Z, Pd = L.P > 0 ? L.P : 1, n = (size_t)h->nb_ws;
+  (void)nb;
+  struct { double* p; size_t bytes; } B[] = {
+    { L.ws_z, 8 * n * E * S }, { L.ws_w, 8 * n * E * S }, { L.part, 8 * n * E * L.NC * NPART }, { L.jac, 8 * n * E * Z }, { L.prate, 8 * n * E * Z },
+    { L.bkgA, 8 * n * E * Z }, { L.Aw, 8 * n * E * Z }, { L.err_pix, 8 * n * E * Pd }, { L.ev_li, 8 * n * E }, { L.ev_ll, 8 * n * E },
+    { L.evstat, 8 * n * E * NEVSTAT }, { L.effg, 8 * n * E * (size_t)L.G }, { L.like_pix, 8 * n * E * Pd }, { L.pgw1d, 8 * n * E * Z },
+    { L.full_ev, 8 * n * E * FULLEV }, { L.full_s, 8 * 5 * n * E * S } };
+  for (size_t i = 0; i < sizeof(B) / sizeof(B[0]); i++)
+    if (((mask >> i) & 1) && B[i].p) HIPCHK(hipMemsetAsync(B[i].p, 0x3F, B[i].bytes, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return CHM_OK;
+}
+#endif
 
 extern "C" int chm_sel_create(const chm_sel_desc* d, chm_sel** out) {
   if (!d || !out) return fail(CHM_E_ARG, "chm_sel_create: null argument");
@@ -850,6 +874,9 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   int rc;
   if (like) { rc = like_ensure_ws(like, nb, want_dump); if (rc) return rc; }
   if (sel) { rc = sel_ensure_ws(sel, nb); if (rc) return rc; }
+#ifdef CHM_DIAG
+  if (like && o.poison) { rc = like_poison_ws(like, o.poison, nb, sA); if (rc) return rc; }
+#endif
 
   TabDev td;
   if (tab) {                                                  // plug-in models: the caller's tables of this call, host -> device
@@ -943,7 +970,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     const int few_nb_f = o.few_nb;
     if (like && like->fused_ok && use_fast && !tab && !want_dump && fmode > 0 && (nb <= few_nb_f || fmode >= 2) &&
         like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && like->L.num_bins == 200 &&
-        !o.marg_generic && !o.zf_full) {
+        !o.marg_generic && !o.zf_full && !like->neg_prior) {
       int Tc_call = 0, Tm_call = 0;
       double zmax_min = INFINITY;
       for (int b = 0; b < nb; b++) {
@@ -1155,7 +1182,9 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       const bool zf_ranged = (L.mode == CHM_MODE_MARG || L.mode == CHM_MODE_1D || L.mode == CHM_MODE_APPROX) && !o.zf_full;
       // standard configuration (binning, cut_grid set) -> k_kde_marg_sub<32>, two pixels per wave (16 lanes per pixel measured
       // 30 % slower: 19 KB of LDS per wave halve the occupancy); anything else, or CHM_MARG_GENERIC=1, -> the general kernel
-      const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && (L.Z & 1) == 0 && !o.marg_generic;
+      // (a negative pe_prior -- negative weights, which the reference's arithmetic takes as they come -- goes to the general kernel: the standard
+      //  one bounds its rounding error and skips empty bins on the assumption of weights >= 0; scripts/fuzz_parity.py, round 4)
+      const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && (L.Z & 1) == 0 && !o.marg_generic && !like->neg_prior;
       const int zf_mode = !zf_ranged ? 0 : (L.mode == CHM_MODE_MARG ? 1 : 2);
       hipStream_t sz = (one_stream || zf_ranged) ? sg : ((g & 1) ? sA : sB);
       // ~2048 blocks in all: each stages the draw's (zt, It) tables in LDS once and walks over E_cnt / gridDim.x events

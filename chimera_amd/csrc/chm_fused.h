@@ -98,6 +98,9 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
   if (fast) {
     const int glo = gl[klo], ghi = gl[khi];
     rlo = glo > 0 ? glo - 1 : 0;
+    // an event whose smallest distance lies beyond the table's last node still needs the record of the LAST interval (z clamps to z_last through it,
+    // z_from_lut_x2): without this line its slice began at node Tc - 1 and the clamp read the record in front of the slice (scripts/fuzz_parity.py, round 4)
+    rlo = rlo > Tc - 2 ? (Tc >= 2 ? Tc - 2 : 0) : rlo;
     rlo = rlo < i_lo ? i_lo : rlo;
     rhi = ghi + lmax; rhi = rhi > i_lo + ns - 1 ? i_lo + ns - 1 : rhi;
     ns_e = rhi - rlo + 1; nk_e = khi - klo + 1;

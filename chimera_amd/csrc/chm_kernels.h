@@ -31,6 +31,8 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   int mode, kernel, bw_method, binning, num_bins, G, has_cut, NC;
   int e_off, E_cnt;               // event group handled by this launch: events [e_off, e_off + E_cnt)
   int ev_publish;                 // k_marg_fixup writes every event's L_i / log L_i (ev_li, ev_ll): few-draw calls, where the one-block reduction is on the critical path
+  int neg_w;                      // some pe_prior < 0 (set at upload): negative sample weights -- the prefix-sum forms of the binned Epanechnikov KDE bound their
+                                  // rounding and clamp at 0 on the assumption of weights >= 0; the dense sums of the reference are taken instead
   int nb, no_dense;               // draws in this call; no_dense (diagnostics, CHM_NO_DENSE_NODE=1): the standard GW kernel keeps the prefix differences everywhere
                                   // (hot kernels fold the draw into blockIdx.x, draw fastest, so that the
                                   // blocks working on the same samples / p_cat rows for different draws run together and share L2)
@@ -1497,7 +1499,7 @@ DEVFN void kde_marg_general(const LikeDev& L, const DevParams* params, const int
     // density on the effective grid: always Epanechnikov here (kde1d is called without kernel=, likelihood.py:192)
     const double inv_bw = 1. / bw;
     const double dbin = (hi - lo) / (double)B;
-    const bool fast = L.binning && dbin > 0. && bw > 0. && bw < 1e300 && tot == tot && (tot > 0. || tot < 0.);
+    const bool fast = L.binning && dbin > 0. && bw > 0. && bw < 1e300 && tot == tot && (tot > 0. || tot < 0.) && !L.neg_w;
     if (fast) {
       const int jl1 = wave_prefix3(data, wgt, N, lo, P0, P1, P2);
       bsync();
@@ -2168,7 +2170,7 @@ __global__ void __launch_bounds__(256) k_kde1d(LikeDev L, const DevParams* param
   const bool epan = L.kernel == 0;
   const double inv_bw = 1. / bw;
   const double dbin = (hi - lo) / (double)B;
-  const bool fast = epan && L.binning && dbin > 0. && bw > 0. && bw < 1e300 && tot == tot && (tot > 0. || tot < 0.);
+  const bool fast = epan && L.binning && dbin > 0. && bw > 0. && bw < 1e300 && tot == tot && (tot > 0. || tot < 0.) && !L.neg_w;
   if (fast) {
     double* P0 = hw; double* P1 = hw + (N + 1); double* P2 = hw + 2 * (N + 1);
     if (wid == 0) { int j = wave_prefix3(data, wgt, N, lo, P0, P1, P2); if (lane == 0) s_jl1 = j; }

@@ -517,7 +517,9 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
   if (__any(den == 0.)) { if (den == 0.) w = num / den; }   // m1 at the lowest node of the grid: the IEEE quotient (x/0 = inf, 0/0 = NaN) as the reference forms it
   // sec = 0 -> p_m2m1 = 0 (or 0/0 = NaN -> 0): w = p_m1 * 0
   if (zero || (w != w && cn == 0.)) w = Pn * 0.;
-  if (m1 != m1) w = m1;
+  // a NaN primary mass: the smoothing window of bpl / plp turns p_m1 NaN (NaN * 0 = NaN); the truncated power law has no window, every factor
+  // is a masked 0 there (mass.py:240-245, 334-341: p_m1 = 0, p_m2m1 = NaN -> 0) -- found by scripts/fuzz_parity.py in round 4
+  if (mass_model != 0 && m1 != m1) w = m1;
   return w;
 }
 

@@ -300,7 +300,8 @@ enum {
   CHM_OPT_DIAG_FULL_CHAIN = 100, CHM_OPT_DIAG_NO_DENSE_NODE = 101, CHM_OPT_DIAG_MARG_GENERIC = 102, CHM_OPT_DIAG_SAMPLES_GENERIC = 103,
   CHM_OPT_DIAG_SELECTION_GENERIC = 104, CHM_OPT_DIAG_NO_GRID_PREP = 105, CHM_OPT_DIAG_ZF_FULL = 106, CHM_OPT_DIAG_KDE_IPW = 107,
   CHM_OPT_DIAG_SAMP_CPB = 108, CHM_OPT_DIAG_SELF_BLOCKS = 109, CHM_OPT_DIAG_FEW_NB = 110, CHM_OPT_DIAG_NO_ZERO_COPY = 111,
-  CHM_OPT_DIAG_NO_ZF_SEL = 112, CHM_OPT_DIAG_HOST_PROF = 113, CHM_OPT_DIAG_FUSED_NW = 114
+  CHM_OPT_DIAG_NO_ZF_SEL = 112, CHM_OPT_DIAG_HOST_PROF = 113, CHM_OPT_DIAG_FUSED_NW = 114,
+  CHM_OPT_DIAG_POISON = 115       /* bit mask of per-call workspaces filled with a finite garbage pattern before every evaluation: a result that moves read one of them before writing it */
 };
 int chm_like_set_option(chm_like* like, int32_t option, int64_t value);
 int chm_sel_set_option(chm_sel* sel, int32_t option, int64_t value);

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Long randomized parity run on the GPU box (one gpurun call):  python3 scripts/fuzz_parity.py [N=200] [seed0=0] [budget_s=540]
+
+The generator of tests/test_gpu_parity.py::test_random_configurations_against_the_numpy_oracle with wider shapes (up to 4096 samples, 32 pixels,
+400 grid points: the ranges in which the production kernels -- direct-index sample stage, k_kde_marg_sub2<32, *, 200>, the sample-stationary 3-D
+kernel -- are the ones that run), half of the marginalized cases forced onto the standard configuration (binning, cut_grid, 200 bins, even Z).
+Per configuration: compute_all against the NumPy oracle (per-event log-likelihoods, log N_exp, log hyper-likelihood), the scalar call against a
+batch of the same draw (must be equal to the bit), and for the standard marginalized configuration the fused event kernel (CHM_OPT_FUSED = 2)
+against the separate kernels (per-event values to 1e-12).  Prints one line per failure and a summary; exit code 1 on any failure."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests import helpers as H                                 # noqa: E402
+
+RTOL_L = 1e-9
+HOSTILE_SHARE = float(os.environ.get('FUZZ_HOSTILE', '0.15'))
+
+
+def one(rng):
+  pixelated = rng.random() < 0.85
+  kind = rng.choice(['marginalized', 'marginalized', 'marginalized', 'approximate', 'full']) if pixelated else None
+  big = rng.random() < 0.5
+  E = int(rng.integers(1, 5))
+  S = int(rng.choice([256, 1024, 2048, 4096])) if big else int(rng.integers(40, 700))
+  P = int(rng.integers(2, 33)) if big else int(rng.integers(1, 7))
+  Z = 2 * int(rng.integers(20, 200)) if big else int(rng.integers(12, 90))
+  if kind == 'full' and big:                                   # the NumPy oracle's 3-D KDE is O(S Z P) exps per event
+    S, P, Z = min(S, 2048), min(P, 16), min(Z, 300)
+  cfg, ev, inj = H.small_config(E=E, S=S, P=P, Z=Z, I=int(rng.integers(300, 6000)), seed=int(rng.integers(1, 10**6)),
+                                ragged=bool(rng.random() < 0.5), pixelated=pixelated)
+  hostile = rng.random() < HOSTILE_SHARE                      # inputs the fast front ends must hand to the general route, as the reference's arithmetic does
+  what, e = -1, -1
+  if hostile:
+    ev, inj = dict(ev), dict(inj)
+    for k in ('dL', 'm1det', 'm2det', 'pe_prior'):
+      ev[k] = np.array(ev[k], dtype=np.float64, copy=True)
+    for k in ('dL', 'm1det', 'm2det', 'p_draw'):
+      inj[k] = np.array(inj[k], dtype=np.float64, copy=True)
+    e = int(rng.integers(0, E))
+    j = int(rng.integers(0, S))
+    what = int(rng.integers(0, 18))
+    bad = [np.nan, np.inf, 0., -1.][int(rng.integers(0, 4))]
+    if what == 0:
+      ev['dL'][e, j] = np.nan                                  # NaN distance: the event's statistics turn NaN
+    elif what == 1:
+      ev['dL'][e] *= 40.                                       # far beyond the distance table: z clamps at the table's end
+    elif what == 2:
+      ev['dL'][e] *= 1e-3                                      # below the first non-zero node
+    elif what == 3:
+      ev['m1det'][e, : S // 3] = 1e4                             # masses above every m_high: weight 0
+    elif what == 4:
+      ev['m1det'][e, j] = np.nan                               # NaN primary: NaN weight (bpl, plp) or 0 (tpl: every factor is a masked 0)
+    elif what == 5:
+      ev['m2det'][e, j] = np.nan                               # NaN secondary: p_m2m1 = NaN -> 0
+    elif what == 6:
+      ev['m1det'][e, j] = bad                                  # inf / 0 / negative primary
+    elif what == 7:
+      ev['m2det'][e, j] = bad
+    elif what == 8:
+      ev['dL'][e, j] = bad                                     # inf / 0 / negative distance
+    elif what == 9:
+      ev['pe_prior'][e, j] = bad                               # NaN-free but singular prior: w / 0, w / inf, negative weights
+    elif what == 10:
+      ev['pe_prior'][e, j] = np.nan
+    elif what == 11:
+      ev['dL'][e] = ev['dL'][e, 0]                             # every sample at one distance: zero-width histogram / zero bandwidth
+    elif what == 12:
+      ev['m1det'][e] = 1e4                                     # no sample of the event inside the population's range: sum w = 0
+    elif what == 13:
+      k = int(rng.integers(0, inj['dL'].size)); inj['dL'].reshape(-1)[k] = bad if bad == bad else np.nan
+    elif what == 14:
+      k = int(rng.integers(0, inj['m1det'].size)); inj['m1det'].reshape(-1)[k] = [np.nan, np.inf, 0., -1.][int(rng.integers(0, 4))]
+    elif what == 15:
+      k = int(rng.integers(0, inj['m2det'].size)); inj['m2det'].reshape(-1)[k] = [np.nan, np.inf, 0., -1.][int(rng.integers(0, 4))]
+    elif what == 16:
+      k = int(rng.integers(0, inj['p_draw'].size)); inj['p_draw'].reshape(-1)[k] = [np.nan, np.inf, 0., -1.][int(rng.integers(0, 4))]
+    else:
+      ev['dL'][e, : S // 2] *= 1e-6                            # half of the event's samples at z ~ 0
+    what = (what, bad) if what in (6, 7, 8, 9, 13) else what
+  standard = kind == 'marginalized' and rng.random() < 0.5
+  if standard:
+    like_kw = dict(num_bins=200, pe_neff=float(rng.choice([2., 5.])), cut_grid=float(rng.choice([1.0, 2.0, 3.5])), binning=True,
+                   bw_method=[None, 'scott', 'silverman', 0.25][int(rng.integers(0, 4))])
+    if Z % 2:
+      standard = False
+  else:
+    like_kw = dict(num_bins=int(rng.choice([3, 17, 64, 200, 333, 600])), pe_neff=float(rng.choice([2., 5., 50.])))
+    if kind != 'full':
+      like_kw['cut_grid'] = [None, 1.0, 2.0, 3.5][int(rng.integers(0, 4))]
+      like_kw['bw_method'] = [None, 'scott', 'silverman', 0.25][int(rng.integers(0, 4))]
+      like_kw['binning'] = bool(rng.random() < 0.75)
+    if kind in (None, 'approximate'):
+      like_kw['kernel'] = str(rng.choice(['epan', 'gauss']))
+  models = dict(mass=str(rng.choice(['plp', 'plp', 'tpl', 'bpl'])), cosmo=str(rng.choice(['flrw', 'flrw', 'mg_flrw'])),
+                rate=str(rng.choice(['power_law', 'madau_dickinson', 'madau_dickinson', 'trunc_power_law', 'trunc_madau_dickinson'])))
+  if models['rate'].startswith('trunc'):
+    models['rate_kw'] = dict(zmax=float(rng.uniform(1.5, 4.)))
+  pop_kw = dict(scale_free=bool(rng.random() < 0.7), R0=float(rng.uniform(5., 40.)), Tobs=float(rng.uniform(0.5, 3.)))
+  N_eff = [None, 5.][int(rng.integers(0, 2))]
+  lam = dict(H0=float(rng.uniform(55., 95.)), Om0=float(rng.uniform(0.2, 0.4)), gamma=float(rng.uniform(1., 3.5)),
+             m_low=float(rng.uniform(3.5, 6.)), m_high=float(rng.uniform(75., 110.)), beta=float(rng.uniform(0., 2.)))
+  if models['cosmo'] == 'mg_flrw':
+    lam.update(Xi0=float(rng.uniform(0.6, 2.5)), n=float(rng.uniform(0.5, 2.5)))
+  if rng.random() < 0.6:                                      # the shape parameters of the mass and rate models too
+    if models['mass'] == 'plp':
+      lam.update(alpha=float(rng.uniform(2., 4.5)), lambda_peak=float(rng.uniform(0.01, 0.2)), mu_g=float(rng.uniform(28., 40.)),
+                 sigma_g=float(rng.uniform(2., 6.)), delta_m=float(rng.uniform(2., 7.)))
+    elif models['mass'] == 'bpl':
+      lam.update(alpha_1=float(rng.uniform(1., 2.5)), alpha_2=float(rng.uniform(3., 7.)), break_fraction=float(rng.uniform(0.2, 0.7)),
+                 delta_m=float(rng.uniform(2., 7.)))
+    else:
+      lam.update(alpha=float(rng.uniform(1.5, 4.)))
+    if 'madau' in models['rate']:
+      lam.update(kappa=float(rng.uniform(2., 5.)), zp=float(rng.uniform(1., 3.)))
+  desc = (f'HOSTILE(what={what}, event={e}) ' if hostile else '') + f"kind={kind} shape=({E},{S},{P},{Z}) like_kw={like_kw} models={models} pop_kw={pop_kw} N_eff={N_eff} lam={lam}"
+  like_o, _, _ = H.build_oracle(ev, inj, pixelated=pixelated, kind=kind, models=models, like_kw=like_kw, pop_kw=pop_kw, N_eff=N_eff)
+  like_p, _, sel_p = H.build_product(ev, inj, pixelated=pixelated, kind=kind, models=models, like_kw=like_kw, pop_kw=pop_kw, N_eff=N_eff)
+  checks = []
+  try:
+    with np.errstate(all='ignore'):
+      ro, rp = like_o.compute_all(**lam), like_p.compute_all(**lam)
+    H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
+    # (every sample of an event at ONE distance: whether the spread comes out as an exact 0 -- KDE 0/0 = NaN -> log L_i = -inf -- or as 1e-16 -- KDE 0,
+    #  log L_i = -1.797e308 -- hangs on the summation order of the mean (NumPy's pairwise sum here, XLA's tree in the reference, the shifted one-pass
+    #  sums on the device): same class per event, checked above; the TOTAL of such a catalogue is not compared)
+    if np.isfinite(ro[3]) and what != 11:
+      np.testing.assert_allclose(rp[2], ro[2], rtol=1e-10)
+      np.testing.assert_allclose(rp[3], ro[3], rtol=1e-12, atol=1e-7 * np.sqrt(E))
+    checks.append('oracle')
+    with np.errstate(all='ignore'):
+      a, b = like_p(**lam), like_p.batch([lam, dict(lam, H0=lam['H0'] + 1.)])[0]
+    assert (a == b) or (np.isnan(a) and np.isnan(b)), f"scalar call {a!r} != batched {b!r}"
+    checks.append('scalar==batch')
+    if standard and P <= 64 and S % 2 == 0:
+      like_p.set_option('fused', 2)
+      with np.errstate(all='ignore'):
+        rf = like_p.compute_all(**lam)
+      like_p.set_option('fused', 0)
+      H.assert_loglike_close(rf[0], rp[0], rtol=1e-12, atol=1e-12)
+      checks.append('fused')
+  except AssertionError as err:
+    extra = ''
+    if os.environ.get('FUZZ_DIAG'):                            # (a -DCHM_DIAG library: which kernel family disagrees?)
+      for opt in ('diag_samples_generic', 'diag_marg_generic', 'diag_zf_full', 'diag_no_dense_node'):
+        try:
+          like_p.set_option(opt, 1)
+          with np.errstate(all='ignore'):
+            r2 = like_p.compute_all(**lam)
+          like_p.set_option(opt, 0)
+          extra += f"\n    with {opt}: {r2[0]}"
+        except Exception as ex:                                # noqa: BLE001
+          extra += f"\n    option {opt}: {ex}"
+    return False, desc + '\n' + str(err)[:1500] + extra, checks
+  finally:
+    like_p.close()
+    sel_p.close()
+  return True, desc, checks
+
+
+def main():
+  n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+  seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+  budget = float(sys.argv[3]) if len(sys.argv) > 3 else 540.
+  t0, fails, done, counts, by_kind = time.time(), 0, 0, {}, {}
+  for i in range(n):
+    if time.time() - t0 > budget:
+      break
+    ok, desc, checks = one(np.random.default_rng(77000 + seed0 + i))
+    done += 1
+    for c in checks:
+      counts[c] = counts.get(c, 0) + 1
+    if not ok:
+      fails += 1
+      kind_of = desc.split(')')[0] if desc.startswith('HOSTILE') else 'plain'
+      kind_of = kind_of.split(', event')[0]
+      by_kind[kind_of] = by_kind.get(kind_of, 0) + 1
+      if by_kind[kind_of] <= 3:                                # three examples per kind of hostile input
+        print(f"FAIL seed {seed0 + i}: {desc[:1800]}", flush=True)
+    if done % 500 == 0:
+      print(f"... {done} configurations, {fails} failures, {time.time() - t0:.0f} s", flush=True)
+  print('failures by kind of hostile input:', by_kind)
+  print(f"fuzz_parity: {done} configurations (seeds {seed0}..{seed0 + done - 1}), {fails} failures; checks passed: {counts}; {time.time() - t0:.0f} s")
+  sys.exit(1 if fails else 0)
+
+
+if __name__ == '__main__':
+  main()

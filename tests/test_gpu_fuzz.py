@@ -1,0 +1,82 @@
+"""GPU: a short run of scripts/fuzz_parity.py (the randomized parity generator with hostile inputs) + the regressions its long runs found in round 4."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+
+
+@pytest.mark.parametrize('share,seed0', [(0.15, 0), (1.0, 20000)])
+def test_randomized_configurations_and_hostile_inputs(share, seed0):
+  """150 random configurations per parameter set (shapes up to 4096 samples x 32 pixels x 400 grid points, every mode / model / KDE option; with
+  `share` of them carrying one hostile input: NaN / inf / 0 / negative masses, distances or priors, distances beyond or below the table, events
+  without weight, zero spread, hostile injections): compute_all against the NumPy oracle, scalar call == batched call to the bit, the fused event
+  kernel against the separate kernels.  (Round 4 ran 30 000 of them: profiles/r04/fuzz_parity.txt.)"""
+  import fuzz_parity as F
+  F.HOSTILE_SHARE = share
+  bad = []
+  for i in range(150):
+    ok, desc, _ = F.one(np.random.default_rng(77000 + seed0 + i))
+    if not ok:
+      bad.append(f"seed {seed0 + i}: {desc[:1200]}")
+  assert not bad, '\n'.join(bad)
+
+
+@pytest.mark.parametrize('mass', ['tpl', 'plp', 'bpl'])
+@pytest.mark.parametrize('kind', ['marginalized', None])
+def test_nan_primary_mass_by_mass_model(mass, kind):
+  """[r4, found by the fuzz run] A NaN primary mass: the smoothing window of bpl / plp turns p_m1 NaN (the event's sums, L_i, log L_i follow); the
+  truncated power law has no window and every factor is a masked 0 (mass.py:240-245, 334-341) -- the sample simply carries no weight.  The fast
+  sample stage made it NaN for every model."""
+  pix = kind is not None
+  cfg, ev, inj = H.small_config(E=3, S=260, P=4, Z=64, I=1500, seed=5, pixelated=pix)
+  ev = dict(ev); ev['m1det'] = ev['m1det'].copy(); ev['m1det'][1, 17] = np.nan
+  lo, _, _ = H.build_oracle(ev, inj, pixelated=pix, kind=kind, models=dict(mass=mass))
+  lp, _, sp = H.build_product(ev, inj, pixelated=pix, kind=kind, models=dict(mass=mass))
+  with np.errstate(all='ignore'):
+    ro, rp = lo.compute_all(H0=70.), lp.compute_all(H0=70.)
+  assert bool(H.neginf_class(ro[0][1])) == (mass != 'tpl')
+  H.assert_loglike_close(rp[0], ro[0], rtol=1e-9, atol=1e-9)
+  if mass == 'tpl':
+    np.testing.assert_allclose(rp[3], ro[3], rtol=1e-12, atol=1e-7)
+  lp.close(); sp.close()
+
+
+@pytest.mark.parametrize('like_kw', [dict(), dict(cut_grid=None, num_bins=64), dict(binning=False)])
+@pytest.mark.parametrize('kind', ['marginalized', 'approximate'])
+def test_negative_pe_prior_takes_the_dense_sums(kind, like_kw):
+  """[r4, found by the fuzz run] A negative pe_prior gives a negative sample weight, which the reference's arithmetic takes as it comes.  The
+  prefix-sum forms of the binned Epanechnikov KDE (standard GW kernel, general kernel, 1-D kernel) clamp at 0 and bound their rounding on the
+  assumption of weights >= 0: a handle that saw a negative prior at upload uses the dense sums (LikeDev.neg_w) -- 1e-3 off before."""
+  cfg, ev, inj = H.small_config(E=4, S=1024, P=8, Z=132, I=1500, seed=8)
+  ev = dict(ev); ev['pe_prior'] = np.array(ev['pe_prior'], dtype=np.float64, copy=True)
+  ev['pe_prior'][2, 100:140] = -ev['pe_prior'][2, 100:140]
+  lo, _, _ = H.build_oracle(ev, inj, kind=kind, like_kw=like_kw)
+  lp, _, sp = H.build_product(ev, inj, kind=kind, like_kw=like_kw)
+  with np.errstate(all='ignore'):
+    ro, rp = lo.compute_all(H0=68.), lp.compute_all(H0=68.)
+  H.assert_loglike_close(rp[0], ro[0], rtol=1e-9, atol=1e-9)
+  lp.close(); sp.close()
+
+
+def test_fused_kernel_event_beyond_the_distance_table():
+  """[r4, found by the fuzz run] An event whose every distance lies beyond the last node of the draw's dL table (z clamps to z_max): the fused event
+  kernel's per-event slice of the node records began behind the record the clamp reads."""
+  cfg, ev, inj = H.small_config(E=3, S=1024, P=21, Z=58, I=1500, seed=12)
+  ev = dict(ev); ev['dL'] = ev['dL'].copy(); ev['dL'][0] *= 40.
+  lo, _, _ = H.build_oracle(ev, inj, like_kw=dict(cut_grid=2.0))
+  lp, _, sp = H.build_product(ev, inj, like_kw=dict(cut_grid=2.0))
+  with np.errstate(all='ignore'):
+    ro, rp = lo.compute_all(H0=60.2, Om0=0.22), lp.compute_all(H0=60.2, Om0=0.22)
+    lp.set_option('fused', 2)
+    rf = lp.compute_all(H0=60.2, Om0=0.22)
+  assert H.neginf_class(ro[0][0])
+  H.assert_loglike_close(rp[0], ro[0], rtol=1e-9, atol=1e-9)
+  H.assert_loglike_close(rf[0], rp[0], rtol=1e-12, atol=1e-12)
+  lp.close(); sp.close()
