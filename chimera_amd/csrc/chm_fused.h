@@ -108,6 +108,9 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
   }
   const int key0e = key0s + klo;
   const double x_last = g_dLt[Tc - 1], z_last = g_zt[Tc - 1];
+  // an event with a distance beyond the table's last node (z clamps at z_max) takes the exact route: the slice arithmetic above is laid out for
+  // distances inside the table, and two all-beyond events of the round-4 fuzz run came out with run-to-run garbage on the fast route
+  fast = fast && xhi <= x_last;
   // window of the mass grid the event's source-frame primary masses can reach: log m1 = log m1det - log(1 + z) with log m1det in the event's
   // [lm1.x, lm1.y] and z between the first and one past the last node record of its slice (their log(1 + z) are in the records); 4 entries of
   // margin on either side (rounding of the position, the stepping loops of p_m1m2_fused).  A window that does not fit: tables read from L2.
