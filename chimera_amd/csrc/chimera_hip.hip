@@ -322,6 +322,8 @@ struct chm_like {
   // widest event in octaves of distance / in keys of the direct-index table (LDS reserved per block)
   FusedDesc FD = {};
   bool fused_ok = false;
+  const unsigned char* d_ev_bad = nullptr;   // (E) 1 = an input that multiplies EVERY grid point of the event's integrand holds a NaN (p_cat of a live pixel, P_compl, gw_loc2d_pdf, z_grids):
+                                             // the reference's trapz sums 0 * NaN = NaN also where p_gw is zero -> L_i = NaN for every draw; the kernels skip those points, the reductions apply the flag
   bool neg_prior = false;    // some pe_prior < 0: negative sample weights -- the standard GW kernel's rounding bound and empty-bin shortcuts assume weights >= 0
   double ev_oct_max = 0.; int ev_nk_max = 0;
   int* d_redo = nullptr;          // (shared with the clones) count of dense redos, diagnostics
@@ -593,6 +595,27 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
     if (d->dec_pix) UP(dec_pix, d->dec_pix, P);
     UP(neff_pixels, d->neff_pixels, 1);
   }
+  {                                                          // NaNs in the per-event inputs of the integrand (see d_ev_bad)
+    std::vector<unsigned char> bad(E, 0);
+    bool any = false;
+    for (size_t e = 0; e < E; e++) {
+      const size_t ge = (size_t)e0 + e;
+      bool b = false;
+      const double* zg = d->z_grids + ge * Z;
+      for (size_t k = 0; k < Z && !b; k++) b = zg[k] != zg[k];
+      if (pixelated && !b) {
+        const size_t np_ = (size_t)std::min<long long>(std::max<long long>(d->neff_pixels[ge], 0), (long long)P);
+        const double* pc = d->p_cat + ge * P * Z;
+        for (size_t q = 0; q < np_ * Z && !b; q++) b = pc[q] != pc[q];
+        const double* cm = d->P_compl + ge * Z;
+        for (size_t k = 0; k < Z && !b; k++) b = cm[k] != cm[k];
+        const double* gp = d->gw_loc2d_pdf + ge * P;
+        for (size_t q = 0; q < np_ && !b; q++) b = gp[q] != gp[q];
+      }
+      bad[e] = b ? 1 : 0; any = any || b;
+    }
+    if (any) { rc = upload(*h->owned_sp, (const unsigned char*)bad.data(), E, &h->d_ev_bad, s); if (rc) { chm_like_destroy(h); return rc; } HIPCHK(hipStreamSynchronize(s)); }
+  }
 #undef UP
   // the logs of the detector-frame masses as the device forms them (k_fill_logs): over the host's std::log values in both copies
   hipLaunchKernelGGL(k_fill_logs, dim3(1024), dim3(256), 0, s, L.m1det, L.m2det, const_cast<double*>(L.lm1det), const_cast<double*>(L.lm2det),
@@ -644,7 +667,7 @@ extern "C" int chm_like_clone(const chm_like* src, chm_like** out) {
   L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.Aw = L.evstat = L.effg = L.pgw1d = L.like_pix = L.err_pix = L.p_gw_dump = L.ev_li = L.ev_ll = nullptr; L.full_todo = nullptr; L.full_ev = L.full_s = nullptr;
   L.krange = nullptr; L.tab_pm = L.tab_rate = L.tab_bkg = L.tab_jac = nullptr; L.zg_i = nullptr; L.zg_t = L.zg_lz = nullptr;
   h->F = src->F; h->fast_ok = src->fast_ok; h->dl_gmin = src->dl_gmin; h->dl_gmax = src->dl_gmax;
-  h->neg_prior = src->neg_prior;
+  h->neg_prior = src->neg_prior; h->d_ev_bad = src->d_ev_bad;
   h->FD = src->FD; h->fused_ok = src->fused_ok; h->ev_oct_max = src->ev_oct_max; h->ev_nk_max = src->ev_nk_max; h->d_redo = src->d_redo;
   const size_t EZ = (size_t)L.E * L.Z;
   hipError_t e1 = hipMalloc(&h->d_zg_i, sizeof(int) * EZ), e2 = hipMalloc(&h->d_zg_t, sizeof(double) * EZ), e3 = hipMalloc(&h->d_zg_lz, sizeof(double) * EZ);
@@ -1356,7 +1379,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   if (like && !one_kernel) {
     hipLaunchKernelGGL(k_reduce_events, dim3(nblk_ev, nb), dim3(256), 0, sA, like->L.E, like->L.P > 0 ? like->L.P : 1,
                        (const double*)like->L.like_pix, c.d_evpart, d_lle, d_nle, ev_from_fixup ? (const double*)like->L.ev_li : nullptr,
-                       ev_from_fixup ? (const double*)like->L.ev_ll : nullptr);
+                       ev_from_fixup ? (const double*)like->L.ev_ll : nullptr, like->d_ev_bad);
     HIPCHK(hipGetLastError());
   }
   if (sel && !fuse_sel) HIPCHK(hipStreamWaitEvent(sA, c.evb[2], 0));     // join: selection sums
@@ -1365,7 +1388,8 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
                        like ? (const double*)like->L.like_pix : nullptr, sel ? sel->S.nblocks : 0,
                        sel ? (const double*)sel->S.partial : nullptr, c.d_partials, dp, Etot, sel ? sel->S.N_inj : 1.,
                        sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, multi ? 0 : 1, out3, d_lle, d_nle,
-                       ev_from_fixup ? (const double*)like->L.ev_li : nullptr, ev_from_fixup ? (const double*)like->L.ev_ll : nullptr);
+                       ev_from_fixup ? (const double*)like->L.ev_li : nullptr, ev_from_fixup ? (const double*)like->L.ev_ll : nullptr,
+                       like ? like->d_ev_bad : (const unsigned char*)nullptr);
   } else {
     hipLaunchKernelGGL(k_final, dim3(nb), dim3(256), 0, sA, nblk_ev, (const double*)c.d_evpart, sel ? sel->S.nblocks : 0,
                        sel ? (const double*)sel->S.partial : nullptr, c.d_partials, dp, Etot, sel ? sel->S.N_inj : 1.,

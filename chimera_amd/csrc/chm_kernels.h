@@ -3074,7 +3074,8 @@ DEVFN double pixel_sum(const double* lp, int Pd) {
 
 // k_reduce_events: one thread per event: L_i = sum_p like_pix (likelihood.py:280), log, nan_to_num (:296-297); block sums
 __global__ void __launch_bounds__(256) k_reduce_events(int E, int Pd, const double* like_pix, double* ev_partial /* (nb, nblk) */,
-                                                        double* log_like_evs, double* numlike_evs, const double* ev_li, const double* ev_ll) {
+                                                        double* log_like_evs, double* numlike_evs, const double* ev_li, const double* ev_ll,
+                                                        const unsigned char* ev_bad) {
   __shared__ double red[16];
   const int b = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
   double ll = 0.;
@@ -3086,6 +3087,7 @@ __global__ void __launch_bounds__(256) k_reduce_events(int E, int Pd, const doub
       Li = pixel_sum(lp, Pd);
       ll = log_like_of(Li);
     }
+    if (ev_bad && ev_bad[e]) { Li = __builtin_nan(""); ll = -__builtin_inf(); }      // a NaN among the event's catalogue / grid inputs: 0 * NaN on every grid point (chm_like::d_ev_bad)
     if (numlike_evs) numlike_evs[(size_t)b * E + e] = Li;
     if (log_like_evs) log_like_evs[(size_t)b * E + e] = ll;
   }
@@ -3142,7 +3144,7 @@ __global__ void __launch_bounds__(1024) k_reduce_final(int E, int Pd, const doub
                                                         double* partials, const DevParams* params, double E_total, double N_inj,
                                                         double N_eff, int has_neff, int has_like, int has_sel, int do_combine,
                                                         double* out3, double* log_like_evs, double* numlike_evs,
-                                                        const double* ev_li, const double* ev_ll) {
+                                                        const double* ev_li, const double* ev_ll, const unsigned char* ev_bad) {
   __shared__ double red[16];
   const int b = blockIdx.x, t = threadIdx.x;
   double acc = 0., s1 = 0., s2 = 0.;
@@ -3154,6 +3156,7 @@ __global__ void __launch_bounds__(1024) k_reduce_final(int E, int Pd, const doub
       Li = pixel_sum(lp, Pd);                                        // jnp.sum over pixels          likelihood.py:280
       ll = log_like_of(Li);                                          // likelihood.py:296,329; nan_to_num(nan=-inf)
     }
+    if (ev_bad && ev_bad[e]) { Li = __builtin_nan(""); ll = -__builtin_inf(); }      // (chm_like::d_ev_bad)
     if (numlike_evs) numlike_evs[(size_t)b * E + e] = Li;
     if (log_like_evs) log_like_evs[(size_t)b * E + e] = ll;
     acc += ll;

@@ -19,6 +19,7 @@ from tests import helpers as H                                 # noqa: E402
 
 RTOL_L = 1e-9
 HOSTILE_SHARE = float(os.environ.get('FUZZ_HOSTILE', '0.15'))
+EXTREME_SHARE = float(os.environ.get('FUZZ_EXTREME', '0.2'))
 
 
 def one(rng):
@@ -43,7 +44,7 @@ def one(rng):
       inj[k] = np.array(inj[k], dtype=np.float64, copy=True)
     e = int(rng.integers(0, E))
     j = int(rng.integers(0, S))
-    what = int(rng.integers(0, 18))
+    what = int(rng.integers(0, 24))
     bad = [np.nan, np.inf, 0., -1.][int(rng.integers(0, 4))]
     if what == 0:
       ev['dL'][e, j] = np.nan                                  # NaN distance: the event's statistics turn NaN
@@ -79,8 +80,25 @@ def one(rng):
       k = int(rng.integers(0, inj['m2det'].size)); inj['m2det'].reshape(-1)[k] = [np.nan, np.inf, 0., -1.][int(rng.integers(0, 4))]
     elif what == 16:
       k = int(rng.integers(0, inj['p_draw'].size)); inj['p_draw'].reshape(-1)[k] = [np.nan, np.inf, 0., -1.][int(rng.integers(0, 4))]
-    else:
+    elif what == 17:
       ev['dL'][e, : S // 2] *= 1e-6                            # half of the event's samples at z ~ 0
+    elif what in (18, 19, 20) and pixelated:
+      ev['p_cat'] = np.array(ev['p_cat'], dtype=np.float64, copy=True)
+      q = int(rng.integers(0, max(1, int(ev['neff_pixels'][e]))))
+      if what == 18:
+        ev['p_cat'][e, q] = 0.                                 # a pixel without galaxies
+      elif what == 19:
+        ev['p_cat'][e, q, int(rng.integers(0, Z))] = np.nan    # a NaN in the catalogue term
+      else:
+        ev['p_cat'][e, q, :: 3] = -100.                        # the padding sentinel inside a live row (p_gal passes it through, likelihood.py:270-275)
+    elif what == 21:
+      ev['z_grids'] = np.array(ev['z_grids'], dtype=np.float64, copy=True)
+      g = ev['z_grids'][e]
+      ev['z_grids'][e] = g[0] + (g[-1] - g[0]) * np.linspace(0., 1., Z) ** 1.7      # a grid that is not a linspace (the index guesses must fall back)
+    elif what == 22:
+      ev['m2det'][e] = ev['m1det'][e]                          # equal masses: m2 = m1 on the edge of the secondary's support
+    else:
+      ev['m1det'][e], ev['m2det'][e] = ev['m2det'][e].copy(), ev['m1det'][e].copy()      # m2 > m1 for every sample: outside the support, weight 0
     what = (what, bad) if what in (6, 7, 8, 9, 13) else what
   standard = kind == 'marginalized' and rng.random() < 0.5
   if standard:
@@ -117,6 +135,16 @@ def one(rng):
       lam.update(alpha=float(rng.uniform(1.5, 4.)))
     if 'madau' in models['rate']:
       lam.update(kappa=float(rng.uniform(2., 5.)), zp=float(rng.uniform(1., 3.)))
+  if rng.random() < EXTREME_SHARE:                             # hyper-parameters at the edges of what a sampler's prior box allows
+    k = int(rng.integers(0, 8))
+    if k == 0: lam.update(H0=float(rng.choice([20., 200.])))
+    elif k == 1: lam.update(Om0=float(rng.choice([0.01, 0.99])))
+    elif k == 2: lam.update(gamma=float(rng.choice([-3., 0., 12.])))
+    elif k == 3: lam.update(beta=float(rng.choice([-4., 0., 12.])))
+    elif k == 4: lam.update(m_low=float(rng.choice([2., 10.])), m_high=float(rng.choice([50., 200.])))
+    elif k == 5 and models['mass'] == 'plp': lam.update(lambda_peak=float(rng.choice([0., 1.])), sigma_g=float(rng.choice([0.5, 15.])))
+    elif k == 6 and models['mass'] != 'tpl': lam.update(delta_m=float(rng.choice([0.01, 0.5, 15.])))
+    elif k == 7 and 'madau' in models['rate']: lam.update(kappa=float(rng.choice([0., 10.])), zp=float(rng.choice([0.1, 6.])))
   desc = (f'HOSTILE(what={what}, event={e}) ' if hostile else '') + f"kind={kind} shape=({E},{S},{P},{Z}) like_kw={like_kw} models={models} pop_kw={pop_kw} N_eff={N_eff} lam={lam}"
   like_o, _, _ = H.build_oracle(ev, inj, pixelated=pixelated, kind=kind, models=models, like_kw=like_kw, pop_kw=pop_kw, N_eff=N_eff)
   like_p, _, sel_p = H.build_product(ev, inj, pixelated=pixelated, kind=kind, models=models, like_kw=like_kw, pop_kw=pop_kw, N_eff=N_eff)

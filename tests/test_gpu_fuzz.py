@@ -80,3 +80,28 @@ def test_fused_kernel_event_beyond_the_distance_table():
   H.assert_loglike_close(rp[0], ro[0], rtol=1e-9, atol=1e-9)
   H.assert_loglike_close(rf[0], rp[0], rtol=1e-12, atol=1e-12)
   lp.close(); sp.close()
+
+
+@pytest.mark.parametrize('kind', ['marginalized', 'approximate', 'full'])
+@pytest.mark.parametrize('field', ['p_cat', 'z_grids'])
+def test_nan_in_the_catalogue_term_or_the_grid_of_an_event(kind, field):
+  """[r4, found by the fuzz run] A NaN in p_cat (a live pixel) or in the z grid of an event: the reference's integrand is 0 * NaN = NaN on that grid
+  point also where p_gw is zero, trapz sums it, L_i = NaN -> log L_i = -inf for every draw.  The kernels skip the grid points outside the KDE's
+  support (a NaN out there was not seen); the flag is formed at upload (chm_like::d_ev_bad) and applied where the per-event values are reduced."""
+  cfg, ev, inj = H.small_config(E=4, S=300, P=5, Z=60, I=1500, seed=21)
+  ev = dict(ev)
+  ev[field] = np.array(ev[field], dtype=np.float64, copy=True)
+  if field == 'p_cat':
+    ev['p_cat'][2, 0, 0] = np.nan; ev['p_cat'][2, 0, -1] = np.nan            # the two ends of the grid: outside the KDE's support
+  else:
+    ev['z_grids'][2, -1] = np.nan
+  lo, _, _ = H.build_oracle(ev, inj, kind=kind)
+  lp, _, sp = H.build_product(ev, inj, kind=kind)
+  with np.errstate(all='ignore'):
+    ro, rp = lo.compute_all(H0=70.), lp.compute_all(H0=70.)
+    assert np.isnan(lo.compute_numlike_evs(lo.population.update(H0=70.))[2]) and np.isnan(lp.compute_numlike_evs(lp.population.update(H0=70.))[2])
+    batch = lp.batch([dict(H0=70.), dict(H0=64.)])
+  assert ro[0][2] == -np.inf and rp[0][2] == -np.inf
+  H.assert_loglike_close(rp[0], ro[0], rtol=1e-9, atol=1e-9)
+  assert np.all(np.isneginf(batch)) and ro[3] == -np.inf and lp(H0=70.) == -np.inf
+  lp.close(); sp.close()
