@@ -2264,6 +2264,19 @@ __global__ void __launch_bounds__(256) k_integrate_1d(LikeDev L, const DevParams
   }
 }
 
+// sum(W^2), W = w / sum(w), of one event (math.py:173-176 normalise the weights first).  The partial sums carry sum(w) and sum(w^2) un-normalised:
+// below sum(w) ~ 1e-140 (a mass model that puts its whole weight many widths away from every sample: found by scripts/fuzz_parity.py with
+// lambda_peak = 1, sigma_g = 0.5) w^2 underflows and sum(w)^2 with it, while the reference's normalised weights are fine -- the block then sums
+// (w / sum w)^2 over the event's samples.  Uniform over the block (every thread combines the same partials).
+DEVFN double full_mode_sW2(const double* part, int NC, const double* ww, int S, double* red) {
+  double sw = 0., sw2 = 0.;
+  for (int c = 0; c < NC; c++) { sw += part[(size_t)c * NPART + PT_SW]; sw2 += part[(size_t)c * NPART + PT_SW2]; }
+  if (sw >= 1e-140 || !(sw > 0.)) return sw2 / (sw * sw);
+  double a = 0.;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) { const double r = ww[s] / sw; a += r * r; }
+  return block_reduce<RED_SUM>(a, red);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // k_full_kde: 3-D Gaussian KDE, one block (256 threads) per (event, pixel, draw)   likelihood.py:211-260, math.py:154-229
 // ------------------------------------------------------------------------------------------------------
@@ -2317,6 +2330,7 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
   const double* part = L.part + ((size_t)b * L.E + e) * L.NC * NPART;
   const EvStats st = combine_stats(part, L.NC, S);
   const bool ok = !(st.n_eff < L.pe_neff);                // `if n_effs[ev] < pe_neff: continue`   likelihood.py:234
+  const double sW2_ev = full_mode_sW2(part, L.NC, L.ws_w + ((size_t)b * L.E + e) * S, S, red);
   if (t == 0) {
     // weighted mean / covariance of (z, ra, dec) (math.py:173-190) from the shifted un-normalised moments, then
     // inv_cov / factor^2 and its lower Cholesky factor (math.py:191-195)
@@ -2327,7 +2341,8 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
       a[0] += q[PT_WD0]; a[1] += q[PT_WD1]; a[2] += q[PT_WD2];
       m[0] += q[PT_W00]; m[1] += q[PT_W01]; m[2] += q[PT_W02]; m[3] += q[PT_W11]; m[4] += q[PT_W12]; m[5] += q[PT_W22];
     }
-    double sW2 = sw2 / (sw * sw);                         // sum(W^2), W = w / sum(w)
+    (void)sw2;
+    double sW2 = sW2_ev;                                  // sum(W^2), W = w / sum(w)  (full_mode_sW2)
     double m0 = a[0] / sw, m1 = a[1] / sw, m2 = a[2] / sw;
     double den = 1. - sW2;
     double c00 = (m[0] / sw - m0 * m0) / den, c01 = (m[1] / sw - m0 * m1) / den, c02 = (m[2] / sw - m0 * m2) / den;
@@ -2541,6 +2556,7 @@ __global__ void __launch_bounds__(256) k_full_prep(LikeDev L) {
   const double* part = L.part + ((size_t)b * L.E + e) * L.NC * NPART;
   const EvStats st = combine_stats(part, L.NC, S);
   const bool ok = !(st.n_eff < L.pe_neff);                // `if n_effs[ev] < pe_neff: continue`   likelihood.py:234
+  const double sW2_ev = full_mode_sW2(part, L.NC, ww, S, red);
   if (t == 0) {
     // weighted covariance of (z, ra, dec), inv_cov / factor^2, its lower Cholesky factor and log_norm (math.py:173-195, 215): as in k_full_kde
     double sw = 0., sw2 = 0., a[3] = {0., 0., 0.}, m[6] = {0., 0., 0., 0., 0., 0.};
@@ -2550,7 +2566,8 @@ __global__ void __launch_bounds__(256) k_full_prep(LikeDev L) {
       a[0] += q[PT_WD0]; a[1] += q[PT_WD1]; a[2] += q[PT_WD2];
       m[0] += q[PT_W00]; m[1] += q[PT_W01]; m[2] += q[PT_W02]; m[3] += q[PT_W11]; m[4] += q[PT_W12]; m[5] += q[PT_W22];
     }
-    double sW2 = sw2 / (sw * sw);
+    (void)sw2;
+    double sW2 = sW2_ev;
     double m0 = a[0] / sw, m1 = a[1] / sw, m2 = a[2] / sw;
     double den = 1. - sW2;
     double c00 = (m[0] / sw - m0 * m0) / den, c01 = (m[1] / sw - m0 * m1) / den, c02 = (m[2] / sw - m0 * m2) / den;

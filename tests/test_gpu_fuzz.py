@@ -105,3 +105,19 @@ def test_nan_in_the_catalogue_term_or_the_grid_of_an_event(kind, field):
   H.assert_loglike_close(rp[0], ro[0], rtol=1e-9, atol=1e-9)
   assert np.all(np.isneginf(batch)) and ro[3] == -np.inf and lp(H0=70.) == -np.inf
   lp.close(); sp.close()
+
+
+def test_full_mode_with_vanishing_weight_sums():
+  """[r4, found by the fuzz run] lambda_peak = 1, sigma_g = 0.5: the mass model is a 0.5 M_sun wide Gaussian, every sample of an event lies tens of
+  widths away, sum(w) ~ 1e-200.  The reference's n_eff = sum(w)^2 / sum(w^2) is 0 / 0 = NaN there, `NaN < pe_neff` is False and the 3-D KDE goes
+  ahead with weights it normalises first (log L_i ~ -470 ... -700).  The device formed sum(W^2) as sum(w^2) / sum(w)^2 from the un-normalised partial
+  sums -- both underflow -- and returned NaN; k_full_prep / k_full_kde now sum (w / sum w)^2 over the samples below sum(w) = 1e-140."""
+  import fuzz_parity as F
+  F.HOSTILE_SHARE, F.EXTREME_SHARE = 0.6, 0.3
+  try:
+    for seed in (402278, 402329, 403751):
+      ok, desc, _ = F.one(np.random.default_rng(77000 + seed))
+      assert 'lambda_peak\': 1.0' in desc and 'kind=full' in desc
+      assert ok, desc[:1500]
+  finally:
+    F.HOSTILE_SHARE, F.EXTREME_SHARE = 0.15, 0.2
