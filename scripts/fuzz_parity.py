@@ -6,7 +6,7 @@ The generator of tests/test_gpu_parity.py::test_random_configurations_against_th
 kernel -- are the ones that run), half of the marginalized cases forced onto the standard configuration (binning, cut_grid, 200 bins, even Z).
 Per configuration: compute_all against the NumPy oracle (per-event log-likelihoods, log N_exp, log hyper-likelihood), the scalar call against a
 batch of the same draw (must be equal to the bit), and for the standard marginalized configuration the fused event kernel (CHM_OPT_FUSED = 2)
-against the separate kernels (per-event values to 1e-12).  Prints one line per failure and a summary; exit code 1 on any failure."""
+against the separate kernels (per-event values to 1e-11).  Prints one line per failure and a summary; exit code 1 on any failure."""
 import os
 import sys
 import time
@@ -20,9 +20,10 @@ from tests import helpers as H                                 # noqa: E402
 RTOL_L = 1e-9
 HOSTILE_SHARE = float(os.environ.get('FUZZ_HOSTILE', '0.15'))
 EXTREME_SHARE = float(os.environ.get('FUZZ_EXTREME', '0.2'))
+MANY_EVERY = int(os.environ.get('FUZZ_MANY_EVERY', '0'))      # every n-th configuration: 500+ small events (the event-group path of ten-draw batches)
 
 
-def one(rng):
+def one(rng, many_events=False):
   pixelated = rng.random() < 0.85
   kind = rng.choice(['marginalized', 'marginalized', 'marginalized', 'approximate', 'full']) if pixelated else None
   big = rng.random() < 0.5
@@ -30,6 +31,9 @@ def one(rng):
   S = int(rng.choice([256, 1024, 2048, 4096])) if big else int(rng.integers(40, 700))
   P = int(rng.integers(2, 33)) if big else int(rng.integers(1, 7))
   Z = 2 * int(rng.integers(20, 200)) if big else int(rng.integers(12, 90))
+  if many_events:                                            # shards of >= 500 events take the event-group path (groups alternate between two streams) when a
+    E, S, P, Z = 500 + E * 37, min(S, 96) & ~1, min(P, 3), min(Z, 30) & ~1      # call carries more than 8 draws: small events, many of them (the random draws above keep their order)
+    S, Z = max(S, 40), max(Z, 12)
   if kind == 'full' and big:                                   # the NumPy oracle's 3-D KDE is O(S Z P) exps per event
     S, P, Z = min(S, 2048), min(P, 16), min(Z, 300)
   cfg, ev, inj = H.small_config(E=E, S=S, P=P, Z=Z, I=int(rng.integers(300, 6000)), seed=int(rng.integers(1, 10**6)),
@@ -151,7 +155,11 @@ def one(rng):
   checks = []
   try:
     with np.errstate(all='ignore'):
-      ro, rp = like_o.compute_all(**lam), like_p.compute_all(**lam)
+      try:
+        ro = like_o.compute_all(**lam)
+      except np.linalg.LinAlgError:                          # full mode: np.linalg.cholesky of a degenerate event raises in the reference's callback too (math.py:193)
+        return True, desc, ['oracle raised LinAlgError: skipped']
+      rp = like_p.compute_all(**lam)
     if kind == 'full':
       # full mode, an event whose weight sits on ONE sample (n_eff - 1 ~ 1e-12: a mass model many widths away from every sample, log L_i < -100):
       # the covariance is divided by 1 - sum(W^2) (math.py:189), which amplifies the rounding of sum(W^2) by 1e12 in the reference as on the device --
@@ -187,7 +195,7 @@ def one(rng):
       with np.errstate(all='ignore'):
         rf = like_p.compute_all(**lam)
       like_p.set_option('fused', 0)
-      H.assert_loglike_close(rf[0], rp[0], rtol=1e-12, atol=1e-12)
+      H.assert_loglike_close(rf[0], rp[0], rtol=1e-11, atol=1e-11)       # (the fused kernel adds a bin's weights in another order: 2.5e-12 seen once in 574 events)
       checks.append('fused')
   except AssertionError as err:
     extra = ''
@@ -216,7 +224,7 @@ def main():
   for i in range(n):
     if time.time() - t0 > budget:
       break
-    ok, desc, checks = one(np.random.default_rng(77000 + seed0 + i))
+    ok, desc, checks = one(np.random.default_rng(77000 + seed0 + i), many_events=(MANY_EVERY > 0 and (seed0 + i) % MANY_EVERY == MANY_EVERY - 1))
     done += 1
     for c in checks:
       counts[c] = counts.get(c, 0) + 1
