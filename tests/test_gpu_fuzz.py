@@ -12,17 +12,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'scripts'))
 
 
-@pytest.mark.parametrize('share,seed0', [(0.15, 0), (1.0, 20000)])
-def test_randomized_configurations_and_hostile_inputs(share, seed0):
+@pytest.mark.parametrize('share,seed0,many', [(0.15, 0, 0), (1.0, 20000, 0), (0.5, 600000, 4)])
+def test_randomized_configurations_and_hostile_inputs(share, seed0, many):
   """150 random configurations per parameter set (shapes up to 4096 samples x 32 pixels x 400 grid points, every mode / model / KDE option; with
   `share` of them carrying one hostile input: NaN / inf / 0 / negative masses, distances or priors, distances beyond or below the table, events
-  without weight, zero spread, hostile injections): compute_all against the NumPy oracle, scalar call == batched call to the bit, the fused event
-  kernel against the separate kernels.  (Round 4 ran 30 000 of them: profiles/r04/fuzz_parity.txt.)"""
+  without weight, zero spread, hostile injections): compute_all against the NumPy oracle, scalar call == draws of a two- and a ten-draw batch to the bit, the
+  fused event kernel against the separate kernels.  (Round 4 ran 30 000 of them: profiles/r04/fuzz_parity.txt.)"""
   import fuzz_parity as F
   F.HOSTILE_SHARE = share
   bad = []
-  for i in range(150):
-    ok, desc, _ = F.one(np.random.default_rng(77000 + seed0 + i))
+  for i in range(150 if not many else 60):                   # (many: every 4th configuration has 500+ small events -- the event-group path of ten-draw batches)
+    ok, desc, _ = F.one(np.random.default_rng(77000 + seed0 + i), many_events=bool(many) and (seed0 + i) % many == many - 1)
     if not ok:
       bad.append(f"seed {seed0 + i}: {desc[:1200]}")
   assert not bad, '\n'.join(bad)
