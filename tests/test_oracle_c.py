@@ -101,3 +101,43 @@ def test_full_mode_matches_numpy_oracle(like_kw, models, lam):
   np.testing.assert_allclose(OC.numlike_full(like, popu, nthreads=1), like.compute_numlike_evs(popu), rtol=RT, atol=1e-300)
   if np.isfinite(ro[3]):
     np.testing.assert_allclose(rc[3], ro[3], rtol=0, atol=1e-9)
+
+
+def test_random_hostile_configurations_c_against_numpy():
+  """[r4] The generator of scripts/fuzz_parity.py (random shapes, modes, models, KDE options; 60 % of the configurations with one hostile input out of
+  24 kinds, 30 % with a hyper-parameter at the edge of a prior box) with the C restatement in the product's place: the two restatements of the
+  reference algorithm must agree on every one -- also on the inputs on which the round-4 GPU campaign found the product wrong (NaN primary mass with
+  the truncated power law, negative priors, NaNs in the catalogue term, vanishing weight sums).  7 500 configurations were run that way in round 4
+  (profiles/r04/fuzz_parity.txt); 80 of them here."""
+  import os
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  sys.path.insert(0, os.path.join(root, 'scripts'))
+  import fuzz_parity as F
+
+  class CLike:
+    def __init__(self, like_o): self.o = like_o
+    def compute_all(self, **lam): return OC.compute_all(self.o, lam, nthreads=2)
+    def __call__(self, **lam): return 0.                    # (the bit-for-bit checks of the generator concern the device: neutralised)
+    def batch(self, lams): return np.zeros(len(lams))
+    def set_option(self, *a): raise AssertionError('no fused kernel here')
+    def close(self): pass
+  cap = {}
+  orig_o, orig_p, shares = H.build_oracle, H.build_product, (F.HOSTILE_SHARE, F.EXTREME_SHARE)
+
+  def bo(ev, inj, **kw):
+    r = orig_o(ev, inj, **kw)
+    cap['o'] = r[0]
+    return r
+  H.build_oracle, H.build_product = bo, (lambda ev, inj, **kw: (CLike(cap['o']), None, CLike(cap['o'])))
+  F.HOSTILE_SHARE, F.EXTREME_SHARE = 0.6, 0.3
+  try:
+    bad = []
+    for i in range(80):
+      ok, desc, _ = F.one(np.random.default_rng(77000 + 700000 + i))
+      if not ok and 'no fused kernel here' not in desc:
+        bad.append(desc[:800])
+    assert not bad, '\n'.join(bad)
+  finally:
+    H.build_oracle, H.build_product = orig_o, orig_p
+    F.HOSTILE_SHARE, F.EXTREME_SHARE = shares
