@@ -20,6 +20,7 @@ from tests import helpers as H                                 # noqa: E402
 RTOL_L = 1e-9
 HOSTILE_SHARE = float(os.environ.get('FUZZ_HOSTILE', '0.15'))
 EXTREME_SHARE = float(os.environ.get('FUZZ_EXTREME', '0.2'))
+CHECK_PGW = bool(int(os.environ.get('FUZZ_PGW', '0')))      # also compare the p_gw arrays of the API
 MANY_EVERY = int(os.environ.get('FUZZ_MANY_EVERY', '0'))      # every n-th configuration: 500+ small events (the event-group path of ten-draw batches)
 
 
@@ -190,6 +191,19 @@ def one(rng, many_events=False):
     for c in (many[0], many[9]):
       assert (a == c) or (np.isnan(a) and np.isnan(c)), f"scalar call {a!r} != draw of a ten-draw batch {c!r}"
     checks.append('scalar==batch10')
+    if CHECK_PGW:                                             # (4) the p_gw arrays of the API (hyperlikelihood.p_gw3d / p_gw1d) against the oracle's
+      with np.errstate(all='ignore'):
+        pop_o, pop_p = like_o.population.update(**lam), like_p.population.update(**lam)
+        go = like_o.p_gw3d(pop_o) if pixelated else like_o.p_gw1d(pop_o)
+        gp = like_p.p_gw3d(pop_p) if pixelated else like_p.p_gw1d(pop_p)
+      if pixelated:                                           # padded pixels are masked out of the integrand (likelihood.py:274-277): the real ones
+        valid = np.arange(go.shape[1])[None, :] < np.asarray(like_o.neff_pixels)[:, None]
+        go, gp = go[valid], gp[valid]
+      fin = np.isfinite(go)
+      assert np.array_equal(fin, np.isfinite(gp)), f"p_gw: finite where the oracle's is not (or the reverse) in {int(np.sum(fin != np.isfinite(gp)))} of {fin.size} entries"
+      if fin.any():
+        np.testing.assert_allclose(gp[fin], go[fin], rtol=1e-9, atol=1e-9 * np.max(np.abs(go[fin])))
+      checks.append('p_gw')
     if standard and P <= 64 and S % 2 == 0:
       like_p.set_option('fused', 2)
       with np.errstate(all='ignore'):
