@@ -211,6 +211,8 @@ class hyperlikelihood(object):
     import copy
     if self.comm is not None and getattr(self.comm, 'nranks', 1) >= 1 and comm is None:
       raise ValueError("hyperlikelihood.lane: a lane of a likelihood with a communicator needs a communicator of its own (comm=)")
+    if self.scheme == 'both' and not (hasattr(comm, 'world') and hasattr(comm, 'ngroups')):
+      raise ValueError("hyperlikelihood.lane: a lane under scheme='both' needs a group communicator of its own (chimera_amd.parallel.split)")
     self._handle()
     new = copy.copy(self)
     new._handles = {}
