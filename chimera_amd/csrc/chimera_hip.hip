@@ -1211,7 +1211,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       const int zf_mode = !zf_ranged ? 0 : (L.mode == CHM_MODE_MARG ? 1 : 2);
       hipStream_t sz = (one_stream || zf_ranged) ? sg : ((g & 1) ? sA : sB);
       // ~2048 blocks in all: each stages the draw's (zt, It) tables in LDS once and walks over E_cnt / gridDim.x events
-      const int zf_target = 2048 / nb > 1 ? 2048 / nb : 1;
+#ifndef CHM_ZF_TARGET
+#define CHM_ZF_TARGET 2048     // (A/B, profiles/r04/ab_zf_target.txt: 1536 = one full round of 6 blocks per CU, and 1024: -0.3 .. -0.8 % of the step -- inside the run-to-run spread; unchanged)
+#endif
+      const int zf_target = CHM_ZF_TARGET / nb > 1 ? CHM_ZF_TARGET / nb : 1;
       // few draws per call, standard marginalized configuration: the per-z-factor kernel forms the event statistics itself
       const bool zf_stats = zf_mode == 1 && marg_std && tab_zfac && nb <= few_nb;
       const int zf_epb = zf_stats ? 4 / CHM_ZF_WPE_FEW : 4;       // ranged: events per block pass (a wave per event; CHM_ZF_WPE_FEW waves per event for few draws)
