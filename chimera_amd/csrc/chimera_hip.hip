@@ -40,6 +40,7 @@ extern "C" int chm_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != 
 // exists for same-box A/B runs and for the tests that compare code paths -- set_option refuses it unless the library was built with -DCHM_DIAG
 // (scripts/build_variant.sh diag -DCHM_DIAG), and only such a build takes its initial values from CHM_* environment variables, once, when
 // a handle is created.
+#define CHM_MAX_GROUPS 128     // event groups of one call (CHM_OPT_GROUPS): 4 timing events + 1 fork event each per context
 struct Opts {
   int serial = 0;            // 1: every kernel of a call on one stream
   int groups = 0;            // event groups alternating between two streams (0: automatic; 1: one group)
@@ -78,7 +79,7 @@ static int opts_set(Opts& o, int32_t option, int64_t value) {
   const int v = (int)value;
   switch (option) {
     case CHM_OPT_SERIAL: o.serial = v != 0; return CHM_OK;
-    case CHM_OPT_GROUPS: if (v < 0 || v > 16) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_GROUPS must be in [0, 16]"); o.groups = v; return CHM_OK;
+    case CHM_OPT_GROUPS: if (v < 0 || v > CHM_MAX_GROUPS) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_GROUPS must be in [0, 128]"); o.groups = v; return CHM_OK;
     case CHM_OPT_FUSED: if (v < 0 || v > 2) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_FUSED must be 0, 1 or 2"); o.fused = v; return CHM_OK;
     case CHM_OPT_TIMING: if (v < 0 || v > 2) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_TIMING must be 0, 1 or 2"); o.timing = v; return CHM_OK;
     case CHM_OPT_GRAPH_MAX_NB: if (v < 0) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_GRAPH_MAX_NB must be >= 0"); o.graph_max_nb = v; return CHM_OK;
@@ -139,8 +140,8 @@ struct Ctx {
   double* h_out = nullptr;             // pinned (nb,6)
   hipStream_t stream2 = nullptr;        // second lane of the event-group pipeline
   hipStream_t stream3 = nullptr;        // selection function
-  hipEvent_t evg[64] = {};              // per event-group timing: [4g+0..1] sample stage, [4g+2..3] GW kernel
-  hipEvent_t evf[16] = {};              // per event-group fork of the per-z-factor kernel onto the other lane
+  hipEvent_t evg[4 * CHM_MAX_GROUPS] = {};              // per event-group timing: [4g+0..1] sample stage, [4g+2..3] GW kernel
+  hipEvent_t evf[CHM_MAX_GROUPS] = {};              // per event-group fork of the per-z-factor kernel onto the other lane
   double *d_lle = nullptr, *d_nle = nullptr;   // (nb,E) per-event outputs (log L_i, L_i), grown on demand, kept across calls
   size_t lle_cap = 0, nle_cap = 0;
   hipEvent_t ev[8] = {};                // timing on `stream`
@@ -161,8 +162,8 @@ static int ctx_init(Ctx& c, int device) {
   HIPCHK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&c.stream3, hipStreamNonBlocking));
-  for (int i = 0; i < 64; i++) HIPCHK(hipEventCreate(&c.evg[i]));
-  for (int i = 0; i < 16; i++) HIPCHK(hipEventCreateWithFlags(&c.evf[i], hipEventDisableTiming));
+  for (int i = 0; i < 4 * CHM_MAX_GROUPS; i++) HIPCHK(hipEventCreate(&c.evg[i]));
+  for (int i = 0; i < CHM_MAX_GROUPS; i++) HIPCHK(hipEventCreateWithFlags(&c.evf[i], hipEventDisableTiming));
   for (int i = 0; i < 8; i++) HIPCHK(hipEventCreate(&c.ev[i]));
   for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&c.evb[i]));
   c.init = true;
@@ -187,8 +188,8 @@ static void ctx_destroy(Ctx& c) {
   ctx_free_tables(c);
   for (int i = 0; i < 8; i++) if (c.ev[i]) (void)hipEventDestroy(c.ev[i]);
   for (int i = 0; i < 4; i++) if (c.evb[i]) (void)hipEventDestroy(c.evb[i]);
-  for (int i = 0; i < 64; i++) if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
-  for (int i = 0; i < 16; i++) if (c.evf[i]) (void)hipEventDestroy(c.evf[i]);
+  for (int i = 0; i < 4 * CHM_MAX_GROUPS; i++) if (c.evg[i]) (void)hipEventDestroy(c.evg[i]);
+  for (int i = 0; i < CHM_MAX_GROUPS; i++) if (c.evf[i]) (void)hipEventDestroy(c.evf[i]);
   (void)hipFree(c.d_lle); (void)hipFree(c.d_nle); c.d_lle = c.d_nle = nullptr; c.lle_cap = c.nle_cap = 0;
   if (c.stream3) (void)hipStreamDestroy(c.stream3);
   if (c.stream2) (void)hipStreamDestroy(c.stream2);
@@ -1165,11 +1166,11 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     // most 8; CHM_GROUPS=n overrides (1: one group).  Few-draw calls stay a single chain (one_stream).
     const int env_groups = o.groups;
     ngroups = env_groups > 0 ? env_groups : (nb > few_nb ? (L0.E / 250 < 1 ? 1 : (L0.E / 250 > 8 ? 8 : L0.E / 250)) : 1);
-    if (ngroups > 16) ngroups = 16;
+    if (ngroups > CHM_MAX_GROUPS) ngroups = CHM_MAX_GROUPS;
     if (ngroups > L0.E) ngroups = L0.E;
     if (one_stream) ngroups = 1;
     if ((L0.E + ngroups - 1) / ngroups > 65535) ngroups = (L0.E + 65534) / 65535;      // the GW kernel's grid carries the event in blockIdx.z
-    if (ngroups > 16) return fail(CHM_E_ARG, "chm_eval: more than 16 x 65535 events in one shard");
+    if (ngroups > CHM_MAX_GROUPS) return fail(CHM_E_ARG, "chm_eval: more than 128 x 65535 events in one shard");
     for (int g = 0; g < ngroups; g++) {
       hipStream_t sg = (g & 1) ? sB : sA;
       LikeDev L = like->L;

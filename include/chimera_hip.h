@@ -286,7 +286,7 @@ int chm_like_full_general_pixels(chm_like* like, int32_t nb, int64_t* count);
  * computes, and on which streams, follows from the handle.  A call that carries both handles uses the options of `like`.
  *   CHM_OPT_SERIAL        1: every kernel of a call on one stream (per-kernel timings without overlap)
  *   CHM_OPT_GROUPS        event groups alternating between two streams: 0 automatic (one per 250 events, at most 8, for calls of more than
- *                         8 draws), 1 one group, n <= 16
+ *                         8 draws), 1 one group, n <= 128
  *   CHM_OPT_FUSED         the fused event kernel (one block per (event, draw): samples, statistics, histograms, KDE, integrand; results equal
  *                         to the separate kernels' to rounding, ~1e-15 per event): 0 never (default), 1 calls of <= 8 draws, 2 every call
  *   CHM_OPT_TIMING        0 no timing events in the streams, 1 default, 2 per-kernel events also under a communicator / with event groups
