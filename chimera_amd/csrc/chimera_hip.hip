@@ -55,6 +55,7 @@ struct Opts {
   int kde_ipw = 0, samp_cpb = 0, self_blocks = 8192, few_nb = 8, no_zero_copy = 0, no_zf_sel = 0, host_prof = 0;
   int fused_nw = 0;          // 16: few-draw calls of the fused event kernel with 16 waves per block (-DCHM_FUSED_NW16 builds; A/B)
   long long poison = 0;      // bit mask of the per-call workspaces overwritten with a finite garbage pattern before every evaluation (like_poison_ws)
+  long long epoch = 0;       // bumped by every set_option: part of the key of the captured graph (a replayed graph must not outlive the options it was captured under)
 };
 #ifdef CHM_DIAG
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
@@ -77,6 +78,7 @@ static void opts_init(Opts& o) {
 }
 static int opts_set(Opts& o, int32_t option, int64_t value) {
   const int v = (int)value;
+  o.epoch++;
   switch (option) {
     case CHM_OPT_SERIAL: o.serial = v != 0; return CHM_OK;
     case CHM_OPT_GROUPS: if (v < 0 || v > CHM_MAX_GROUPS) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_GROUPS must be in [0, 128]"); o.groups = v; return CHM_OK;
@@ -357,17 +359,36 @@ struct chm_comm {
 // enqueues its all-reduce only when every lower ticket has enqueued its own.
 #include <mutex>
 #include <condition_variable>
+#include <chrono>
+#ifndef CHM_TICKET_TIMEOUT_S
+#define CHM_TICKET_TIMEOUT_S 120
+#endif
 static struct CollSeq { std::mutex m; std::condition_variable cv; long long next = 0; } g_seq;
 struct TicketTurn {
   chm_comm* c; bool held = false;
   explicit TicketTurn(chm_comm* c_) : c(c_ && c_->ticket >= 0 ? c_ : nullptr) {}
-  void acquire() { if (c && !held) { std::unique_lock<std::mutex> lk(g_seq.m); g_seq.cv.wait(lk, [&] { return g_seq.next >= c->ticket; }); held = true; } }
+  // false: the lower tickets did not come within CHM_TICKET_TIMEOUT_S (a lane whose host thread raised before chm_eval, a skipped ticket, a call made
+  // with collective=False): the caller fails with CHM_E_RCCL instead of hanging this lane and its RCCL peers; chm_comm_ticket_skip forfeits a ticket
+  bool acquire() {
+    if (c && !held) {
+      std::unique_lock<std::mutex> lk(g_seq.m);
+      if (!g_seq.cv.wait_for(lk, std::chrono::seconds(CHM_TICKET_TIMEOUT_S), [&] { return g_seq.next >= c->ticket; })) return false;
+      held = true;
+    }
+    return true;
+  }
   void release() { if (c && held) { { std::lock_guard<std::mutex> lk(g_seq.m); if (g_seq.next <= c->ticket) g_seq.next = c->ticket + 1; } c->ticket = -1; held = false; c = nullptr; g_seq.cv.notify_all(); } }
-  ~TicketTurn() { if (c) { acquire(); release(); } }      // a call that failed before its collective still passes the turn on
+  ~TicketTurn() { if (c) { if (acquire()) release(); else { c->ticket = -1; } } }      // a call that failed before its collective still passes the turn on
 };
 extern "C" int chm_comm_set_ticket(chm_comm* c, int64_t ticket) {
   if (!c) return fail(CHM_E_ARG, "chm_comm_set_ticket: null communicator");
   c->ticket = (long long)ticket;
+  return CHM_OK;
+}
+// forfeit ticket k (a step that will not reach its collective: the lanes behind it go on) -- e.g. from a try / finally around a failed step
+extern "C" int chm_comm_ticket_skip(int64_t ticket) {
+  { std::lock_guard<std::mutex> lk(g_seq.m); if (g_seq.next <= (long long)ticket) g_seq.next = (long long)ticket + 1; }
+  g_seq.cv.notify_all();
   return CHM_OK;
 }
 extern "C" int chm_comm_ticket_reset(int64_t next) {
@@ -683,8 +704,10 @@ static int like_ensure_ws(chm_like* h, int nb, bool dump) {
   like_free_ws(h);
   LikeDev& L = h->L;
   size_t E = L.E, S = L.S, Z = L.Z, Pd = L.P > 0 ? L.P : 1, n = nb;
-  HIPCHK(hipMalloc(&L.ws_z, sizeof(double) * n * E * S));
-  HIPCHK(hipMalloc(&L.ws_w, sizeof(double) * n * E * S));
+  HIPCHK(hipMalloc(&L.ws_z, sizeof(double) * (n * E * S + CHM_WS_PAD)));      // (padded: the standard GW kernel reads whole register rounds past a pixel's segment)
+  HIPCHK(hipMalloc(&L.ws_w, sizeof(double) * (n * E * S + CHM_WS_PAD)));
+  HIPCHK(hipMemsetAsync(L.ws_z + n * E * S, 0, sizeof(double) * CHM_WS_PAD, h->ctx.stream));
+  HIPCHK(hipMemsetAsync(L.ws_w + n * E * S, 0, sizeof(double) * CHM_WS_PAD, h->ctx.stream));
   HIPCHK(hipMalloc(&L.part, sizeof(double) * n * E * L.NC * NPART));
   HIPCHK(hipMalloc(&L.jac, sizeof(double) * n * E * Z));
   HIPCHK(hipMalloc(&L.prate, sizeof(double) * n * E * Z));
@@ -1079,17 +1102,22 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   // ---- graph bookkeeping: the key lists everything the captured launch arguments depend on
   std::vector<long long> key;
   bool capturing = false;
+  long long zmax_bits = 0; { const double zm = params[0].z_max; memcpy(&zmax_bits, &zm, 8); }
   if (graph_ok) {
     key = { (long long)(intptr_t)like, (long long)(intptr_t)sel, nb, (long long)E_total, like ? like->nb_ws : 0, sel ? sel->nb_ws : 0, c.nb_cap, c.TcMax, c.TmMax,
             Tc_host, Tm_host, use_fast, lutA.key0, lutA.nk, lutA.cap, (long long)lds_fast, params[0].mass_model, out->partials != nullptr,
             sel_fast, lutB.key0, lutB.nk, lutB.cap, (long long)lds_sel, (long long)(intptr_t)lutB.lut, fuse_sel,
             (long long)(intptr_t)c.d_evpart, (long long)(intptr_t)(like ? like->L.ws_z : nullptr), (long long)(intptr_t)(sel ? sel->S.partial : nullptr),
-            zg_use, zg_make, (long long)(intptr_t)comm, use_fused, fused_nw, (long long)lds_fused, FDc.cap_rec, FDc.cap_keys, FDc.cap_m, zc_use, zc_make };
+            zg_use, zg_make, (long long)(intptr_t)comm, use_fused, fused_nw, (long long)lds_fused, FDc.cap_rec, FDc.cap_keys, FDc.cap_m, zc_use, zc_make,
+            // [r5] k_znodes takes z_max by value and k_tables reads the cached nodes: a graph captured for one z_max must never be replayed
+            // for another (a z_max scan with scalar calls: A, B, A replayed B's nodes under A's parameters) -- the bit pattern of z_max is part of the key;
+            // so are the options of both handles (serial, groups, diagnostics: a replay would ignore a set_option made after the capture)
+            zmax_bits, like ? like->opts.epoch : -1, sel ? sel->opts.epoch : -1 };
     if (c.gexec && key == c.gkey) {                           // replay
       const double hp1 = host_prof_on() ? now_us() : 0.;
       HIPCHK(hipGraphLaunch(c.gexec, sA));
       if (comm) {                                             // the graph ends at the rank's partials: all-reduce + combination behind it
-        turn.acquire();
+        if (!turn.acquire()) return fail(CHM_E_RCCL, "chm_eval: the calls with lower tickets never enqueued their collectives (chm_comm_set_ticket; timeout)");
         NCCLCHK(ncclAllReduce(c.d_partials, c.d_partials, (size_t)nb * 3, ncclDouble, ncclSum, comm->comm, sA));
         turn.release();
         hipLaunchKernelGGL(k_combine, dim3((nb + 63) / 64), dim3(64), 0, sA, nb, (const DevParams*)c.d_params, (const double*)c.d_partials,
@@ -1414,7 +1442,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   };
   if (multi) {
     if (capturing) { rc = end_capture(); if (rc) return rc; }      // the collective stays outside the graph
-    turn.acquire();
+    if (!turn.acquire()) return fail(CHM_E_RCCL, "chm_eval: the calls with lower tickets never enqueued their collectives (chm_comm_set_ticket; timeout)");
     NCCLCHK(ncclAllReduce(c.d_partials, c.d_partials, (size_t)nb * 3, ncclDouble, ncclSum, comm->comm, sA));
     turn.release();
     hipLaunchKernelGGL(k_combine, dim3((nb + 63) / 64), dim3(64), 0, sA, nb, dp, (const double*)c.d_partials, Etot,

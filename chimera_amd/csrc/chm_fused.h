@@ -213,7 +213,7 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
       bool bad = true;
       if (FITS) {
         z_from_lut_x2(dl[0], dl[1], rec, luts, key0e, nk_e, rlo, ns_e, lmax, Tc, x_last, z_last, zz[0], zz[1], z0[0], z0[1], lz0[0], lz0[1], bad);
-        if (__any(bad)) { if (bad) { zz[0] = jnp_interp(dl[0], g_dLt, g_zt, Tc, false, 0., 0.); zz[1] = jnp_interp(dl[1], g_dLt, g_zt, Tc, false, 0., 0.); } }
+        if (wave_any(bad)) { if (bad) { zz[0] = jnp_interp(dl[0], g_dLt, g_zt, Tc, false, 0., 0.); zz[1] = jnp_interp(dl[1], g_dLt, g_zt, Tc, false, 0., 0.); } }
       } else { zz[0] = L.ws_z[so + (s < S ? s : S - 1)]; zz[1] = L.ws_z[so + (s + 1 < S ? s + 1 : S - 1)]; }     // the pre-pass's values
       double wv[2];
 #pragma unroll
@@ -227,7 +227,7 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
           double vv;
           lz = log1pz_from_node(z, z0[h], lz0[h], r, vv);
           const bool nolog = bad || !(vv <= 0.02);
-          if (__any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
+          if (wave_any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
         } else lz = chm_log_pos(zp1);
         const double wgt = p_m1m2_fused<MASS>(P, m1, m2, l1[h] - lz, l2[h] - lz, mgA, cdfA, ex) * ipr[h];      // w = p_m1m2 / pe_prior (pop_wrapper.py:79)
         wv[h] = wgt;
@@ -301,7 +301,7 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
     for (int pg = w; pg < PG; pg += NW) {
       const int p = 2 * pg + sub;
       const bool live = p < Pn && p < npx;
-      if (!ok || !__any(live)) {                            // uniform: every pixel of the event (of this pair: padded pixels) is 0 (or 0 * NaN)
+      if (!ok || !wave_any(live)) {                            // uniform: every pixel of the event (of this pair: padded pixels) is 0 (or 0 * NaN)
         if (p < Pn && sl == 0) { lik[p] = (live && poisoned) ? __builtin_nan("") : 0.; err[p] = 0.; }
         continue;
       }

@@ -864,7 +864,7 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
       bool bad = true;
       if (FITS) {                                     // z = z_from_dGW(dL) (cosmo.py:260-264)
         z_from_lut_x2(dl[0], dl[1], rec, luts, key0, nk, i_lo, ns, lmax, Tc, x_last, z_last, zz[0], zz[1], z0[0], z0[1], lz0[0], lz0[1], bad);
-        if (__any(bad)) {                             // NaN / non-positive / infinite distances: the plain search on the global tables
+        if (wave_any(bad)) {                             // NaN / non-positive / infinite distances: the plain search on the global tables
           if (bad) { zz[0] = jnp_interp(dl[0], g_dLt, g_zt, Tc, false, 0., 0.); zz[1] = jnp_interp(dl[1], g_dLt, g_zt, Tc, false, 0., 0.); }
         }
       } else z_from_dGW_x2(P, dl[0], dl[1], g_dLt, g_zt, zz[0], zz[1]);
@@ -897,7 +897,7 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
           double v;
           lz = log1pz_from_node(z, z0[h], lz0[h], r, v);
           const bool nolog = bad || !(v <= 0.02);
-          if (__any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
+          if (wave_any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
         } else lz = chm_log_pos(zp1);
         const double lm1 = LOGS_HERE ? chm_log(md1[h]) : l1[h], lm2 = LOGS_HERE ? chm_log(md2[h]) : l2[h];
 #if CHM_SF_RELOAD
@@ -971,6 +971,13 @@ DEVFN int bin_index_r(double z, double lo, double d, double r, double dB) {
   double q = x * r;
   q = fma(fma(-q, d, x), r, q);
   return med3_i32(cvt_i32_sat(q * dB), 0, (int)dB - 1);
+}
+// the same bin with the upper clamp B - 1 held in a scalar register and the lower one as the inline constant 0 (see med3_i32_0s)
+DEVFN int bin_index_rs(double z, double lo, double d, double r, double dB, int bm1_sgpr) {
+  double x = z - lo;
+  double q = x * r;
+  q = fma(fma(-q, d, x), r, q);
+  return med3_i32_0s(cvt_i32_sat(q * dB), bm1_sgpr);
 }
 
 DEVFN double kde_bandwidth_factor(int bw_method, double bw_scalar, double neff, int d) {
@@ -1697,6 +1704,10 @@ template <int SW> DEVFN double sg_max(double v) {
 #ifndef CHM_NRS
 #define CHM_NRS 256
 #endif
+#ifndef CHM_GW_DIET
+#define CHM_GW_DIET 1            // [r5] 0: the round-4 set-up of kde_sub_item (A/B builds, profiles/r05/ab_gw_setup_diet.txt)
+#endif
+#define CHM_WS_PAD 512           // doubles behind the (z, w) workspaces: the register rounds of the standard GW kernel read past a pixel's segment unconditionally
 // Instruction-level helpers of the standard GW kernel.  On gfx950 every VALU instruction except the simplest 32-bit ones (v_mov_b32,
 // v_add/sub_u32, v_and_b32, v_ashrrev_i32, v_fma/mul_f32) occupies the SIMD for 4 cycles per wave64 -- fp64 arithmetic, 64-bit moves,
 // v_cndmask, v_med3, DPP moves and v_readlane alike (profiles/r03/issue_cost.txt) -- so the kernel is written for the fewest
@@ -1739,6 +1750,32 @@ template <int SW> DEVFN double sg_last_perm(double x) {
   return __hiloint2double(hi, lo);
 }
 
+// [r5] totals of a group of <= 32 lanes on the LDS crossbar: butterfly exchange with ds_swizzle_b32 (bit-mask mode: lane ^ k inside each half of
+// the wave; no LDS memory, no VALU slot for the two moves of a level -- a DPP level costs two v_mov_b32_dpp + the add).  Every lane ends with the
+// total, so the broadcast of the group's last lane (ds_bpermute) goes too.  For the quantities of which only the total is used: max z of the
+// pixel, sum of the squared bin weights, the pixel's integral and its rounding bound.  The additions pair up differently from the scan's
+// (butterfly instead of left to right): the same sum to rounding, the same bits in every call shape (all go through this function).
+#ifndef CHM_GW_SWZ
+#define CHM_GW_SWZ 0
+#endif
+template <int XOR>
+DEVFN double swz_xor(double x) {
+  constexpr int pat = 0x1f | (XOR << 10);
+  return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(x), pat), __builtin_amdgcn_ds_swizzle(__double2loint(x), pat));
+}
+template <int SW> DEVFN double sg_allsum_swz(double x) {
+  static_assert(SW <= 32, "ds_swizzle does not cross the halves of a wave");
+  x += swz_xor<1>(x); x += swz_xor<2>(x); x += swz_xor<4>(x); x += swz_xor<8>(x);
+  if (SW >= 32) x += swz_xor<16>(x);
+  return x;
+}
+template <int SW> DEVFN double sg_allmax_swz(double x) {
+  static_assert(SW <= 32, "ds_swizzle does not cross the halves of a wave");
+  x = vmax_f64(x, swz_xor<1>(x)); x = vmax_f64(x, swz_xor<2>(x)); x = vmax_f64(x, swz_xor<4>(x)); x = vmax_f64(x, swz_xor<8>(x));
+  if (SW >= 32) x = vmax_f64(x, swz_xor<16>(x));
+  return x;
+}
+
 // kde_sub_item<SW, NR, BINS, DUMP>: one pixel per group of SW lanes.  Preconditions checked by the host (chm_eval): binning with the
 // effective grid cut (cut_grid set), an even number of grid points Z (16-byte pairs (k, k+1), k even, never leave the row).
 // [r3] The grid loop was rewritten for the instruction count (191 -> ~110 VALU per pass of 2 x SW grid points):
@@ -1756,6 +1793,9 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
                         const int pp, const bool live, const bool poisoned, const int s0, const int s1, double (&zr)[NR], double (&wr)[NR],
                         const double hi_pre = 0., double* Q12 = nullptr, double* out_like_pre = nullptr, double* out_err_pre = nullptr, const int nit = NR) {
 #pragma clang fp contract(fast)                  // a*b+c may fuse in this body; the bin index lives in bin_index_r() (contract off)
+  // [r5] FAST (the production instantiations: compile-time bin count, histogram formed here): the set-up sheds what the compiler had wrapped
+  // round its arithmetic -- see the notes at each step (profiles/r05/ab_gw_setup_diet.txt)
+  constexpr bool FAST = !PRE && BINS > 0 && (CHM_GW_DIET != 0);
   const int lane = threadIdx.x, sl = lane % SW;
   const int S = L.S, Z = L.Z, B = BINS > 0 ? BINS : L.num_bins, G = L.G;      // BINS > 0: the bin count is a compile-time constant (LDS offsets, loop bounds)
   const double zmin = es[0], norm = es[3], lb = es[6], ub = es[7];
@@ -1820,31 +1860,53 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   // hi = max(where(mask, z, min z)) (likelihood.py:180, math.py:36).  jnp.max propagates NaN: a NaN among the pixel's z is a NaN among
   // the event's z, and then lo -- jnp.min over all of them (combine_stats, NaN-propagating) -- is NaN already
   double hi = PRE ? hi_pre : lo;
+  // FAST: the register rounds hold whatever stands at the lane's positions (k_kde_marg_sub2::run loads them unconditionally: the rows are padded);
+  // `rem` = samples of the lane's pixel from its first position on -- round i holds one of them iff SW i < rem
+  const int rem = s1 - (s0 + sl);
   if (!PRE) {
     // nit (uniform): register rounds that hold a sample of one of the wave's pixels -- the rounds beyond it were not loaded and are not touched
 #pragma unroll
-    for (int i = 0; i < NR; i++) if (i < nit) hi = vmax_f64(hi, zr[i]);
+    for (int i = 0; i < NR; i++) if (i < nit) {
+      if (FAST) { if (SW * i < rem) { asm volatile(""); hi = vmax_f64(hi, zr[i]); } }     // (the empty asm keeps this an exec-mask region: as selects it is two v_cndmask_b32 more)
+      else hi = vmax_f64(hi, zr[i]);
+    }
     if (nit >= NR) for (int s = s0 + sl + SW * NR; s < s1; s += SW) hi = vmax_f64(hi, wz[s]);
   }
   double* const Q0 = Q; double* const Q1 = PRE ? Q12 : Q + (B + 1); double* const Q2 = PRE ? Q12 + (B + 1) : Q + 2 * (B + 1);      // P0 | -2 P1 | P2, (B + 1) doubles each
+  constexpr int PERC = BINS > 0 ? (BINS + SW - 1) / SW : 1;  // bins per lane (compile-time bin count)
   if (!PRE) {
-    hi = sg_last_perm<SW>(sg_scan_max0<SW>(hi));            // z >= 0: z_from_dGW interpolates a table that starts at z = 0 (cosmo.py:43-46)
+    if (FAST && CHM_GW_SWZ && SW <= 32) hi = sg_allmax_swz<(SW <= 32 ? SW : 32)>(hi);
+    else hi = sg_last_perm<SW>(sg_scan_max0<SW>(hi));       // z >= 0: z_from_dGW interpolates a table that starts at z = 0 (cosmo.py:43-46)
     if (lo != lo) hi = lo;
-    for (int j = sl; j < B; j += SW) Q0[j] = 0.;
+    if (FAST) {
+      // PERC stores per lane at immediate offsets, no loop, no bound: [0, PERC SW) covers the B counts and runs into the first slots of the
+      // -2 P1 array (B + 1 .. PERC SW - 1 of this pixel's slice), which the prefix pass below rewrites -- the lanes whose bins lie beyond B then
+      // read zeros there without a test
+      static_assert(BINS <= 0 || PERC * SW <= 2 * (BINS + 1), "zero padding must stay inside the pixel's own prefix arrays");
+#pragma unroll
+      for (int i = 0; i < PERC; i++) Q0[sl + SW * i] = 0.;
+    } else for (int j = sl; j < B; j += SW) Q0[j] = 0.;
     wave_sync();
   }
   const double dB = (double)B;
   const double dhl = hi - lo, rhl = 1. / dhl;
   const double dbin = dhl * L.inv_B;                        // c'_j = c_j - lo = (j + 1/2) dbin for the uniform edges of math.py:37-39
   if (!PRE) {
+    if (FAST) {
+      int bm1 = B - 1;
+      asm volatile("" : "+s"(bm1));                       // the upper clamp of the bin index in ONE scalar register for all rounds
 #pragma unroll
-    for (int i = 0; i < NR; i++) if (i < nit) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q0[bin_index_r(zr[i], lo, dhl, rhl, dB)], wr[i]); }
+      for (int i = 0; i < NR; i++) if (i < nit) { if (SW * i < rem) { asm volatile(""); atomicAdd(&Q0[bin_index_rs(zr[i], lo, dhl, rhl, dB, bm1)], wr[i]); } }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NR; i++) if (i < nit) { int s = s0 + sl + SW * i; if (s < s1) atomicAdd(&Q0[bin_index_r(zr[i], lo, dhl, rhl, dB)], wr[i]); }
+    }
     if (nit >= NR) for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q0[bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
     wave_sync();
   }
   // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins (a compile-time 7 for 200 bins on 32 lanes)
   const int per = (B + SW - 1) / SW;
-  const int j0 = sl * per < B ? sl * per : B, j1 = min(j0 + per, B);
+  const int j0 = FAST ? sl * per : (sl * per < B ? sl * per : B), j1 = min(j0 + per, B);     // FAST: unclamped -- the lanes beyond B read the zero padding
 #ifndef CHM_MAXPER
 #define CHM_MAXPER 8
 #endif
@@ -1857,7 +1919,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   const double c_first = ((double)j0 + 0.5) * dbin;
   if (small) {                                              // the lane's bin counts: all loads in flight at once, summed in bin order
 #pragma unroll
-    for (int i = 0; i < MAXPER; i++) wv[i] = (j0 + i < j1) ? Q0[j0 + i] : 0.;
+    for (int i = 0; i < MAXPER; i++) wv[i] = FAST ? Q0[j0 + i] : ((j0 + i < j1) ? Q0[j0 + i] : 0.);      // FAST: zeros beyond B (padding above), no test
     double cc = c_first;
 #pragma unroll
     for (int i = 0; i < MAXPER; i++) { const double w = wv[i], t = w * cc; s0w += w; s1w += t; s2w = fma(t, cc, s2w); sq = fma(w, w, sq); cc += dbin; }
@@ -1866,7 +1928,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   }
   const double x0 = sg_scan_add0<SW>(s0w), x1 = sg_scan_add0<SW>(s1w), x2 = sg_scan_add0<SW>(s2w);
   const double tot = sg_last_perm<SW>(x0);
-  const double sum2 = sg_last_perm<SW>(sg_scan_add0<SW>(sq));
+  const double sum2 = (FAST && CHM_GW_SWZ && SW <= 32) ? sg_allsum_swz<(SW <= 32 ? SW : 32)>(sq) : sg_last_perm<SW>(sg_scan_add0<SW>(sq));
   // End of the last lane chunk of bins that holds any weight.  The prefix values of the lanes after it come out of different
   // summation trees and agree only to an ulp: a node that sees nothing but the empty bins above the data would get 1e-16 of the
   // peak where the dense sum (math.py:80) has an exact zero -- which decides log L_i when the catalogue term is only non-zero out
@@ -1888,7 +1950,10 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
       for (int i = 0; i < MAXPER; i++) {
         const double w = wv[i], t = w * cc;
         r0 += w; r1 += t; r2 = fma(t, cc, r2); cc += dbin;
-        if (j0 + i < j1) { Q0[j0 + i + 1] = r0; Q1[j0 + i + 1] = -2. * r1; Q2[j0 + i + 1] = r2; }
+        // FAST: bin j0 + i exists iff the lane lies below the one that holds bin B (all of its PERC bins) or is that lane and i < B mod PERC:
+        // two lane predicates for the PERC stores instead of an add and a compare for each
+        const bool st = FAST ? (sl < B / PERC || (sl == B / PERC && i < B % PERC)) : (j0 + i < j1);
+        if (st) { Q0[j0 + i + 1] = r0; Q1[j0 + i + 1] = -2. * r1; Q2[j0 + i + 1] = r2; }
       }
     } else {                                                // many bins per lane: the count of bin j+1 shares the slot of P0[j+1]
       double a0 = r0, a1 = r1, a2 = r2;
@@ -1935,7 +2000,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   const double zlo = degenerate ? lb : __builtin_fmax(lb, lo - bw - de), zhi = degenerate ? ub : __builtin_fmin(ub, hi + bw + de);
   // density (without the common factor `scale`) at the node with g' = g - lo whose bin range comes from the truncations of xa, xb
   auto node = [&](double gp, double xa, double xb) {
-    const int ia = med3_i32(cvt_i32_sat(xa), 0, jl1);
+    const int ia = CHM_GW_DIET ? med3_i32_0v(cvt_i32_sat(xa), jl1) : med3_i32(cvt_i32_sat(xa), 0, jl1);
     const int ib = med3_i32(cvt_i32_sat(xb), ia, jl1);
     const double S0 = Q0[ib] - Q0[ia], S1 = Q1[ib] - Q1[ia], S2 = Q2[ib] - Q2[ia];   // S1 = -2 sum W c'
     const double qq = fma(gp, fma(gp, S0, S1), S2);         // sum W (g' - c')^2 over the support
@@ -1978,7 +2043,13 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
     // (the empty volatile asm keeps this a branch on the exec mask: as selects it is four v_cndmask_b32 per point)
     if (inrange && pcv != -100.) { asm volatile(""); const double cz = fma(fR, pcv, bk) * ak; acc = fma(pgw, cz, acc); accC += fabs(cz); }   // catalog.py:202, likelihood.py:275
   };
-  auto do_pass = [&](const int k, const Pass& q) {
+  // [r5] a pass in which no lane's FIRST point lies at or below its pixel's zhi ends the loop: the grid ascends, so every later point of either
+  // pixel is beyond the support too (p_gw = 0 exactly: nothing to add to the integral; the rounding bound then sums |C_k| over [k_lo, here),
+  // which still covers the support).  A NaN grid point or a NaN zhi keeps the loop going.  Not in the instantiation that stores p_gw.
+  constexpr bool EXIT_EARLY = FAST && !DUMP && CHM_GW_PAIRS;
+  const double zhi_v = live ? zhi : -__builtin_inf();       // (a lane beyond k_hi holds the row's last pair: it may keep the loop going, which ends at k_hi anyway)
+  auto do_pass = [&](const int k, const Pass& q) -> bool {
+    if (EXIT_EARLY && !wave_any(!(q.z.x > zhi_v))) return false;     // (ONE compare under the vote: a conjunction makes the compiler rebuild the mask through a VGPR)
     if (k <= k_hi && live) {
       const double z0 = q.z.x, z1 = q.z.y;
       const bool v1 = CHM_GW_PAIRS ? true : (k + SW <= k_hi);    // stride-1 lanes: the second point of the last pass may lie beyond the range
@@ -1990,7 +2061,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
         const double tp0 = floor(zr0 * inv_de), tp1 = floor(zr1 * inv_de);
         const double dtp = tp1 - tp0;
         const bool same = dtp == 0.;
-        if (__all(same || dtp == 1.)) {                     // uniform: every lane at work here shares nodes between its two points
+        if (wave_all(same || dtp == 1.)) {                     // uniform: every lane at work here shares nodes between its two points
           const double ga = fma(tp0, de, lbl), ta = fma(tp0, dd, t0);
           const double n0 = node(ga, ta + oa1, ta + oa2), n1 = node(ga + de, ta + ob1, ta + ob2), n2 = node(ga + de2, ta + oc1, ta + oc2);
           const double f0 = interp(zr0, tp0, n0, n1), f1 = interp(zr1, tp1, same ? n0 : n1, same ? n1 : n2);
@@ -2013,21 +2084,25 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
       integrand(k, pg0, q.pc.x, q.bk.x, q.a.x);
       integrand(k + (CHM_GW_PAIRS ? 1 : SW), pg1, q.pc.y, q.bk.y, q.a.y, v1);
     }
+    return true;
   };
   // one pass = SW lanes x 2 consecutive grid points per pixel.  Software pipeline in two alternating register sets: the loads of the next
   // pass are issued before the arithmetic of this one and waited for where that pass begins (no register rotation, no wait at the loop end)
   for (int kb = k_lo; kb <= k_hi; kb += 4 * SW) {
     const int k = kb + (CHM_GW_PAIRS ? 2 * sl : sl);
     const Pass nxt = load_pass(k + 2 * SW);
-    do_pass(k, cur);
+    if (!do_pass(k, cur)) break;                            // uniform
     if (kb + 2 * SW > k_hi) break;                          // uniform
     cur = load_pass(k + 4 * SW);
-    do_pass(k + 2 * SW, nxt);
+    if (!do_pass(k + 2 * SW, nxt)) break;
   }
   // (same-address LDS atomics for these reductions -- ds_max_f64 / ds_add_f64 on one cell per pixel, no VALU slots -- were measured:
   //  5.53 instead of 4.43 ms for the kernel, the LDS pipe serialises the 32 lanes of every such instruction)
-  acc = sg_scan_add0<SW>(acc);                              // the group's last lane holds the pixel's integral
-  accC = sg_scan_add0<SW>(accC);
+  if (FAST && CHM_GW_SWZ && SW <= 32) { acc = sg_allsum_swz<(SW <= 32 ? SW : 32)>(acc); accC = sg_allsum_swz<(SW <= 32 ? SW : 32)>(accC); }
+  else {
+    acc = sg_scan_add0<SW>(acc);                            // the group's last lane holds the pixel's integral
+    accC = sg_scan_add0<SW>(accC);
+  }
   if (sl == SW - 1 && live) {
     *out_like = poisoned ? nan : acc;
     *out_err = (degenerate || poisoned) ? 0. : errD * accC * fabs(scale * ng);     // NaN results stay NaN: nothing to redo
@@ -2069,7 +2144,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevPar
   auto run = [&](const int pgi, const int p, const int pp, const int q0, const int q1, const bool first, const int nq0 = 0, const int nq1 = 0) {
     if (pgi >= PG) return;                                  // uniform
     const bool live = p < L.P && p < npx;
-    if (!ok || !__any(live)) {                              // uniform: every pixel of the event (of this item: padded pixels) is 0 (or 0 * NaN)
+    if (!ok || !wave_any(live)) {                              // uniform: every pixel of the event (of this item: padded pixels) is 0 (or 0 * NaN)
       if (p < L.P) {
         if (sl == 0) { L.like_pix[((size_t)b * L.E + e) * L.P + p] = (live && poisoned) ? __builtin_nan("") : 0.; L.err_pix[((size_t)b * L.E + e) * L.P + p] = 0.; }
         if (DUMP) { double* d = L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z; for (int k = sl; k < Z; k += SW) d[k] = 0.; }
@@ -2089,8 +2164,20 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevPar
     const int nit = min((nmax + SW - 1) / SW, NR);
 #endif
     double zr[NR], wr[NR];
+    if (BINS > 0 && CHM_GW_DIET) {
+      // [r5] unconditional loads at ONE 32-bit lane offset + an immediate per round (uniform row base in scalar registers): what stands behind the
+      // pixel's segment is the next pixel's samples or the CHM_WS_PAD doubles behind the workspace, and kde_sub_item uses round i only where
+      // SW i < s1 - (s0 + sl).  Before: per round a compare, two 64-bit address computations and two moves of the neutral values.
+      const size_t boff = (size_t)((unsigned)(s0 + sl) * 8u);
 #pragma unroll
-    for (int j = 0; j < NR; j++) if (j < nit) { int s = s0 + sl + SW * j; zr[j] = s < s1 ? wz[s] : lo; wr[j] = s < s1 ? ww[s] : 0.; }
+      for (int j = 0; j < NR; j++) if (j < nit) {
+        zr[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(wz) + boff + (size_t)(8 * SW * j));
+        wr[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ww) + boff + (size_t)(8 * SW * j));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NR; j++) if (j < nit) { int s = s0 + sl + SW * j; zr[j] = s < s1 ? wz[s] : lo; wr[j] = s < s1 ? ww[s] : 0.; }
+    }
     int t1 = 0, t2 = 0;
     if (CHM_GW_TOUCH) {
       const int ts = nq0 + sl * 16;
@@ -3005,7 +3092,7 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
       bool bad = true;
       if (fits) {                                   // z = z_from_dGW(dL)   cosmo.py:260-264
         z_from_lut_x2(dl[0], dl[1], rec, luts, key0, nk, i_lo, ns, lmax, Tc, x_last, z_last, zz[0], zz[1], z0[0], z0[1], lz0[0], lz0[1], bad);
-        if (__any(bad)) {
+        if (wave_any(bad)) {
           if (bad) { zz[0] = jnp_interp(dl[0], g_dLt, g_zt, Tc, false, 0., 0.); zz[1] = jnp_interp(dl[1], g_dLt, g_zt, Tc, false, 0., 0.); }
         }
       } else z_from_dGW_x2(P, dl[0], dl[1], g_dLt, g_zt, zz[0], zz[1]);
@@ -3018,7 +3105,7 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
         double vv;
         double lz = log1pz_from_node(z, z0[h], lz0[h], r, vv);
         const bool nolog = !fits || bad || !(vv <= 0.02);
-        if (__any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
+        if (wave_any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
         const double pm = p_m1m2_fused<MASS>(P, m1, m2, l1[h] - lz, l2[h] - lz, mg, cdf, ex);
         const double Ez = E_at_z_lr(P, z, zp1, r, lz);
         const double dCt = dl[h] * r;                                    // original distances: cosmo.py:191-192,215-216

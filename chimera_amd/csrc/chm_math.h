@@ -48,6 +48,14 @@ DEVFN double vmax_f64(double a, double b) { double r; asm("v_max_f64 %0, %1, %2"
 DEVFN double vmin_f64(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 DEVFN int cvt_i32_sat(double x) { int r; asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(x)); return r; }
 DEVFN int med3_i32(int x, int lo, int hi) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi)); return r; }
+// wave votes straight on the ballot (a v_cmp into a scalar pair + s_cmp): HIP's __any / __all take an int, and the bool -> int -> "!= 0" round trip
+// survives as v_cndmask_b32 + v_cmp_ne_u32 in front of every vote -- two VALU instructions per vote in the per-sample / per-pass loops
+DEVFN bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+DEVFN bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+// clamp to [0, hi]: the lower bound is the inline constant 0 (the three-register form above made the compiler materialise a VGPR 0, and a VGPR
+// copy of a literal upper bound, in front of EVERY use: two v_mov_b32 per binned sample); `hi` in a vector / in a scalar register
+DEVFN int med3_i32_0v(int x, int hi) { int r; asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "v"(hi)); return r; }
+DEVFN int med3_i32_0s(int x, int hi) { int r; asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(hi)); return r; }
 
 // a / b without the IEEE special-case scaffolding (v_div_scale / v_div_fmas / v_div_fixup): reciprocal seed, two Newton steps,
 // quotient and one residual correction -- 8 instructions instead of 11, the correctly rounded quotient except for rare last-bit

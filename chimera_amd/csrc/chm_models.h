@@ -499,7 +499,7 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
   int i = (t >= 0.) ? (t < (double)n ? (int)t + 1 : n - 1) : 1;
   i = i < 1 ? 1 : (i > n - 1 ? n - 1 : i);
   double x0 = mg[i - 1], x1 = mg[i];
-  if (__any((i > 1 && x0 > m1) || (i < n - 1 && x1 <= m1))) {
+  if (wave_any((i > 1 && x0 > m1) || (i < n - 1 && x1 <= m1))) {
     while (i > 1 && mg[i - 1] > m1) i--;
     while (i < n - 1 && mg[i] <= m1) i++;
     x0 = mg[i - 1]; x1 = mg[i];
@@ -514,7 +514,7 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
   // capped at 1e300 (a factor 1e-300 on the weight); a zero interpolant (m1 at the lowest node) gives NaN here and 0 below
   const double num = (Pn * p.inv_norm_p_m1) * dx, den = vmin_f64((D1 * D2) * cn, 1e300);
   double w = chm_div(num, den);
-  if (__any(den == 0.)) { if (den == 0.) w = num / den; }   // m1 at the lowest node of the grid: the IEEE quotient (x/0 = inf, 0/0 = NaN) as the reference forms it
+  if (wave_any(den == 0.)) { if (den == 0.) w = num / den; }   // m1 at the lowest node of the grid: the IEEE quotient (x/0 = inf, 0/0 = NaN) as the reference forms it
   // sec = 0 -> p_m2m1 = 0 (or 0/0 = NaN -> 0): w = p_m1 * 0
   if (zero || (w != w && cn == 0.)) w = Pn * 0.;
   // a NaN primary mass: the smoothing window of bpl / plp turns p_m1 NaN (NaN * 0 = NaN); the truncated power law has no window, every factor

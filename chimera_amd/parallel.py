@@ -231,6 +231,12 @@ class Comm(object):
   def reset_tickets(next_ticket=0):
     _lib.check(_lib.lib().chm_comm_ticket_reset(int(next_ticket)))
 
+  @staticmethod
+  def skip_ticket(ticket):
+    """Forfeit a ticket (``chm_comm_ticket_skip``): the step that carried it will not reach its collective -- call it from the ``except`` /
+    ``finally`` of a failed step so that the other lanes' higher tickets are served instead of waiting for the timeout."""
+    _lib.check(_lib.lib().chm_comm_ticket_skip(int(ticket)))
+
   def close(self):
     if self._h:
       _lib.lib().chm_comm_destroy(self._h)
@@ -323,6 +329,13 @@ def _group_address(address, group):
   return (address[0], int(address[1]) + 1 + int(group))
 
 
+def _split_address(address, ngroups):
+  """where the ranks of an RCCL world meet to split it (distinct from the job's own address and from every group address)"""
+  if isinstance(address, str):
+    return f"{address}.split"
+  return (address[0], int(address[1]) + 1 + int(ngroups))
+
+
 def split(world, ngroups, rendezvous=None):
   """A COLLECTIVE over ``world``: the communicator of this rank's group under the 'both' scheme (the reference's ``comm.Split(color=batch_id,
   key=rank)``, CHIMERA/parallel.py:149-156).  The result is what the selection function and the likelihood of the group are built on
@@ -339,7 +352,9 @@ def split(world, ngroups, rendezvous=None):
     world.rendezvous.barrier()                                 # every group is connected before anybody goes on
   else:
     own = rendezvous is None
-    rdzv = Rendezvous(world.nranks, world.rank) if own else rendezvous
+    #  the temporary rendezvous meets at an address of its own -- the job's default address may still be held by the job's
+    # rendezvous: a second listener would unlink a live Unix socket, and fail with EADDRINUSE on TCP while the other ranks wait on the old one
+    rdzv = Rendezvous(world.nranks, world.rank, address=_split_address(default_address(), ngroups)) if own else rendezvous
     try:
       ids = rdzv.broadcast_bytes(b''.join(new_unique_id() for _ in range(int(ngroups))) if world.rank == 0 else None)
     finally:

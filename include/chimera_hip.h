@@ -268,6 +268,9 @@ int chm_comm_nranks(chm_comm* c);
  * (step k: ticket k).  chm_comm_ticket_reset(n): the next ticket to be served.  Calls without a ticket are not sequenced.                   */
 int chm_comm_set_ticket(chm_comm* c, int64_t ticket);
 int chm_comm_ticket_reset(int64_t next);
+/* forfeit ticket t: a step that will not reach its collective (its host thread failed before chm_eval) lets the higher tickets pass.  A ticketed
+ * call whose turn does not come within 120 s fails with CHM_E_RCCL instead of hanging the lane and its RCCL peers.                              */
+int chm_comm_ticket_skip(int64_t ticket);
 /* hipDeviceSynchronize on `device`: the barrier bracket of a timed region (chm_eval itself returns after its stream drained). */
 int chm_device_synchronize(int32_t device);
 

@@ -363,7 +363,7 @@ def test_options_select_streams_and_launch_paths_not_results(cfg_pix):
   with pytest.raises(ValueError):
     like.set_option('no_such_option', 1)
   with pytest.raises(ValueError):
-    like.set_option('groups', 99)
+    like.set_option('groups', 129)
   with pytest.raises(ValueError):
     like.set_option('fused', 7)
   like.set_option('serial', 1)
