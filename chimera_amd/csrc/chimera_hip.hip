@@ -232,6 +232,12 @@ static int check_params(const chm_params* p) {
   return CHM_OK;
 }
 
+// an infinite rate parameter the model reads (gamma; kappa and z_p of the Madau-Dickinson forms): rate.py:96-122 under NumPy / XLA has a value
+// class of its own there (merger_rate_special)
+static bool params_rate_special(const chm_params* p) {
+  const bool md = p->rate_model == 1 || p->rate_model == 3;
+  return std::isinf(p->rate[0]) || (md && (std::isinf(p->rate[1]) || std::isinf(p->rate[2])));
+}
 static void fill_dev_params(const chm_params* p, DevParams* d) {
   memset(d, 0, sizeof(DevParams));
   d->cosmo_model = p->cosmo_model; d->mass_model = p->mass_model; d->rate_model = p->rate_model;
@@ -244,6 +250,7 @@ static void fill_dev_params(const chm_params* p, DevParams* d) {
   for (int i = 0; i < 8; i++) d->m[i] = p->mass[i];
   for (int i = 0; i < 4; i++) d->r[i] = p->rate[i];
   d->R0 = p->R0; d->Tobs = p->Tobs; d->zc0 = p->compl_z0; d->zc1 = p->compl_z1;
+  d->rate_special = params_rate_special(p) ? 1 : 0;
   // End nodes of the mass grid, jnp.logspace(log10 m_low, log10 m_high)[0], [-1] (mass.py:46).  Whether they pass the
   // `m_low <= m <= m_high` test of tpl_notnorm (mass.py:240-245) decides if the first / last trapezoid node of cdf_m2 and
   // norm_p_m1 counts -- an O(1e-3) effect hanging on the last bit of pow().  The host's libm forms them (as NumPy / the CPU
@@ -653,6 +660,7 @@ static void like_free_ws(chm_like* h) {
   LikeDev& L = h->L;
   (void)hipFree(L.ws_z); (void)hipFree(L.ws_w); (void)hipFree(L.part); (void)hipFree(L.jac); (void)hipFree(L.prate); (void)hipFree(L.bkgA);
   (void)hipFree(h->d_lut); (void)hipFree(h->d_lutinfo); h->d_lut = nullptr; h->d_lutinfo = nullptr;
+  (void)hipFree(L.ev_rbad); L.ev_rbad = nullptr;
   (void)hipFree(L.err_pix); L.err_pix = nullptr; (void)hipFree(L.ev_li); (void)hipFree(L.ev_ll); L.ev_li = L.ev_ll = nullptr; (void)hipFree(L.full_todo); L.full_todo = nullptr; (void)hipFree(L.full_ev); (void)hipFree(L.full_s); L.full_ev = L.full_s = nullptr;
   (void)hipFree(L.pgw1d); (void)hipFree(L.like_pix); (void)hipFree(L.p_gw_dump); (void)hipFree(L.Aw); (void)hipFree(L.evstat); (void)hipFree(L.effg); (void)hipFree(L.krange); L.krange = nullptr;
   L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.pgw1d = L.like_pix = L.p_gw_dump = L.Aw = L.evstat = L.effg = nullptr;
@@ -687,7 +695,7 @@ extern "C" int chm_like_clone(const chm_like* src, chm_like** out) {
   h->L = src->L;
   LikeDev& L = h->L;                                        // workspaces are the clone's own (allocated by the first call)
   L.ws_z = L.ws_w = L.part = L.jac = L.prate = L.bkgA = L.Aw = L.evstat = L.effg = L.pgw1d = L.like_pix = L.err_pix = L.p_gw_dump = L.ev_li = L.ev_ll = nullptr; L.full_todo = nullptr; L.full_ev = L.full_s = nullptr;
-  L.krange = nullptr; L.tab_pm = L.tab_rate = L.tab_bkg = L.tab_jac = nullptr; L.zg_i = nullptr; L.zg_t = L.zg_lz = nullptr;
+  L.krange = nullptr; L.tab_pm = L.tab_rate = L.tab_bkg = L.tab_jac = nullptr; L.zg_i = nullptr; L.zg_t = L.zg_lz = nullptr; L.ev_rbad = nullptr;
   h->F = src->F; h->fast_ok = src->fast_ok; h->dl_gmin = src->dl_gmin; h->dl_gmax = src->dl_gmax;
   h->neg_prior = src->neg_prior; h->d_ev_bad = src->d_ev_bad;
   h->FD = src->FD; h->fused_ok = src->fused_ok; h->ev_oct_max = src->ev_oct_max; h->ev_nk_max = src->ev_nk_max; h->d_redo = src->d_redo;
@@ -720,6 +728,7 @@ static int like_ensure_ws(chm_like* h, int nb, bool dump) {
   if (L.mode == CHM_MODE_MARG) { HIPCHK(hipMalloc(&L.err_pix, sizeof(double) * n * E * Pd)); HIPCHK(hipMalloc(&L.ev_li, sizeof(double) * n * E)); HIPCHK(hipMalloc(&L.ev_ll, sizeof(double) * n * E)); HIPCHK(hipMalloc(&L.Aw, sizeof(double) * n * E * Z)); HIPCHK(hipMalloc(&L.evstat, sizeof(double) * n * E * NEVSTAT));
                                  HIPCHK(hipMalloc(&L.effg, sizeof(double) * n * E * L.G)); }
   HIPCHK(hipMalloc(&L.like_pix, sizeof(double) * n * E * Pd));
+  HIPCHK(hipMalloc(&L.ev_rbad, n * E)); HIPCHK(hipMemsetAsync(L.ev_rbad, 0, n * E, h->ctx.stream));
   if (L.mode == CHM_MODE_FULL) {
     HIPCHK(hipMalloc(&L.full_todo, sizeof(int) * n * E * Pd));
     HIPCHK(hipMalloc(&L.full_ev, sizeof(double) * n * E * FULLEV));
@@ -957,6 +966,11 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   // per-event outputs, no caller tables.  A configuration runs eagerly the first time it is seen (function attributes, workspaces), is
   // captured the second time and replayed afterwards.  [r3] With a communicator the graph ends at the rank's partial sums; the RCCL
   // all-reduce and k_combine follow it on the same stream (the 8-GPU job keeps the replayed path of the scalar call).
+  // [r5] a draw with an infinite rate parameter: the whole call takes the kernels that multiply every grid point out (the reference's 0 * inf = NaN
+  // where p_gw vanishes must come out of the arithmetic) and the general selection kernel (the reference's order of quotients)
+  bool rate_special_call = false;
+  for (int b = 0; b < nb; b++) rate_special_call = rate_special_call || params_rate_special(&params[b]);
+  const bool opt_zf_full = o.zf_full || rate_special_call, opt_marg_generic = o.marg_generic || rate_special_call;
   const int graph_max_nb = o.graph_max_nb;
   const bool zc_env = !o.no_zero_copy;
   const bool zero_copy = zc_env && nb <= 8;               // parameters read from / results written to pinned host memory by the kernels themselves
@@ -1017,7 +1031,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     const int few_nb_f = o.few_nb;
     if (like && like->fused_ok && use_fast && !tab && !want_dump && fmode > 0 && (nb <= few_nb_f || fmode >= 2) &&
         like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && like->L.num_bins == 200 &&
-        !o.marg_generic && !o.zf_full && !like->neg_prior) {
+        !opt_marg_generic && !opt_zf_full && !like->neg_prior) {
       int Tc_call = 0, Tm_call = 0;
       double zmax_min = INFINITY;
       for (int b = 0; b < nb; b++) {
@@ -1050,7 +1064,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   }
   // k_selection_fast: built-in models of an FLRW draw (cosmo_model 0), the same mass model for every draw; table slice capacity as above
   LutDesc lutB = {};
-  bool sel_fast = sel && sel->fast_ok && !td.pm_i && !td.rate_i && !td.bkg_i && !td.jac_i && !td.zt && !o.selection_generic;
+  bool sel_fast = sel && sel->fast_ok && !td.pm_i && !td.rate_i && !td.bkg_i && !td.jac_i && !td.zt && !o.selection_generic && !rate_special_call;
   size_t lds_sel = 0;
   if (sel_fast) {
     int Tc_call = 0, Tm_call = 0;
@@ -1081,7 +1095,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   const bool fuse_env = !o.no_zf_sel;
   const size_t lds_zfac_call = sizeof(double) * (size_t)2 * c.TcMax;
   const bool fuse_sel = fuse_env && !use_fused && !serial && like && sel && sel_fast && nb <= few_nb && !td.rate_g && !td.bkg_g && !td.jac_g &&
-                        like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && !o.marg_generic && !o.zf_full &&
+                        like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && !opt_marg_generic && !opt_zf_full &&
                         !(o.groups > 1) && lds_zfac_call <= 64 * 1024 && like->L.E <= 65535;
   const bool one_stream = serial || fuse_sel;
   if (fuse_sel) { sB = sA; sC = sA; }
@@ -1231,12 +1245,12 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         ev_from_fixup = true;
         continue;
       }
-      const bool zf_ranged = (L.mode == CHM_MODE_MARG || L.mode == CHM_MODE_1D || L.mode == CHM_MODE_APPROX) && !o.zf_full;
+      const bool zf_ranged = (L.mode == CHM_MODE_MARG || L.mode == CHM_MODE_1D || L.mode == CHM_MODE_APPROX) && !opt_zf_full;
       // standard configuration (binning, cut_grid set) -> k_kde_marg_sub<32>, two pixels per wave (16 lanes per pixel measured
       // 30 % slower: 19 KB of LDS per wave halve the occupancy); anything else, or CHM_MARG_GENERIC=1, -> the general kernel
       // (a negative pe_prior -- negative weights, which the reference's arithmetic takes as they come -- goes to the general kernel: the standard
       //  one bounds its rounding error and skips empty bins on the assumption of weights >= 0; scripts/fuzz_parity.py, round 4)
-      const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && (L.Z & 1) == 0 && !o.marg_generic && !like->neg_prior;
+      const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && (L.Z & 1) == 0 && !opt_marg_generic && !like->neg_prior;
       const int zf_mode = !zf_ranged ? 0 : (L.mode == CHM_MODE_MARG ? 1 : 2);
       hipStream_t sz = (one_stream || zf_ranged) ? sg : ((g & 1) ? sA : sB);
       // ~2048 blocks in all: each stages the draw's (zt, It) tables in LDS once and walks over E_cnt / gridDim.x events
@@ -1268,6 +1282,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       if (!zf_ranged) {
         launch_zfactors();
         HIPCHK(hipGetLastError());
+        if (rate_special_call) {                            // [r5] rewrite the rate factors of the draws with an infinite rate parameter, flag the poisoned grids
+          hipLaunchKernelGGL(k_rate_special, dim3(L.E_cnt, nb), dim3(256), 0, sz, L, dp);
+          HIPCHK(hipGetLastError());
+        }
         if (sz != sg) HIPCHK(hipEventRecord(c.evf[g], sz));
       }
       // sample stage
@@ -1315,7 +1333,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         // [r3] sample-stationary kernel first; the pixels it cannot do (non-uniform stretch of the grid, very coarse grid, > 4096 samples) are
         // flagged in full_todo and done by the general kernel, whose other blocks return at once.  CHM_FULL_CHAIN=0: general kernel only.
-        const bool full_chain = o.full_chain != 0;         // (CHM_OPT_DIAG_FULL_CHAIN 0: the general kernel alone; tests compare the two)
+        const bool full_chain = o.full_chain != 0 && !rate_special_call;         // (CHM_OPT_DIAG_FULL_CHAIN 0: the general kernel alone; tests compare the two)
         if (full_chain) {
           hipLaunchKernelGGL(k_full_prep, dim3(L.E_cnt, nb), dim3(256), 0, sg, L); HIPCHK(hipGetLastError());
           hipLaunchKernelGGL(k_full_kde_chain, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp, L.full_todo); HIPCHK(hipGetLastError());
@@ -1383,6 +1401,8 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       const int mm = params[0].mass_model;
       if (mm == 0) LAUNCH_SELF(0); else if (mm == 1) LAUNCH_SELF(1); else LAUNCH_SELF(2);
 #undef LAUNCH_SELF
+    } else if (rate_special_call) {                          // a draw with an infinite rate parameter: the reference's own operations for the rate (merger_rate_special)
+      hipLaunchKernelGGL((k_selection<false, true>), dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
     } else if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
       hipLaunchKernelGGL(k_selection<true>, dim3(S.nblocks, nb), dim3(256), lds_samp, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
     } else hipLaunchKernelGGL(k_selection<false>, dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);

@@ -69,9 +69,18 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   double *full_ev;                // (nb,E,FULLEV) full mode: k_full_prep's record of every (draw, event)
   double *full_s;                 // (5,nb_alloc,E,S) full mode: whitened coordinates a, y1, y2, normalised weight, step factor U of every sample
   int nb_alloc, pad_full;         // draws the workspaces are allocated for (the stride of full_s's five planes)
+  unsigned char *ev_rbad;         // (nb,E) [r5] calls with an infinite rate parameter only: 1 = the rate factor prate/jac is inf or NaN at some point of the event grid
+                                  // (k_zfactors, whole-grid launch) -- the reference's trapz then holds a 0 * inf = NaN where p_gw vanishes (event_poisoned)
 };
 
 struct EvStats { double zmin, zmax, sd, norm, n_eff, sumw; };
+// L_i of (draw, event) is NaN whatever the KDE: NaN distance factors on the event grid (grid_is_poisoned), or -- a draw with an infinite rate
+// parameter -- a rate factor that is inf / NaN somewhere on the grid.  The kernels skip grid points where p_gw vanishes; the reference multiplies
+// them out (likelihood.py:274-278: 0 * inf = NaN).  (Corner not reproduced: every such point inside the KDE's support AND the value +inf -> the
+// reference has +inf where this gives NaN.)
+DEVFN bool event_poisoned(const LikeDev& L, const DevParams& P, int b, int e, const double* zg, int Z) {
+  return grid_is_poisoned(P.z_bad, zg, Z) || (P.rate_special && L.ev_rbad && L.ev_rbad[(size_t)b * L.E + e]);
+}
 
 // Combine the chunk partials of one event.  std via the shifted one-pass form: var = <d^2> - <d>^2 with
 // d = z - z_ref (jnp.std two-pass result to ~1e-15 relative; likelihood.py:118,186,222).
@@ -1379,6 +1388,33 @@ DEVFN void zfactors_body(const LikeDev& L, const DevParams* params, const double
   }
 }
 
+// [r5] k_rate_special: after a WHOLE-GRID k_zfactors launch of a call that carries a draw with an infinite rate parameter -- one block per (event, draw)
+// of such a draw rewrites the draw's rate factors (prate, and the rate factor inside A_k) with merger_rate_special, the reference's own operations
+// (rate.py:96-122: value classes of C99 pow), and flags the event when prate / jac is inf or NaN anywhere on its grid (event_poisoned).  Draws
+// with finite rate parameters are left alone (their flag is cleared).
+__global__ void __launch_bounds__(256) k_rate_special(LikeDev L, const DevParams* params) {
+  const int b = blockIdx.y, e = L.e_off + blockIdx.x, t = threadIdx.x, Z = L.Z;
+  const DevParams& P = params[b];
+  if (!P.rate_special) { if (t == 0 && L.ev_rbad) L.ev_rbad[(size_t)b * L.E + e] = 0; return; }
+  const size_t zo = ((size_t)b * L.E + e) * Z;
+  const double* zg = L.z_grids + (size_t)e * Z;
+  bool rbad = false;
+  for (int k = t; k < Z; k += 256) {
+    const double z = zg[k], zp1 = 1. + z;
+    const double r = L.tab_rate ? L.tab_rate[zo + k] : merger_rate_special(P, z);
+    const double pr = r / zp1, jac = L.jac[zo + k];                 // pop_wrapper.py:85
+    L.prate[zo + k] = pr;
+    if (L.Aw) {
+      const double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
+      L.Aw[zo + k] = (pr / jac) * (0.5 * ((z - zl) + (zr - z)));   // likelihood.py:275-278: p_z / jac times the trapezoid weight
+    }
+    const double f = pr / jac;
+    rbad = rbad || !(fabs(f) < __builtin_inf());
+  }
+  const int any = __syncthreads_or(rbad ? 1 : 0);
+  if (t == 0 && L.ev_rbad) L.ev_rbad[(size_t)b * L.E + e] = any ? 1 : 0;
+}
+
 template <bool LDS_TAB, bool STATS = false>
 __global__ void __launch_bounds__(256, CHM_ZF_WPE) k_zfactors(LikeDev L, const DevParams* params, const double* zt_all, const double* It_all,
                                                    int TcMax, int ranged) {
@@ -1433,7 +1469,7 @@ DEVFN void kde_marg_general(const LikeDev& L, const DevParams* params, const int
   const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
   const double zmin = es[0], norm = es[3], n_eff = es[4], lb = es[6], ub = es[7];
   const bool ok = n_eff >= L.pe_neff;                       // lax.cond(n_eff >= pe_neff, ...)   likelihood.py:199
-  const bool poisoned = grid_is_poisoned(P.z_bad, L.z_grids + (size_t)e * Z, Z);
+  const bool poisoned = event_poisoned(L, P, b, e, L.z_grids + (size_t)e * Z, Z);
   const double* zg = L.z_grids + (size_t)e * Z;
   const double* pc = L.p_cat + ((size_t)e * L.P + p) * Z;
 
@@ -2047,9 +2083,10 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   // pixel is beyond the support too (p_gw = 0 exactly: nothing to add to the integral; the rounding bound then sums |C_k| over [k_lo, here),
   // which still covers the support).  A NaN grid point or a NaN zhi keeps the loop going.  Not in the instantiation that stores p_gw.
   constexpr bool EXIT_EARLY = FAST && !DUMP && CHM_GW_PAIRS;
-  const double zhi_v = live ? zhi : -__builtin_inf();       // (a lane beyond k_hi holds the row's last pair: it may keep the loop going, which ends at k_hi anyway)
   auto do_pass = [&](const int k, const Pass& q) -> bool {
-    if (EXIT_EARLY && !wave_any(!(q.z.x > zhi_v))) return false;     // (ONE compare under the vote: a conjunction makes the compiler rebuild the mask through a VGPR)
+    // (a lane beyond k_hi holds the row's last pair and may keep the loop going, which ends at k_hi anyway.  Folding `live` into zhi -- ONE compare under
+    //  the vote instead of the mask rebuilt through a VGPR, two instructions fewer per pass -- costs two spilled registers at the 128-register cap.)
+    if (EXIT_EARLY && !wave_any(live && !(q.z.x > zhi))) return false;
     if (k <= k_hi && live) {
       const double z0 = q.z.x, z1 = q.z.y;
       const bool v1 = CHM_GW_PAIRS ? true : (k + SW <= k_hi);    // stride-1 lanes: the second point of the last pass may lie beyond the range
@@ -2131,7 +2168,7 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevPar
   if (IPW > 2) { c0 = so_[ppC]; c1 = so_[ppC + 1]; d0 = so_[ppD]; d1 = so_[ppD + 1]; }
   const int npx = L.neff_pixels[e];
   const double* zg = L.z_grids + (size_t)e * Z;
-  const bool poisoned = grid_is_poisoned(params[b].z_bad, zg, Z);
+  const bool poisoned = grid_is_poisoned(params[b].z_bad, zg, Z);      // (a call with an infinite rate parameter -- event_poisoned -- never takes this kernel)
   const size_t so = ((size_t)b * L.E + e) * L.S;
   const double* wz = L.ws_z + so;
   const double* ww = L.ws_w + so;
@@ -2292,7 +2329,7 @@ __global__ void __launch_bounds__(256) k_integrate_1d(LikeDev L, const DevParams
   const int Z = L.Z;
   const bool pixelated = L.mode != 0;
   const size_t zo = ((size_t)b * L.E + e) * Z;
-  const bool poisoned = grid_is_poisoned(P.z_bad, L.z_grids + (size_t)e * Z, Z);
+  const bool poisoned = event_poisoned(L, P, b, e, L.z_grids + (size_t)e * Z, Z);
   const double* g1 = L.pgw1d + zo;
   // p_gw1d vanishes outside [k_lo, k_hi] (found by k_kde1d): those terms of the trapezoid are exact zeros and are skipped;
   // inside, sum_k p_gw3d[k] p_z[k]/jac[k] tw[k] with the per-z factors folded into A[k] (see k_kde_marg)
@@ -2471,7 +2508,10 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
   NS = NS < 1 ? 1 : (NS > FULL_NSMAX ? FULL_NSMAX : NS);
   const int cpp = nt / NS;                                // chunks per pass
   double accl = 0.;
-  if (dump) for (int k = t; k < Z; k += nt) if (!ok || k < k_first || k > k_last) dump[k] = 0.;
+  // outside the mask the reference's row is kde_vals (zeros) * norm (likelihood.py:250-253): 0 * norm -- NaN for an event whose mean weight is NaN or
+  // inf (a NaN mass, prior or distance among its samples), from end to end; an event skipped by the n_eff guard keeps its zeros
+  const double zero_n = ok ? 0. * st.norm : 0.;
+  if (dump) for (int k = t; k < Z; k += nt) if (!ok || k < k_first || k > k_last) dump[k] = zero_n;
   const double inv_sumw = 1. / st.sumw;
   for (int cb = 0; cb < nch && ok; cb += cpp) {
     const int c = cb + t / NS, sl = t % NS;
@@ -2568,7 +2608,7 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
         { const double hq = chd[cl]; const int ii = h0 + i; if (hq >= 0.) v *= chm_exp(-hq * (double)(ii * ii)); }
         const double z = zg[k];
         const bool inm = (z <= zhi) && (z >= zlo);
-        double pgw = inm ? v * st.norm : 0.;              // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
+        double pgw = inm ? v * st.norm : zero_n;          // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
         if (dump) dump[k] = pgw;
         double pcv = pc[k];
         double y = 0.;
@@ -2584,7 +2624,8 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
     }
   }
   accl = block_reduce<RED_SUM>(accl, red);
-  if (t == 0) *out_like = grid_is_poisoned(P.z_bad, zg, Z) ? __builtin_nan("") : 0.5 * accl;   // NaN factors on the grid: 0 * NaN
+  // (+ zero_n: the grid points outside the mask enter the reference's trapezoid as 0 * norm * p_z / jac -- NaN when the event's mean weight is)
+  if (t == 0) *out_like = event_poisoned(L, P, b, e, zg, Z) ? __builtin_nan("") : 0.5 * accl + zero_n;   // NaN factors on the grid: 0 * NaN
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2735,14 +2776,15 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
   const double* zg = L.z_grids + (size_t)e * Z;
   const int k_first = (int)fe[FE_KFIRST], k_last = (int)fe[FE_KLAST];
   const int npt = k_last - k_first + 1;
+  const double zero_n = fe[FE_OK] != 0. ? 0. * fe[FE_NORM] : 0.;      // the reference's 0 * norm outside the mask (see k_full_kde)
   if (fe[FE_OK] == 0. || npt <= 0) {                       // nothing to integrate: the general kernel's answer for these, without it
-    if (t == 0) { *out_like = grid_is_poisoned(P.z_bad, zg, Z) ? __builtin_nan("") : 0.; *my_todo = 0; }
-    if (dump) for (int k = t; k < Z; k += nt) dump[k] = 0.;
+    if (t == 0) { *out_like = grid_is_poisoned(P.z_bad, zg, Z) ? __builtin_nan("") : zero_n; *my_todo = 0; }
+    if (dump) for (int k = t; k < Z; k += nt) dump[k] = zero_n;
     return;
   }
   if (fe[FE_CHAIN] == 0.) { if (t == 0) *my_todo = 1; return; }        // (k_full_kde writes the whole pixel, dump included)
   if (t == 0) *my_todo = 0;
-  if (dump) for (int k = t; k < Z; k += nt) if (k < k_first || k > k_last) dump[k] = 0.;
+  if (dump) for (int k = t; k < Z; k += nt) if (k < k_first || k > k_last) dump[k] = zero_n;
   const double rp = L.ra_pix[(size_t)e * L.P + p], dp = L.dec_pix[(size_t)e * L.P + p];
   const double q1 = rp * fe[FE_L11] + dp * fe[FE_L21], q2 = dp * fe[FE_L22], t_base = rp * fe[FE_L10] + dp * fe[FE_L20];      // whitened query (math.py:196)
   const size_t zo = ((size_t)b * L.E + e) * Z;
@@ -2903,7 +2945,7 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
     const double val = ((vw[0][r] + vw[1][r]) + (vw[2][r] + vw[3][r])) * fe[FE_CF + r % LK];
     const double z = zg[k];
     const bool inm = (z <= fe[FE_ZHI]) && (z >= fe[FE_ZLO]);
-    const double pgw = inm ? val * fe[FE_NORM] : 0.;       // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
+    const double pgw = inm ? val * fe[FE_NORM] : zero_n;   // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
     if (dump) dump[k] = pgw;
     const double pcv = pc[k];
     double y = 0.;
@@ -2916,7 +2958,7 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
     accl += y * ((z - zl) + (zr - z));                     // trapezoid: y_k enters the two adjacent intervals
   }
   accl = block_reduce<RED_SUM>(accl, red);
-  if (t == 0) *out_like = grid_is_poisoned(P.z_bad, zg, Z) ? __builtin_nan("") : 0.5 * accl;
+  if (t == 0) *out_like = grid_is_poisoned(P.z_bad, zg, Z) ? __builtin_nan("") : 0.5 * accl + zero_n;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2935,7 +2977,7 @@ struct SelDev {
 };
 
 // one injection: dN/dtheta_det / p_draw                                     pop_wrapper.py:102-111, selection_function.py:38
-template <class A1, class A2>
+template <bool SPECIAL = false, class A1, class A2>
 DEVFN double sel_term(const DevParams& P, double dl, double m1d, double m2d, double l1d, double l2d, double ipd, double z,
                       A1 mg, A2 cdf, const double* tpm, const double* trate, const double* tbkg, const double* tjac) {
 #pragma clang fp contract(fast)                  // smooth arithmetic only: a*b+c may fuse (the translation unit default is off)
@@ -2947,7 +2989,7 @@ DEVFN double sel_term(const DevParams& P, double dl, double m1d, double m2d, dou
   double Ez = own_cosmo ? E_at_z_l(P, z, lzp1) : 1.;
   double dCt = own_cosmo ? dL2dCt_l(P, dl, z, lzp1) : 0.;          // original distances: cosmo.py:191-192,215-216
   double p_z = tbkg ? *tbkg : dVcdz_from_dCt_E(P, dCt, Ez);        // gal_cat.p_bkg              pop_wrapper.py:106
-  p_z = p_z * ((trate ? *trate : merger_rate_l(P, z, lzp1)) / (1. + z));              //         pop_wrapper.py:107
+  p_z = p_z * ((trate ? *trate : ((SPECIAL && P.rate_special) ? merger_rate_special(P, z) : merger_rate_l(P, z, lzp1))) / (1. + z));      //         pop_wrapper.py:107
   double dN = P.R0 * (tpm ? *tpm : p_m1m2_fused(P, m1, m2, l1d - lzp1, l2d - lzp1, mg, cdf)) * p_z;   // pop_wrapper.py:108
   double jacobian = tjac ? *tjac : fabs(ddLdz_from_dCt_E(P, dCt, z, Ez, lzp1)) * (zp1 * zp1);      //           pop_wrapper.py:109
   dN = dN / jacobian;
@@ -2957,7 +2999,8 @@ DEVFN double sel_term(const DevParams& P, double dl, double m1d, double m2d, dou
 // Blocks of 256 threads stage the draw's tables in LDS once and walk over tiles of SEL_TILE injections (tile = blockIdx.x,
 // += gridDim.x); a thread takes two consecutive injections per pass (16 B loads, lock-step table searches).
 #define SEL_TILE 1024
-template <bool LDS_TAB>
+// SPECIAL: the instantiation chm_eval launches for a call that carries a draw with an infinite rate parameter (merger_rate_special)
+template <bool LDS_TAB, bool SPECIAL = false>
 __global__ void __launch_bounds__(256) k_selection(SelDev Sd, const DevParams* params, const double* zt_all, const double* It_all,
                                                     const double* dLt_all, const double* mg_all, const double* cdf_all,
                                                     int TcMax, int TmMax) {
@@ -2992,7 +3035,7 @@ __global__ void __launch_bounds__(256) k_selection(SelDev Sd, const DevParams* p
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const size_t ti = (size_t)b * (size_t)I + (size_t)(i + (two ? h : 0));      // plug-in models: (nb,I) tables of the caller
-        double dN = sel_term(P, dl[h], md1[h], md2[h], l1[h], l2[h], ipd[h], zz[h], T.mg, T.cdf, Sd.tab_pm ? Sd.tab_pm + ti : nullptr,
+        double dN = sel_term<SPECIAL>(P, dl[h], md1[h], md2[h], l1[h], l2[h], ipd[h], zz[h], T.mg, T.cdf, Sd.tab_pm ? Sd.tab_pm + ti : nullptr,
                              Sd.tab_rate ? Sd.tab_rate + ti : nullptr, Sd.tab_bkg ? Sd.tab_bkg + ti : nullptr, Sd.tab_jac ? Sd.tab_jac + ti : nullptr);
         if (h == 0 || two) {
           if (dN == dN) s1 += dN;                                    // nansum                     selection_function.py:39

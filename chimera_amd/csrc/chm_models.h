@@ -10,7 +10,8 @@
 #define CHM_PI 3.141592653589793238462643383279502884
 
 struct DevParams {
-  int cosmo_model, mass_model, rate_model, Tc, Tm, scale_free, has_catalog, pad0;
+  int cosmo_model, mass_model, rate_model, Tc, Tm, scale_free, has_catalog;
+  int rate_special;                      // 1: a rate parameter the model reads is infinite -- merger_rate takes the reference's own operations (pow_c99), see merger_rate_special
   double z_max;
   double H0, Om0, Ok0, Or0, w0, wa, Xi0, n_mg;
   double Ode0, dH;                       // cosmo.py:79-84
@@ -526,6 +527,36 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
 // ------------------------------------------------------------------------------------------------------
 // rate  (population/rate.py:96-122)
 // ------------------------------------------------------------------------------------------------------
+// pow() with the value classes of C99 / IEEE 754 (what jnp.power and NumPy's ** return for infinite or zero operands); ordinary arguments go
+// through exp(y log x) like every other power on the device
+DEVFN double pow_c99(double x, double y) {
+  const double inf = __builtin_inf(), nan = __builtin_nan("");
+  if (y == 0. || x == 1.) return 1.;
+  if (x != x || y != y) return nan;
+  const double ax = fabs(x);
+  if (fabs(y) == inf) return ax == 1. ? 1. : (((ax > 1.) == (y > 0.)) ? inf : 0.);
+  const bool yint = floor(y) == y, yodd = yint && fabs(y) < 9007199254740992. && (((long long)y) & 1ll);
+  if (ax == inf || ax == 0.) {
+    const bool big = (ax == inf) == (y > 0.), neg = __builtin_signbit(x) && yodd;
+    return big ? (neg ? -inf : inf) : (neg ? -0. : 0.);
+  }
+  if (x < 0.) { if (!yint) return nan; const double v = chm_exp(y * chm_log_pos(ax)); return yodd ? -v : v; }
+  return chm_exp(y * chm_log_pos(x));
+}
+// merger_rate (rate.py:96-122) for a draw with an infinite gamma, kappa or z_p, in the reference's own operations: two powers, one quotient, one
+// product -- NumPy / XLA reach a finite limit, 0, inf or NaN there (e.g. kappa = +inf: (1+z)^gamma below z_p, 0 above; gamma = +inf: inf / NaN),
+// where exp(y log x) on y log x = inf - inf or 0 * inf gives NaN throughout.  Kept OUT of the per-point / per-injection loops of the production kernels
+// (inlined there it cost k_zfactors 40 scalar spills and a private segment): a call with such a draw runs the whole-grid per-z factors, then
+// k_rate_special rewrites the draw's rate factors with this function and flags the events whose grid holds a non-finite one (event_poisoned), and
+// takes k_selection<., true> for the selection sums.
+DEVFN double merger_rate_special(const DevParams& p, double z) {
+  const double g = p.r[0], zp1 = 1. + z;
+  if (p.rate_model == 0) return pow_c99(zp1, g);
+  if (p.rate_model == 2) { const double pdf = pow_c99(zp1, g); return z < p.r[3] ? pdf / p.tpl_rate_norm : 0.; }
+  const double md = pow_c99(zp1, g) / (1. + pow_c99(zp1 / (1. + p.r[2]), g + p.r[1]));
+  const double v = p.md_norm * md;
+  return (p.rate_model == 1 || z < p.r[3]) ? v : 0.;
+}
 DEVFN double merger_rate_l(const DevParams& p, double z, double lzp1) {
   double g = p.r[0];
   if (p.rate_model == 0) return pow_l(lzp1, g);
@@ -539,7 +570,7 @@ DEVFN double merger_rate_l(const DevParams& p, double z, double lzp1) {
   if (p.rate_model == 1) return p.md_norm * md;
   return z < p.r[3] ? p.md_norm * md : 0.;
 }
-DEVFN double merger_rate(const DevParams& p, double z) { return merger_rate_l(p, z, chm_log(1. + z)); }
+DEVFN double merger_rate(const DevParams& p, double z) { return p.rate_special ? merger_rate_special(p, z) : merger_rate_l(p, z, chm_log(1. + z)); }
 // merger_rate_l as a quotient num/den (k_selection_fast folds den into its one division); the same value classes: a cut model is
 // 0 / den above its z cut, (1 + ...) overflowing to inf gives 0 as the division does.
 // (EX: the exp the powers go through -- ExpTab in the fast selection kernel: v_ldexp_f64 saturates where chm_exp tests its range)

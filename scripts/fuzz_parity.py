@@ -16,6 +16,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests import helpers as H                                 # noqa: E402
+from oracle import chimera_oracle as O                         # noqa: E402  (the checker: weights of the conditioning number)
 
 RTOL_L = 1e-9
 HOSTILE_SHARE = float(os.environ.get('FUZZ_HOSTILE', '0.15'))
@@ -141,7 +142,7 @@ def one(rng, many_events=False):
     if 'madau' in models['rate']:
       lam.update(kappa=float(rng.uniform(2., 5.)), zp=float(rng.uniform(1., 3.)))
   if rng.random() < EXTREME_SHARE:                             # hyper-parameters at the edges of what a sampler's prior box allows
-    k = int(rng.integers(0, 8))
+    k = int(rng.integers(0, 9))
     if k == 0: lam.update(H0=float(rng.choice([20., 200.])))
     elif k == 1: lam.update(Om0=float(rng.choice([0.01, 0.99])))
     elif k == 2: lam.update(gamma=float(rng.choice([-3., 0., 12.])))
@@ -150,6 +151,9 @@ def one(rng, many_events=False):
     elif k == 5 and models['mass'] == 'plp': lam.update(lambda_peak=float(rng.choice([0., 1.])), sigma_g=float(rng.choice([0.5, 15.])))
     elif k == 6 and models['mass'] != 'tpl': lam.update(delta_m=float(rng.choice([0.01, 0.5, 15.])))
     elif k == 7 and 'madau' in models['rate']: lam.update(kappa=float(rng.choice([0., 10.])), zp=float(rng.choice([0.1, 6.])))
+    elif k == 8:                                               # [r5] infinite rate parameters: value classes of C99 pow (rate.py:96-122; merger_rate_special)
+      names = ['gamma', 'kappa', 'zp'] if 'madau' in models['rate'] else ['gamma']
+      lam.update({str(rng.choice(names)): float(rng.choice([np.inf, -np.inf]))})
   desc = (f'HOSTILE(what={what}, event={e}) ' if hostile else '') + f"kind={kind} shape=({E},{S},{P},{Z}) like_kw={like_kw} models={models} pop_kw={pop_kw} N_eff={N_eff} lam={lam}"
   like_o, _, _ = H.build_oracle(ev, inj, pixelated=pixelated, kind=kind, models=models, like_kw=like_kw, pop_kw=pop_kw, N_eff=N_eff)
   like_p, _, sel_p = H.build_product(ev, inj, pixelated=pixelated, kind=kind, models=models, like_kw=like_kw, pop_kw=pop_kw, N_eff=N_eff)
@@ -162,13 +166,20 @@ def one(rng, many_events=False):
         return True, desc, ['oracle raised LinAlgError: skipped']
       rp = like_p.compute_all(**lam)
     if kind == 'full':
-      # full mode, an event whose weight sits on ONE sample (n_eff - 1 ~ 1e-12: a mass model many widths away from every sample, log L_i < -100):
-      # the covariance is divided by 1 - sum(W^2) (math.py:189), which amplifies the rounding of sum(W^2) by 1e12 in the reference as on the device --
-      # the two agree to ~1e-4 of log L_i there and no better
+      # full mode, an event whose weight sits on ONE sample (a mass model many widths away from every sample): the covariance is divided by
+      # 1 - sum(W^2) (math.py:189), which amplifies the rounding of sum(W^2) (1e-16) by 1 / (1 - sum W^2) in the reference as on the device.
+      # [r5] The events left out of the 1e-9 comparison are named by that CONDITIONING NUMBER, computed from the oracle's weights alone -- never
+      # by how far the two results lie apart: cond = 1 - sum(W^2) < 1e-10 (the two then agree to ~1e-16 / cond of the covariance and no better);
+      # their value class is still compared, and so is a loose bound on the value itself.
       ro0, rp0 = np.array(ro[0], dtype=np.float64), np.array(rp[0], dtype=np.float64)
-      ill = np.isfinite(ro0) & np.isfinite(rp0) & (ro0 < -100.) & (np.abs(rp0 - ro0) <= 1e-3 * np.abs(ro0))
-      rp0[ill] = ro0[ill]
-      H.assert_loglike_close(rp0, ro0, rtol=RTOL_L, atol=1e-9)
+      _, w_o = O.get_theta_src_and_weights(like_o.population.update(**lam), like_o.theta_gw_det)
+      W = np.asarray(w_o, dtype=np.float64) / np.sum(w_o, axis=-1, keepdims=True)
+      cond = 1. - np.sum(W * W, axis=-1)
+      ill = np.isfinite(cond) & (cond < 1e-10)
+      assert np.array_equal(H.neginf_class(rp0[ill]), H.neginf_class(ro0[ill])), 'value class of an ill-conditioned full-mode event'
+      both = ill & np.isfinite(ro0) & np.isfinite(rp0)
+      assert np.all(np.abs(rp0[both] - ro0[both]) <= 1e-2 * np.abs(ro0[both]) + 1e-2), f'ill-conditioned full-mode events (1 - sum W^2 = {cond[both]}): {rp0[both]} against {ro0[both]}'
+      H.assert_loglike_close(rp0[~ill], ro0[~ill], rtol=RTOL_L, atol=1e-9)
       if ill.any():
         ro = (ro[0], ro[1], ro[2], np.nan)                    # (the total carries the same difference: not compared)
     else:
@@ -191,7 +202,8 @@ def one(rng, many_events=False):
     for c in (many[0], many[9]):
       assert (a == c) or (np.isnan(a) and np.isnan(c)), f"scalar call {a!r} != draw of a ten-draw batch {c!r}"
     checks.append('scalar==batch10')
-    if CHECK_PGW:                                             # (4) the p_gw arrays of the API (hyperlikelihood.p_gw3d / p_gw1d) against the oracle's
+    if CHECK_PGW and what != 11:                              # (4) the p_gw arrays of the API (hyperlikelihood.p_gw3d / p_gw1d) against the oracle's
+      # (what = 11, every sample of an event at one distance: whether the spread is an exact 0 or 1e-16 hangs on the summation order -- see above)
       with np.errstate(all='ignore'):
         pop_o, pop_p = like_o.population.update(**lam), like_p.population.update(**lam)
         go = like_o.p_gw3d(pop_o) if pixelated else like_o.p_gw1d(pop_o)

@@ -20,6 +20,7 @@ def test_randomized_configurations_and_hostile_inputs(share, seed0, many):
   fused event kernel against the separate kernels.  (Round 4 ran 30 000 of them: profiles/r04/fuzz_parity.txt.)"""
   import fuzz_parity as F
   F.HOSTILE_SHARE = share
+  F.CHECK_PGW = True                                        # [r5] also the p_gw arrays of the API (p_gw3d / p_gw1d): NaN / 0 pattern and values against the oracle's
   bad = []
   for i in range(150 if not many else 60):                   # (many: every 4th configuration has 500+ small events -- the event-group path of ten-draw batches)
     ok, desc, _ = F.one(np.random.default_rng(77000 + seed0 + i), many_events=bool(many) and (seed0 + i) % many == many - 1)

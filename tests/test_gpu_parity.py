@@ -926,8 +926,7 @@ def test_nan_hyperparameters_behave_like_the_reference(cfg_pix, kind):
   """[r4] A NaN hyper-parameter (and an infinite cosmological or mass one) must come out as it does from the reference's arithmetic: NaN
   weights -> NaN sums -> L_i = NaN -> log L_i in the -inf class, log of the selection bias -inf, total NaN -- or, for a parameter the
   configured models never read, the unchanged finite answer.  The fast kernels drop NaNs in places (v_min / v_max clamps, saturating
-  conversions) and rely on the NaN having been caught elsewhere: this is the check that it is.  Not covered: INFINITE rate parameters
-  (gamma, kappa, zp = inf), where numpy's power / division reach a finite limit or -inf and the table-driven exponentials give NaN."""
+  conversions) and rely on the NaN having been caught elsewhere: this is the check that it is.  (Infinite rate parameters: the next test.)"""
   cfg, ev, inj = cfg_pix
   like_o, _, _ = H.build_oracle(ev, inj, kind=kind)
   like_p, _, _ = H.build_product(ev, inj, kind=kind)
@@ -945,6 +944,116 @@ def test_nan_hyperparameters_behave_like_the_reference(cfg_pix, kind):
       raise AssertionError(f'{name} = {bad}\n{err}')
     seen_nan += bool(np.isnan(ro[3]).all()); seen_finite += bool(np.isfinite(ro[3]).all())
   assert seen_nan >= 10 and seen_finite >= 2
+  like_p.close()
+
+
+@pytest.mark.parametrize('kind', [None, 'marginalized'])
+def test_a_sample_within_an_ulp_of_a_bin_edge_lands_in_one_of_the_two_neighbouring_bins(kind):
+  """[r5] The documented exception to the 1e-9 on L_i, pinned: binning1d takes idx = floor((z - lo)/(hi - lo) * B) (CHIMERA/utils/math.py:41), device
+  and oracle compute z to a few ulp of each other, so a sample whose quotient sits within an ulp of an integer may land in either of two neighbouring
+  bins -- and with few samples per bin that moves L_i by far more than 1e-9.  The distance of one sample is bisected (with the oracle's own arithmetic)
+  down to the two ADJACENT doubles d_a < d_b between which the oracle's bin index flips; the oracle's L_i at d_a and at d_b are the two admissible
+  answers (everything else moves by 1e-16).  The device must give one of them at either distance -- either neighbouring bin, nothing else."""
+  from oracle import chimera_oracle as O
+  pix = kind is not None
+  cfg, ev, inj = H.small_config(E=3, S=96, P=2, Z=64, I=1500, seed=31, ragged=False, pixelated=pix)
+  B, e, j = 17, 1, 40
+  like_kw = dict(num_bins=B, pe_neff=1.)
+  ev = dict(ev); ev['dL'] = np.array(ev['dL'], dtype=np.float64, copy=True)
+  if pix:                                                        # a sample in the middle of a well-filled pixel (not the pixel's largest z: that one defines the range)
+    ids = ev['pixels_pe_opt_nside'][e]
+    mine = np.flatnonzero(ids == ids[j])
+    assert len(mine) > 8
+    j = int(mine[np.argsort(ev['dL'][e, mine])[len(mine) // 2]])
+
+  def quotient(d):
+    """t = (z_j - lo)/(hi - lo) * B of sample j of event e at distance d: the oracle's operations (math.py:36-41 on the pixel's masked samples)"""
+    ev['dL'][e, j] = d
+    lo_, pop, _ = H.build_oracle(ev, inj, pixelated=pix, kind=kind, like_kw=like_kw)
+    th, w = O.get_theta_src_and_weights(pop.update(H0=70.) if hasattr(pop, 'update') else pop, lo_.theta_gw_det)
+    z = np.asarray(th.z[e])
+    if pix:
+      m = ev['pixels_pe_opt_nside'][e] == ev['pixels_pe_opt_nside'][e, j]
+      zm = np.where(m, z, z.min())                               # likelihood.py:180
+    else:
+      zm = z
+    lo, hi = zm.min(), zm.max()
+    return (z[j] - lo) / (hi - lo) * B
+
+  d0 = float(ev['dL'][e, j])
+  for f in (1.004, 1.008, 1.015, 1.03):                              # the narrowest bracket with a bin edge inside
+    a, b = d0 / f, d0 * f
+    ta, tb = quotient(a), quotient(b)
+    if np.floor(ta) < np.floor(tb):
+      break
+  assert np.floor(ta) < np.floor(tb) < B - 1 and ta > 1.             # an edge in between, the sample is neither the range's lower nor its upper end
+  edge = np.floor(ta) + 1.
+  while np.nextafter(a, np.inf) < b:                                 # bisection on the doubles: quotient(a) < edge <= quotient(b)
+    mid = 0.5 * (a + b)
+    if mid <= a or mid >= b:
+      break
+    if quotient(mid) < edge:
+      a = mid
+    else:
+      b = mid
+  assert np.nextafter(a, np.inf) == b and np.floor(quotient(a)) == edge - 1. and np.floor(quotient(b)) == edge
+  vals_o, vals_p = [], []
+  for d in (a, b):
+    ev['dL'][e, j] = d
+    lo_, _, _ = H.build_oracle(ev, inj, pixelated=pix, kind=kind, like_kw=like_kw)
+    lp_, _, sp_ = H.build_product(ev, inj, pixelated=pix, kind=kind, like_kw=like_kw)
+    vals_o.append(lo_.compute_all(H0=70.)[0]); vals_p.append(lp_.compute_all(H0=70.)[0])
+    lp_.close(); sp_.close()
+  oa, ob = vals_o[0][e], vals_o[1][e]
+  assert abs(oa - ob) > 1e-7 * abs(oa)                               # the flip is visible: 100x the stated tolerance
+  for vp in vals_p:
+    assert min(abs(vp[e] - oa), abs(vp[e] - ob)) <= 1e-9 * abs(oa), (vp[e], oa, ob)
+    for other in (0, 2):                                             # the other events do not notice
+      np.testing.assert_allclose(vp[other], vals_o[0][other], rtol=1e-9)
+
+
+@pytest.mark.parametrize('kind', ['marginalized', 'approximate', 'full', None])
+@pytest.mark.parametrize('rate', ['madau_dickinson', 'power_law', 'trunc_power_law', 'trunc_madau_dickinson'])
+def test_infinite_rate_parameters_behave_like_the_reference(kind, rate):
+  """[r5] gamma, kappa, z_p = +-inf (CHIMERA/population/rate.py:96-122 under NumPy / XLA: C99 pow, one quotient, one product): kappa = +inf and
+  z_p = +-inf leave a finite rate ((1+z)^gamma below z_p, 0 above; the plain power law), gamma = +inf an infinite one -- 0 * inf = NaN wherever
+  p_gw vanishes on an event grid, so every L_i is NaN (log L_i in the -inf class) and N_exp = inf --, gamma = -inf and kappa = -inf NaN throughout.
+  exp(y log x) on the device gives NaN for all of them; such a draw takes merger_rate_special and the kernels that report the poisoned grids.
+  Scalar and batched calls (a batch mixes ordinary and infinite draws: the whole call takes the general kernels) must agree."""
+  pixelated = kind is not None
+  cfg, ev, inj = H.small_config(E=6, S=256, P=4, Z=64, I=3000, seed=11, ragged=True, pixelated=pixelated)
+  models = dict(rate=rate)
+  like_o, _, _ = H.build_oracle(ev, inj, pixelated=pixelated, kind=kind, models=models)
+  like_p, _, _ = H.build_product(ev, inj, pixelated=pixelated, kind=kind, models=models)
+  names = ['gamma'] + (['kappa', 'zp'] if 'madau' in rate else [])
+  cases = [{n: v} for n in names for v in (np.inf, -np.inf)] + [{'H0': 68.}]
+  seen = set()
+  res_o = []
+  for lam in cases:
+    with np.errstate(all='ignore'):
+      ro, rp = like_o.compute_all(**lam), like_p.compute_all(**lam)
+    res_o.append(ro[3])
+    try:
+      H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
+      np.testing.assert_allclose(rp[1], ro[1], rtol=1e-10, atol=0, equal_nan=True)
+      np.testing.assert_allclose(rp[2], ro[2], rtol=1e-10, atol=0, equal_nan=True)
+      np.testing.assert_allclose(rp[3], ro[3], rtol=1e-10, atol=1e-8, equal_nan=True)
+    except AssertionError as err:
+      raise AssertionError(f'{rate} {kind} {lam}\n{err}')
+    seen.add('nan' if np.isnan(ro[3]) else ('finite' if np.isfinite(ro[3]) else 'inf'))
+  assert 'finite' in seen and ('nan' in seen or 'inf' in seen)
+  # one batch with ordinary and infinite draws side by side == the scalar calls
+  with np.errstate(all='ignore'):
+    got = like_p.batch(cases)
+  np.testing.assert_allclose(got, np.array(res_o), rtol=1e-10, atol=1e-8, equal_nan=True)
+  # the free function through chm_model_eval
+  import chimera_amd as CH
+  from oracle import chimera_oracle as O
+  z = np.array([0., 0.3, 1., 2., 4.63, 7.])
+  for lam in cases[:-1]:
+    rp_, ro_ = getattr(CH.rate, rate)(**lam), getattr(O, rate)(**lam)
+    with np.errstate(all='ignore'):
+      np.testing.assert_allclose(CH.rate.merger_rate(rp_, z), O.merger_rate(ro_, z), rtol=1e-13, equal_nan=True, err_msg=str(lam))
   like_p.close()
 
 
