@@ -33,6 +33,7 @@ same at the clock the chip held under the profile, and the real fp64 flops (FMA 
 library's differs, no fraction is printed.  The HBM view (unique bytes of the launch and PMC fabric traffic against 8 TB/s) is kept.
 """
 import argparse
+import ctypes as C_
 import glob
 import json
 import os
@@ -191,6 +192,40 @@ def kernel_roofline(label, prefix, ms, unique_bytes, pmc, units=None):
   return out
 
 
+def spawn_ranks(n):
+  """Launcher of last resort: n child processes `python3 bench.py <same arguments>` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+  set (one rank per GPU, the ranks meet over chimera_amd.parallel.Rendezvous as under torch.distributed.run).  Rank 0's stdout -- the JSON line --
+  is this process's.  No GPU call is made here (hipGetDeviceCount only).  Returns the exit status: non-zero when any rank failed, or when the
+  node shows fewer GPUs than ranks and the call does not ask for the host-socket rehearsal."""
+  import socket
+  import subprocess
+  from chimera_amd import _lib
+  ndev = _lib.lib().chm_device_count()
+  if ndev < n and '--host-comm' not in sys.argv:
+    print(f"bench.py: --gpus {n} but {ndev} HIP device(s) visible and no launcher environment (WORLD_SIZE): refusing to run fewer ranks under an "
+          f"{n}-GPU label (use --host-comm for a rehearsal on fewer GPUs)", file=sys.stderr)
+    return 2
+  with socket.socket() as sk:
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+  procs = []
+  for r in range(n):
+    env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                  stdout=None if r == 0 else subprocess.DEVNULL))
+  rc = 0
+  try:
+    for p_ in procs:
+      r_ = p_.wait()
+      rc = rc or r_
+  finally:
+    for p_ in procs:
+      if p_.poll() is None:
+        p_.kill()
+  return rc
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -214,6 +249,12 @@ def main():
   ap.add_argument('--cpu-events', type=int, default=1000, help='events of the workload the CPU baseline evaluates (1000 = all of C3)')
   ap.add_argument('--cpu-evals', type=int, default=20, help='timed CPU evaluations (median + IQR)')
   args = ap.parse_args()
+
+  # [r5] `python3 bench.py --gpus N` WITHOUT a torchrun-style launcher (no WORLD_SIZE in the environment): this process becomes the launcher --
+  # it starts the N ranks as child processes BEFORE anything touches a GPU and exits with their status; it never runs one rank under an N-GPU
+  # label (such a call used to print a line with n_gpus = 1 -- a driver launching it plainly would have recorded a flat curve)
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    raise SystemExit(spawn_ranks(args.gpus))
 
   # stdout must carry ONE JSON line: RCCL prints its version banner to fd 1 when it comes up, so fd 1 points at stderr for the
   # whole run and the JSON line goes to the saved descriptor
@@ -408,7 +449,18 @@ def main():
         ta = time.perf_counter()
         comm.allreduce_sum(x)
         ar.append(1e6 * (time.perf_counter() - ta))
+    # [r5] the PCI bus id of every rank's device: N distinct ids = N ranks on N GPUs (each rank fills its row of a (world, 32) table of character codes)
+    buf = C_.create_string_buffer(64)
+    _lib.check(L.chm_device_pci_bus_id(device, buf, 64))
+    tab_ids = np.zeros((world, 32))
+    code = np.frombuffer(buf.value[:32], dtype=np.uint8)
+    tab_ids[rank, :len(code)] = code
+    tab_ids = np.asarray(rdzv.allreduce_sum(tab_ids.ravel())).reshape(world, 32)
+    bus_ids = [bytes(int(v) for v in row if v > 0).decode() for row in tab_ids]
+    if not args.host_comm and len(set(bus_ids)) != world:
+      raise SystemExit(f"bench.py: {world} ranks on {len(set(bus_ids))} distinct GPUs ({bus_ids}): no line is printed")
     multi_info = {"collective": "host sockets (--host-comm rehearsal)" if args.host_comm else "RCCL", "ncclCommCount": nccl_count, "world": world,
+                  "pci_bus_ids": bus_ids, "distinct_gpus": len(set(bus_ids)),
                   "rank_ms_per_step": {"max": 1e3 * dt / max(args.steps, 1), "min": 1e3 * dt_min / max(args.steps, 1)},
                   "allreduce_us": {"median": float(np.median(ar[5:])), "calls": len(ar) - 5, "doubles": 3 * nb,
                                    "note": "host call to return, incl. H2D / D2H of the buffer: an upper bound on what the in-stream collective adds"} if len(ar) > 5 else None,

@@ -70,10 +70,10 @@ class chm_tab(C.Structure):
 SYMBOLS = ['chm_version', 'chm_device_count', 'chm_last_error', 'chm_like_create', 'chm_like_destroy',
            'chm_sel_create', 'chm_sel_destroy', 'chm_like_clone', 'chm_sel_clone', 'chm_eval', 'chm_eval_tabulated', 'chm_model_eval', 'chm_model_tables',
            'chm_comm_unique_id', 'chm_comm_init_rank', 'chm_comm_destroy', 'chm_comm_allreduce_sum', 'chm_comm_nranks',
-           'chm_device_synchronize',
+           'chm_device_synchronize', 'chm_device_pci_bus_id',
            'chm_last_timing', 'chm_like_full_general_pixels', 'chm_pcat_compute', 'chm_kde2d_pixels',
            'chm_kde1d', 'chm_binning1d', 'chm_gkde_nd', 'chm_gkde_nd_log', 'chm_trapz', 'chm_cumtrapz',
-           'chm_like_set_option', 'chm_sel_set_option', 'chm_diag_build', 'chm_comm_set_ticket', 'chm_comm_ticket_reset', 'chm_comm_ticket_skip']
+           'chm_like_set_option', 'chm_sel_set_option', 'chm_diag_build', 'chm_has_fused', 'chm_comm_set_ticket', 'chm_comm_ticket_reset', 'chm_comm_ticket_skip']
 
 # options of a handle (include/chimera_hip.h: CHM_OPT_*); ids >= 100 need a library built with -DCHM_DIAG
 OPTION = {'serial': 1, 'groups': 2, 'fused': 3, 'timing': 4, 'graph_max_nb': 5, 'spin_wait': 6,
@@ -127,9 +127,11 @@ def lib():
   L.chm_like_set_option.argtypes = [vp, i32, i64]
   L.chm_sel_set_option.argtypes = [vp, i32, i64]
   L.chm_diag_build.argtypes = []
+  L.chm_has_fused.argtypes = []
   L.chm_comm_set_ticket.argtypes = [vp, i64]
   L.chm_comm_ticket_reset.argtypes = [i64]
   L.chm_comm_ticket_skip.argtypes = [i64]
+  L.chm_device_pci_bus_id.argtypes = [i32, C.c_char_p, i32]
   for name in SYMBOLS:
     if name not in ('chm_version', 'chm_last_error'):
       getattr(L, name).restype = C.c_int

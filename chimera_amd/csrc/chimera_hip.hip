@@ -12,7 +12,12 @@
 
 #include "../../include/chimera_hip.h"
 #include "chm_kernels.h"
+// [r5] the fused per-(event, draw) kernel of round 4 (chm_fused.h: parity-green, 5.8x less fabric traffic, 40 % slower -- two waves per SIMD under 78.75 KB
+// of LDS per block, profiles/r04/ab_fused_event_kernel.txt) is NOT part of the release library: -DCHM_WITH_FUSED builds (scripts/build_variant.sh
+// fused -DCHM_WITH_FUSED; tests/test_zz_variant_builds.py) compile it and accept CHM_OPT_FUSED > 0
+#ifdef CHM_WITH_FUSED
 #include "chm_fused.h"
+#endif
 
 #define CHM_MAXP 1024
 static_assert(sizeof(chm_params) % 8 == 0, "chm_params layout");
@@ -82,7 +87,11 @@ static int opts_set(Opts& o, int32_t option, int64_t value) {
   switch (option) {
     case CHM_OPT_SERIAL: o.serial = v != 0; return CHM_OK;
     case CHM_OPT_GROUPS: if (v < 0 || v > CHM_MAX_GROUPS) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_GROUPS must be in [0, 128]"); o.groups = v; return CHM_OK;
-    case CHM_OPT_FUSED: if (v < 0 || v > 2) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_FUSED must be 0, 1 or 2"); o.fused = v; return CHM_OK;
+    case CHM_OPT_FUSED: if (v < 0 || v > 2) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_FUSED must be 0, 1 or 2");
+#ifndef CHM_WITH_FUSED
+      if (v != 0) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_FUSED > 0 -- this library was built without -DCHM_WITH_FUSED (the fused event kernel is a variant build)");
+#endif
+      o.fused = v; return CHM_OK;
     case CHM_OPT_TIMING: if (v < 0 || v > 2) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_TIMING must be 0, 1 or 2"); o.timing = v; return CHM_OK;
     case CHM_OPT_GRAPH_MAX_NB: if (v < 0) return fail(CHM_E_ARG, "chm_*_set_option: CHM_OPT_GRAPH_MAX_NB must be >= 0"); o.graph_max_nb = v; return CHM_OK;
     case CHM_OPT_SPIN_WAIT: o.spin_wait = v != 0; return CHM_OK;
@@ -113,6 +122,13 @@ static int opts_set(Opts& o, int32_t option, int64_t value) {
     return fail(CHM_E_ARG, "chm_*_set_option: diagnostic option -- this library was built without -DCHM_DIAG");
 #endif
   return fail(CHM_E_ARG, "chm_*_set_option: unknown option");
+}
+extern "C" int chm_has_fused(void) {
+#ifdef CHM_WITH_FUSED
+  return 1;
+#else
+  return 0;
+#endif
 }
 extern "C" int chm_diag_build(void) {
 #ifdef CHM_DIAG
@@ -330,7 +346,9 @@ struct chm_like {
   double zg_zmax = -1.; int zg_Tc = 0;
   // k_marg_fused (chm_fused.h): pixel of every sorted sample, largest distance of every pixel, plain-event flags (uploaded once, marginalized mode);
   // widest event in octaves of distance / in keys of the direct-index table (LDS reserved per block)
+#ifdef CHM_WITH_FUSED
   FusedDesc FD = {};
+#endif
   bool fused_ok = false;
   const unsigned char* d_ev_bad = nullptr;   // (E) 1 = an input that multiplies EVERY grid point of the event's integrand holds a NaN (p_cat of a live pixel, P_compl, gw_loc2d_pdf, z_grids):
                                              // the reference's trapz sums 0 * NaN = NaN also where p_gw is zero -> L_i = NaN for every draw; the kernels skip those points, the reductions apply the flag
@@ -505,6 +523,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
     rc = upload(*h->owned_sp, (const int*)perm_all.data(), E * S, &L.perm, s); if (rc) { chm_like_destroy(h); return rc; }
     // inputs of the fused event kernel (chm_fused.h): the local pixel of every sorted sample (255: none), the largest distance of every
     // pixel's samples, and which events hold only finite positive distances (their min / max z follow from the extreme distances)
+#ifdef CHM_WITH_FUSED
     if (P <= 64 && (S & 1) == 0) {
       const size_t NTl = (S + SF_TILE - 1) / SF_TILE;
       fused_pix.assign(E * NTl * SF_TILE, (unsigned char)255);
@@ -550,6 +569,7 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
       h->FD.redo_count = h->d_redo;
       h->fused_ok = true;
     }
+#endif
   } else {
     UP(dL, d->dL, S); UP(m1det, d->m1det, S); UP(m2det, d->m2det, S);
     tmp.resize(E * S);
@@ -698,7 +718,10 @@ extern "C" int chm_like_clone(const chm_like* src, chm_like** out) {
   L.krange = nullptr; L.tab_pm = L.tab_rate = L.tab_bkg = L.tab_jac = nullptr; L.zg_i = nullptr; L.zg_t = L.zg_lz = nullptr; L.ev_rbad = nullptr;
   h->F = src->F; h->fast_ok = src->fast_ok; h->dl_gmin = src->dl_gmin; h->dl_gmax = src->dl_gmax;
   h->neg_prior = src->neg_prior; h->d_ev_bad = src->d_ev_bad;
-  h->FD = src->FD; h->fused_ok = src->fused_ok; h->ev_oct_max = src->ev_oct_max; h->ev_nk_max = src->ev_nk_max; h->d_redo = src->d_redo;
+#ifdef CHM_WITH_FUSED
+  h->FD = src->FD;
+#endif
+  h->fused_ok = src->fused_ok; h->ev_oct_max = src->ev_oct_max; h->ev_nk_max = src->ev_nk_max; h->d_redo = src->d_redo;
   const size_t EZ = (size_t)L.E * L.Z;
   hipError_t e1 = hipMalloc(&h->d_zg_i, sizeof(int) * EZ), e2 = hipMalloc(&h->d_zg_t, sizeof(double) * EZ), e3 = hipMalloc(&h->d_zg_lz, sizeof(double) * EZ);
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { chm_like_destroy(h); return fail(CHM_E_NOMEM, "chm_like_clone: grid bracket arrays"); }
@@ -1015,7 +1038,11 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   // k_marg_fused (chm_fused.h): the standard marginalized configuration in ONE kernel per (event, draw) -- few-draw calls by default
   // (CHM_OPT_FUSED 1: few-draw calls, 2: calls of any size; default off).  LDS per block: P histograms of num_bins + 1 doubles, the overlay region
   // (the draw's mass tables + the widest event's slice of the distance tables + NW - 1 boundary rows | 4 NW prefix arrays) and ~2 KB.
+#ifdef CHM_WITH_FUSED
   FusedDesc FDc = {};
+#else
+  struct { int cap_rec = 0, cap_keys = 0, cap_m = 0; } FDc;      // (keeps the graph key's layout)
+#endif
   size_t lds_fused = 0;
   // 4 waves per block, two blocks per CU.  (16 waves per block -- one block per CU, 154 KB of LDS with all 32 pixels' prefix arrays at once, 128
   // VGPRs -- was measured for few-draw calls: 54 spilled registers, 0.294 against 0.219 ms per scalar call; profiles/r04/ab_fused_event_kernel.txt.
@@ -1026,6 +1053,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   const int fused_nw = 4;
 #endif
   bool use_fused = false;
+#ifdef CHM_WITH_FUSED
   {
     const int fmode = o.fused;                              // off by default: measured slower than the separate kernels at every call size (profiles/r04/ab_fused_event_kernel.txt)
     const int few_nb_f = o.few_nb;
@@ -1062,6 +1090,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       use_fused = lds_fused <= 160 * 1024;
     }
   }
+#endif
   // k_selection_fast: built-in models of an FLRW draw (cosmo_model 0), the same mass model for every draw; table slice capacity as above
   LutDesc lutB = {};
   bool sel_fast = sel && sel->fast_ok && !td.pm_i && !td.rate_i && !td.bkg_i && !td.jac_i && !td.zt && !o.selection_generic && !rate_special_call;
@@ -1070,7 +1099,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     int Tc_call = 0, Tm_call = 0;
     double zmax_min = INFINITY;
     for (int b = 0; b < nb; b++) {
-      if (params[b].mass_model != params[0].mass_model || params[b].cosmo_model != 0) sel_fast = false;
+      if (params[b].mass_model != params[0].mass_model || params[b].cosmo_model != params[0].cosmo_model) sel_fast = false;      // [r5] mg_flrw too (MG instantiation)
       Tc_call = params[b].z_grid_res > Tc_call ? params[b].z_grid_res : Tc_call;
       Tm_call = params[b].mass_grid_res > Tm_call ? params[b].mass_grid_res : Tm_call;
       zmax_min = params[b].z_max < zmax_min ? params[b].z_max : zmax_min;
@@ -1094,7 +1123,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   const int few_nb = o.few_nb;
   const bool fuse_env = !o.no_zf_sel;
   const size_t lds_zfac_call = sizeof(double) * (size_t)2 * c.TcMax;
-  const bool fuse_sel = fuse_env && !use_fused && !serial && like && sel && sel_fast && nb <= few_nb && !td.rate_g && !td.bkg_g && !td.jac_g &&
+  const bool fuse_sel = fuse_env && !use_fused && !serial && like && sel && sel_fast && params[0].cosmo_model == 0 && nb <= few_nb && !td.rate_g && !td.bkg_g && !td.jac_g &&
                         like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && !opt_marg_generic && !opt_zf_full &&
                         !(o.groups > 1) && lds_zfac_call <= 64 * 1024 && like->L.E <= 65535;
   const bool one_stream = serial || fuse_sel;
@@ -1126,7 +1155,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
             // [r5] k_znodes takes z_max by value and k_tables reads the cached nodes: a graph captured for one z_max must never be replayed
             // for another (a z_max scan with scalar calls: A, B, A replayed B's nodes under A's parameters) -- the bit pattern of z_max is part of the key;
             // so are the options of both handles (serial, groups, diagnostics: a replay would ignore a set_option made after the capture)
-            zmax_bits, like ? like->opts.epoch : -1, sel ? sel->opts.epoch : -1 };
+            zmax_bits, like ? like->opts.epoch : -1, sel ? sel->opts.epoch : -1, params[0].cosmo_model, rate_special_call };
     if (c.gexec && key == c.gkey) {                           // replay
       const double hp1 = host_prof_on() ? now_us() : 0.;
       HIPCHK(hipGraphLaunch(c.gexec, sA));
@@ -1224,6 +1253,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       L.e_off = eb; L.E_cnt = ee - eb; L.nb = nb;
       // per-z factors of the group's events: on the other lane, concurrently with the sample stage -- except in marginalized
       // mode, where they follow k_event_prep on the group's own lane and cover only the support of each event's KDE
+#ifdef CHM_WITH_FUSED
       if (use_fused) {                                      // the whole event side of the call in one kernel (chm_fused.h)
         SampFast Fq = like->F; Fq.lut = lutA;
         L.ev_publish = 1;
@@ -1245,6 +1275,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         ev_from_fixup = true;
         continue;
       }
+#endif
       const bool zf_ranged = (L.mode == CHM_MODE_MARG || L.mode == CHM_MODE_1D || L.mode == CHM_MODE_APPROX) && !opt_zf_full;
       // standard configuration (binning, cut_grid set) -> k_kde_marg_sub<32>, two pixels per wave (16 lanes per pixel measured
       // 30 % slower: 19 KB of LDS per wave halve the occupancy); anything else, or CHM_MARG_GENERIC=1, -> the general kernel
@@ -1392,8 +1423,9 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     S.tab_pm = td.pm_i; S.tab_rate = td.rate_i; S.tab_bkg = td.bkg_i; S.tab_jac = td.jac_i;
     if (timing_all) HIPCHK(hipEventRecord(c.evb[1], sC));
     if (sel_fast) {
-#define LAUNCH_SELF(M) do { allow_lds(k_selection_fast<M>, lds_sel); \
-        hipLaunchKernelGGL((k_selection_fast<M>), dim3(gx, nb), dim3(256), lds_sel, sC, S, lutB, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm); } while (0)
+#define LAUNCH_SELF_(M, G) do { allow_lds((k_selection_fast<M, G>), lds_sel); \
+        hipLaunchKernelGGL((k_selection_fast<M, G>), dim3(gx, nb), dim3(256), lds_sel, sC, S, lutB, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm); } while (0)
+#define LAUNCH_SELF(M) do { if (params[0].cosmo_model == 1) LAUNCH_SELF_(M, true); else LAUNCH_SELF_(M, false); } while (0)
       // every block stages the draw's table slice (tens of KB): ~8192 blocks in all, each walking over several tiles of injections
       const int self_blocks = (sel ? sel->opts.self_blocks : 8192) > 0 ? (sel ? sel->opts.self_blocks : 8192) : 8192;
       int gx = self_blocks / nb;
@@ -1401,6 +1433,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       const int mm = params[0].mass_model;
       if (mm == 0) LAUNCH_SELF(0); else if (mm == 1) LAUNCH_SELF(1); else LAUNCH_SELF(2);
 #undef LAUNCH_SELF
+#undef LAUNCH_SELF_
     } else if (rate_special_call) {                          // a draw with an infinite rate parameter: the reference's own operations for the rate (merger_rate_special)
       hipLaunchKernelGGL((k_selection<false, true>), dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
     } else if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
@@ -1837,6 +1870,15 @@ extern "C" int chm_comm_nranks(chm_comm* c) {
   int n = 0;
   if (ncclCommCount(c->comm, &n) != ncclSuccess) return 0;     // what RCCL itself says, not what the caller passed
   return n;
+}
+
+// PCI bus id of a device ("0000:c1:00.0"): an N-rank job records one per rank -- N distinct ids prove N ranks on N GPUs (bench.py: multi_gpu.pci_bus_ids)
+extern "C" int chm_device_pci_bus_id(int32_t device, char* out, int32_t len) {
+  if (!out || len < 16) return fail(CHM_E_ARG, "chm_device_pci_bus_id: need a buffer of at least 16 bytes");
+  int ndev = chm_device_count();
+  if (device < 0 || device >= ndev) return fail(CHM_E_HIP, "chm_device_pci_bus_id: no such HIP device");
+  HIPCHK(hipDeviceGetPCIBusId(out, len, device));
+  return CHM_OK;
 }
 
 extern "C" int chm_device_synchronize(int32_t device) {

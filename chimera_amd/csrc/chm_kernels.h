@@ -3061,8 +3061,11 @@ __global__ void __launch_bounds__(256) k_selection(SelDev Sd, const DevParams* p
 #ifndef CHM_SELF_MINW
 #define CHM_SELF_MINW 3
 #endif
+// [r5] MG (cosmo_model 1, modified GW propagation: cosmo.py:225-257): with q = (1+z)^-n (one table exp), Xi = Xi0 + (1 - Xi0) q,
+//   dCt = dL / Xi / (1+z),   |ddL_gw/dz| E = |Xi (dCt E + dH (1+z)) + dCt E n (Xi0 - 1) q|   (dL_flrw dXi/dz = dCt n (Xi0 - 1) q)
+// in place of X; everything else is the FLRW line.  BASELINE config 5 ran the general kernel (880 instructions per injection) before.
 // (body shared by k_selection_fast and k_zf_sel: block bx of nbx, draw b; red: 16 doubles of LDS)
-template <int MASS>
+template <int MASS, bool MG = false>
 DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevParams* params, const double* zt_all, const double* dLt_all,
                                const double* mg_all, const double* cdf_all, const double* rec_all, int TcMax, int TmMax,
                                const int b, const int bx, const int nbx, double* lds, double* red) {
@@ -3151,8 +3154,15 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
         if (wave_any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
         const double pm = p_m1m2_fused<MASS>(P, m1, m2, l1[h] - lz, l2[h] - lz, mg, cdf, ex);
         const double Ez = E_at_z_lr(P, z, zp1, r, lz);
-        const double dCt = dl[h] * r;                                    // original distances: cosmo.py:191-192,215-216
-        const double X = __builtin_fma(dCt, Ez, P.dH * zp1);
+        double dCt = dl[h] * r;                                          // original distances: cosmo.py:191-192,215-216
+        double X;
+        if (MG) {
+          const double q = ex.pw(lz, -P.n_mg);                           // (1+z)^-n
+          const double Xi = __builtin_fma(1. - P.Xi0, q, P.Xi0);         // cosmo.py:225-228
+          dCt = chm_div(dCt, Xi);                                        // cosmo.py:230-235
+          const double cE = dCt * Ez;
+          X = __builtin_fma(Xi, __builtin_fma(P.dH, zp1, cE), (cE * (P.n_mg * (P.Xi0 - 1.))) * q);      // cosmo.py:245-257, times E(z)
+        } else X = __builtin_fma(dCt, Ez, P.dH * zp1);
         double rnum, rden;
         merger_rate_nd(P, z, lz, rnum, rden, ex);
         const double num = ((c0 * pm) * (dCt * dCt)) * (rnum * ipd[h]);
@@ -3174,13 +3184,13 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
   }
 }
 
-template <int MASS>
+template <int MASS, bool MG = false>
 __global__ void __launch_bounds__(256, CHM_SELF_MINW) k_selection_fast(SelDev Sd, LutDesc lut, const DevParams* params, const double* zt_all,
                                                              const double* dLt_all, const double* mg_all, const double* cdf_all,
                                                              const double* rec_all, int TcMax, int TmMax) {
   extern __shared__ double lds[];
   __shared__ double red[16];
-  selection_fast_body<MASS>(Sd, lut, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.y, blockIdx.x, gridDim.x, lds, red);
+  selection_fast_body<MASS, MG>(Sd, lut, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.y, blockIdx.x, gridDim.x, lds, red);
 }
 
 // k_zf_sel<MASS>: the per-z factors (with the event statistics: zfactors_body<true, true>) and the selection sums in ONE launch -- blocks

@@ -273,6 +273,9 @@ int chm_comm_ticket_reset(int64_t next);
 int chm_comm_ticket_skip(int64_t ticket);
 /* hipDeviceSynchronize on `device`: the barrier bracket of a timed region (chm_eval itself returns after its stream drained). */
 int chm_device_synchronize(int32_t device);
+/* PCI bus id of `device` ("0000:c1:00.0", NUL-terminated; len >= 16): a sharded job (CHIMERA/parallel.py:94-99: one rank per chunk of events) records one per
+ * rank, so that its report shows N ranks on N distinct GPUs.                                                                                      */
+int chm_device_pci_bus_id(int32_t device, char* out, int32_t len);
 
 /* Timing of the last chm_eval on a handle, from HIP events recorded on the handle's own stream:
  * ms[0] = whole evaluation, ms[1] = tables, ms[2] = sample stage, ms[3] = KDE+integrand kernel,
@@ -291,7 +294,9 @@ int chm_like_full_general_pixels(chm_like* like, int32_t nb, int64_t* count);
  *   CHM_OPT_GROUPS        event groups alternating between two streams: 0 automatic (one per 250 events, at most 8, for calls of more than
  *                         8 draws), 1 one group, n <= 128
  *   CHM_OPT_FUSED         the fused event kernel (one block per (event, draw): samples, statistics, histograms, KDE, integrand; results equal
- *                         to the separate kernels' to rounding, ~1e-15 per event): 0 never (default), 1 calls of <= 8 draws, 2 every call
+ *                         to the separate kernels' to rounding, ~1e-15 per event): 0 never (default), 1 calls of <= 8 draws, 2 every call.
+ *                         [r5] A VARIANT build only (-DCHM_WITH_FUSED; chm_has_fused() tells): it is slower than the separate kernels at every
+ *                         call size measured (profiles/r04/ab_fused_event_kernel.txt), so the release library refuses values > 0
  *   CHM_OPT_TIMING        0 no timing events in the streams, 1 default, 2 per-kernel events also under a communicator / with event groups
  *   CHM_OPT_GRAPH_MAX_NB  calls of at most this many draws without per-event outputs are replayed from a HIP graph (default 8; 0: never)
  *   CHM_OPT_SPIN_WAIT     1 (default): calls of <= 8 draws poll their stream for completion instead of sleeping on an interrupt
@@ -309,6 +314,7 @@ enum {
 int chm_like_set_option(chm_like* like, int32_t option, int64_t value);
 int chm_sel_set_option(chm_sel* sel, int32_t option, int64_t value);
 int chm_diag_build(void);                                   /* 1: built with -DCHM_DIAG (diagnostic options, CHM_* environment defaults) */
+int chm_has_fused(void);                                    /* 1: built with -DCHM_WITH_FUSED (the fused event kernel; CHM_OPT_FUSED > 0 accepted) */
 
 #ifdef __cplusplus
 }

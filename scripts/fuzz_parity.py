@@ -22,7 +22,19 @@ RTOL_L = 1e-9
 HOSTILE_SHARE = float(os.environ.get('FUZZ_HOSTILE', '0.15'))
 EXTREME_SHARE = float(os.environ.get('FUZZ_EXTREME', '0.2'))
 CHECK_PGW = bool(int(os.environ.get('FUZZ_PGW', '0')))      # also compare the p_gw arrays of the API
+INF_RATE_SHARE = float(os.environ.get('FUZZ_INF_RATE', '0.03'))      # share of configurations with one infinite rate parameter
 MANY_EVERY = int(os.environ.get('FUZZ_MANY_EVERY', '0'))      # every n-th configuration: 500+ small events (the event-group path of ten-draw batches)
+
+
+def _has_fused():
+  from chimera_amd import _lib
+  try:
+    return bool(_lib.lib().chm_has_fused())
+  except Exception:                                          # noqa: BLE001 -- no library (CPU-side uses of the generator)
+    return False
+
+
+HAS_FUSED = _has_fused()
 
 
 def one(rng, many_events=False):
@@ -142,7 +154,7 @@ def one(rng, many_events=False):
     if 'madau' in models['rate']:
       lam.update(kappa=float(rng.uniform(2., 5.)), zp=float(rng.uniform(1., 3.)))
   if rng.random() < EXTREME_SHARE:                             # hyper-parameters at the edges of what a sampler's prior box allows
-    k = int(rng.integers(0, 9))
+    k = int(rng.integers(0, 8))
     if k == 0: lam.update(H0=float(rng.choice([20., 200.])))
     elif k == 1: lam.update(Om0=float(rng.choice([0.01, 0.99])))
     elif k == 2: lam.update(gamma=float(rng.choice([-3., 0., 12.])))
@@ -151,9 +163,11 @@ def one(rng, many_events=False):
     elif k == 5 and models['mass'] == 'plp': lam.update(lambda_peak=float(rng.choice([0., 1.])), sigma_g=float(rng.choice([0.5, 15.])))
     elif k == 6 and models['mass'] != 'tpl': lam.update(delta_m=float(rng.choice([0.01, 0.5, 15.])))
     elif k == 7 and 'madau' in models['rate']: lam.update(kappa=float(rng.choice([0., 10.])), zp=float(rng.choice([0.1, 6.])))
-    elif k == 8:                                               # [r5] infinite rate parameters: value classes of C99 pow (rate.py:96-122; merger_rate_special)
-      names = ['gamma', 'kappa', 'zp'] if 'madau' in models['rate'] else ['gamma']
-      lam.update({str(rng.choice(names)): float(rng.choice([np.inf, -np.inf]))})
+  # [r5] infinite rate parameters: value classes of C99 pow (rate.py:96-122; merger_rate_special).  Drawn LAST, so that the configurations of the
+  # seeds recorded in earlier rounds (tests/test_gpu_fuzz.py) stay what they were
+  if rng.random() < INF_RATE_SHARE:
+    names = ['gamma', 'kappa', 'zp'] if 'madau' in models['rate'] else ['gamma']
+    lam.update({str(rng.choice(names)): float(rng.choice([np.inf, -np.inf]))})
   desc = (f'HOSTILE(what={what}, event={e}) ' if hostile else '') + f"kind={kind} shape=({E},{S},{P},{Z}) like_kw={like_kw} models={models} pop_kw={pop_kw} N_eff={N_eff} lam={lam}"
   like_o, _, _ = H.build_oracle(ev, inj, pixelated=pixelated, kind=kind, models=models, like_kw=like_kw, pop_kw=pop_kw, N_eff=N_eff)
   like_p, _, sel_p = H.build_product(ev, inj, pixelated=pixelated, kind=kind, models=models, like_kw=like_kw, pop_kw=pop_kw, N_eff=N_eff)
@@ -167,19 +181,22 @@ def one(rng, many_events=False):
       rp = like_p.compute_all(**lam)
     if kind == 'full':
       # full mode, an event whose weight sits on ONE sample (a mass model many widths away from every sample): the covariance is divided by
-      # 1 - sum(W^2) (math.py:189), which amplifies the rounding of sum(W^2) (1e-16) by 1 / (1 - sum W^2) in the reference as on the device.
-      # [r5] The events left out of the 1e-9 comparison are named by that CONDITIONING NUMBER, computed from the oracle's weights alone -- never
-      # by how far the two results lie apart: cond = 1 - sum(W^2) < 1e-10 (the two then agree to ~1e-16 / cond of the covariance and no better);
-      # their value class is still compared, and so is a loose bound on the value itself.
+      # 1 - sum(W^2) (math.py:189), so the rounding of sum(W^2) -- ~10 eps, whatever the order of the sum -- enters the covariance, the quadratic form
+      # and with it log L_i (~ -d^2 / 2) amplified by 1 / (1 - sum W^2), in the reference as on the device.
+      # [r5] The tolerance of an event follows from that CONDITIONING NUMBER, computed from the oracle's weights alone -- never from how far the two
+      # results lie apart:  rtol_i = max(1e-9, 100 eps / cond_i),  cond_i = 1 - sum(W^2)  (1e-9 for every event with cond > 2e-5; an event whose
+      # weights are all zero has cond = NaN and keeps 1e-9).  The value classes are compared for every event.
       ro0, rp0 = np.array(ro[0], dtype=np.float64), np.array(rp[0], dtype=np.float64)
       _, w_o = O.get_theta_src_and_weights(like_o.population.update(**lam), like_o.theta_gw_det)
-      W = np.asarray(w_o, dtype=np.float64) / np.sum(w_o, axis=-1, keepdims=True)
-      cond = 1. - np.sum(W * W, axis=-1)
-      ill = np.isfinite(cond) & (cond < 1e-10)
-      assert np.array_equal(H.neginf_class(rp0[ill]), H.neginf_class(ro0[ill])), 'value class of an ill-conditioned full-mode event'
-      both = ill & np.isfinite(ro0) & np.isfinite(rp0)
-      assert np.all(np.abs(rp0[both] - ro0[both]) <= 1e-2 * np.abs(ro0[both]) + 1e-2), f'ill-conditioned full-mode events (1 - sum W^2 = {cond[both]}): {rp0[both]} against {ro0[both]}'
-      H.assert_loglike_close(rp0[~ill], ro0[~ill], rtol=RTOL_L, atol=1e-9)
+      with np.errstate(all='ignore'):
+        W = np.asarray(w_o, dtype=np.float64) / np.sum(w_o, axis=-1, keepdims=True)
+        cond = 1. - np.sum(W * W, axis=-1)
+      rtol_e = np.where(np.isfinite(cond) & (cond > 0.), np.maximum(RTOL_L, 100. * 2.220446049250313e-16 / np.where(cond > 0., cond, 1.)), RTOL_L)
+      ill = rtol_e > RTOL_L
+      assert np.array_equal(H.neginf_class(rp0), H.neginf_class(ro0)), f"-inf-class mismatch: got {rp0}, ref {ro0}"
+      fin = ~H.neginf_class(ro0)
+      bad_e = fin & ~(np.abs(rp0 - ro0) <= rtol_e * np.abs(ro0) + 1e-9)
+      assert not bad_e.any(), f"full mode: events {np.flatnonzero(bad_e)}: {rp0[bad_e]} against {ro0[bad_e]} (1 - sum W^2 = {cond[bad_e]}, rtol {rtol_e[bad_e]})"
       if ill.any():
         ro = (ro[0], ro[1], ro[2], np.nan)                    # (the total carries the same difference: not compared)
     else:
@@ -216,7 +233,7 @@ def one(rng, many_events=False):
       if fin.any():
         np.testing.assert_allclose(gp[fin], go[fin], rtol=1e-9, atol=1e-9 * np.max(np.abs(go[fin])))
       checks.append('p_gw')
-    if standard and P <= 64 and S % 2 == 0:
+    if standard and P <= 64 and S % 2 == 0 and HAS_FUSED:     # (a -DCHM_WITH_FUSED variant build: CHIMERA_LIB=.../libchimera_hip_fused.so)
       like_p.set_option('fused', 2)
       with np.errstate(all='ignore'):
         rf = like_p.compute_all(**lam)

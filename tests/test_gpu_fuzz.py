@@ -66,23 +66,6 @@ def test_negative_pe_prior_takes_the_dense_sums(kind, like_kw):
   lp.close(); sp.close()
 
 
-def test_fused_kernel_event_beyond_the_distance_table():
-  """[r4, found by the fuzz run] An event whose every distance lies beyond the last node of the draw's dL table (z clamps to z_max): the fused event
-  kernel's per-event slice of the node records began behind the record the clamp reads."""
-  cfg, ev, inj = H.small_config(E=3, S=1024, P=21, Z=58, I=1500, seed=12)
-  ev = dict(ev); ev['dL'] = ev['dL'].copy(); ev['dL'][0] *= 40.
-  lo, _, _ = H.build_oracle(ev, inj, like_kw=dict(cut_grid=2.0))
-  lp, _, sp = H.build_product(ev, inj, like_kw=dict(cut_grid=2.0))
-  with np.errstate(all='ignore'):
-    ro, rp = lo.compute_all(H0=60.2, Om0=0.22), lp.compute_all(H0=60.2, Om0=0.22)
-    lp.set_option('fused', 2)
-    rf = lp.compute_all(H0=60.2, Om0=0.22)
-  assert H.neginf_class(ro[0][0])
-  H.assert_loglike_close(rp[0], ro[0], rtol=1e-9, atol=1e-9)
-  H.assert_loglike_close(rf[0], rp[0], rtol=1e-12, atol=1e-12)
-  lp.close(); sp.close()
-
-
 @pytest.mark.parametrize('kind', ['marginalized', 'approximate', 'full'])
 @pytest.mark.parametrize('field', ['p_cat', 'z_grids'])
 def test_nan_in_the_catalogue_term_or_the_grid_of_an_event(kind, field):

@@ -1156,9 +1156,14 @@ def test_standard_marginalized_kernel_takes_the_dense_sum_where_the_prefix_diffe
   like_p, _, _ = H.build_product(ev, inj)
   rp = like_p.compute_all(H0=70.)
   H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
-  like_p.set_option('fused', 2)                              # the fused event kernel applies the same bound and redo (chm_fused.h)
-  rf = like_p.compute_all(H0=70.)
-  H.assert_loglike_close(rf[0], ro[0], rtol=RTOL_L, atol=1e-9)
+  from chimera_amd import _lib
+  if _lib.lib().chm_has_fused():                             # (-DCHM_WITH_FUSED variant: the fused event kernel applies the same bound and redo, chm_fused.h)
+    like_p.set_option('fused', 2)
+    rf = like_p.compute_all(H0=70.)
+    H.assert_loglike_close(rf[0], ro[0], rtol=RTOL_L, atol=1e-9)
+  else:
+    with pytest.raises(ValueError):                           # [r5] the release library carries no fused kernel
+      like_p.set_option('fused', 2)
   with pytest.raises(ValueError):                             # the release library refuses the diagnostic switch
     like_p.set_option('diag_no_dense_node', 1)
   like_p.close()
@@ -1227,6 +1232,24 @@ def test_vectorised_call_and_sampler_glue(cfg_pix):
     like(H0=np.array([60., 70.]), alpha=np.array([3., 3.1, 3.2]))
 
 
+def test_bench_starts_its_ranks_itself_without_a_launcher():
+  """[r5] `bench.py --gpus 2 --host-comm` with no WORLD_SIZE in the environment: the process becomes the launcher, two ranks come up as children
+  (here on ONE GPU, through the host sockets: a rehearsal, and the line says so), rank 0's JSON line is the process's stdout and carries n_gpus = 2,
+  the world size RCCL / the sockets saw and the PCI bus id of every rank's device."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+  p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--host-comm', '--events', '24', '--inj', '3000', '--nbatch', '12',
+                      '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-single-call'], cwd=root, env=env,
+                     stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+  assert p.returncode == 0, p.stderr[-1500:]
+  line = json.loads(p.stdout.strip().split('\n')[-1])
+  assert line['n_gpus'] == 2 and line['multi_gpu']['world'] == 2 and len(line['multi_gpu']['pci_bus_ids']) == 2
+  assert 'rehearsal' in line['multi_gpu']['collective'] and np.isfinite(line['value'])
+
+
 def test_last_timing_reports_the_stages_of_an_eager_call(cfg_pix):
   """bench.py's roofline block divides by these HIP-event durations: a batched (eager) call must report positive times for the whole
   evaluation, the sample stage, the GW kernel and the selection function; a graph-replayed scalar call carries no events (zeros)."""
@@ -1241,7 +1264,7 @@ def test_last_timing_reports_the_stages_of_an_eager_call(cfg_pix):
 
 
 @pytest.mark.parametrize('models', [dict(), dict(mass='bpl'), dict(mass='tpl', rate='power_law'), dict(cosmo='mg_flrw', cosmo_kw=dict(Xi0=1.6, n=2.1))],
-                         ids=['flrw-plp (k_selection_fast)', 'flrw-bpl', 'flrw-tpl-powerlaw', 'mg_flrw (k_selection)'])
+                         ids=['flrw-plp (k_selection_fast)', 'flrw-bpl', 'flrw-tpl-powerlaw', 'mg_flrw (k_selection_fast<., MG>)'])
 def test_selection_function_with_hostile_injections(cfg_pix, models):
   """Injections the direct-index front end cannot key (zero, negative, NaN, infinite distances), distances below and beyond the table,
   masses outside the population, an odd count (the last pair is half empty), duplicates: N_exp and the N_eff guard follow the
@@ -1260,7 +1283,7 @@ def test_selection_function_with_hostile_injections(cfg_pix, models):
     for N_eff in (None, 5.):
       _, pop_o, sel_o = H.build_oracle(ev, inj, models=models, N_eff=N_eff)
       like_p, pop_p, sel_p = H.build_product(ev, inj, models=models, N_eff=N_eff)
-      lams = [dict(H0=58.), dict(H0=70.), dict(H0=93., Om0=0.4)] + [dict(H0=60. + j) for j in range(9)]
+      lams = [dict(H0=58.), dict(H0=70.), dict(H0=93., Om0=0.4)] + [dict(H0=60. + j) for j in range(9)] + [dict(H0=66., Xi0=0.7, n=0.6), dict(Xi0=3.1, n=2.9)]      # (Xi0, n: read by mg_flrw only)
       with np.errstate(all='ignore'):
         ref = np.array([sel_o.N_exp(pop_o.update(**l)) for l in lams])
       one = np.array([sel_p.N_exp(pop_p.update(**l)) for l in lams])

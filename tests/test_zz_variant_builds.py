@@ -40,3 +40,17 @@ def test_k_tables_runs_with_a_private_segment_at_1024_threads():
   p = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'probe_tables_scratch.py')], cwd=ROOT, capture_output=True, text=True, timeout=600)
   assert p.returncode == 0, p.stdout + p.stderr
   assert 'ts512: rc 0' in p.stdout and 'ts1024: rc 0' in p.stdout, p.stdout
+
+
+def test_fused_event_kernel_variant_build():
+  """[r5] The fused per-(event, draw) kernel (chm_fused.h) left the release library -- it is parity-green and moves 5.8x fewer bytes, but is slower
+  than the separate kernels at every call size measured (profiles/r04/ab_fused_event_kernel.txt).  It stays buildable and tested: the
+  -DCHM_WITH_FUSED variant runs the round-4 tests of the kernel (tests/tools/fused_kernel_checks.py: against the oracle, against the separate kernels,
+  bit-reproducible, the exact route for hostile distances / unsorted tables) in a process of its own."""
+  lib = _build('fused', ['-DCHM_WITH_FUSED'])
+  env = dict(os.environ, CHIMERA_LIB=lib, CHIMERA_NO_REBUILD='1')
+  p = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests', 'tools', 'fused_kernel_checks.py'), '-q', '-m', 'gpu', '-x', '-p', 'no:cacheprovider'],
+                     cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+  assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1500:]
+  assert ' passed' in p.stdout and 'failed' not in p.stdout, p.stdout[-1500:]
+

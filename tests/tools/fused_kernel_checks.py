@@ -1,4 +1,6 @@
-"""GPU tests of the fused event kernel (chimera_amd/csrc/chm_fused.h, CHM_OPT_FUSED): samples -> statistics -> per-pixel histograms -> per-z
+"""[r5: NOT collected by the suite -- the fused kernel left the release library; tests/test_zz_variant_builds.py builds the -DCHM_WITH_FUSED variant
+and runs this file in a process of its own with CHIMERA_LIB pointing at it.]
+GPU tests of the fused event kernel (chimera_amd/csrc/chm_fused.h, CHM_OPT_FUSED): samples -> statistics -> per-pixel histograms -> per-z
 factors -> KDE + integrand of one (event, draw) in one block, z and w never leaving the CU.  It is off by default (slower than the separate
 kernels, profiles/r04/ab_fused_event_kernel.txt), so these tests switch it on: against the oracle to the stated tolerance (per-event log L_i
 rtol 1e-9, log_hyper atol 1e-7 sqrt(E)), against the separate kernels to rounding (the sums that carry no order in the reference -- a bin's
@@ -132,3 +134,20 @@ def test_fused_kernel_at_the_headline_shape_against_the_c_oracle():
     np.testing.assert_array_equal(many['log_like_evs'][i], rp[0])
     np.testing.assert_array_equal(many['log_like_evs'][i + 6], rp[0])
   like_p.close()
+
+
+def test_fused_kernel_event_beyond_the_distance_table():
+  """[r4, found by the fuzz run] An event whose every distance lies beyond the last node of the draw's dL table (z clamps to z_max): the fused event
+  kernel's per-event slice of the node records began behind the record the clamp reads."""
+  cfg, ev, inj = H.small_config(E=3, S=1024, P=21, Z=58, I=1500, seed=12)
+  ev = dict(ev); ev['dL'] = ev['dL'].copy(); ev['dL'][0] *= 40.
+  lo, _, _ = H.build_oracle(ev, inj, like_kw=dict(cut_grid=2.0))
+  lp, _, sp = H.build_product(ev, inj, like_kw=dict(cut_grid=2.0))
+  with np.errstate(all='ignore'):
+    ro, rp = lo.compute_all(H0=60.2, Om0=0.22), lp.compute_all(H0=60.2, Om0=0.22)
+    lp.set_option('fused', 2)
+    rf = lp.compute_all(H0=60.2, Om0=0.22)
+  assert H.neginf_class(ro[0][0])
+  H.assert_loglike_close(rp[0], ro[0], rtol=1e-9, atol=1e-9)
+  H.assert_loglike_close(rf[0], rp[0], rtol=1e-12, atol=1e-12)
+  lp.close(); sp.close()
