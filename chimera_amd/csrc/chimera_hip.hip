@@ -156,6 +156,8 @@ struct Ctx {
   double* d_partials = nullptr;        // (nb,3)
   double* d_out3 = nullptr;            // (nb,3)
   double* h_out = nullptr;             // pinned (nb,6)
+  long long* h_seq = nullptr;          // pinned (1 + nb): [0] the sequence number of the call (host -> device), [1 + b] draw b's completion flag (device -> host), see wait_flags
+  long long seq = 0;
   hipStream_t stream2 = nullptr;        // second lane of the event-group pipeline
   hipStream_t stream3 = nullptr;        // selection function
   hipEvent_t evg[4 * CHM_MAX_GROUPS] = {};              // per event-group timing: [4g+0..1] sample stage, [4g+2..3] GW kernel
@@ -192,7 +194,7 @@ static void ctx_free_tables(Ctx& c) {
   (void)hipFree(c.d_params); (void)hipHostFree(c.h_params);
   (void)hipFree(c.zt); (void)hipFree(c.It); (void)hipFree(c.dLt); (void)hipFree(c.mg); (void)hipFree(c.cdf); (void)hipFree(c.tmp); (void)hipFree(c.rec); c.rec = nullptr;
   (void)hipFree(c.zt_c); (void)hipFree(c.lz_c); c.zt_c = c.lz_c = nullptr; c.zc_zmax = -1.; c.zc_Tc = 0;
-  (void)hipFree(c.d_partials); (void)hipFree(c.d_out3); (void)hipHostFree(c.h_out); (void)hipFree(c.d_evpart);
+  (void)hipFree(c.d_partials); (void)hipFree(c.d_out3); (void)hipHostFree(c.h_out); (void)hipHostFree(c.h_seq); c.h_seq = nullptr; (void)hipFree(c.d_evpart);
   c.d_evpart = nullptr; c.evpart_cap = 0;
   c.d_params = nullptr; c.h_params = nullptr; c.zt = c.It = c.dLt = c.mg = c.cdf = c.tmp = nullptr;
   c.d_partials = c.d_out3 = nullptr; c.h_out = nullptr;
@@ -234,7 +236,9 @@ static int ctx_ensure(Ctx& c, int nb, int Tc, int Tm) {
   HIPCHK(hipMalloc(&c.lz_c, sizeof(double) * Tcn));
   HIPCHK(hipMalloc(&c.d_partials, sizeof(double) * nbn * 3));
   HIPCHK(hipMalloc(&c.d_out3, sizeof(double) * nbn * 3));
-  HIPCHK(hipHostMalloc(&c.h_out, sizeof(double) * nbn * 6));
+  HIPCHK(hipHostMalloc(&c.h_out, sizeof(double) * nbn * 6, hipHostMallocCoherent | hipHostMallocMapped));
+  HIPCHK(hipHostMalloc(&c.h_seq, sizeof(long long) * (nbn + 1), hipHostMallocCoherent | hipHostMallocMapped));
+  memset(c.h_seq, 0, sizeof(long long) * (nbn + 1));
   c.nb_cap = nbn; c.TcMax = Tcn; c.TmMax = Tmn;
   return CHM_OK;
 }
@@ -918,6 +922,24 @@ static hipError_t wait_stream(hipStream_t s, bool spin) {
   if (spin) { hipError_t e; while ((e = hipStreamQuery(s)) == hipErrorNotReady) {} return e; }
   return hipStreamSynchronize(s);
 }
+// [r5] Completion of a zero-copy few-draw call through the flags the last kernel stores behind the results (completion_flag, chm_kernels.h): the host spins on
+// pinned memory; every 4096 looks it asks the stream, so that a kernel that faulted (the flags never come) surfaces as an error instead of a hang
+static hipError_t wait_flags(const long long* h_seq, int nb, long long seq, hipStream_t s) {
+  const volatile long long* f = h_seq + 1;
+  for (unsigned it = 1;; it++) {
+    bool done = true;
+    for (int b = 0; b < nb; b++) if (f[b] != seq) { done = false; break; }
+    if (done) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return hipSuccess; }
+    if ((it & 0xFFFu) == 0u) {
+      hipError_t e = hipStreamQuery(s);
+      if (e == hipErrorNotReady) continue;
+      if (e != hipSuccess) return e;
+      for (int b = 0; b < nb; b++) if (f[b] != seq) return hipErrorUnknown;      // the stream drained and the flags are not there
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);
+      return hipSuccess;
+    }
+  }
+}
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static thread_local bool g_host_prof = false;               // (CHM_OPT_DIAG_HOST_PROF of the handle being evaluated)
 static bool host_prof_on() { return g_host_prof; }
@@ -1143,6 +1165,11 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   if (zc_use && !(params[0].z_max > 0.)) zc_use = false;
   if (zc_use && (c.zc_zmax != params[0].z_max || c.zc_Tc != params[0].z_grid_res)) zc_make = true;
   // ---- graph bookkeeping: the key lists everything the captured launch arguments depend on
+  // completion through the flags in pinned memory (wait_flags): zero-copy results, spinning wait, nothing copied back behind the last kernel
+#ifndef CHM_DONE_FLAGS
+#define CHM_DONE_FLAGS 1        // 0 (A/B builds): completion through hipStreamQuery as in round 4
+#endif
+  const bool use_flags = CHM_DONE_FLAGS && zero_copy && o.spin_wait != 0 && nb <= o.few_nb && !out->partials && !out->log_like_evs && !out->numlike_evs && !want_dump && !tab;
   std::vector<long long> key;
   bool capturing = false;
   long long zmax_bits = 0; { const double zm = params[0].z_max; memcpy(&zmax_bits, &zm, 8); }
@@ -1155,9 +1182,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
             // [r5] k_znodes takes z_max by value and k_tables reads the cached nodes: a graph captured for one z_max must never be replayed
             // for another (a z_max scan with scalar calls: A, B, A replayed B's nodes under A's parameters) -- the bit pattern of z_max is part of the key;
             // so are the options of both handles (serial, groups, diagnostics: a replay would ignore a set_option made after the capture)
-            zmax_bits, like ? like->opts.epoch : -1, sel ? sel->opts.epoch : -1, params[0].cosmo_model, rate_special_call };
+            zmax_bits, like ? like->opts.epoch : -1, sel ? sel->opts.epoch : -1, params[0].cosmo_model, rate_special_call, use_flags, (long long)(intptr_t)c.h_seq };
     if (c.gexec && key == c.gkey) {                           // replay
       const double hp1 = host_prof_on() ? now_us() : 0.;
+      if (use_flags) { c.h_seq[0] = ++c.seq; __atomic_thread_fence(__ATOMIC_RELEASE); }
       HIPCHK(hipGraphLaunch(c.gexec, sA));
       if (comm) {                                             // the graph ends at the rank's partials: all-reduce + combination behind it
         if (!turn.acquire()) return fail(CHM_E_RCCL, "chm_eval: the calls with lower tickets never enqueued their collectives (chm_comm_set_ticket; timeout)");
@@ -1165,11 +1193,13 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         turn.release();
         hipLaunchKernelGGL(k_combine, dim3((nb + 63) / 64), dim3(64), 0, sA, nb, (const DevParams*)c.d_params, (const double*)c.d_partials,
                            comm ? (double)E_total : (like ? (double)like->L.E : 0.), sel ? sel->S.N_inj : 1., sel ? sel->S.N_eff : 0.,
-                           sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, zero_copy ? c.h_out : c.d_out3);
+                           sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, zero_copy ? c.h_out : c.d_out3,
+                           (const long long*)c.h_seq, use_flags ? c.h_seq + 1 : (long long*)nullptr);
         HIPCHK(hipGetLastError());
         if (!zero_copy) HIPCHK(hipMemcpyAsync(c.h_out, c.d_out3, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
       }
       const double hp2 = host_prof_on() ? now_us() : 0.;
+      if (use_flags) HIPCHK(wait_flags(c.h_seq, nb, c.seq, sA)); else
       HIPCHK(wait_stream(sA, o.spin_wait != 0));
       if (host_prof_on()) { const double hp3 = now_us(); g_hp.pre.push_back(hp1 - hp0); g_hp.launch.push_back(hp2 - hp1); g_hp.sync.push_back(hp3 - hp2); }
       for (int b = 0; b < nb; b++) {
@@ -1188,6 +1218,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     } else c.gwarm = key;
   }
   const bool timing = timing_env && !capturing;
+  // (an eager call that carries timing events waits for its stream as before: chm_last_timing reads the events; the captured call is launched once at
+  //  the end of its capture and takes the flags, as every replay after it)
+  const bool flags_now = use_flags && !timing;
+  if (flags_now) { c.h_seq[0] = ++c.seq; __atomic_thread_fence(__ATOMIC_RELEASE); }
   // with a communicator (multi-GPU shards: short calls) only the whole evaluation and the GW kernel are timed: each event record
   // costs ~3 us of stream time (measured: 35 us per call for the full set); CHM_TIMING_ALL=1 keeps the full set (diagnosing a multi-GPU line)
   const bool timing_all_env = o.timing >= 2;
@@ -1294,8 +1328,14 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       const int zf_epb = zf_stats ? 4 / CHM_ZF_WPE_FEW : 4;       // ranged: events per block pass (a wave per event; CHM_ZF_WPE_FEW waves per event for few draws)
       const int zf_units = zf_mode ? (L.E_cnt + zf_epb - 1) / zf_epb : L.E_cnt;
       const int zf_blocks = zf_units < zf_target ? zf_units : zf_target;
+      // [r5] the selection blocks of a fused few-draw call ride in the SAMPLE-stage launch (k_samp_sel) when that is the fast sample kernel: the
+      // per-z-factor launch is then its own short self (k_zf_sel lasted as long as one selection block)
+#ifndef CHM_SAMP_SEL
+#define CHM_SAMP_SEL 1          // 0 (A/B builds): the round-4 placement, selection blocks in the per-z-factor launch (k_zf_sel)
+#endif
+      const bool sel_in_samples = CHM_SAMP_SEL && fuse_sel && use_fast && L.mode != CHM_MODE_FULL;
       auto launch_zfactors = [&]() {
-        if (fuse_sel) {                                     // + the selection sums: blocks [zf_blocks, zf_blocks + gx)
+        if (fuse_sel && !sel_in_samples) {                  // + the selection sums: blocks [zf_blocks, zf_blocks + gx)
           SelDev S = sel->S;
           int gx = 8192 / nb; gx = gx < 1 ? 1 : (gx > S.nblocks ? S.nblocks : gx);
           const size_t lds_f = lds_zfac > lds_sel ? lds_zfac : lds_sel;
@@ -1337,7 +1377,17 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       samp_blocks = samp_blocks < 1 ? 1 : (samp_blocks > 1024 ? 1024 : samp_blocks);
       dim3 g1(samp_blocks * nb, 1);
       const bool fullm = L.mode == CHM_MODE_FULL;
-      if (use_fast) {
+      if (sel_in_samples) {
+        SampFast F = like->F; F.lut = lutA;
+        SelDev Ss = sel->S;
+        int gx = 8192 / nb; gx = gx < 1 ? 1 : (gx > Ss.nblocks ? Ss.nblocks : gx);
+        const size_t lds_f = lds_fast > lds_sel ? lds_fast : lds_sel;
+#define LAUNCH_SS(M) do { allow_lds((k_samp_sel<M>), lds_f); \
+          hipLaunchKernelGGL((k_samp_sel<M>), dim3(g1.x + gx * nb), dim3(64 * CHM_SF_WAVES), lds_f, sg, L, F, Ss, lutB, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm, gx); } while (0)
+        const int mm = params[0].mass_model;
+        if (mm == 0) LAUNCH_SS(0); else if (mm == 1) LAUNCH_SS(1); else LAUNCH_SS(2);
+#undef LAUNCH_SS
+      } else if (use_fast) {
         SampFast F = like->F; F.lut = lutA;
 #define LAUNCH_FAST_(M, FU, NTL) do { allow_lds((k_samples_fast<M, FU, NTL>), lds_fast); \
           hipLaunchKernelGGL((k_samples_fast<M, FU, NTL>), g1, dim3(64 * CHM_SF_WAVES), lds_fast, sg, L, F, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm); } while (0)
@@ -1474,11 +1524,12 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
                        sel ? (const double*)sel->S.partial : nullptr, c.d_partials, dp, Etot, sel ? sel->S.N_inj : 1.,
                        sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, multi ? 0 : 1, out3, d_lle, d_nle,
                        ev_from_fixup ? (const double*)like->L.ev_li : nullptr, ev_from_fixup ? (const double*)like->L.ev_ll : nullptr,
-                       like ? like->d_ev_bad : (const unsigned char*)nullptr);
+                       like ? like->d_ev_bad : (const unsigned char*)nullptr, (const long long*)c.h_seq, (flags_now && !multi) ? c.h_seq + 1 : (long long*)nullptr);
   } else {
     hipLaunchKernelGGL(k_final, dim3(nb), dim3(256), 0, sA, nblk_ev, (const double*)c.d_evpart, sel ? sel->S.nblocks : 0,
                        sel ? (const double*)sel->S.partial : nullptr, c.d_partials, dp, Etot, sel ? sel->S.N_inj : 1.,
-                       sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, multi ? 0 : 1, out3);
+                       sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, multi ? 0 : 1, out3,
+                       (const long long*)c.h_seq, (flags_now && !multi) ? c.h_seq + 1 : (long long*)nullptr);
   }
   HIPCHK(hipGetLastError());
   if (out->partials) HIPCHK(hipMemcpyAsync(c.h_out + 3 * nb, c.d_partials, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
@@ -1499,7 +1550,8 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     NCCLCHK(ncclAllReduce(c.d_partials, c.d_partials, (size_t)nb * 3, ncclDouble, ncclSum, comm->comm, sA));
     turn.release();
     hipLaunchKernelGGL(k_combine, dim3((nb + 63) / 64), dim3(64), 0, sA, nb, dp, (const double*)c.d_partials, Etot,
-                       sel ? sel->S.N_inj : 1., sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, out3);
+                       sel ? sel->S.N_inj : 1., sel ? sel->S.N_eff : 0., sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, out3,
+                       (const long long*)c.h_seq, flags_now ? c.h_seq + 1 : (long long*)nullptr);
     HIPCHK(hipGetLastError());
   }
   if (!zero_copy) HIPCHK(hipMemcpyAsync(c.h_out, c.d_out3, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
@@ -1512,6 +1564,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     HIPCHK(hipMemcpyAsync(out->p_gw, src, sizeof(double) * nb * El * Pd * like->L.Z, hipMemcpyDeviceToHost, sA));
   }
   if (capturing) { rc = end_capture(); if (rc) return rc; }
+  if (flags_now) HIPCHK(wait_flags(c.h_seq, nb, c.seq, sA)); else
   HIPCHK(wait_stream(sA, o.spin_wait != 0 && nb <= few_nb));
   for (int b = 0; b < nb; b++) {
     if (out->log_hyper) out->log_hyper[b] = c.h_out[b * 3];

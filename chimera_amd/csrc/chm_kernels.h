@@ -770,12 +770,12 @@ static_assert(SAMPLE_WPB % CHM_SF_WAVES == 0, "records per chunk must be a multi
 #ifndef CHM_SF_NPV_PF
 #define CHM_SF_NPV_PF 0
 #endif
-template <int MASS, bool FULL, bool NT = false, bool PF = (CHM_SF_PREFETCH != 0) || (NT && CHM_SF_PREFETCH_NT != 0)>
-__global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast(LikeDev L, SampFast F, const DevParams* params, const double* zt_all,
-                                                                    const double* dLt_all, const double* mg_all, const double* cdf_all,
-                                                                    const double* rec_all, int TcMax, int TmMax) {
+// (body shared by k_samples_fast and k_samp_sel: block bx of nbx of draw b)
+template <int MASS, bool FULL, bool NT, bool PF>
+DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParams* params, const double* zt_all,
+                             const double* dLt_all, const double* mg_all, const double* cdf_all,
+                             const double* rec_all, int TcMax, int TmMax, const int b, const int bx, const int nbx, double* lds) {
 #pragma clang fp contract(fast)                  // sums of products may fuse; z comes from z_from_lut_x2 / jnp_interp (contract off) untouched
-  extern __shared__ double lds[];
 #ifndef CHM_SF_LOGS_INLINE
 #define CHM_SF_LOGS_INLINE 0      // measured (profiles/r03/ab_scalar_call_r03.txt): 66.6 against 59.8 us for the one-draw kernel with the logs formed here -- off
 #endif
@@ -785,7 +785,7 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
   if (NT && CHM_SF_STAGGER > 0 && (blockIdx.x & 1)) { for (int i = 0; i < CHM_SF_STAGGER; i++) __builtin_amdgcn_s_sleep(32); }
   constexpr bool LOGS_HERE = NT && (CHM_SF_LOGS_INLINE != 0);
   constexpr int NT_ = 64 * CHM_SF_WAVES;
-  const int b = blockIdx.x % L.nb, bx = blockIdx.x / L.nb, nbx = gridDim.x / L.nb, t = threadIdx.x, lane = t & 63;
+  const int t = threadIdx.x, lane = t & 63;
   DevParams P = params[b];            // by value: uniform loads at kernel start, nothing re-read in the loops
 #ifndef CHM_SF_NPV
 #define CHM_SF_NPV 4
@@ -957,6 +957,13 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
       }
     }
   }
+}
+template <int MASS, bool FULL, bool NT = false, bool PF = (CHM_SF_PREFETCH != 0) || (NT && CHM_SF_PREFETCH_NT != 0)>
+__global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast(LikeDev L, SampFast F, const DevParams* params, const double* zt_all,
+                                                                    const double* dLt_all, const double* mg_all, const double* cdf_all,
+                                                                    const double* rec_all, int TcMax, int TmMax) {
+  extern __shared__ double lds[];
+  samples_fast_body<MASS, FULL, NT, PF>(L, F, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.x % L.nb, blockIdx.x / L.nb, gridDim.x / L.nb, lds);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -3210,6 +3217,27 @@ __global__ void __launch_bounds__(256, CHM_SELF_MINW) k_zf_sel(LikeDev L, SelDev
   else selection_fast_body<MASS>(Sd, lut, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.y, blockIdx.x, sel_blocks, lds, red);
 }
 
+// [r5] k_samp_sel<MASS>: the sample stage of a few-draw call (k_samples_fast<MASS, false, true>) with the selection sums in the SAME launch -- the first
+// sel_blocks * nb blocks are selection blocks (dispatched first), the rest the sample stage's.  In round 3-4 the selection blocks rode in the
+// per-z-factor launch (k_zf_sel): that launch then lasted as long as ONE selection block (~14 us: a block stages its tables and walks 512 injections),
+// twice what the per-z factors need on their own; inside the 50 us sample stage they cost nothing.  The selection function depends on the
+// tables only, as the sample stage does.
+template <int MASS>
+__global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SELF_MINW) k_samp_sel(LikeDev L, SampFast F, SelDev Sd, LutDesc lutB, const DevParams* params,
+                                                                const double* zt_all, const double* dLt_all, const double* mg_all, const double* cdf_all,
+                                                                const double* rec_all, int TcMax, int TmMax, int sel_blocks) {
+  static_assert(CHM_SF_WAVES == 4, "the selection body reduces over blocks of 256 threads");
+  extern __shared__ double lds[];
+  __shared__ double red[16];
+  const int nsel = sel_blocks * L.nb;
+  if ((int)blockIdx.x < nsel) selection_fast_body<MASS>(Sd, lutB, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.x % L.nb, blockIdx.x / L.nb, sel_blocks, lds, red);
+  else {
+    const int i = (int)blockIdx.x - nsel;
+    samples_fast_body<MASS, false, true, (CHM_SF_PREFETCH_NT != 0)>(L, F, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, i % L.nb, i / L.nb,
+                                                                    ((int)gridDim.x - nsel) / L.nb, lds);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------------------
@@ -3253,6 +3281,14 @@ __global__ void __launch_bounds__(256) k_reduce_events(int E, int Pd, const doub
 }
 
 // N_exp with the N_eff guard (selection_function.py:38-47) and the final combination (likelihood.py:298-300, 313-316)
+// [r5] Completion of a few-draw call seen through MEMORY: the kernel that stores a draw's three results in pinned host memory (zero-copy) then
+// stores the call's sequence number -- which the host wrote into the same pinned block before the launch -- into the draw's flag, behind a
+// system-scope fence; the host spins on the flags instead of on hipStreamQuery (the end-of-kernel release, the completion signal of the graph and the
+// runtime's look at it are then off the call's critical path).
+DEVFN void completion_flag(long long* flag, long long seq) {
+  __threadfence_system();
+  __builtin_nontemporal_store(seq, flag);
+}
 DEVFN void combine_one(const DevParams& P, double log_num, double s1, double s2, double E_total, double N_inj, double N_eff,
                        int has_neff, int has_like, int has_sel, double* out) {
   double Nexp = __builtin_nan("");
@@ -3277,9 +3313,11 @@ DEVFN void combine_one(const DevParams& P, double log_num, double s1, double s2,
 // the final combination (single GPU); otherwise k_combine runs after the all-reduce.
 __global__ void __launch_bounds__(256) k_final(int nblk_ev, const double* ev_partial, int nblk_sel, const double* sel_partial,
                                                 double* partials /* (nb,3) */, const DevParams* params, double E_total, double N_inj,
-                                                double N_eff, int has_neff, int has_like, int has_sel, int do_combine, double* out3) {
+                                                double N_eff, int has_neff, int has_like, int has_sel, int do_combine, double* out3,
+                                                const long long* seq_in, long long* seq_out) {
   __shared__ double red[16];
   const int b = blockIdx.x, t = threadIdx.x;
+  const long long seq = (t == 0 && seq_out) ? __builtin_nontemporal_load(seq_in) : 0;      // (completion_flag: requested early, used at the end)
   double acc = 0., s1 = 0., s2 = 0.;
   for (int i = t; i < nblk_ev; i += blockDim.x) acc += ev_partial[(size_t)b * nblk_ev + i];
   for (int i = t; i < nblk_sel; i += blockDim.x) {
@@ -3292,6 +3330,7 @@ __global__ void __launch_bounds__(256) k_final(int nblk_ev, const double* ev_par
   if (t == 0) {
     partials[b * 3] = acc; partials[b * 3 + 1] = s1; partials[b * 3 + 2] = s2;
     if (do_combine) combine_one(params[b], acc, s1, s2, E_total, N_inj, N_eff, has_neff, has_like, has_sel, out3 + b * 3);
+    if (do_combine && seq_out) completion_flag(seq_out + b, seq);
   }
 }
 
@@ -3301,9 +3340,11 @@ __global__ void __launch_bounds__(1024) k_reduce_final(int E, int Pd, const doub
                                                         double* partials, const DevParams* params, double E_total, double N_inj,
                                                         double N_eff, int has_neff, int has_like, int has_sel, int do_combine,
                                                         double* out3, double* log_like_evs, double* numlike_evs,
-                                                        const double* ev_li, const double* ev_ll, const unsigned char* ev_bad) {
+                                                        const double* ev_li, const double* ev_ll, const unsigned char* ev_bad,
+                                                        const long long* seq_in, long long* seq_out) {
   __shared__ double red[16];
   const int b = blockIdx.x, t = threadIdx.x;
+  const long long seq = (t == 0 && seq_out) ? __builtin_nontemporal_load(seq_in) : 0;      // (completion_flag: requested early, used at the end)
   double acc = 0., s1 = 0., s2 = 0.;
   for (int e = t; e < E; e += blockDim.x) {
     double Li, ll;
@@ -3328,15 +3369,18 @@ __global__ void __launch_bounds__(1024) k_reduce_final(int E, int Pd, const doub
   if (t == 0) {
     partials[b * 3] = acc; partials[b * 3 + 1] = s1; partials[b * 3 + 2] = s2;
     if (do_combine) combine_one(params[b], acc, s1, s2, E_total, N_inj, N_eff, has_neff, has_like, has_sel, out3 + b * 3);
+    if (do_combine && seq_out) completion_flag(seq_out + b, seq);
   }
 }
 
 __global__ void k_combine(int nb, const DevParams* params, const double* partials, double E_total, double N_inj, double N_eff,
-                          int has_neff, int has_like, int has_sel, double* out3) {
+                          int has_neff, int has_like, int has_sel, double* out3, const long long* seq_in, long long* seq_out) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
+  const long long seq = seq_out ? __builtin_nontemporal_load(seq_in) : 0;
   combine_one(params[b], partials[b * 3], partials[b * 3 + 1], partials[b * 3 + 2], E_total, N_inj, N_eff, has_neff, has_like,
               has_sel, out3 + b * 3);
+  if (seq_out) completion_flag(seq_out + b, seq);
 }
 
 // ------------------------------------------------------------------------------------------------------

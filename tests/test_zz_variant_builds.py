@@ -20,7 +20,7 @@ def _build(name, flags):
 def test_diagnostic_build_compares_the_code_paths_the_release_library_does_not_expose():
   """-DCHM_DIAG: the general kernels against the production ones, the two full-mode kernels against each other, and the decades case WITHOUT
   the dense redo (wrong by > 1e-3: the case does exercise the limit of the prefix-sum form) -- tests/tools/diag_checks.py."""
-  lib = _build('diag', ['-DCHM_DIAG'])
+  lib = _build('diag', ['-DCHM_DIAG', '-DCHM_WITH_FUSED'])      # (with the fused event kernel: diag_checks.py compares it too)
   env = dict(os.environ, CHIMERA_LIB=lib, CHIMERA_NO_REBUILD='1')
   p = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'tools', 'diag_checks.py')], cwd=ROOT, env=env, capture_output=True, text=True,
                      timeout=900)
