@@ -1330,9 +1330,8 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       const int zf_blocks = zf_units < zf_target ? zf_units : zf_target;
       // [r5] the selection blocks of a fused few-draw call ride in the SAMPLE-stage launch (k_samp_sel) when that is the fast sample kernel: the
       // per-z-factor launch is then its own short self (k_zf_sel lasted as long as one selection block)
-#ifndef CHM_SAMP_SEL
-#define CHM_SAMP_SEL 1          // 0 (A/B builds): the round-4 placement, selection blocks in the per-z-factor launch (k_zf_sel)
-#endif
+      // (-DCHM_SAMP_SEL=1 builds, A/B: measured SLOWER -- profiles/r05/ab_scalar_call_r05.txt: the merged kernel needs 159 VGPRs, three waves per SIMD, and
+      //  the one-draw sample stage goes from 57 to 71 us, the scalar call from 0.168 to 0.182 ms -- the default keeps k_zf_sel)
       const bool sel_in_samples = CHM_SAMP_SEL && fuse_sel && use_fast && L.mode != CHM_MODE_FULL;
       auto launch_zfactors = [&]() {
         if (fuse_sel && !sel_in_samples) {                  // + the selection sums: blocks [zf_blocks, zf_blocks + gx)
@@ -1377,6 +1376,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       samp_blocks = samp_blocks < 1 ? 1 : (samp_blocks > 1024 ? 1024 : samp_blocks);
       dim3 g1(samp_blocks * nb, 1);
       const bool fullm = L.mode == CHM_MODE_FULL;
+#if CHM_SAMP_SEL
       if (sel_in_samples) {
         SampFast F = like->F; F.lut = lutA;
         SelDev Ss = sel->S;
@@ -1387,7 +1387,9 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         const int mm = params[0].mass_model;
         if (mm == 0) LAUNCH_SS(0); else if (mm == 1) LAUNCH_SS(1); else LAUNCH_SS(2);
 #undef LAUNCH_SS
-      } else if (use_fast) {
+      } else
+#endif
+      if (use_fast) {
         SampFast F = like->F; F.lut = lutA;
 #define LAUNCH_FAST_(M, FU, NTL) do { allow_lds((k_samples_fast<M, FU, NTL>), lds_fast); \
           hipLaunchKernelGGL((k_samples_fast<M, FU, NTL>), g1, dim3(64 * CHM_SF_WAVES), lds_fast, sg, L, F, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm); } while (0)

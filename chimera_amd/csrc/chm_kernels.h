@@ -3217,6 +3217,10 @@ __global__ void __launch_bounds__(256, CHM_SELF_MINW) k_zf_sel(LikeDev L, SelDev
   else selection_fast_body<MASS>(Sd, lut, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.y, blockIdx.x, sel_blocks, lds, red);
 }
 
+#ifndef CHM_SAMP_SEL
+#define CHM_SAMP_SEL 0          // 1 (A/B builds): the selection blocks of a fused few-draw call inside the sample-stage launch (k_samp_sel) -- measured slower, see chm_eval
+#endif
+#if CHM_SAMP_SEL
 // [r5] k_samp_sel<MASS>: the sample stage of a few-draw call (k_samples_fast<MASS, false, true>) with the selection sums in the SAME launch -- the first
 // sel_blocks * nb blocks are selection blocks (dispatched first), the rest the sample stage's.  In round 3-4 the selection blocks rode in the
 // per-z-factor launch (k_zf_sel): that launch then lasted as long as ONE selection block (~14 us: a block stages its tables and walks 512 injections),
@@ -3237,6 +3241,7 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SELF_MINW) k_samp_sel(L
                                                                     ((int)gridDim.x - nsel) / L.nb, lds);
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------------
 // reductions

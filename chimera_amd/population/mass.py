@@ -103,3 +103,19 @@ def p_m1m2(mass, m1, m2=None):
   if not hasattr(mass, '_pack'):                 # plug-in mass model (population/plugins.py): its own host function
     return np.asarray(mass.p_m1m2(np.asarray(m1, dtype=np.float64), np.asarray(m2, dtype=np.float64)), dtype=np.float64)
   return model_eval(make_params(mass=mass), _lib.F_PM1M2, m1, m2)
+
+
+def pdf_joint_and_marg(mass, res=(5000, 2500)):
+  """mass.py:351-362 (the reference's plotting helper): the joint pdf on a (res[1], res[0]) mesh of [m_low, m_high]^2 and its two marginals, each
+  normalised by its own trapezoid.  The joint pdf comes from the device (``chm_model_eval``: the arithmetic of the hot path's ``p_m1m2``), the four
+  trapezoids from ``utils.math.trapz`` (``chm_trapz``)."""
+  from ..utils.math import trapz
+  m1 = np.linspace(mass.m_low, mass.m_high, int(res[0]))
+  m2 = np.linspace(mass.m_low, mass.m_high, int(res[1]))
+  m1mesh, m2mesh = np.meshgrid(m1, m2)
+  p_joint = np.asarray(p_m1m2(mass, m1mesh, m2mesh)).reshape(m1mesh.shape)
+  p1_marg = trapz(p_joint, x=m2, axis=0)
+  p1_marg = p1_marg / trapz(p1_marg, x=m1)
+  p2_marg = trapz(p_joint, x=m1, axis=1)
+  p2_marg = p2_marg / trapz(p2_marg, x=m2)
+  return {'m1': m1, 'm2': m2, 'm1mesh': m1mesh, 'm2mesh': m2mesh, 'p_joint': p_joint, 'p_m1_marg': p1_marg, 'p_m2_marg': p2_marg}

@@ -378,6 +378,19 @@ def p_m1m2(mass, m1, m2):
   return p_m1 * p_m2m1
 
 
+def pdf_joint_and_marg(mass, res=(5000, 2500)):
+  """mass.py:351-362 (plotting helper on p_m1m2 + trapz)."""
+  m1 = jnp_linspace(mass.m_low, mass.m_high, res[0])
+  m2 = jnp_linspace(mass.m_low, mass.m_high, res[1])
+  m1mesh, m2mesh = np.meshgrid(m1, m2)
+  p_joint = p_m1m2(mass, m1mesh, m2mesh)
+  p1_marg = trapz(p_joint, m2[:, None] * np.ones_like(p_joint), axis=0)
+  p1_marg = p1_marg / trapz(p1_marg, m1)
+  p2_marg = trapz(p_joint, m1, axis=1)
+  p2_marg = p2_marg / trapz(p2_marg, m2)
+  return {'m1': m1, 'm2': m2, 'm1mesh': m1mesh, 'm2mesh': m2mesh, 'p_joint': p_joint, 'p_m1_marg': p1_marg, 'p_m2_marg': p2_marg}
+
+
 # ----------------------------------------------------------------------------------------------------------
 # models: rate  (CHIMERA/population/rate.py)
 # ----------------------------------------------------------------------------------------------------------

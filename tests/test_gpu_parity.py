@@ -1232,6 +1232,21 @@ def test_vectorised_call_and_sampler_glue(cfg_pix):
     like(H0=np.array([60., 70.]), alpha=np.array([3., 3.1, 3.2]))
 
 
+@pytest.mark.parametrize('mname', ['plp', 'bpl', 'tpl'])
+def test_pdf_joint_and_marg_matches_the_oracle(mname):
+  """[r5] CHIMERA/population/mass.py:351-362, the reference's plotting helper: joint pdf on a mesh of [m_low, m_high]^2 (chm_model_eval) and its two
+  trapezoid-normalised marginals (chm_trapz), against the oracle's restatement; each marginal integrates to 1."""
+  mp, mo = getattr(CH.mass, mname)(), getattr(O, mname)()
+  dp, do = CH.mass.pdf_joint_and_marg(mp, res=(600, 250)), O.pdf_joint_and_marg(mo, res=(600, 250))
+  assert dp['p_joint'].shape == (250, 600) and dp['m1mesh'].shape == (250, 600)
+  for k in ('m1', 'm2', 'm1mesh', 'm2mesh'):
+    np.testing.assert_allclose(dp[k], do[k], rtol=1e-15)
+  np.testing.assert_allclose(dp['p_joint'], do['p_joint'], rtol=1e-11, atol=1e-300)
+  for k, x in (('p_m1_marg', 'm1'), ('p_m2_marg', 'm2')):
+    np.testing.assert_allclose(dp[k], do[k], rtol=1e-11, atol=1e-300)
+    assert abs(np.trapezoid(dp[k], dp[x]) - 1.) < 1e-12
+
+
 def test_bench_starts_its_ranks_itself_without_a_launcher():
   """[r5] `bench.py --gpus 2 --host-comm` with no WORLD_SIZE in the environment: the process becomes the launcher, two ranks come up as children
   (here on ONE GPU, through the host sockets: a rehearsal, and the line says so), rank 0's JSON line is the process's stdout and carries n_gpus = 2,
