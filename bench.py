@@ -179,7 +179,10 @@ def kernel_roofline(label, prefix, ms, unique_bytes, pmc, units=None):
                   "fp64_frac_of_78.6_TFLOPs": flops * 64 / sec / 1e12 / FP64_PEAK_TFLOPS if flops else None})
       mi = next((v for kk, v in MIN_INST.items() if prefix.startswith(kk)), None)
       if mi and units:
-        out["min_inst"] = {"per_unit_minimal": mi[0], "unit": mi[1], "per_unit_achieved": insts / units, "achieved_over_minimal": insts / units / mi[0]}
+        # [r5] labelled for what it is: a paper count of the author's, not a measurement -- a diagnostic beside `frac`, not evidence
+        out["min_inst"] = {"per_unit_minimal_paper_estimate": mi[0], "unit": mi[1], "per_unit_achieved": insts / units,
+                           "achieved_over_paper_estimate": insts / units / mi[0],
+                           "note": "the minimum is an ESTIMATE made on paper (DESIGN section 4), not a measured microkernel"}
       if k.get('GRBM_GUI_ACTIVE') and k.get('profiled_ms'):
         clk = k['GRBM_GUI_ACTIVE'] / 8 / (k['profiled_ms'] * 1e-3)         # 8 XCDs count the launch's cycles
         out["clock_GHz_under_profile"] = clk / 1e9
@@ -560,7 +563,7 @@ def main():
                     "(PMC class counters of the committed passes of this command x 4 cycles, profiles/r03/issue_cost.txt) / (1024 SIMDs x 2.4 GHz x the "
                     "launch's LIVE HIP-event duration): what the kernel achieves.  issue_busy_frac prices EVERY VALU instruction at its measured issue "
                     "cost (4 cycles; a few simple 32-bit opcodes 2, fp64 rcp/sqrt 16) -- how full the issue ports are, moves and selects included; "
-                    "..._at_held_clock uses the clock under the profile.  min_inst: instructions per unit of work against the stated minimum.  "
+                    "..._at_held_clock uses the clock under the profile.  min_inst: instructions per unit of work against a PAPER ESTIMATE of the minimum (a diagnostic, not a measurement).  "
                     "fp64_TFLOPs_real counts FMA = 2, add / mul = 1 (PMC).  No fraction is printed when the PMC file was collected from another code "
                     "object than the one loaded.  hbm.* is the same launch against 8 TB/s: unique bytes (shared inputs once, per-draw arrays x nbatch) "
                     "and PMC fabric traffic; the call-level HBM fraction of the scalar call is single_call.hbm_frac",

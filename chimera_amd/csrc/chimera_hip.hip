@@ -1432,12 +1432,15 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         if (fast) {
           // several pixel groups (pairs of pixels) of the same (event, draw) per wave, one after the other: event statistics and segment
           // offsets once (four items per wave: 5.45 ms at C3 / 128 draws, two: 5.51, one: 5.66)
-          const int PG2 = (Pd + 1) / 2;
+          // [r5] CHM_GW_SW (build knob, A/B): lanes per pixel in the standard GW kernel -- 32 (two pixels per wave, the default) or 64 (one pixel per wave:
+          // 4.8 KB of LDS per wave, which lifts the cap of 16 waves per CU that 9.6 KB per wave set; profiles/r05/ab_gw_kernel_r05.txt)
+          constexpr int GW_SW = CHM_GW_SW, GW_NPW = 64 / GW_SW;
+          const int PG2 = (Pd + GW_NPW - 1) / GW_NPW;
           const int ipw_env = o.kde_ipw;                    // diagnostics: 2 or 4 items per wave
           // (few draws per call: two items per wave -- twice the waves, half the serial chain of each: 0.238 -> 0.229 ms for the scalar call at C3)
           const int ipw = ipw_env == 2 || ipw_env == 4 ? ipw_env : ((PG2 >= 4 && nb > 8) ? 4 : 2);
-          const size_t lds_sub = sizeof(double) * (3 * N + 3) * 2;
-#define LAUNCH_SUB2(I, BN, DU) hipLaunchKernelGGL((k_kde_marg_sub2<32, I, BN, DU>), dim3(nb, (PG2 + I - 1) / I, L.E_cnt), dim3(64), lds_sub, sg, L, dp)
+          const size_t lds_sub = sizeof(double) * (3 * N + 3) * GW_NPW;
+#define LAUNCH_SUB2(I, BN, DU) hipLaunchKernelGGL((k_kde_marg_sub2<GW_SW, I, BN, DU>), dim3(nb, (PG2 + I - 1) / I, L.E_cnt), dim3(64), lds_sub, sg, L, dp)
           if (L.p_gw_dump) { if (ipw == 4) LAUNCH_SUB2(4, 0, true); else LAUNCH_SUB2(2, 0, true); }    // p_gw3d requested (tests, hyperlikelihood.p_gw3d): the instantiation that stores it
           else if (L.num_bins == 200) { if (ipw == 4) LAUNCH_SUB2(4, 200, false); else LAUNCH_SUB2(2, 200, false); }      // the reference's default bin count (likelihood.py:59): compile-time
           else { if (ipw == 4) LAUNCH_SUB2(4, 0, false); else LAUNCH_SUB2(2, 0, false); }

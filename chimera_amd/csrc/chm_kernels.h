@@ -2153,8 +2153,14 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   }
 }
 
+#ifndef CHM_GW_SW
+#define CHM_GW_SW 32             // lanes per pixel of the standard GW kernel the host launches (64: one pixel per wave, A/B builds)
+#endif
+#ifndef CHM_GW_MINW64
+#define CHM_GW_MINW64 5          // waves per SIMD the one-pixel-per-wave instantiation is compiled for
+#endif
 template <int SW, int IPW, int BINS, bool DUMP>
-__global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevParams* params) {
+__global__ void __launch_bounds__(64, (SW == 64 ? CHM_GW_MINW64 : 4)) k_kde_marg_sub2(LikeDev L, const DevParams* params) {
   extern __shared__ double lds_all[];
   constexpr int NPW = 64 / SW;
   constexpr int NR = CHM_NRS / SW;
@@ -2225,7 +2231,11 @@ __global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevPar
     int t1 = 0, t2 = 0;
     if (CHM_GW_TOUCH) {
       const int ts = nq0 + sl * 16;
-      if (ts < nq1) { t1 = __builtin_nontemporal_load(reinterpret_cast<const int*>(wz + ts)); t2 = __builtin_nontemporal_load(reinterpret_cast<const int*>(ww + ts)); }
+      // (round 4 measured this with NON-TEMPORAL loads -- a streaming hint: the lines need not stay in L2 -- and lost 9 %; CHM_GW_TOUCH = 2 asks with plain loads)
+      if (ts < nq1) {
+        if (CHM_GW_TOUCH == 2) { t1 = *reinterpret_cast<const int*>(wz + ts); t2 = *reinterpret_cast<const int*>(ww + ts); }
+        else { t1 = __builtin_nontemporal_load(reinterpret_cast<const int*>(wz + ts)); t2 = __builtin_nontemporal_load(reinterpret_cast<const int*>(ww + ts)); }
+      }
     }
     kde_sub_item<SW, NR, BINS, DUMP, (IPW <= 2)>(L, params, Q, es, b, e, p, pp, live, poisoned, s0, s1, zr, wr, 0., nullptr, nullptr, nullptr, nit);
     if (CHM_GW_TOUCH) asm volatile("" :: "v"(t1), "v"(t2));

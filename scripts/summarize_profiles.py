@@ -104,7 +104,7 @@ def headline(rnd):
                'issue ports busy with ANY VALU instruction %.3f (%.3f at the %.2f GHz held); %.0f VALU instructions per %s against a stated minimum of %.0f (x %.2f); real fp64 %.1f of 78.6 TFLOP/s; '
                'HBM: unique bytes %.2f GB per launch = %.2f of 8 TB/s, PMC traffic %.2f GB = %.2f | `bench.json: roofline` |'
                % (r['bound'], r['kernel'], r['frac'] or 0., r['achieved'] or 0., r['peak'], r['issue_busy_frac'] or 0., r.get('issue_busy_frac_at_held_clock') or 0., dk.get('clock_GHz_under_profile') or 0.,
-                  mi.get('per_unit_achieved') or 0., mi.get('unit') or 'unit', mi.get('per_unit_minimal') or 0., mi.get('achieved_over_minimal') or 0.,
+                  mi.get('per_unit_achieved') or 0., mi.get('unit') or 'unit', (mi.get('per_unit_minimal_paper_estimate') or mi.get('per_unit_minimal') or 0.), (mi.get('achieved_over_paper_estimate') or mi.get('achieved_over_minimal') or 0.),
                   r['fp64_TFLOPs_real'] or 0., r['hbm']['unique_bytes_per_launch'] / 1e9, r['hbm']['frac'], (r['traffic'] or 0) / 1e9, r['hbm']['traffic_frac'] or 0.))
     if s.get('hbm_frac') is not None:
       out.append('| Scalar call against the HBM roofline (call level) | %.1f MB of algorithmic bytes in %.4f ms = %.2f TB/s = **%.3f of 8 TB/s** | `single_call.hbm_frac` |'
@@ -119,7 +119,7 @@ def headline(rnd):
       out.append('| `%s` | %.3f ms per launch; useful (fp64 add / mul / fma) %s; %.4g VALU instructions x %.2f cycles -> busy %.2f at 2.4 GHz, %.2f at the %.2f GHz held%s; real fp64 %.1f TFLOP/s; PMC traffic %.2f GB -> %.2f of 8 TB/s | `roofline.kernels` |'
                  % (k['kernel'], k['kernel_ms'], ('**%.3f**' % k['useful_frac']) if k.get('useful_frac') else '—', k['valu_inst_per_launch'], k['cycles_per_valu_inst'], k['valu_busy_frac'],
                     k.get('valu_busy_frac_at_held_clock') or 0., k.get('clock_GHz_under_profile') or 0.,
-                    ('; %.0f instructions per %s, minimum %.0f (x %.2f)' % (mi['per_unit_achieved'], mi['unit'], mi['per_unit_minimal'], mi['achieved_over_minimal'])) if mi else '',
+                    ('; %.0f instructions per %s, paper estimate of the minimum %.0f (x %.2f)' % (mi['per_unit_achieved'], mi['unit'], mi.get('per_unit_minimal_paper_estimate', mi.get('per_unit_minimal')), mi.get('achieved_over_paper_estimate', mi.get('achieved_over_minimal')))) if mi else '',
                     k.get('fp64_TFLOPs_real') or 0., (k.get('traffic_bytes_per_launch') or 0) / 1e9, k.get('hbm_traffic_frac') or 0.))
   if b1:
     for k in b1['roofline']['kernels']:
