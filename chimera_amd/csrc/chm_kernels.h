@@ -540,9 +540,12 @@ __device__ unsigned long long g_phase[8], g_phase_s[8];
 #define PHS_INIT unsigned long long ph_prev = clock64(); const bool ph_on = threadIdx.x == 0 && (blockIdx.x & 63) == 0; if (ph_on) atomicAdd(&g_phase_s[7], 1ull)
 #define PHS(i) do { __builtin_amdgcn_s_waitcnt(0); unsigned long long ph_t = clock64(); if (ph_on) atomicAdd(&g_phase_s[i], ph_t - ph_prev); ph_prev = clock64(); } while (0)
 #define PH(i) do { __builtin_amdgcn_s_waitcnt(0); unsigned long long ph_t = clock64(); if (ph_on) atomicAdd(&g_phase[i], ph_t - ph_prev); ph_prev = clock64(); } while (0)
+// [r5] phase marks of the standard GW kernel (scripts/phase_gw.py): the clock travels into kde_sub_item through two extra arguments
+#define PHG(i) do { if (ph_prev_p) { __builtin_amdgcn_s_waitcnt(0); unsigned long long ph_t = clock64(); if (ph_on_) atomicAdd(&g_phase[i], ph_t - *ph_prev_p); *ph_prev_p = clock64(); } } while (0)
 #else
 #define PH_INIT
 #define PH(i)
+#define PHG(i)
 #define PHS_INIT
 #define PHS(i)
 #endif
@@ -1747,6 +1750,9 @@ template <int SW> DEVFN double sg_max(double v) {
 #ifndef CHM_NRS
 #define CHM_NRS 256
 #endif
+#ifndef CHM_GW_PREF
+#define CHM_GW_PREF 0            // [r5] 1 (A/B builds): the next item's samples are loaded into the register rounds right after this item's histogram
+#endif
 #ifndef CHM_GW_DIET
 #define CHM_GW_DIET 1            // [r5] 0: the round-4 set-up of kde_sub_item (A/B builds, profiles/r05/ab_gw_setup_diet.txt)
 #endif
@@ -1834,7 +1840,8 @@ template <int SW> DEVFN double sg_allmax_swz(double x) {
 template <int SW, int NR, int BINS, bool DUMP, bool NT, bool PRE = false>
 DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, const double* es, const int b, const int e, const int p,
                         const int pp, const bool live, const bool poisoned, const int s0, const int s1, double (&zr)[NR], double (&wr)[NR],
-                        const double hi_pre = 0., double* Q12 = nullptr, double* out_like_pre = nullptr, double* out_err_pre = nullptr, const int nit = NR) {
+                        const double hi_pre = 0., double* Q12 = nullptr, double* out_like_pre = nullptr, double* out_err_pre = nullptr, const int nit = NR,
+                        unsigned long long* ph_prev_p = nullptr, const bool ph_on_ = false, const unsigned nxt_boff = 0u, const int nxt_nit = 0) {
 #pragma clang fp contract(fast)                  // a*b+c may fuse in this body; the bin index lives in bin_index_r() (contract off)
   // [r5] FAST (the production instantiations: compile-time bin count, histogram formed here): the set-up sheds what the compiler had wrapped
   // round its arithmetic -- see the notes at each step (profiles/r05/ab_gw_setup_diet.txt)
@@ -1892,6 +1899,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
     q.a = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(Aw) + off);
     return q;
   };
+  PHG(0);                                                   // (phase 0: the item's samples have arrived)
   // p_cat, grid, background and trapezoid factors of the first pass: in flight during the histogram phase
   const int k_first = k_lo + (CHM_GW_PAIRS ? 2 * sl : sl);
   Pass cur = load_pass(k_first);
@@ -1946,7 +1954,17 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
     }
     if (nit >= NR) for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q0[bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
     wave_sync();
+    // [r5] CHM_GW_PREF: the register rounds are dead from here on -- the NEXT item's samples are requested into them now and arrive under the prefix
+    // sums, the bandwidth and the grid loop of this item (a wave waited ~1.1 us per item for its samples: 14 % of its life, scripts/phase_gw.py)
+    if (FAST && CHM_GW_PREF && nxt_nit > 0) {
+#pragma unroll
+      for (int j = 0; j < NR; j++) if (j < nxt_nit) {
+        zr[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(wz) + (size_t)nxt_boff + (size_t)(8 * SW * j));
+        wr[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ww) + (size_t)nxt_boff + (size_t)(8 * SW * j));
+      }
+    }
   }
+  PHG(1);                                                   // (phase 1: max z, zeroing, histogram -- and the first pass's loads, waited for here by the mark)
   // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins (a compile-time 7 for 200 bins on 32 lanes)
   const int per = (B + SW - 1) / SW;
   const int j0 = FAST ? sl * per : (sl * per < B ? sl * per : B), j1 = min(j0 + per, B);     // FAST: unclamped -- the lanes beyond B read the zero padding
@@ -2012,6 +2030,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
     if (sl == 0) Q0[0] = 0.;
     wave_sync();
   }
+  PHG(2);                                                   // (phase 2: bin sums, four scans, prefix stores)
   // (quotients that feed smooth arithmetic only: reciprocal seed + two Newton steps instead of the IEEE division sequence)
   const double neff_k = chm_div(tot * tot, sum2);
   const double stdc = dhl * L.std_unit;
@@ -2130,6 +2149,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
     }
     return true;
   };
+  PHG(3);                                                   // (phase 3: bandwidth and the pixel's constants)
   // one pass = SW lanes x 2 consecutive grid points per pixel.  Software pipeline in two alternating register sets: the loads of the next
   // pass are issued before the arithmetic of this one and waited for where that pass begins (no register rotation, no wait at the loop end)
   for (int kb = k_lo; kb <= k_hi; kb += 4 * SW) {
@@ -2142,6 +2162,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   }
   // (same-address LDS atomics for these reductions -- ds_max_f64 / ds_add_f64 on one cell per pixel, no VALU slots -- were measured:
   //  5.53 instead of 4.43 ms for the kernel, the LDS pipe serialises the 32 lanes of every such instruction)
+  PHG(4);                                                   // (phase 4: the grid loop)
   if (FAST && CHM_GW_SWZ && SW <= 32) { acc = sg_allsum_swz<(SW <= 32 ? SW : 32)>(acc); accC = sg_allsum_swz<(SW <= 32 ? SW : 32)>(accC); }
   else {
     acc = sg_scan_add0<SW>(acc);                            // the group's last lane holds the pixel's integral
@@ -2151,6 +2172,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
     *out_like = poisoned ? nan : acc;
     *out_err = (degenerate || poisoned) ? 0. : errD * accC * fabs(scale * ng);     // NaN results stay NaN: nothing to redo
   }
+  PHG(5);                                                   // (phase 5: the two final scans and the stores)
 }
 
 #ifndef CHM_GW_SW
@@ -2186,12 +2208,31 @@ __global__ void __launch_bounds__(64, (SW == 64 ? CHM_GW_MINW64 : 4)) k_kde_marg
   const double* wz = L.ws_z + so;
   const double* ww = L.ws_w + so;
   const double lo = es[0];
+#ifdef CHM_PHASE_PROF
+  unsigned long long ph_clock = clock64();
+  const bool ph_on_k = threadIdx.x == 0 && (blockIdx.x & 63) == 0 && (blockIdx.z & 15) == 0;
+  if (ph_on_k) atomicAdd(&g_phase[7], 1ull);
+  unsigned long long* const ph_ptr = &ph_clock;
+#else
+  unsigned long long* const ph_ptr = nullptr; const bool ph_on_k = false;
+#endif
 #ifndef CHM_GW_TOUCH
 #define CHM_GW_TOUCH 0
 #endif
   // CHM_GW_TOUCH (A/B): while an item is worked on, one dword of every 128-byte line of the NEXT item's (z, w) segment is requested and dropped --
   // the lines are then in L2 when the next item's loads ask for them (the segment was written by the sample stage milliseconds ago: an HBM round trip)
-  auto run = [&](const int pgi, const int p, const int pp, const int q0, const int q1, const bool first, const int nq0 = 0, const int nq1 = 0) {
+  double zr[NR], wr[NR];                                     // the register rounds of the item at work (CHM_GW_PREF: then of the next one)
+  bool have = false;                                        // (uniform) zr / wr already hold this item's samples
+  auto nit_of = [&](const int p, const int q0, const int q1) {   // rounds of SW samples the wave's pixels of an item need (uniform); 0: no live pixel
+    const bool lv = p < L.P && p < npx;
+    if (!wave_any(lv)) return 0;
+    const int len = lv ? q1 - q0 : 0;
+    int nmax = 0;
+#pragma unroll
+    for (int g = 0; g < NPW; g++) nmax = max(nmax, __builtin_amdgcn_readlane(len, g * SW));
+    return max(1, min((nmax + SW - 1) / SW, NR));
+  };
+  auto run = [&](const int pgi, const int p, const int pp, const int q0, const int q1, const bool first, const int nq0 = 0, const int nq1 = 0, const int np = 0, const int npgi = 1 << 30) {
     if (pgi >= PG) return;                                  // uniform
     const bool live = p < L.P && p < npx;
     if (!ok || !wave_any(live)) {                              // uniform: every pixel of the event (of this item: padded pixels) is 0 (or 0 * NaN)
@@ -2213,8 +2254,11 @@ __global__ void __launch_bounds__(64, (SW == 64 ? CHM_GW_MINW64 : 4)) k_kde_marg
 #else
     const int nit = min((nmax + SW - 1) / SW, NR);
 #endif
-    double zr[NR], wr[NR];
-    if (BINS > 0 && CHM_GW_DIET) {
+    // CHM_GW_PREF: what kde_sub_item is to request for the item after this one (none: the last item, an item without a live pixel)
+    const int nxt_nit = (CHM_GW_PREF && BINS > 0 && CHM_GW_DIET && npgi < PG) ? nit_of(np, nq0, nq1) : 0;
+    const unsigned nxt_boff = (unsigned)(nq0 + sl) * 8u;
+    if (have) { /* prefetched by the previous item */ }
+    else if (BINS > 0 && CHM_GW_DIET) {
       // [r5] unconditional loads at ONE 32-bit lane offset + an immediate per round (uniform row base in scalar registers): what stands behind the
       // pixel's segment is the next pixel's samples or the CHM_WS_PAD doubles behind the workspace, and kde_sub_item uses round i only where
       // SW i < s1 - (s0 + sl).  Before: per round a compare, two 64-bit address computations and two moves of the neutral values.
@@ -2237,12 +2281,13 @@ __global__ void __launch_bounds__(64, (SW == 64 ? CHM_GW_MINW64 : 4)) k_kde_marg
         else { t1 = __builtin_nontemporal_load(reinterpret_cast<const int*>(wz + ts)); t2 = __builtin_nontemporal_load(reinterpret_cast<const int*>(ww + ts)); }
       }
     }
-    kde_sub_item<SW, NR, BINS, DUMP, (IPW <= 2)>(L, params, Q, es, b, e, p, pp, live, poisoned, s0, s1, zr, wr, 0., nullptr, nullptr, nullptr, nit);
+    kde_sub_item<SW, NR, BINS, DUMP, (IPW <= 2)>(L, params, Q, es, b, e, p, pp, live, poisoned, s0, s1, zr, wr, 0., nullptr, nullptr, nullptr, nit, ph_ptr, ph_on_k, nxt_boff, nxt_nit);
+    have = nxt_nit > 0;
     if (CHM_GW_TOUCH) asm volatile("" :: "v"(t1), "v"(t2));
   };
-  run(blockIdx.y, pA, ppA, a0, a1, true, b0, b1);
-  run(blockIdx.y + H, pB, ppB, b0, b1, false, c0, c1);
-  if (IPW > 2) { run(blockIdx.y + 2 * H, pC, ppC, c0, c1, false, d0, d1); run(blockIdx.y + 3 * H, pD, ppD, d0, d1, false); }
+  run(blockIdx.y, pA, ppA, a0, a1, true, b0, b1, pB, blockIdx.y + H);
+  run(blockIdx.y + H, pB, ppB, b0, b1, false, c0, c1, pC, IPW > 2 ? blockIdx.y + 2 * H : (1 << 30));
+  if (IPW > 2) { run(blockIdx.y + 2 * H, pC, ppC, c0, c1, false, d0, d1, pD, blockIdx.y + 3 * H); run(blockIdx.y + 3 * H, pD, ppD, d0, d1, false); }
 }
 
 // ------------------------------------------------------------------------------------------------------
