@@ -2221,7 +2221,9 @@ __global__ void __launch_bounds__(64, (SW == 64 ? CHM_GW_MINW64 : 4)) k_kde_marg
 #endif
   // CHM_GW_TOUCH (A/B): while an item is worked on, one dword of every 128-byte line of the NEXT item's (z, w) segment is requested and dropped --
   // the lines are then in L2 when the next item's loads ask for them (the segment was written by the sample stage milliseconds ago: an HBM round trip)
-  double zr[NR], wr[NR];                                     // the register rounds of the item at work (CHM_GW_PREF: then of the next one)
+#if CHM_GW_PREF
+  double zr[NR], wr[NR];                                     // the register rounds of the item at work, then of the next one (they outlive the item)
+#endif
   bool have = false;                                        // (uniform) zr / wr already hold this item's samples
   auto nit_of = [&](const int p, const int q0, const int q1) {   // rounds of SW samples the wave's pixels of an item need (uniform); 0: no live pixel
     const bool lv = p < L.P && p < npx;
@@ -2257,6 +2259,9 @@ __global__ void __launch_bounds__(64, (SW == 64 ? CHM_GW_MINW64 : 4)) k_kde_marg
     // CHM_GW_PREF: what kde_sub_item is to request for the item after this one (none: the last item, an item without a live pixel)
     const int nxt_nit = (CHM_GW_PREF && BINS > 0 && CHM_GW_DIET && npgi < PG) ? nit_of(np, nq0, nq1) : 0;
     const unsigned nxt_boff = (unsigned)(nq0 + sl) * 8u;
+#if !CHM_GW_PREF
+    double zr[NR], wr[NR];                                   // the register rounds of this item: dead after its histogram (the default: see CHM_GW_PREF)
+#endif
     if (have) { /* prefetched by the previous item */ }
     else if (BINS > 0 && CHM_GW_DIET) {
       // [r5] unconditional loads at ONE 32-bit lane offset + an immediate per round (uniform row base in scalar registers): what stands behind the
