@@ -1232,6 +1232,35 @@ def test_vectorised_call_and_sampler_glue(cfg_pix):
     like(H0=np.array([60., 70.]), alpha=np.array([3., 3.1, 3.2]))
 
 
+def test_alternating_z_max_in_scalar_calls_never_replays_another_z_max(cfg_pix):
+  """[r5] k_znodes takes z_max by value and k_tables reads the cached nodes: a HIP graph captured for one z_max must not be replayed for
+  another.  Scalar calls A, A, A (eager, capture, replay), then B, A, B, A, B, B, B, A: every value must be the one a FRESH handle gives for that z_max
+  (a z_max convergence scan with the reference-shaped call; before, the third 'A' after a 'B' replayed B's nodes under A's parameters).  The same with
+  an option changed after the capture (the option epoch is part of the key)."""
+  cfg, ev, inj = cfg_pix
+  seq = [5., 5., 5., 7.5, 5., 7.5, 5., 7.5, 7.5, 7.5, 5.]
+  like, _, _ = H.build_product(ev, inj)
+  got = [like(H0=69., z_max=zm) for zm in seq]
+  want = {}
+  for zm in (5., 7.5):
+    fresh, _, sf = H.build_product(ev, inj)
+    want[zm] = fresh(H0=69., z_max=zm)
+    fresh.close(); sf.close()
+  assert want[5.] != want[7.5]                                 # the table's nodes move with z_max: the two values differ in the last digits at least
+  np.testing.assert_array_equal(np.array(got), np.array([want[zm] for zm in seq]))
+  like_o, _, _ = H.build_oracle(ev, inj)
+  for zm in (5., 7.5):
+    np.testing.assert_allclose(want[zm], like_o(H0=69., z_max=zm), rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
+  # a replayed graph must not outlive the options it was captured under
+  for _ in range(3):
+    a = like(H0=71.)
+  like.set_option('serial', 1)
+  assert like(H0=71.) == a
+  like.set_option('serial', 0)
+  assert like(H0=71.) == a
+  like.close()
+
+
 @pytest.mark.parametrize('mname', ['plp', 'bpl', 'tpl'])
 def test_pdf_joint_and_marg_matches_the_oracle(mname):
   """[r5] CHIMERA/population/mass.py:351-362, the reference's plotting helper: joint pdf on a mesh of [m_low, m_high]^2 (chm_model_eval) and its two
