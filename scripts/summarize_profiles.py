@@ -101,7 +101,7 @@ def headline(rnd):
   if 'issue_busy_frac' in r:                               # round 4 on: frac = the USEFUL fraction (fp64 add / mul / fma issue cycles), the busy fraction beside it
     mi = r.get('min_inst') or {}
     out.append('| `roofline` of the driver line | bound **%s**, kernel `%s`: **frac %.3f** = issue cycles of its fp64 add / mul / fma instructions, %.3f of %.4f Tcycle/s (useful work); '
-               'issue ports busy with ANY VALU instruction %.3f (%.3f at the %.2f GHz held); %.0f VALU instructions per %s against a stated minimum of %.0f (x %.2f); real fp64 %.1f of 78.6 TFLOP/s; '
+               'issue ports busy with ANY VALU instruction %.3f (%.3f at the %.2f GHz held); %.0f VALU instructions per %s against a paper estimate of the minimum of %.0f (x %.2f); real fp64 %.1f of 78.6 TFLOP/s; '
                'HBM: unique bytes %.2f GB per launch = %.2f of 8 TB/s, PMC traffic %.2f GB = %.2f | `bench.json: roofline` |'
                % (r['bound'], r['kernel'], r['frac'] or 0., r['achieved'] or 0., r['peak'], r['issue_busy_frac'] or 0., r.get('issue_busy_frac_at_held_clock') or 0., dk.get('clock_GHz_under_profile') or 0.,
                   mi.get('per_unit_achieved') or 0., mi.get('unit') or 'unit', (mi.get('per_unit_minimal_paper_estimate') or mi.get('per_unit_minimal') or 0.), (mi.get('achieved_over_paper_estimate') or mi.get('achieved_over_minimal') or 0.),
