@@ -731,7 +731,10 @@ DEVFN void z_from_lut_x2(double xa, double xb, const double* rec, const unsigned
   za = vmin_f64(__builtin_fma(xa - ra.x, ra.z, ra.y), z_last);
   zb = vmin_f64(__builtin_fma(xb - rb.x, rb.z, rb.y), z_last);
   z0a = ra.y; z0b = rb.y; lz0a = ra.w; lz0b = rb.w;
-  bad = !oka || !okb;
+  // (ONE compare for "a key outside the table": the wave votes on it in the per-sample loops, and a vote on a disjunction makes the compiler rebuild the
+  //  lane mask through a VGPR -- v_cndmask + v_cmp in front of every vote)
+  const unsigned kmx = (unsigned)ka > (unsigned)kb ? (unsigned)ka : (unsigned)kb;
+  bad = kmx >= (unsigned)nk;
 }
 
 // [r3] log(m1det), log(m2det) of every posterior sample, formed on the device at upload with chm_log -- the function the few-draw variant of
@@ -873,10 +876,11 @@ DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParam
       // (inside the loop over the two samples below: one sample's pair of logs at a time, four at once spill)
       const double l1[2] = { LOGS_HERE ? 0. : ee.x, LOGS_HERE ? 0. : ee.y }, l2[2] = { LOGS_HERE ? 0. : ff.x, LOGS_HERE ? 0. : ff.y };
       double zz[2], wv[2], z0[2] = { 0., 0. }, lz0[2] = { 0., 0. };
-      bool bad = true;
+      bool bad = true, anybad = true;
       if (FITS) {                                     // z = z_from_dGW(dL) (cosmo.py:260-264)
         z_from_lut_x2(dl[0], dl[1], rec, luts, key0, nk, i_lo, ns, lmax, Tc, x_last, z_last, zz[0], zz[1], z0[0], z0[1], lz0[0], lz0[1], bad);
-        if (wave_any(bad)) {                             // NaN / non-positive / infinite distances: the plain search on the global tables
+        anybad = wave_any(bad);
+        if (anybad) {                                    // NaN / non-positive / infinite distances: the plain search on the global tables
           if (bad) { zz[0] = jnp_interp(dl[0], g_dLt, g_zt, Tc, false, 0., 0.); zz[1] = jnp_interp(dl[1], g_dLt, g_zt, Tc, false, 0., 0.); }
         }
       } else z_from_dGW_x2(P, dl[0], dl[1], g_dLt, g_zt, zz[0], zz[1]);
@@ -908,8 +912,7 @@ DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParam
         if (FITS) {
           double v;
           lz = log1pz_from_node(z, z0[h], lz0[h], r, v);
-          const bool nolog = bad || !(v <= 0.02);
-          if (wave_any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
+          if (anybad || wave_any(!(v <= 0.02))) { if (bad || !(v <= 0.02)) lz = chm_log_pos(zp1); }      // (votes on single compares, see z_from_lut_x2)
         } else lz = chm_log_pos(zp1);
         const double lm1 = LOGS_HERE ? chm_log(md1[h]) : l1[h], lm2 = LOGS_HERE ? chm_log(md2[h]) : l2[h];
 #if CHM_SF_RELOAD
@@ -3202,10 +3205,11 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
         l1[0] = l1[1] = Sd.lm1det[i]; l2[0] = l2[1] = Sd.lm2det[i];
       }
       double zz[2], z0[2] = { 0., 0. }, lz0[2] = { 0., 0. };
-      bool bad = true;
+      bool bad = true, anybad = true;
       if (fits) {                                   // z = z_from_dGW(dL)   cosmo.py:260-264
         z_from_lut_x2(dl[0], dl[1], rec, luts, key0, nk, i_lo, ns, lmax, Tc, x_last, z_last, zz[0], zz[1], z0[0], z0[1], lz0[0], lz0[1], bad);
-        if (wave_any(bad)) {
+        anybad = wave_any(bad);
+        if (anybad) {
           if (bad) { zz[0] = jnp_interp(dl[0], g_dLt, g_zt, Tc, false, 0., 0.); zz[1] = jnp_interp(dl[1], g_dLt, g_zt, Tc, false, 0., 0.); }
         }
       } else z_from_dGW_x2(P, dl[0], dl[1], g_dLt, g_zt, zz[0], zz[1]);
@@ -3217,8 +3221,7 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
         const double m1 = md1[h] * r, m2 = md2[h] * r;
         double vv;
         double lz = log1pz_from_node(z, z0[h], lz0[h], r, vv);
-        const bool nolog = !fits || bad || !(vv <= 0.02);
-        if (wave_any(nolog)) { if (nolog) lz = chm_log_pos(zp1); }
+        if (!fits || anybad || wave_any(!(vv <= 0.02))) { if (!fits || bad || !(vv <= 0.02)) lz = chm_log_pos(zp1); }      // (votes on single compares, see z_from_lut_x2)
         const double pm = p_m1m2_fused<MASS>(P, m1, m2, l1[h] - lz, l2[h] - lz, mg, cdf, ex);
         const double Ez = E_at_z_lr(P, z, zp1, r, lz);
         double dCt = dl[h] * r;                                          // original distances: cosmo.py:191-192,215-216

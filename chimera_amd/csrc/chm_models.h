@@ -449,6 +449,23 @@ template <class A> DEVFN double tab_first(A a) { return (double)a[0]; }
 template <class A> DEVFN double tab_last(A a, int n) { return (double)a[n - 1]; }
 DEVFN double tab_first(const TabSlice& a) { return a.first; }
 DEVFN double tab_last(const TabSlice& a, int) { return a.last; }
+// [r5] the end nodes of the mass grid and the last value of cdf_m2 travel with the draw (DevParams: k_tables stores exactly these values in mg[0], mg[Tm - 1],
+// cdf[Tm - 1]): the per-sample loops compare against scalars instead of reading the table ends from LDS for every sample
+#ifndef CHM_MGRID_ENDS_SCALAR
+#define CHM_MGRID_ENDS_SCALAR 1
+#endif
+#if CHM_MGRID_ENDS_SCALAR
+template <class A> DEVFN double mgrid_first(const DevParams& p, A) { return p.mg_first; }
+template <class A> DEVFN double mgrid_last(const DevParams& p, A, int) { return p.mg_last; }
+template <class A> DEVFN double cdf_last_of(const DevParams& p, A, int) { return p.cdf_last; }
+#else
+template <class A> DEVFN double mgrid_first(const DevParams&, A a) { return tab_first(a); }
+template <class A> DEVFN double mgrid_last(const DevParams&, A a, int n) { return tab_last(a, n); }
+template <class A> DEVFN double cdf_last_of(const DevParams&, A a, int n) { return tab_last(a, n); }
+#endif
+DEVFN double mgrid_first(const DevParams&, const TabSlice& a) { return a.first; }
+DEVFN double mgrid_last(const DevParams&, const TabSlice& a, int) { return a.last; }
+DEVFN double cdf_last_of(const DevParams&, const TabSlice& a, int) { return a.last; }
 
 template <int MASS = -1, class A1, class A2, class EX = ExpPoly>
 DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, double lm2, A1 mg, A2 cdf, const EX ex = EX()) {
@@ -508,14 +525,18 @@ DEVFN double p_m1m2_fused(const DevParams& p, double m1, double m2, double lm1, 
   const double f0 = cdf[i - 1], f1 = cdf[i];
   double dx = x1 - x0;
   double cn = f0 * dx + (m1 - x0) * (f1 - f0);
-  if (fabs(dx) <= 4.930380657631324e-32) { cn = f0; dx = 1.; }
-  if (m1 < tab_first(mg)) cn = tab_first(cdf) * dx;
-  if (m1 > tab_last(mg, n)) cn = tab_last(cdf, n) * dx;
+  // (jnp.interp's epsilon rule for a degenerate interval: under a vote -- four selects per sample otherwise, for a case a logspace grid never meets)
+  if (wave_any(fabs(dx) <= 4.930380657631324e-32)) { asm volatile(""); if (fabs(dx) <= 4.930380657631324e-32) { cn = f0; dx = 1.; } }
+  if (m1 < mgrid_first(p, mg)) cn = tab_first(cdf) * dx;
+  if (m1 > mgrid_last(p, mg, n)) cn = cdf_last_of(p, cdf, n) * dx;
   // one quotient without IEEE special cases: every factor is finite (chm_exp_clamped), the product of two saturated denominators is
   // capped at 1e300 (a factor 1e-300 on the weight); a zero interpolant (m1 at the lowest node) gives NaN here and 0 below
   const double num = (Pn * p.inv_norm_p_m1) * dx, den = vmin_f64((D1 * D2) * cn, 1e300);
   double w = chm_div(num, den);
-  if (wave_any(den == 0.)) { if (den == 0.) w = num / den; }   // m1 at the lowest node of the grid: the IEEE quotient (x/0 = inf, 0/0 = NaN) as the reference forms it
+  // m1 at the lowest node of the grid: the IEEE quotient (x/0 = inf, 0/0 = NaN) as the reference forms it.  [r5] The empty asm keeps the IEEE sequence INSIDE
+  // the voted branch: the compiler had hoisted it (a division is speculatable) and every sample paid both quotients -- 11 instructions and a second
+  // v_rcp_f64 -- for a select that is false in all but pathological inputs
+  if (wave_any(den == 0.)) { asm volatile(""); if (den == 0.) w = num / den; }
   // sec = 0 -> p_m2m1 = 0 (or 0/0 = NaN -> 0): w = p_m1 * 0
   if (zero || (w != w && cn == 0.)) w = Pn * 0.;
   // a NaN primary mass: the smoothing window of bpl / plp turns p_m1 NaN (NaN * 0 = NaN); the truncated power law has no window, every factor
