@@ -1419,7 +1419,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         const bool full_chain = o.full_chain != 0 && !rate_special_call;         // (CHM_OPT_DIAG_FULL_CHAIN 0: the general kernel alone; tests compare the two)
         if (full_chain) {
           hipLaunchKernelGGL(k_full_prep, dim3(L.E_cnt, nb), dim3(256), 0, sg, L); HIPCHK(hipGetLastError());
-          hipLaunchKernelGGL(k_full_kde_chain, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp, L.full_todo); HIPCHK(hipGetLastError());
+          hipLaunchKernelGGL(k_full_kde_chain, dim3(L.E_cnt * Pd, nb), dim3(64 * FULLC_NW), 0, sg, L, dp, L.full_todo); HIPCHK(hipGetLastError());
         }
         hipLaunchKernelGGL(k_full_kde, dim3(L.E_cnt * Pd, nb), dim3(256), 0, sg, L, dp, full_chain ? (const int*)L.full_todo : (const int*)nullptr);
       } else if (L.mode == CHM_MODE_MARG) {

@@ -2720,12 +2720,29 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
 #ifndef FULLC_LK
 #define FULLC_LK 32
 #endif
-#define FULLC_SPT 16          // samples a thread keeps in registers: 4096 per block and walk over the stretch
+// [r5] block shape (build knobs, A/B in profiles/r05/ab_full_mode_r05.txt): FULLC_NW waves per block, a thread keeps FULLC_SPT samples in registers
+// (4096 per block and walk over the stretch either way).  4 x 16: 128 + 64 accumulators fit three waves per SIMD; 2 x 32: two waves per SIMD, the
+// cross-lane exchange and the accumulators' reset once per 1024 instead of once per 512 (sample, grid point) pairs of a lane.
+#ifndef FULLC_NW
+#define FULLC_NW 4
+#endif
+#ifndef FULLC_SPT
+#define FULLC_SPT (64 / FULLC_NW)
+#endif
 #ifndef FULLC_MINW
-#define FULLC_MINW 3
+#define FULLC_MINW (FULLC_SPT > 16 ? 2 : 3)
 #endif
 #ifndef FULLC_NPT
 #define FULLC_NPT 1024        // grid points of the stretch (longer: general kernel)
+#endif
+#ifndef FULLC_PB
+#define FULLC_PB 4            // samples of a thread whose values are requested together at the block's start, two such sets at a time (divides FULLC_SPT)
+#endif
+#ifndef FULLC_QPIPE
+#define FULLC_QPIPE 0
+#endif
+#ifndef FULLC_DIAG_NOEXCH
+#define FULLC_DIAG_NOEXCH 0
 #endif
 #ifndef FULLC_REDUCE16
 #define FULLC_REDUCE16 0       // sixteen points x one half of the wave per exchange (44 instead of 68 VALU per chunk): measured 8.41-8.53 against 8.26-8.30 ms -- off
@@ -2823,66 +2840,86 @@ __global__ void __launch_bounds__(256) k_full_prep(LikeDev L) {
   }
 }
 
-__global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, const DevParams* params, int* todo) {
+__global__ void __launch_bounds__(64 * FULLC_NW, FULLC_MINW) k_full_kde_chain(LikeDev L, const DevParams* params, int* todo) {
   constexpr int LK = FULLC_LK;
-  __shared__ double xw[4][8 * FULLC_ROW];                  // per wave: eight grid points x 64 lanes of power sums on their way across the lanes
-  __shared__ double vw[4][FULLC_NPT];                      // per wave: its samples' sums at every grid point of the stretch
+  __shared__ double xw[FULLC_NW][8 * FULLC_ROW];                  // per wave: eight grid points x 64 lanes of power sums on their way across the lanes
+  __shared__ double vw[FULLC_NW][FULLC_NPT];                      // per wave: its samples' sums at every grid point of the stretch
   __shared__ double red[16];
   __shared__ double wh[8];
-  const int t = threadIdx.x, nt = 256;
+  constexpr int nt = 64 * FULLC_NW;
+  const int t = threadIdx.x;
   const int p = blockIdx.x % L.P, e = L.e_off + blockIdx.x / L.P, b = blockIdx.y;
   const DevParams& P = params[b];
   const int S = L.S, Z = L.Z;
   const size_t so = ((size_t)b * L.E + e) * S;
+  PH_INIT;                                                  // (diagnostic builds: scripts/phase_full.py)
   int* my_todo = todo + ((size_t)b * L.E + e) * L.P + p;
   double* out_like = L.like_pix + ((size_t)b * L.E + e) * L.P + p;
   double* dump = L.p_gw_dump ? L.p_gw_dump + (((size_t)b * L.E + e) * L.P + p) * Z : nullptr;
-  if (p >= L.neff_pixels[e]) {                            // result[ev, :npix] only (likelihood.py:253)
+  // [r5] everything the block's start waits for is requested here, before the first branch -- the pixel count, the pixel's direction, the event's
+  // record and the first FULLC_PB owned samples' values: one memory latency, where the branches below had put four one after the other
+  // (a wave spent half its life starting up: scripts/phase_full.py, profiles/r05/phase_full_kernel.txt)
+  const double* fa = L.full_s + so; const double* fy1 = fa + (size_t)L.nb_alloc * L.E * S; const double* fy2 = fy1 + (size_t)L.nb_alloc * L.E * S;
+  const double* fw = fy2 + (size_t)L.nb_alloc * L.E * S; const double* fu = fw + (size_t)L.nb_alloc * L.E * S;
+  constexpr int PB = FULLC_PB, NG = FULLC_SPT / PB;
+  static_assert(FULLC_SPT % PB == 0, "FULLC_PB divides FULLC_SPT");
+  double bA[5][PB], bB[5][PB];                              // two sets of PB samples' (a, y1, y2, weight, U): one in use, one in flight
+#define FULLC_LOADB(dst, sb_, g_) _Pragma("unroll") for (int jj = 0; jj < PB; jj++) { \
+      const int s_ = min((sb_) + t + ((g_) * PB + jj) * nt, S - 1);      /* (beyond the event's last sample: a valid address, the values unused) */ \
+      dst[0][jj] = fa[s_]; dst[1][jj] = fy1[s_]; dst[2][jj] = fy2[s_]; dst[3][jj] = fw[s_]; dst[4][jj] = fu[s_]; }
+  FULLC_LOADB(bA, 0, 0)
+  const int npix_e = L.neff_pixels[e];
+  const double rp = L.ra_pix[(size_t)e * L.P + p], dp = L.dec_pix[(size_t)e * L.P + p];
+  const double* fe = L.full_ev + ((size_t)b * L.E + e) * FULLEV;      // k_full_prep's record of the event (uniform address: scalar loads)
+  double fr[FE_CF];                                         // its scalars (the FULLC_LK factors behind them are read per grid point at the end)
+#pragma unroll
+  for (int i = 0; i < FE_CF; i++) fr[i] = fe[i];
+  if (p >= npix_e) {                                       // result[ev, :npix] only (likelihood.py:253)
     if (t == 0) { *out_like = 0.; *my_todo = 0; }
     if (dump) for (int k = t; k < Z; k += nt) dump[k] = 0.;
     return;
   }
-  const double* fe = L.full_ev + ((size_t)b * L.E + e) * FULLEV;      // k_full_prep's record of the event (uniform address: scalar loads)
   const double* zg = L.z_grids + (size_t)e * Z;
-  const int k_first = (int)fe[FE_KFIRST], k_last = (int)fe[FE_KLAST];
+  const int k_first = (int)fr[FE_KFIRST], k_last = (int)fr[FE_KLAST];
   const int npt = k_last - k_first + 1;
-  const double zero_n = fe[FE_OK] != 0. ? 0. * fe[FE_NORM] : 0.;      // the reference's 0 * norm outside the mask (see k_full_kde)
-  if (fe[FE_OK] == 0. || npt <= 0) {                       // nothing to integrate: the general kernel's answer for these, without it
+  const double zero_n = fr[FE_OK] != 0. ? 0. * fr[FE_NORM] : 0.;      // the reference's 0 * norm outside the mask (see k_full_kde)
+  if (fr[FE_OK] == 0. || npt <= 0) {                       // nothing to integrate: the general kernel's answer for these, without it
     if (t == 0) { *out_like = grid_is_poisoned(P.z_bad, zg, Z) ? __builtin_nan("") : zero_n; *my_todo = 0; }
     if (dump) for (int k = t; k < Z; k += nt) dump[k] = zero_n;
     return;
   }
-  if (fe[FE_CHAIN] == 0.) { if (t == 0) *my_todo = 1; return; }        // (k_full_kde writes the whole pixel, dump included)
+  if (fr[FE_CHAIN] == 0.) { if (t == 0) *my_todo = 1; return; }        // (k_full_kde writes the whole pixel, dump included)
   if (t == 0) *my_todo = 0;
   if (dump) for (int k = t; k < Z; k += nt) if (k < k_first || k > k_last) dump[k] = zero_n;
-  const double rp = L.ra_pix[(size_t)e * L.P + p], dp = L.dec_pix[(size_t)e * L.P + p];
-  const double q1 = rp * fe[FE_L11] + dp * fe[FE_L21], q2 = dp * fe[FE_L22], t_base = rp * fe[FE_L10] + dp * fe[FE_L20];      // whitened query (math.py:196)
+  const double q1 = rp * fr[FE_L11] + dp * fr[FE_L21], q2 = dp * fr[FE_L22], t_base = rp * fr[FE_L10] + dp * fr[FE_L20];      // whitened query (math.py:196)
   const size_t zo = ((size_t)b * L.E + e) * Z;
   const double* pc = L.p_cat + ((size_t)e * L.P + p) * Z;
-  const double D = fe[FE_D], K1 = fe[FE_K1], K2 = fe[FE_K2];
-  const double t0 = fe[FE_ZF] + t_base;
+  const double D = fr[FE_D], K1 = fr[FE_K1], K2 = fr[FE_K2];
+  const double t0 = fr[FE_ZF] + t_base;
   // the pixel's factor of the step factors, u = U V; a pixel further than 30 / D widths from the mean direction forms them directly
-  const double varg = (fe[FE_AREF] - t0) * D;
+  const double varg = (fr[FE_AREF] - t0) * D;
   const bool direct0 = !(fabs(varg) <= 30.);
   const double V = direct0 ? 0. : chm_exp(varg);
   // what a sample's start needs sits in LDS: after the first chunk it is a rare path whose constants would occupy registers of the march
-  if (t == 0) { wh[0] = q1; wh[1] = q2; wh[2] = fe[FE_LOGNORM]; wh[3] = D; wh[4] = V; }
+  if (t == 0) { wh[0] = q1; wh[1] = q2; wh[2] = fr[FE_LOGNORM]; wh[3] = D; wh[4] = V; }
   __syncthreads();
-  const double* fa = L.full_s + so; const double* fy1 = fa + (size_t)L.nb_alloc * L.E * S; const double* fy2 = fy1 + (size_t)L.nb_alloc * L.E * S;
-  const double* fw = fy2 + (size_t)L.nb_alloc * L.E * S; const double* fu = fw + (size_t)L.nb_alloc * L.E * S;
+  PH(0);                                                    // (phase 0: the event's record, the pixel's constants, the first samples' values)
 
   // one sample's starting values at a chunk whose first point sits at tc.  1: started; 0: further than 37 widths ahead (stays (0, 0), looked at
   // again at the next chunk); -1: further than 37 widths behind -- the chunks move away from it, it never enters
-  auto start = [&](int s, double tc, bool direct, double& pw, double& u) -> int {
-    const double d1 = fy1[s] - wh[0], d2 = fy2[s] - wh[1];
-    const double d = fa[s] - tc;
+  auto start_v = [&](double a, double y1, double y2, double w, double us, double tc, bool direct, double& pw, double& u) -> int {
+    const double d1 = y1 - wh[0], d2 = y2 - wh[1];
+    const double d = a - tc;
     const double e1 = -0.5 * (d * d), Dl = wh[3];
     const bool in = e1 > -700.;
     // one exp for W_j exp(log_norm - b_j / 2) exp(-d^2 / 2) (a huge negative argument ends in v_ldexp_f64's 0); |d D| <= 37.5 x 15 / LK
-    pw = in ? fw[s] * chm_exp_nb(fmax(wh[2] + e1 - 0.5 * (d1 * d1 + d2 * d2), -800.)) : 0.;
+    pw = in ? w * chm_exp_nb(fmax(wh[2] + e1 - 0.5 * (d1 * d1 + d2 * d2), -800.)) : 0.;
     if (direct) u = in ? chm_exp_nb(d * Dl) : 0.;
-    else u = in ? fu[s] * wh[4] : 0.;
+    else u = in ? us * wh[4] : 0.;
     return in ? 1 : (d * Dl > 0. ? 0 : -1);
+  };
+  auto start = [&](int s, double tc, bool direct, double& pw, double& u) -> int {
+    return start_v(fa[s], fy1[s], fy2[s], fw[s], fu[s], tc, direct, pw, u);
   };
   const int lane = t & 63, wv = t >> 6;
   double* xb = xw[wv];
@@ -2893,12 +2930,26 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
   const int spt = (min(S - sb, nt * FULLC_SPT) + nt - 1) / nt;
   double pw[FULLC_SPT], uu[FULLC_SPT];
   unsigned waiting = 0;                                    // bit j: owned sample j has not started yet
+  // [r5] the values of the next FULLC_PB owned samples are requested before the starting values of the present ones are formed
+  // (bA holds the set's first FULLC_PB samples: requested at the top of the kernel, or at the end of the set before)
+#define FULLC_STARTB(src, g_) _Pragma("unroll") for (int jj = 0; jj < PB; jj++) { \
+      const int j = (g_) * PB + jj; \
+      double np, nu; \
+      const int r = start_v(src[0][jj], src[1][jj], src[2][jj], src[3][jj], src[4][jj], t0, direct0, np, nu); \
+      const bool own = sb + t + j * nt < S; \
+      pw[j] = own ? np : 0.; uu[j] = own ? nu : 0.; \
+      if (own && r == 0) waiting |= 1u << j; }
 #pragma unroll
-  for (int j = 0; j < FULLC_SPT; j++) {
-    pw[j] = 0.; uu[j] = 0.;
-    const int s = sb + t + j * nt;
-    if (s < S && start(s, t0, direct0, pw[j], uu[j]) == 0) waiting |= 1u << j;
+  for (int g = 0; g < NG; g += 2) {
+    if (g + 1 < NG) { FULLC_LOADB(bB, sb, g + 1) }
+    FULLC_STARTB(bA, g)
+    if (g + 1 < NG) {
+      if (g + 2 < NG) { FULLC_LOADB(bA, sb, g + 2) }
+      FULLC_STARTB(bB, g + 1)
+    }
   }
+  PH(6);                                                    // (phase 6: the owned samples' starting values -- one exp each -- and the wait for their values)
+
 
   // The four waves walk the chunks on their own.  After a chunk a wave adds its 64 lanes' power sums through its private exchange buffer, eight
   // grid points at a time: every lane writes eight sums, lane l adds lanes l%8, l%8 + 8, ... of point l/8 and three DPP steps complete the
@@ -2922,28 +2973,41 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
     __builtin_amdgcn_sched_barrier(0);
     const int ng = min(LK, npt - c * LK);                  // grid points of this chunk (the last one may be short: whole groups of four beyond it are skipped)
     double acc[LK];
-#pragma unroll
-    for (int i = 0; i < LK; i++) acc[i] = 0.;
     if (ng == LK) {
 #pragma unroll
       for (int j = 0; j < FULLC_SPT; j++) {
-        if (j < spt) {
+        if (j == 0 || j < spt) {                           // (spt >= 1)
           double q = pw[j];
           const double u = uu[j];
           const double u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
 #pragma unroll
           for (int i = 0; i < LK; i += 4) {
-            acc[i] += q;
-            acc[i + 1] = __builtin_fma(q, u, acc[i + 1]);
-            acc[i + 2] = __builtin_fma(q, u2, acc[i + 2]);
-            acc[i + 3] = __builtin_fma(q, u3, acc[i + 3]);
+#if FULLC_QPIPE
+            double qn = q * u4;                            // the next group's running product before this group's sums: nothing waits on it
+            asm volatile("" : "+v"(qn));
+#endif
+            if (j == 0) {                                  // [r5] the first sample sets the accumulators (0 + q, fma(q, u, 0): the same roundings) -- no reset
+              acc[i] = q; acc[i + 1] = q * u; acc[i + 2] = q * u2; acc[i + 3] = q * u3;
+            } else {
+              acc[i] += q;
+              acc[i + 1] = __builtin_fma(q, u, acc[i + 1]);
+              acc[i + 2] = __builtin_fma(q, u2, acc[i + 2]);
+              acc[i + 3] = __builtin_fma(q, u3, acc[i + 3]);
+            }
+#if FULLC_QPIPE
+            asm volatile("" : "+v"(acc[i + 3]));
+            q = qn;
+#else
             q *= u4;
+#endif
           }
           pw[j] = q * K1; uu[j] = u * K2;
         }
         __builtin_amdgcn_sched_barrier(0);                 // one sample after the other: hoisting the u^2, u^3, u^4 of all sixteen costs 96 registers
       }
     } else {                                               // the last chunk of the stretch: the groups of four beyond its end are left out (no state to carry on)
+#pragma unroll
+      for (int i = 0; i < LK; i++) acc[i] = 0.;
 #pragma unroll
       for (int j = 0; j < FULLC_SPT; j++) {
         if (j < spt) {
@@ -2964,6 +3028,7 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    PH(1);                                                  // (phase 1: the march of a chunk)
 #if FULLC_REDUCE16
     // sixteen grid points at a time, the two halves of the wave one after the other: the 32 lanes of a half write their sixteen sums, lane l
     // adds lanes l%4, l%4 + 4, ... of point l/4 to its running sum (both halves), two DPP steps complete the point in lane 4 (l/4) + 3
@@ -2988,6 +3053,11 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
         if ((lane & 3) == 3) { double* o = vrow + c * LK + h + (lane >> 2); *o = sb == 0 ? v : *o + v; }
       }
     }
+#elif FULLC_DIAG_NOEXCH      // timing diagnostic only (WRONG results): no cross-lane exchange, one sum per chunk keeps the march alive
+    { double v = 0.;
+#pragma unroll
+      for (int i = 0; i < LK; i++) v += acc[i];
+      if (v == 1.2345e-300) vrow[c * LK] = v; }
 #else
 #pragma unroll
     for (int h = 0; h < LK; h += 8) {
@@ -3005,30 +3075,53 @@ __global__ void __launch_bounds__(256, FULLC_MINW) k_full_kde_chain(LikeDev L, c
       }
     }
 #endif
+    PH(2);                                                  // (phase 2: the chunk's sums across the lanes)
   }
+  if (sb + nt * FULLC_SPT < S) { FULLC_LOADB(bA, sb + nt * FULLC_SPT, 0) }
   }
+#undef FULLC_LOADB
+#undef FULLC_STARTB
+  // [r5] what the integrand of this thread's first grid point needs is requested before the barrier
+  int k = k_first + t;
+  double e_pc = -100., e_bk = 0., e_pr = 0., e_jc = 1., e_z = 0., e_zl = 0., e_zr = 0., e_cf = 0.;
+  auto eload = [&](int kk) {
+    e_cf = fe[FE_CF + (kk - k_first) % LK];
+    e_pc = pc[kk]; e_bk = L.bkgA[zo + kk]; e_pr = L.prate[zo + kk]; e_jc = L.jac[zo + kk];
+    e_z = zg[kk]; e_zl = zg[kk > 0 ? kk - 1 : kk]; e_zr = zg[kk < Z - 1 ? kk + 1 : kk];
+  };
+  if (k <= k_last) eload(k);
+  const double e_zhi = fe[FE_ZHI], e_zlo = fe[FE_ZLO], e_norm = fe[FE_NORM];      // (read again here: held from the top they would sit in registers of the march)
   __syncthreads();
+  PH(3);                                                    // (phase 3: waiting for the block's other waves)
   // p_gw and the integrand of every grid point of the stretch   catalog.py:202, pop_wrapper.py:87, likelihood.py:252-275
   double accl = 0.;
-  for (int k = k_first + t; k <= k_last; k += nt) {
+  for (; k <= k_last; k += nt) {
     const int r = k - k_first;
-    const double val = ((vw[0][r] + vw[1][r]) + (vw[2][r] + vw[3][r])) * fe[FE_CF + r % LK];
-    const double z = zg[k];
-    const bool inm = (z <= fe[FE_ZHI]) && (z >= fe[FE_ZLO]);
-    const double pgw = inm ? val * fe[FE_NORM] : zero_n;   // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
+#if FULLC_NW == 4
+    const double val = ((vw[0][r] + vw[1][r]) + (vw[2][r] + vw[3][r])) * e_cf;
+#else
+    double vs = vw[0][r];
+#pragma unroll
+    for (int w = 1; w < FULLC_NW; w++) vs += vw[w][r];
+    const double val = vs * e_cf;
+#endif
+    const double z = e_z;
+    const bool inm = (z <= e_zhi) && (z >= e_zlo);
+    const double pgw = inm ? val * e_norm : zero_n;        // kde_vals[eff_mask] ... * norm   likelihood.py:252-253
     if (dump) dump[k] = pgw;
-    const double pcv = pc[k];
+    const double pcv = e_pc;
     double y = 0.;
     if (pcv != -100.) {
-      const double p_gal = P.fR * pcv + L.bkgA[zo + k];
-      const double p_z = p_gal * L.prate[zo + k];
-      y = (p_z != -100.) ? pgw * p_z / L.jac[zo + k] : 0.;
+      const double p_gal = P.fR * pcv + e_bk;
+      const double p_z = p_gal * e_pr;
+      y = (p_z != -100.) ? pgw * p_z / e_jc : 0.;
     }
-    const double zl = k > 0 ? zg[k - 1] : z, zr = k < Z - 1 ? zg[k + 1] : z;
-    accl += y * ((z - zl) + (zr - z));                     // trapezoid: y_k enters the two adjacent intervals
+    accl += y * ((z - e_zl) + (e_zr - z));                 // trapezoid: y_k enters the two adjacent intervals
+    if (k + nt <= k_last) eload(k + nt);
   }
   accl = block_reduce<RED_SUM>(accl, red);
   if (t == 0) *out_like = grid_is_poisoned(P.z_bad, zg, Z) ? __builtin_nan("") : 0.5 * accl + zero_n;
+  PH(4);                                                    // (phase 4: integrand and trapezoid of the stretch, the block's sum and the store)
 }
 
 // ------------------------------------------------------------------------------------------------------
