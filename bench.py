@@ -517,8 +517,12 @@ def main():
       sec = kt[3] * 1e-3
       # the power-sum march costs 5 fp64 instructions (4 cycles each) per 4 pairs and lane (4 fma + 1 multiply): peak = 614.4 G wave-inst/s x 64 lanes / 1.25
       pk = N_SIMD * CLK_HZ / CYC_VALU / 1e9 * 64 / 1.25
+      # [r5] what the card sustains on the march ALONE (scripts/march_probe.hip, profiles/r05/march_probe.txt: 20.1-20.4 Tpair/s with one, two or three
+      # waves per SIMD, the clock down to 1.9 GHz under the fp64 FMAs) -- the reachable fraction of `peak_Gpairs_s` is 0.65
+      march_alone = 20420.
       kf.update({"pairs_per_launch": full_pairs, "Gpairs_s": full_pairs / sec / 1e9 if sec > 0 else None,
-                 "peak_Gpairs_s": pk, "pair_frac": full_pairs / sec / 1e9 / pk if sec > 0 else None})
+                 "peak_Gpairs_s": pk, "pair_frac": full_pairs / sec / 1e9 / pk if sec > 0 else None,
+                 "march_alone_Gpairs_s_measured_r05": march_alone, "frac_of_march_alone": full_pairs / sec / 1e9 / march_alone if sec > 0 else None})
     if not (kind == 'marginalized' and args.fused >= 2):        # (the fused event kernel has no sample stage of its own)
       kernels.append(kernel_roofline("sample stage (z(dL), source-frame masses, population weights, event statistics)", "k_samples", kt[2],
                                      sample_kernel_unique_bytes(El, S, nb), pmc, units=El * S * nb / 64.))
