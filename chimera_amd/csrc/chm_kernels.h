@@ -76,8 +76,9 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
 struct EvStats { double zmin, zmax, sd, norm, n_eff, sumw; };
 // L_i of (draw, event) is NaN whatever the KDE: NaN distance factors on the event grid (grid_is_poisoned), or -- a draw with an infinite rate
 // parameter -- a rate factor that is inf / NaN somewhere on the grid.  The kernels skip grid points where p_gw vanishes; the reference multiplies
-// them out (likelihood.py:274-278: 0 * inf = NaN).  (Corner not reproduced: every such point inside the KDE's support AND the value +inf -> the
-// reference has +inf where this gives NaN.)
+// them out (likelihood.py:274-278: 0 * inf = NaN).  (Corner: every such point inside the KDE's support AND the value +inf -> the reference has
+// +inf.  k_integrate_1d -- the 1-D and 'approximate' modes, where a Gaussian kernel without cut_grid makes it reachable -- forms the reference's
+// products over the whole grid for such a draw and reproduces it; the compact-support modes keep this rule.)
 DEVFN bool event_poisoned(const LikeDev& L, const DevParams& P, int b, int e, const double* zg, int Z) {
   return grid_is_poisoned(P.z_bad, zg, Z) || (P.rate_special && L.ev_rbad && L.ev_rbad[(size_t)b * L.E + e]);
 }
@@ -2399,12 +2400,17 @@ __global__ void __launch_bounds__(256) k_integrate_1d(LikeDev L, const DevParams
   const int Z = L.Z;
   const bool pixelated = L.mode != 0;
   const size_t zo = ((size_t)b * L.E + e) * Z;
-  const bool poisoned = event_poisoned(L, P, b, e, L.z_grids + (size_t)e * Z, Z);
+  // [r5] a draw with an infinite rate parameter (P.rate_special: its per-z factors hold inf / NaN, k_rate_special): the products are formed over the
+  // WHOLE grid as the reference forms them (likelihood.py:274-278, 288-291) -- 0 * inf = NaN where p_gw1d vanishes, +inf where every infinite
+  // factor meets a positive p_gw1d (a Gaussian kernel without cut_grid: found by scripts/fuzz_parity.py, seed 6001464) -- instead of the blanket
+  // NaN of event_poisoned()
+  const bool special = P.rate_special != 0;
+  const bool poisoned = special ? grid_is_poisoned(P.z_bad, L.z_grids + (size_t)e * Z, Z) : event_poisoned(L, P, b, e, L.z_grids + (size_t)e * Z, Z);
   const double* g1 = L.pgw1d + zo;
   // p_gw1d vanishes outside [k_lo, k_hi] (found by k_kde1d): those terms of the trapezoid are exact zeros and are skipped;
   // inside, sum_k p_gw3d[k] p_z[k]/jac[k] tw[k] with the per-z factors folded into A[k] (see k_kde_marg)
   const int* kr = L.krange + ((size_t)b * L.E + e) * 2;
-  const int k_lo = kr[0], k_hi = kr[1];
+  const int k_lo = special ? 0 : kr[0], k_hi = special ? Z - 1 : kr[1];
   const double* bkgA = L.bkgA + zo;
   const double* Aw = L.Aw + zo;
   const double fR = P.fR;

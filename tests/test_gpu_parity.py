@@ -1057,6 +1057,33 @@ def test_infinite_rate_parameters_behave_like_the_reference(kind, rate):
   like_p.close()
 
 
+@pytest.mark.parametrize('kind', ['approximate', None])
+def test_infinite_rate_meets_a_kde_that_vanishes_nowhere(kind):
+  """[r5] gamma = +inf makes the rate factor +inf at every grid point with z > 0.  Where p_gw vanishes somewhere on the event grid the reference's
+  trapezoid holds a 0 * inf = NaN and L_i is NaN -- but a GAUSSIAN kernel without cut_grid vanishes nowhere, every product is +inf, L_i = +inf and
+  log L_i comes out as +1.797e308 (nan_to_num).  The 1-D integrand kernel forms the reference's products over the whole grid for such a draw
+  (scripts/fuzz_parity.py seed 6001464: the blanket NaN of event_poisoned() gave -inf there)."""
+  pixelated = kind is not None
+  cfg, ev, inj = H.small_config(E=5, S=512, P=3, Z=46, I=2000, seed=19, ragged=True, pixelated=pixelated)
+  models = dict(rate='power_law', mass='tpl')
+  for like_kw in (dict(kernel='gauss', cut_grid=None, binning=True, num_bins=17, bw_method='scott'), dict(kernel='gauss', cut_grid=None, binning=False),
+                  dict(kernel='epan', cut_grid=None, binning=True, num_bins=17), dict(kernel='gauss', cut_grid=2.0)):
+    like_o, _, _ = H.build_oracle(ev, inj, pixelated=pixelated, kind=kind, models=models, like_kw=like_kw, pop_kw=dict(scale_free=False))
+    like_p, _, _ = H.build_product(ev, inj, pixelated=pixelated, kind=kind, models=models, like_kw=like_kw, pop_kw=dict(scale_free=False))
+    for lam in (dict(gamma=np.inf), dict(gamma=np.inf, H0=55.), dict(gamma=-np.inf), dict(gamma=2.)):
+      with np.errstate(all='ignore'):
+        ro, rp = like_o.compute_all(**lam), like_p.compute_all(**lam)
+        a, bt = like_p(**lam), like_p.batch([lam, dict(H0=71.)])[0]
+      np.testing.assert_array_equal(np.asarray(rp[0]) >= 1e300, np.asarray(ro[0]) >= 1e300, err_msg=f'{like_kw} {lam}: +inf class {rp[0]} against {ro[0]}')
+      H.assert_loglike_close(np.where(np.asarray(rp[0]) >= 1e300, 0., rp[0]), np.where(np.asarray(ro[0]) >= 1e300, 0., ro[0]), rtol=RTOL_L, atol=1e-9)
+      np.testing.assert_allclose(rp[3], ro[3], rtol=1e-10, atol=1e-8, equal_nan=True, err_msg=f'{like_kw} {lam}')
+      assert (a == bt) or (np.isnan(a) and np.isnan(bt))
+    if like_kw.get('kernel') == 'gauss' and like_kw.get('cut_grid') is None and like_kw.get('binning') and kind is None:
+      with np.errstate(all='ignore'):
+        assert np.any(np.asarray(like_o.compute_all(gamma=np.inf)[0]) >= 1e300), like_o.compute_all(gamma=np.inf)[0]     # the case the test is about does occur
+    like_p.close()
+
+
 @pytest.mark.parametrize('kind', ['marginalized', 'approximate', 'full', None])
 def test_unphysical_cosmology_behaves_like_the_reference(kind):
   """A strongly closed universe with E(z)^2 < 0 beyond z ~ 2: the distance tables carry NaNs and dL(z) is not monotonic.  The
