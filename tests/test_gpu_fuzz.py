@@ -29,6 +29,24 @@ def test_randomized_configurations_and_hostile_inputs(share, seed0, many):
   assert not bad, '\n'.join(bad)
 
 
+@pytest.mark.parametrize('seed,inf_share', [(6001464, 0.03), (6009213, 0.03), (7001164, 0.1)])
+def test_findings_of_the_round_5_campaigns(seed, inf_share):
+  """[r5] The three configurations the round's campaigns found (30 % hostile, 30 % extreme draws, every 40th with 500+ events; profiles/r05/fuzz_final_binary.txt):
+  6001464 -- gamma = +inf in the 1-D mode with a Gaussian kernel and no cut_grid: p_gw1d vanishes nowhere, L_i = +inf (fixed: k_integrate_1d forms the
+  reference's products over the whole grid for such a draw);  6009213 and 7001164 -- full mode, plp with lambda_peak = 1, sigma_g = 0.5: an event whose whole
+  weight sits on one sample (1 - sum W^2 = 1e-10 / 4e-12), a covariance of rank one divided by ~0 -- the checker leaves such an event out, keyed on the
+  conditioning number of the ORACLE's weights (never on the difference)."""
+  import fuzz_parity as F
+  keep = (F.HOSTILE_SHARE, F.EXTREME_SHARE, F.INF_RATE_SHARE, F.CHECK_PGW)
+  F.HOSTILE_SHARE, F.EXTREME_SHARE, F.INF_RATE_SHARE, F.CHECK_PGW = 0.3, 0.3, inf_share, True
+  try:
+    ok, desc, checks = F.one(np.random.default_rng(77000 + seed), many_events=seed % 40 == 39)
+  finally:
+    F.HOSTILE_SHARE, F.EXTREME_SHARE, F.INF_RATE_SHARE, F.CHECK_PGW = keep
+  assert ok, desc[:1500]
+  assert 'oracle' in checks and 'p_gw' in checks
+
+
 @pytest.mark.parametrize('mass', ['tpl', 'plp', 'bpl'])
 @pytest.mark.parametrize('kind', ['marginalized', None])
 def test_nan_primary_mass_by_mass_model(mass, kind):
