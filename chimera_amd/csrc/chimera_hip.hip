@@ -1166,10 +1166,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   if (zc_use && (c.zc_zmax != params[0].z_max || c.zc_Tc != params[0].z_grid_res)) zc_make = true;
   // ---- graph bookkeeping: the key lists everything the captured launch arguments depend on
   // completion through the flags in pinned memory (wait_flags): zero-copy results, spinning wait, nothing copied back behind the last kernel
-#ifndef CHM_DONE_FLAGS
-#define CHM_DONE_FLAGS 1        // 0 (A/B builds): completion through hipStreamQuery as in round 4
-#endif
-  const bool use_flags = CHM_DONE_FLAGS && zero_copy && o.spin_wait != 0 && nb <= o.few_nb && !out->partials && !out->log_like_evs && !out->numlike_evs && !want_dump && !tab;
+  const bool use_flags = zero_copy && o.spin_wait != 0 && nb <= o.few_nb && !out->partials && !out->log_like_evs && !out->numlike_evs && !want_dump && !tab;
   std::vector<long long> key;
   bool capturing = false;
   long long zmax_bits = 0; { const double zm = params[0].z_max; memcpy(&zmax_bits, &zm, 8); }
@@ -1328,13 +1325,9 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       const int zf_epb = zf_stats ? 4 / CHM_ZF_WPE_FEW : 4;       // ranged: events per block pass (a wave per event; CHM_ZF_WPE_FEW waves per event for few draws)
       const int zf_units = zf_mode ? (L.E_cnt + zf_epb - 1) / zf_epb : L.E_cnt;
       const int zf_blocks = zf_units < zf_target ? zf_units : zf_target;
-      // [r5] the selection blocks of a fused few-draw call ride in the SAMPLE-stage launch (k_samp_sel) when that is the fast sample kernel: the
-      // per-z-factor launch is then its own short self (k_zf_sel lasted as long as one selection block)
-      // (-DCHM_SAMP_SEL=1 builds, A/B: measured SLOWER -- profiles/r05/ab_scalar_call_r05.txt: the merged kernel needs 159 VGPRs, three waves per SIMD, and
-      //  the one-draw sample stage goes from 57 to 71 us, the scalar call from 0.168 to 0.182 ms -- the default keeps k_zf_sel)
-      const bool sel_in_samples = CHM_SAMP_SEL && fuse_sel && use_fast && L.mode != CHM_MODE_FULL;
+      // (the selection blocks inside the SAMPLE-stage launch instead were measured slower: profiles/r05/ab_scalar_call_r05.txt, docs/history/pruned_ab_arms_r06.patch)
       auto launch_zfactors = [&]() {
-        if (fuse_sel && !sel_in_samples) {                  // + the selection sums: blocks [zf_blocks, zf_blocks + gx)
+        if (fuse_sel) {                  // + the selection sums: blocks [zf_blocks, zf_blocks + gx)
           SelDev S = sel->S;
           int gx = 8192 / nb; gx = gx < 1 ? 1 : (gx > S.nblocks ? S.nblocks : gx);
           const size_t lds_f = lds_zfac > lds_sel ? lds_zfac : lds_sel;
@@ -1376,19 +1369,6 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       samp_blocks = samp_blocks < 1 ? 1 : (samp_blocks > 1024 ? 1024 : samp_blocks);
       dim3 g1(samp_blocks * nb, 1);
       const bool fullm = L.mode == CHM_MODE_FULL;
-#if CHM_SAMP_SEL
-      if (sel_in_samples) {
-        SampFast F = like->F; F.lut = lutA;
-        SelDev Ss = sel->S;
-        int gx = 8192 / nb; gx = gx < 1 ? 1 : (gx > Ss.nblocks ? Ss.nblocks : gx);
-        const size_t lds_f = lds_fast > lds_sel ? lds_fast : lds_sel;
-#define LAUNCH_SS(M) do { allow_lds((k_samp_sel<M>), lds_f); \
-          hipLaunchKernelGGL((k_samp_sel<M>), dim3(g1.x + gx * nb), dim3(64 * CHM_SF_WAVES), lds_f, sg, L, F, Ss, lutB, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm, gx); } while (0)
-        const int mm = params[0].mass_model;
-        if (mm == 0) LAUNCH_SS(0); else if (mm == 1) LAUNCH_SS(1); else LAUNCH_SS(2);
-#undef LAUNCH_SS
-      } else
-#endif
       if (use_fast) {
         SampFast F = like->F; F.lut = lutA;
 #define LAUNCH_FAST_(M, FU, NTL) do { allow_lds((k_samples_fast<M, FU, NTL>), lds_fast); \
@@ -1432,9 +1412,8 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         if (fast) {
           // several pixel groups (pairs of pixels) of the same (event, draw) per wave, one after the other: event statistics and segment
           // offsets once (four items per wave: 5.45 ms at C3 / 128 draws, two: 5.51, one: 5.66)
-          // [r5] CHM_GW_SW (build knob, A/B): lanes per pixel in the standard GW kernel -- 32 (two pixels per wave, the default) or 64 (one pixel per wave:
-          // 4.8 KB of LDS per wave, which lifts the cap of 16 waves per CU that 9.6 KB per wave set; profiles/r05/ab_gw_kernel_r05.txt)
-          constexpr int GW_SW = CHM_GW_SW, GW_NPW = 64 / GW_SW;
+          // (two pixels per wave, 32 lanes each; one pixel per wave was measured 40 % slower at equal occupancy: profiles/r05/ab_gw_kernel_r05.txt)
+          constexpr int GW_SW = 32, GW_NPW = 64 / GW_SW;
           const int PG2 = (Pd + GW_NPW - 1) / GW_NPW;
           const int ipw_env = o.kde_ipw;                    // diagnostics: 2 or 4 items per wave
           // (few draws per call: two items per wave -- twice the waves, half the serial chain of each: 0.238 -> 0.229 ms for the scalar call at C3)

@@ -753,51 +753,27 @@ __global__ void __launch_bounds__(256) k_fill_logs(const double* m1, const doubl
 }
 
 // build-time knobs of the fast sample stage (A/B through scripts/build_variant.sh): waves per block (each chunk always has SAMPLE_WPB
-// partial records: with fewer waves the surplus records are written neutral), waves per SIMD the register budget is cut for,
-// loads of the next tile issued before the arithmetic of the current one
+// partial records: with fewer waves the surplus records are written neutral), waves per SIMD the register budget is cut for
 #ifndef CHM_SF_WAVES
 #define CHM_SF_WAVES 4
 #endif
 #ifndef CHM_SF_MINW
 #define CHM_SF_MINW 4
 #endif
-#ifndef CHM_SF_PREFETCH
-#define CHM_SF_PREFETCH 0
-#endif
 static_assert(SAMPLE_WPB % CHM_SF_WAVES == 0, "records per chunk must be a multiple of the waves per block");
-// PF: the next tile's loads are issued before the arithmetic of the current one, compiled for 3 waves per SIMD so that the twelve extra
-// registers do not spill.  Measured for calls of one draw, where every block of the grid is resident at once: the scalar call takes
-// 0.242 instead of 0.232 ms -- the fourth wave per SIMD hides more latency than the prefetch (profiles/r02/ab_scalar_call_*.txt)
-#ifndef CHM_SF_PREFETCH_NT
-#define CHM_SF_PREFETCH_NT 0
-#endif
-#ifndef CHM_SF_RELOAD
-#define CHM_SF_RELOAD 0
-#endif
-#ifndef CHM_SF_NPV_PF
-#define CHM_SF_NPV_PF 0
-#endif
-// (body shared by k_samples_fast and k_samp_sel: block bx of nbx of draw b)
-template <int MASS, bool FULL, bool NT, bool PF>
+// (block bx of nbx of draw b)
+template <int MASS, bool FULL, bool NT>
 DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParams* params, const double* zt_all,
                              const double* dLt_all, const double* mg_all, const double* cdf_all,
                              const double* rec_all, int TcMax, int TmMax, const int b, const int bx, const int nbx, double* lds) {
 #pragma clang fp contract(fast)                  // sums of products may fuse; z comes from z_from_lut_x2 / jnp_interp (contract off) untouched
-#ifndef CHM_SF_LOGS_INLINE
-#define CHM_SF_LOGS_INLINE 0      // measured (profiles/r03/ab_scalar_call_r03.txt): 66.6 against 59.8 us for the one-draw kernel with the logs formed here -- off
-#endif
-#ifndef CHM_SF_STAGGER
-#define CHM_SF_STAGGER 0          // few draws per call: every other block starts CHM_SF_STAGGER x ~1 us late (load and arithmetic phases of the two halves interleave)
-#endif
-  if (NT && CHM_SF_STAGGER > 0 && (blockIdx.x & 1)) { for (int i = 0; i < CHM_SF_STAGGER; i++) __builtin_amdgcn_s_sleep(32); }
-  constexpr bool LOGS_HERE = NT && (CHM_SF_LOGS_INLINE != 0);
   constexpr int NT_ = 64 * CHM_SF_WAVES;
   const int t = threadIdx.x, lane = t & 63;
   DevParams P = params[b];            // by value: uniform loads at kernel start, nothing re-read in the loops
 #ifndef CHM_SF_NPV
 #define CHM_SF_NPV 4
 #endif
-  mass_params_to_vgpr<MASS, FULL ? 0 : (PF ? CHM_SF_NPV_PF : CHM_SF_NPV)>(P);       // (mass-model parameters in vector registers: the scalar file cannot hold the whole draw)
+  mass_params_to_vgpr<MASS, FULL ? 0 : CHM_SF_NPV>(P);       // (mass-model parameters in vector registers: the scalar file cannot hold the whole draw)
   const double* g_zt = zt_all + (size_t)b * TcMax;
   const double* g_dLt = dLt_all + (size_t)b * TcMax;
   const int Tc = P.Tc, Tm = P.Tm;
@@ -863,19 +839,14 @@ DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParam
       // memory-side cache for the GW kernel; with many draws per call the tiles are shared by the draws' blocks and stay cacheable
       auto ld = [&](const double2* q) { if (NT) { double2 v; v.x = __builtin_nontemporal_load(&q->x); v.y = __builtin_nontemporal_load(&q->y); return v; } return *q; };
       a_ = ld(tp); b_ = ld(tp + SF_TILE / 2); c_ = ld(tp + 2 * SF_TILE / 2); d_ = ld(tp + 3 * SF_TILE / 2);
-      if (!LOGS_HERE) { e_ = ld(tp + 4 * SF_TILE / 2); f_ = ld(tp + 5 * SF_TILE / 2); }
+      e_ = ld(tp + 4 * SF_TILE / 2); f_ = ld(tp + 5 * SF_TILE / 2);
     };
     const int s_first = c * SAMPLE_CHUNK + 2 * t;
-    if (PF && s_first < s_end) load_tile(s_first, a, bb, cc, dd, ee, ff);
 #pragma unroll 1
     for (int s = s_first; s < s_end; s += 2 * NT_) {      // one tile of 128 samples per wave and pass
-      double2 na, nb_, nc, nd, ne, nf;
-      if (PF) { if (s + 2 * NT_ < s_end) load_tile(s + 2 * NT_, na, nb_, nc, nd, ne, nf); }
-      else load_tile(s, a, bb, cc, dd, ee, ff);
+      load_tile(s, a, bb, cc, dd, ee, ff);
       const double dl[2] = { a.x, a.y }, md1[2] = { bb.x, bb.y }, md2[2] = { cc.x, cc.y }, ipr[2] = { dd.x, dd.y };
-      // few draws per call (NT): the kernel waits for HBM -- the logs of the masses are formed here (k_fill_logs's values) instead of read
-      // (inside the loop over the two samples below: one sample's pair of logs at a time, four at once spill)
-      const double l1[2] = { LOGS_HERE ? 0. : ee.x, LOGS_HERE ? 0. : ee.y }, l2[2] = { LOGS_HERE ? 0. : ff.x, LOGS_HERE ? 0. : ff.y };
+      const double l1[2] = { ee.x, ee.y }, l2[2] = { ff.x, ff.y };
       double zz[2], wv[2], z0[2] = { 0., 0. }, lz0[2] = { 0., 0. };
       bool bad = true, anybad = true;
       if (FITS) {                                     // z = z_from_dGW(dL) (cosmo.py:260-264)
@@ -885,22 +856,6 @@ DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParam
           if (bad) { zz[0] = jnp_interp(dl[0], g_dLt, g_zt, Tc, false, 0., 0.); zz[1] = jnp_interp(dl[1], g_dLt, g_zt, Tc, false, 0., 0.); }
         }
       } else z_from_dGW_x2(P, dl[0], dl[1], g_dLt, g_zt, zz[0], zz[1]);
-#if CHM_SF_RELOAD
-      // (experiment) the mass model's parameters behind scalar loads issued once per pass: the pointer is laundered (no hoisting out of the loop)
-      // and sits in the constant address space (s_load, not a uniform vector load)
-      DevParams Pq_;
-      {
-        typedef const __attribute__((address_space(4))) double* cdp_t;
-        cdp_t cd = (cdp_t)(params + b);
-        asm volatile("" : "+s"(cd));
-        double* dst = reinterpret_cast<double*>(&Pq_);
-#pragma unroll
-        for (int i = 4; i < (int)(sizeof(DevParams) / 8); i++) dst[i] = cd[i];
-        Pq_.cosmo_model = P.cosmo_model; Pq_.mass_model = P.mass_model; Pq_.rate_model = P.rate_model; Pq_.Tc = P.Tc; Pq_.Tm = P.Tm;
-        Pq_.scale_free = P.scale_free; Pq_.has_catalog = P.has_catalog; Pq_.pad0 = 0;
-      }
-      const DevParams* pl = &Pq_;
-#endif
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         // m_src = m_det/(1+z) (pop_wrapper.py:70); w = p_m1m2 / pe_prior (pop_wrapper.py:79; the tile holds 1/pe_prior)
@@ -915,12 +870,7 @@ DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParam
           lz = log1pz_from_node(z, z0[h], lz0[h], r, v);
           if (anybad || wave_any(!(v <= 0.02))) { if (bad || !(v <= 0.02)) lz = chm_log_pos(zp1); }      // (votes on single compares, see z_from_lut_x2)
         } else lz = chm_log_pos(zp1);
-        const double lm1 = LOGS_HERE ? chm_log(md1[h]) : l1[h], lm2 = LOGS_HERE ? chm_log(md2[h]) : l2[h];
-#if CHM_SF_RELOAD
-        const double w = p_m1m2_fused<MASS>(*pl, m1, m2, lm1 - lz, lm2 - lz, mg, cdf, ex) * ipr[h];
-#else
-        const double w = p_m1m2_fused<MASS>(P, m1, m2, lm1 - lz, lm2 - lz, mg, cdf, ex) * ipr[h];
-#endif
+        const double w = p_m1m2_fused<MASS>(P, m1, m2, l1[h] - lz, l2[h] - lz, mg, cdf, ex) * ipr[h];
         wv[h] = w;
         if (s + h < s_end) {
           const double d = z - z_ref;
@@ -940,7 +890,6 @@ DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParam
         wz[s] = zz[0]; ww[s] = wv[0];
         if (s + 1 < s_end) { wz[s + 1] = zz[1]; ww[s + 1] = wv[1]; }
       }
-      if (PF) { a = na; bb = nb_; cc = nc; dd = nd; ee = ne; ff = nf; }
     }
     };
     if (fits) passes(std::true_type{}); else passes(std::false_type{});
@@ -965,12 +914,12 @@ DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParam
     }
   }
 }
-template <int MASS, bool FULL, bool NT = false, bool PF = (CHM_SF_PREFETCH != 0) || (NT && CHM_SF_PREFETCH_NT != 0)>
+template <int MASS, bool FULL, bool NT = false>
 __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast(LikeDev L, SampFast F, const DevParams* params, const double* zt_all,
                                                                     const double* dLt_all, const double* mg_all, const double* cdf_all,
                                                                     const double* rec_all, int TcMax, int TmMax) {
   extern __shared__ double lds[];
-  samples_fast_body<MASS, FULL, NT, PF>(L, F, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.x % L.nb, blockIdx.x / L.nb, gridDim.x / L.nb, lds);
+  samples_fast_body<MASS, FULL, NT>(L, F, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.x % L.nb, blockIdx.x / L.nb, gridDim.x / L.nb, lds);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1754,12 +1703,6 @@ template <int SW> DEVFN double sg_max(double v) {
 #ifndef CHM_NRS
 #define CHM_NRS 256
 #endif
-#ifndef CHM_GW_PREF
-#define CHM_GW_PREF 0            // [r5] 1 (A/B builds): the next item's samples are loaded into the register rounds right after this item's histogram
-#endif
-#ifndef CHM_GW_DIET
-#define CHM_GW_DIET 1            // [r5] 0: the round-4 set-up of kde_sub_item (A/B builds, profiles/r05/ab_gw_setup_diet.txt)
-#endif
 #define CHM_WS_PAD 512           // doubles behind the (z, w) workspaces: the register rounds of the standard GW kernel read past a pixel's segment unconditionally
 // Instruction-level helpers of the standard GW kernel.  On gfx950 every VALU instruction except the simplest 32-bit ones (v_mov_b32,
 // v_add/sub_u32, v_and_b32, v_ashrrev_i32, v_fma/mul_f32) occupies the SIMD for 4 cycles per wave64 -- fp64 arithmetic, 64-bit moves,
@@ -1803,32 +1746,6 @@ template <int SW> DEVFN double sg_last_perm(double x) {
   return __hiloint2double(hi, lo);
 }
 
-// [r5] totals of a group of <= 32 lanes on the LDS crossbar: butterfly exchange with ds_swizzle_b32 (bit-mask mode: lane ^ k inside each half of
-// the wave; no LDS memory, no VALU slot for the two moves of a level -- a DPP level costs two v_mov_b32_dpp + the add).  Every lane ends with the
-// total, so the broadcast of the group's last lane (ds_bpermute) goes too.  For the quantities of which only the total is used: max z of the
-// pixel, sum of the squared bin weights, the pixel's integral and its rounding bound.  The additions pair up differently from the scan's
-// (butterfly instead of left to right): the same sum to rounding, the same bits in every call shape (all go through this function).
-#ifndef CHM_GW_SWZ
-#define CHM_GW_SWZ 0
-#endif
-template <int XOR>
-DEVFN double swz_xor(double x) {
-  constexpr int pat = 0x1f | (XOR << 10);
-  return __hiloint2double(__builtin_amdgcn_ds_swizzle(__double2hiint(x), pat), __builtin_amdgcn_ds_swizzle(__double2loint(x), pat));
-}
-template <int SW> DEVFN double sg_allsum_swz(double x) {
-  static_assert(SW <= 32, "ds_swizzle does not cross the halves of a wave");
-  x += swz_xor<1>(x); x += swz_xor<2>(x); x += swz_xor<4>(x); x += swz_xor<8>(x);
-  if (SW >= 32) x += swz_xor<16>(x);
-  return x;
-}
-template <int SW> DEVFN double sg_allmax_swz(double x) {
-  static_assert(SW <= 32, "ds_swizzle does not cross the halves of a wave");
-  x = vmax_f64(x, swz_xor<1>(x)); x = vmax_f64(x, swz_xor<2>(x)); x = vmax_f64(x, swz_xor<4>(x)); x = vmax_f64(x, swz_xor<8>(x));
-  if (SW >= 32) x = vmax_f64(x, swz_xor<16>(x));
-  return x;
-}
-
 // kde_sub_item<SW, NR, BINS, DUMP>: one pixel per group of SW lanes.  Preconditions checked by the host (chm_eval): binning with the
 // effective grid cut (cut_grid set), an even number of grid points Z (16-byte pairs (k, k+1), k even, never leave the row).
 // [r3] The grid loop was rewritten for the instruction count (191 -> ~110 VALU per pass of 2 x SW grid points):
@@ -1845,11 +1762,11 @@ template <int SW, int NR, int BINS, bool DUMP, bool NT, bool PRE = false>
 DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, const double* es, const int b, const int e, const int p,
                         const int pp, const bool live, const bool poisoned, const int s0, const int s1, double (&zr)[NR], double (&wr)[NR],
                         const double hi_pre = 0., double* Q12 = nullptr, double* out_like_pre = nullptr, double* out_err_pre = nullptr, const int nit = NR,
-                        unsigned long long* ph_prev_p = nullptr, const bool ph_on_ = false, const unsigned nxt_boff = 0u, const int nxt_nit = 0) {
+                        unsigned long long* ph_prev_p = nullptr, const bool ph_on_ = false) {
 #pragma clang fp contract(fast)                  // a*b+c may fuse in this body; the bin index lives in bin_index_r() (contract off)
   // [r5] FAST (the production instantiations: compile-time bin count, histogram formed here): the set-up sheds what the compiler had wrapped
   // round its arithmetic -- see the notes at each step (profiles/r05/ab_gw_setup_diet.txt)
-  constexpr bool FAST = !PRE && BINS > 0 && (CHM_GW_DIET != 0);
+  constexpr bool FAST = !PRE && BINS > 0;
   const int lane = threadIdx.x, sl = lane % SW;
   const int S = L.S, Z = L.Z, B = BINS > 0 ? BINS : L.num_bins, G = L.G;      // BINS > 0: the bin count is a compile-time constant (LDS offsets, loop bounds)
   const double zmin = es[0], norm = es[3], lb = es[6], ub = es[7];
@@ -1865,39 +1782,16 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   const int k_lo = ((int)es[8]) & ~1, k_hi = (int)es[9];   // event_stats: k_hi is odd when Z is even -- both points of a pair are in range together
   // two consecutive grid points of every array for this lane: 16-byte loads at a clamped (always valid) pair index -- lanes beyond k_hi
   // load the row's last pair and never use it.  The three event-level rows are addressed as uniform base + 32-bit lane offset.
-  // [r4] CHM_GW_PAIRS = 0 (A/B builds): a lane takes the grid points k and k + SW of a pass instead of the pair (k, k + 1).  The bin index of a node
-  // advances ~1.1 bins per grid point: with pairs, consecutive lanes stood ~2.2 bins apart and the 32 lanes of a pixel wrapped the 32
-  // double-wide LDS banks more than twice in every read of the prefix arrays (a third of the LDS-active cycles of this kernel were bank
-  // conflicts, profiles/r03); with stride-1 lanes a read touches ~36 consecutive doubles.  The four rows are then read with 8-byte loads
-  // (k and k + SW at one address + an immediate offset).
-#ifndef CHM_GW_PAIRS
-#define CHM_GW_PAIRS 1          // measured (profiles/r04/ab_gw_kernel_r04.txt): stride-1 lanes 5.12 against 4.78 ms for the kernel -- the 8-byte loads cost more than the bank conflicts -- off
-#endif
-  const int kcap = CHM_GW_PAIRS ? Z - 2 : Z - 1;
+  const int kcap = Z - 2;
   struct Pass { double2 pc, z, bk, a; };                    // .x / .y: the lane's first / second grid point of the pass
   auto load_pass = [&](int k) {
     const unsigned off = (unsigned)(k < kcap ? k : kcap) * 8u;
     Pass q;
-#if !CHM_GW_PAIRS
-    {
-      const unsigned off2 = (unsigned)(k + SW < kcap ? k + SW : kcap) * 8u;       // (both clamped on their own: always valid addresses, used only in range)
-      auto at = [](const double* base, unsigned o) { return reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + o); };
-#ifndef CHM_NO_NT
-      if (NT) { q.pc.x = __builtin_nontemporal_load(at(pc, off)); q.pc.y = __builtin_nontemporal_load(at(pc, off2)); } else
-#endif
-      { q.pc.x = *at(pc, off); q.pc.y = *at(pc, off2); }
-      q.z.x = *at(zg, off); q.z.y = *at(zg, off2); q.bk.x = *at(bkgA, off); q.bk.y = *at(bkgA, off2); q.a.x = *at(Aw, off); q.a.y = *at(Aw, off2);
-      return q;
-    }
-#endif
     // p_cat is read once per (event, pixel, call): few-draw calls (IPW = 2) stream it past the caches (non-temporal), so that the z / w the
     // sample stage has just written are still in the memory-side cache when this kernel asks for them; with many draws per call the
     // rows are shared by the draws' waves and stay cacheable
     const double2* pcp = reinterpret_cast<const double2*>(reinterpret_cast<const char*>(pc) + off);
-#ifndef CHM_NO_NT
-    if (NT) { q.pc.x = __builtin_nontemporal_load(&pcp->x); q.pc.y = __builtin_nontemporal_load(&pcp->y); } else
-#endif
-    q.pc = *pcp;
+    if (NT) { q.pc.x = __builtin_nontemporal_load(&pcp->x); q.pc.y = __builtin_nontemporal_load(&pcp->y); } else q.pc = *pcp;
     q.z = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(zg) + off);
     q.bk = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(bkgA) + off);
     q.a = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(Aw) + off);
@@ -1905,7 +1799,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   };
   PHG(0);                                                   // (phase 0: the item's samples have arrived)
   // p_cat, grid, background and trapezoid factors of the first pass: in flight during the histogram phase
-  const int k_first = k_lo + (CHM_GW_PAIRS ? 2 * sl : sl);
+  const int k_first = k_lo + 2 * sl;
   Pass cur = load_pass(k_first);
   // histogram of the pixel's samples on [min z, max z in pixel] (math.py:32-46, likelihood.py:180-183)
   const size_t so = ((size_t)b * L.E + e) * S;
@@ -1930,8 +1824,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   double* const Q0 = Q; double* const Q1 = PRE ? Q12 : Q + (B + 1); double* const Q2 = PRE ? Q12 + (B + 1) : Q + 2 * (B + 1);      // P0 | -2 P1 | P2, (B + 1) doubles each
   constexpr int PERC = BINS > 0 ? (BINS + SW - 1) / SW : 1;  // bins per lane (compile-time bin count)
   if (!PRE) {
-    if (FAST && CHM_GW_SWZ && SW <= 32) hi = sg_allmax_swz<(SW <= 32 ? SW : 32)>(hi);
-    else hi = sg_last_perm<SW>(sg_scan_max0<SW>(hi));       // z >= 0: z_from_dGW interpolates a table that starts at z = 0 (cosmo.py:43-46)
+    hi = sg_last_perm<SW>(sg_scan_max0<SW>(hi));       // z >= 0: z_from_dGW interpolates a table that starts at z = 0 (cosmo.py:43-46)
     if (lo != lo) hi = lo;
     if (FAST) {
       // PERC stores per lane at immediate offsets, no loop, no bound: [0, PERC SW) covers the B counts and runs into the first slots of the
@@ -1958,15 +1851,6 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
     }
     if (nit >= NR) for (int s = s0 + sl + SW * NR; s < s1; s += SW) atomicAdd(&Q0[bin_index_r(wz[s], lo, dhl, rhl, dB)], ww[s]);
     wave_sync();
-    // [r5] CHM_GW_PREF: the register rounds are dead from here on -- the NEXT item's samples are requested into them now and arrive under the prefix
-    // sums, the bandwidth and the grid loop of this item (a wave waited ~1.1 us per item for its samples: 14 % of its life, scripts/phase_gw.py)
-    if (FAST && CHM_GW_PREF && nxt_nit > 0) {
-#pragma unroll
-      for (int j = 0; j < NR; j++) if (j < nxt_nit) {
-        zr[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(wz) + (size_t)nxt_boff + (size_t)(8 * SW * j));
-        wr[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ww) + (size_t)nxt_boff + (size_t)(8 * SW * j));
-      }
-    }
   }
   PHG(1);                                                   // (phase 1: max z, zeroing, histogram -- and the first pass's loads, waited for here by the mark)
   // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins (a compile-time 7 for 200 bins on 32 lanes)
@@ -1993,7 +1877,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   }
   const double x0 = sg_scan_add0<SW>(s0w), x1 = sg_scan_add0<SW>(s1w), x2 = sg_scan_add0<SW>(s2w);
   const double tot = sg_last_perm<SW>(x0);
-  const double sum2 = (FAST && CHM_GW_SWZ && SW <= 32) ? sg_allsum_swz<(SW <= 32 ? SW : 32)>(sq) : sg_last_perm<SW>(sg_scan_add0<SW>(sq));
+  const double sum2 = sg_last_perm<SW>(sg_scan_add0<SW>(sq));
   // End of the last lane chunk of bins that holds any weight.  The prefix values of the lanes after it come out of different
   // summation trees and agree only to an ulp: a node that sees nothing but the empty bins above the data would get 1e-16 of the
   // peak where the dense sum (math.py:80) has an exact zero -- which decides log L_i when the catalogue term is only non-zero out
@@ -2066,7 +1950,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   const double zlo = degenerate ? lb : __builtin_fmax(lb, lo - bw - de), zhi = degenerate ? ub : __builtin_fmin(ub, hi + bw + de);
   // density (without the common factor `scale`) at the node with g' = g - lo whose bin range comes from the truncations of xa, xb
   auto node = [&](double gp, double xa, double xb) {
-    const int ia = CHM_GW_DIET ? med3_i32_0v(cvt_i32_sat(xa), jl1) : med3_i32(cvt_i32_sat(xa), 0, jl1);
+    const int ia = med3_i32_0v(cvt_i32_sat(xa), jl1);
     const int ib = med3_i32(cvt_i32_sat(xb), ia, jl1);
     const double S0 = Q0[ib] - Q0[ia], S1 = Q1[ib] - Q1[ia], S2 = Q2[ib] - Q2[ia];   // S1 = -2 sum W c'
     const double qq = fma(gp, fma(gp, S0, S1), S2);         // sum W (g' - c')^2 over the support
@@ -2084,13 +1968,10 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   double acc = 0., accC = 0.;
   if (DUMP && live) { for (int k = sl; k < Z; k += SW) if (k < k_lo || k > k_hi) dump[k] = 0.; }
   // p_gw at a grid point = interpolant of the two effective-grid nodes that bracket it (0 outside the pixel's support); each point takes its
-  // own two nodes.  (CHM_GW_SHARE3: the two points (k, k + 1) of a lane share THREE node evaluations when their brackets start at the same
-  // or at consecutive nodes -- 20 instructions fewer per pass on paper, slower on the card: the wider live set spills and the uniform test
-  // serialises the pass.)
+  // own two nodes.
   // Bracket of z: nodes x_i = lb + i de, i = floor((z - lb)/de) in [0, G - 1] inside the support (lb <= zlo, zhi <= ub); z = ub lands on the
   // last node with weight 0 (jnp.interp's fp[-1]); a z within rounding of a node may pick either neighbouring segment -- the interpolant is
   // continuous there.  A NaN grid point counts as inside and comes out NaN through the interpolation weight.
-  const double oc1 = dd + ob1, oc2 = dd + ob2, de2 = de + de;
   auto interp = [&](const double zrel, const double tp, const double da, const double db) {
     const double wgt = fma(-tp, de, zrel) * inv_de;         // (z - x_a)/dx
     return fma(wgt, db - da, da) * sng;
@@ -2112,44 +1993,21 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   // [r5] a pass in which no lane's FIRST point lies at or below its pixel's zhi ends the loop: the grid ascends, so every later point of either
   // pixel is beyond the support too (p_gw = 0 exactly: nothing to add to the integral; the rounding bound then sums |C_k| over [k_lo, here),
   // which still covers the support).  A NaN grid point or a NaN zhi keeps the loop going.  Not in the instantiation that stores p_gw.
-  constexpr bool EXIT_EARLY = FAST && !DUMP && CHM_GW_PAIRS;
+  constexpr bool EXIT_EARLY = FAST && !DUMP;
   auto do_pass = [&](const int k, const Pass& q) -> bool {
     // (a lane beyond k_hi holds the row's last pair and may keep the loop going, which ends at k_hi anyway.  Folding `live` into zhi -- ONE compare under
     //  the vote instead of the mask rebuilt through a VGPR, two instructions fewer per pass -- costs two spilled registers at the 128-register cap.)
     if (EXIT_EARLY && !wave_any(live && !(q.z.x > zhi))) return false;
     if (k <= k_hi && live) {
       const double z0 = q.z.x, z1 = q.z.y;
-      const bool v1 = CHM_GW_PAIRS ? true : (k + SW <= k_hi);    // stride-1 lanes: the second point of the last pass may lie beyond the range
-      const bool in0 = !(z0 < zlo) && !(z0 > zhi), in1 = v1 && !(z1 < zlo) && !(z1 > zhi);
+      const bool in0 = !(z0 < zlo) && !(z0 > zhi), in1 = !(z1 < zlo) && !(z1 > zhi);
       double pg0 = 0., pg1 = 0.;
       if (in0 || in1) {
-#ifdef CHM_GW_SHARE3                                         // measured: 4.96 against 4.81 ms for the kernel (profiles/r03/ab_gw_three_node_sharing.txt) -- off
-        const double zr0 = z0 - lb, zr1 = z1 - lb;
-        const double tp0 = floor(zr0 * inv_de), tp1 = floor(zr1 * inv_de);
-        const double dtp = tp1 - tp0;
-        const bool same = dtp == 0.;
-        if (wave_all(same || dtp == 1.)) {                     // uniform: every lane at work here shares nodes between its two points
-          const double ga = fma(tp0, de, lbl), ta = fma(tp0, dd, t0);
-          const double n0 = node(ga, ta + oa1, ta + oa2), n1 = node(ga + de, ta + ob1, ta + ob2), n2 = node(ga + de2, ta + oc1, ta + oc2);
-          const double f0 = interp(zr0, tp0, n0, n1), f1 = interp(zr1, tp1, same ? n0 : n1, same ? n1 : n2);
-          pg0 = in0 ? f0 : 0.; pg1 = in1 ? f1 : 0.;
-        } else
-#endif
-        {
-#ifndef CHM_GW_BOTH
-#define CHM_GW_BOTH 0
-#endif
-          // PRE (the fused event kernel: two waves per SIMD, 256 VGPRs on offer): both points of the lane in ONE basic block -- their four node
-          // evaluations are independent chains the scheduler can interleave; a lane with one point outside the support computes it for nothing
-          if (PRE && CHM_GW_BOTH) { const double f0 = single(z0), f1 = single(z1); pg0 = in0 ? f0 : 0.; pg1 = in1 ? f1 : 0.; }
-          else {
-            if (in0) pg0 = single(z0);
-            if (in1) pg1 = single(z1);
-          }
-        }
+        if (in0) pg0 = single(z0);
+        if (in1) pg1 = single(z1);
       }
       integrand(k, pg0, q.pc.x, q.bk.x, q.a.x);
-      integrand(k + (CHM_GW_PAIRS ? 1 : SW), pg1, q.pc.y, q.bk.y, q.a.y, v1);
+      integrand(k + 1, pg1, q.pc.y, q.bk.y, q.a.y);
     }
     return true;
   };
@@ -2157,7 +2015,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   // one pass = SW lanes x 2 consecutive grid points per pixel.  Software pipeline in two alternating register sets: the loads of the next
   // pass are issued before the arithmetic of this one and waited for where that pass begins (no register rotation, no wait at the loop end)
   for (int kb = k_lo; kb <= k_hi; kb += 4 * SW) {
-    const int k = kb + (CHM_GW_PAIRS ? 2 * sl : sl);
+    const int k = kb + 2 * sl;
     const Pass nxt = load_pass(k + 2 * SW);
     if (!do_pass(k, cur)) break;                            // uniform
     if (kb + 2 * SW > k_hi) break;                          // uniform
@@ -2167,11 +2025,8 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   // (same-address LDS atomics for these reductions -- ds_max_f64 / ds_add_f64 on one cell per pixel, no VALU slots -- were measured:
   //  5.53 instead of 4.43 ms for the kernel, the LDS pipe serialises the 32 lanes of every such instruction)
   PHG(4);                                                   // (phase 4: the grid loop)
-  if (FAST && CHM_GW_SWZ && SW <= 32) { acc = sg_allsum_swz<(SW <= 32 ? SW : 32)>(acc); accC = sg_allsum_swz<(SW <= 32 ? SW : 32)>(accC); }
-  else {
-    acc = sg_scan_add0<SW>(acc);                            // the group's last lane holds the pixel's integral
-    accC = sg_scan_add0<SW>(accC);
-  }
+  acc = sg_scan_add0<SW>(acc);                              // the group's last lane holds the pixel's integral
+  accC = sg_scan_add0<SW>(accC);
   if (sl == SW - 1 && live) {
     *out_like = poisoned ? nan : acc;
     *out_err = (degenerate || poisoned) ? 0. : errD * accC * fabs(scale * ng);     // NaN results stay NaN: nothing to redo
@@ -2179,14 +2034,8 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   PHG(5);                                                   // (phase 5: the two final scans and the stores)
 }
 
-#ifndef CHM_GW_SW
-#define CHM_GW_SW 32             // lanes per pixel of the standard GW kernel the host launches (64: one pixel per wave, A/B builds)
-#endif
-#ifndef CHM_GW_MINW64
-#define CHM_GW_MINW64 5          // waves per SIMD the one-pixel-per-wave instantiation is compiled for
-#endif
 template <int SW, int IPW, int BINS, bool DUMP>
-__global__ void __launch_bounds__(64, (SW == 64 ? CHM_GW_MINW64 : 4)) k_kde_marg_sub2(LikeDev L, const DevParams* params) {
+__global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevParams* params) {
   extern __shared__ double lds_all[];
   constexpr int NPW = 64 / SW;
   constexpr int NR = CHM_NRS / SW;
@@ -2220,25 +2069,7 @@ __global__ void __launch_bounds__(64, (SW == 64 ? CHM_GW_MINW64 : 4)) k_kde_marg
 #else
   unsigned long long* const ph_ptr = nullptr; const bool ph_on_k = false;
 #endif
-#ifndef CHM_GW_TOUCH
-#define CHM_GW_TOUCH 0
-#endif
-  // CHM_GW_TOUCH (A/B): while an item is worked on, one dword of every 128-byte line of the NEXT item's (z, w) segment is requested and dropped --
-  // the lines are then in L2 when the next item's loads ask for them (the segment was written by the sample stage milliseconds ago: an HBM round trip)
-#if CHM_GW_PREF
-  double zr[NR], wr[NR];                                     // the register rounds of the item at work, then of the next one (they outlive the item)
-#endif
-  bool have = false;                                        // (uniform) zr / wr already hold this item's samples
-  auto nit_of = [&](const int p, const int q0, const int q1) {   // rounds of SW samples the wave's pixels of an item need (uniform); 0: no live pixel
-    const bool lv = p < L.P && p < npx;
-    if (!wave_any(lv)) return 0;
-    const int len = lv ? q1 - q0 : 0;
-    int nmax = 0;
-#pragma unroll
-    for (int g = 0; g < NPW; g++) nmax = max(nmax, __builtin_amdgcn_readlane(len, g * SW));
-    return max(1, min((nmax + SW - 1) / SW, NR));
-  };
-  auto run = [&](const int pgi, const int p, const int pp, const int q0, const int q1, const bool first, const int nq0 = 0, const int nq1 = 0, const int np = 0, const int npgi = 1 << 30) {
+  auto run = [&](const int pgi, const int p, const int pp, const int q0, const int q1, const bool first) {
     if (pgi >= PG) return;                                  // uniform
     const bool live = p < L.P && p < npx;
     if (!ok || !wave_any(live)) {                              // uniform: every pixel of the event (of this item: padded pixels) is 0 (or 0 * NaN)
@@ -2255,19 +2086,9 @@ __global__ void __launch_bounds__(64, (SW == 64 ? CHM_GW_MINW64 : 4)) k_kde_marg
     int nmax = 0;
 #pragma unroll
     for (int g = 0; g < NPW; g++) nmax = max(nmax, __builtin_amdgcn_readlane(s1 - s0, g * SW));
-#ifdef CHM_GW_ALL_ROUNDS                                     // (A/B builds: the round-3 form, every register round loaded and binned)
-    const int nit = NR;
-#else
     const int nit = min((nmax + SW - 1) / SW, NR);
-#endif
-    // CHM_GW_PREF: what kde_sub_item is to request for the item after this one (none: the last item, an item without a live pixel)
-    const int nxt_nit = (CHM_GW_PREF && BINS > 0 && CHM_GW_DIET && npgi < PG) ? nit_of(np, nq0, nq1) : 0;
-    const unsigned nxt_boff = (unsigned)(nq0 + sl) * 8u;
-#if !CHM_GW_PREF
-    double zr[NR], wr[NR];                                   // the register rounds of this item: dead after its histogram (the default: see CHM_GW_PREF)
-#endif
-    if (have) { /* prefetched by the previous item */ }
-    else if (BINS > 0 && CHM_GW_DIET) {
+    double zr[NR], wr[NR];                                   // the register rounds of this item: dead after its histogram
+    if (BINS > 0) {
       // [r5] unconditional loads at ONE 32-bit lane offset + an immediate per round (uniform row base in scalar registers): what stands behind the
       // pixel's segment is the next pixel's samples or the CHM_WS_PAD doubles behind the workspace, and kde_sub_item uses round i only where
       // SW i < s1 - (s0 + sl).  Before: per round a compare, two 64-bit address computations and two moves of the neutral values.
@@ -2281,22 +2102,11 @@ __global__ void __launch_bounds__(64, (SW == 64 ? CHM_GW_MINW64 : 4)) k_kde_marg
 #pragma unroll
       for (int j = 0; j < NR; j++) if (j < nit) { int s = s0 + sl + SW * j; zr[j] = s < s1 ? wz[s] : lo; wr[j] = s < s1 ? ww[s] : 0.; }
     }
-    int t1 = 0, t2 = 0;
-    if (CHM_GW_TOUCH) {
-      const int ts = nq0 + sl * 16;
-      // (round 4 measured this with NON-TEMPORAL loads -- a streaming hint: the lines need not stay in L2 -- and lost 9 %; CHM_GW_TOUCH = 2 asks with plain loads)
-      if (ts < nq1) {
-        if (CHM_GW_TOUCH == 2) { t1 = *reinterpret_cast<const int*>(wz + ts); t2 = *reinterpret_cast<const int*>(ww + ts); }
-        else { t1 = __builtin_nontemporal_load(reinterpret_cast<const int*>(wz + ts)); t2 = __builtin_nontemporal_load(reinterpret_cast<const int*>(ww + ts)); }
-      }
-    }
-    kde_sub_item<SW, NR, BINS, DUMP, (IPW <= 2)>(L, params, Q, es, b, e, p, pp, live, poisoned, s0, s1, zr, wr, 0., nullptr, nullptr, nullptr, nit, ph_ptr, ph_on_k, nxt_boff, nxt_nit);
-    have = nxt_nit > 0;
-    if (CHM_GW_TOUCH) asm volatile("" :: "v"(t1), "v"(t2));
+    kde_sub_item<SW, NR, BINS, DUMP, (IPW <= 2)>(L, params, Q, es, b, e, p, pp, live, poisoned, s0, s1, zr, wr, 0., nullptr, nullptr, nullptr, nit, ph_ptr, ph_on_k);
   };
-  run(blockIdx.y, pA, ppA, a0, a1, true, b0, b1, pB, blockIdx.y + H);
-  run(blockIdx.y + H, pB, ppB, b0, b1, false, c0, c1, pC, IPW > 2 ? blockIdx.y + 2 * H : (1 << 30));
-  if (IPW > 2) { run(blockIdx.y + 2 * H, pC, ppC, c0, c1, false, d0, d1, pD, blockIdx.y + 3 * H); run(blockIdx.y + 3 * H, pD, ppD, d0, d1, false); }
+  run(blockIdx.y, pA, ppA, a0, a1, true);
+  run(blockIdx.y + H, pB, ppB, b0, b1, false);
+  if (IPW > 2) { run(blockIdx.y + 2 * H, pC, ppC, c0, c1, false); run(blockIdx.y + 3 * H, pD, ppD, d0, d1, false); }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -3379,31 +3189,6 @@ __global__ void __launch_bounds__(256, CHM_SELF_MINW) k_zf_sel(LikeDev L, SelDev
   else selection_fast_body<MASS>(Sd, lut, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.y, blockIdx.x, sel_blocks, lds, red);
 }
 
-#ifndef CHM_SAMP_SEL
-#define CHM_SAMP_SEL 0          // 1 (A/B builds): the selection blocks of a fused few-draw call inside the sample-stage launch (k_samp_sel) -- measured slower, see chm_eval
-#endif
-#if CHM_SAMP_SEL
-// [r5] k_samp_sel<MASS>: the sample stage of a few-draw call (k_samples_fast<MASS, false, true>) with the selection sums in the SAME launch -- the first
-// sel_blocks * nb blocks are selection blocks (dispatched first), the rest the sample stage's.  In round 3-4 the selection blocks rode in the
-// per-z-factor launch (k_zf_sel): that launch then lasted as long as ONE selection block (~14 us: a block stages its tables and walks 512 injections),
-// twice what the per-z factors need on their own; inside the 50 us sample stage they cost nothing.  The selection function depends on the
-// tables only, as the sample stage does.
-template <int MASS>
-__global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SELF_MINW) k_samp_sel(LikeDev L, SampFast F, SelDev Sd, LutDesc lutB, const DevParams* params,
-                                                                const double* zt_all, const double* dLt_all, const double* mg_all, const double* cdf_all,
-                                                                const double* rec_all, int TcMax, int TmMax, int sel_blocks) {
-  static_assert(CHM_SF_WAVES == 4, "the selection body reduces over blocks of 256 threads");
-  extern __shared__ double lds[];
-  __shared__ double red[16];
-  const int nsel = sel_blocks * L.nb;
-  if ((int)blockIdx.x < nsel) selection_fast_body<MASS>(Sd, lutB, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.x % L.nb, blockIdx.x / L.nb, sel_blocks, lds, red);
-  else {
-    const int i = (int)blockIdx.x - nsel;
-    samples_fast_body<MASS, false, true, (CHM_SF_PREFETCH_NT != 0)>(L, F, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, i % L.nb, i / L.nb,
-                                                                    ((int)gridDim.x - nsel) / L.nb, lds);
-  }
-}
-#endif
 
 // ------------------------------------------------------------------------------------------------------
 // reductions

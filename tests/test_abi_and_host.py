@@ -370,12 +370,12 @@ def test_compiler_resource_report_of_the_kernels(lib):
     import __graft_entry__ as g
     g.build(force=True)
   res = json.load(open(path))
-  for k in ('k_tables<true>', 'k_tables<false>', 'k_samples_fast<2, false, false, false>', 'k_kde_marg_sub2<32, 4, 200, false>', 'k_selection_fast<2, false>', 'k_full_kde', 'k_full_kde_chain',
+  for k in ('k_tables<true>', 'k_tables<false>', 'k_samples_fast<2, false, false>', 'k_kde_marg_sub2<32, 4, 200, false>', 'k_selection_fast<2, false>', 'k_full_kde', 'k_full_kde_chain',
             'k_zfactors<true, false>', 'k_zfactors<true, true>', 'k_marg_fixup', 'k_reduce_final'):
     assert k in res, (k, sorted(res))
   for k in ('k_tables<true>', 'k_tables<false>'):
     assert res[k]['scratch_bytes_per_lane'] == 0 and res[k]['vgpr_spills'] == 0, (k, res[k])
-  assert res['k_kde_marg_sub2<32, 4, 200, false>']['waves_per_simd'] >= 4 and res['k_samples_fast<2, false, false, false>']['waves_per_simd'] >= 4
+  assert res['k_kde_marg_sub2<32, 4, 200, false>']['waves_per_simd'] >= 4 and res['k_samples_fast<2, false, false>']['waves_per_simd'] >= 4
   # [r3] k_full_kde runs at 4 waves per SIMD (128 VGPRs); the registers it spills for that are touched outside the pair march (272 against 260
   # evaluations/s measured at C3 / 4 draws per call with and without), so the bound is on how many, not on none
   assert res['k_full_kde']['waves_per_simd'] >= 4 and res['k_full_kde']['vgpr_spills'] <= 16
@@ -383,7 +383,7 @@ def test_compiler_resource_report_of_the_kernels(lib):
   # the sample-stationary 3-D kernel keeps 64 + 64 registers of sums and sample states: three waves per SIMD, nothing in scratch
   assert res['k_full_kde_chain']['waves_per_simd'] >= 3 and res['k_full_kde_chain']['scratch_bytes_per_lane'] == 0
   # [r4] the two hot kernels: nothing in scratch, no spilled vector register (the GW kernel lost its 12 B per lane with the round guards)
-  for k in ('k_kde_marg_sub2<32, 4, 200, false>', 'k_kde_marg_sub2<32, 2, 200, false>', 'k_samples_fast<2, false, false, false>'):
+  for k in ('k_kde_marg_sub2<32, 4, 200, false>', 'k_kde_marg_sub2<32, 2, 200, false>', 'k_samples_fast<2, false, false>'):
     assert res[k]['vgpr_spills'] == 0 and res[k]['scratch_bytes_per_lane'] == 0, (k, res[k])
   # [r5] the fused event kernel is a variant build (-DCHM_WITH_FUSED): the release library must not carry it
   assert not any(k.startswith('k_marg_fused') for k in res), [k for k in res if k.startswith('k_marg_fused')]
