@@ -195,22 +195,45 @@ def kernel_roofline(label, prefix, ms, unique_bytes, pmc, units=None):
   return out
 
 
+def visible_gpus_sysfs():
+  """GPUs of this node as the kernel driver lists them (/sys/class/kfd/kfd/topology/nodes/*/properties: a node with simd_count > 0 is a GPU),
+  cut down to the devices ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES leave -- read from sysfs, so that the LAUNCHER never opens the HIP runtime
+  (a process that holds a device context beside rank 0 for the whole run).  0 when there is no kfd topology (no AMD GPU driver: no GPU)."""
+  base = '/sys/class/kfd/kfd/topology/nodes'
+  try:
+    n = 0
+    for d in os.listdir(base):
+      try:
+        with open(os.path.join(base, d, 'properties')) as f:
+          props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+      except OSError:
+        continue
+      if int(props.get('simd_count', 0)) > 0:
+        n += 1
+  except OSError:
+    return 0
+  for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+    v = os.environ.get(var)
+    if v is not None:
+      n = min(n, len([x for x in v.split(',') if x.strip() != '']))
+  return n
+
+
 def spawn_ranks(n):
   """Launcher of last resort: n child processes `python3 bench.py <same arguments>` with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
   set (one rank per GPU, the ranks meet over chimera_amd.parallel.Rendezvous as under torch.distributed.run).  Rank 0's stdout -- the JSON line --
-  is this process's.  No GPU call is made here (hipGetDeviceCount only).  Returns the exit status: non-zero when any rank failed, or when the
-  node shows fewer GPUs than ranks and the call does not ask for the host-socket rehearsal."""
-  import socket
+  is this process's.  The launcher makes NO HIP call: the GPUs are counted from sysfs.  Returns the exit status: non-zero when any rank failed
+  (the first rank to fail ends the others: a rank that died leaves its peers in the rendezvous or in a collective), or when the node shows fewer
+  GPUs than ranks and the call does not ask for the host-socket rehearsal."""
   import subprocess
-  from chimera_amd import _lib
-  ndev = _lib.lib().chm_device_count()
+  ndev = visible_gpus_sysfs()
   if ndev < n and '--host-comm' not in sys.argv:
-    print(f"bench.py: --gpus {n} but {ndev} HIP device(s) visible and no launcher environment (WORLD_SIZE): refusing to run fewer ranks under an "
+    print(f"bench.py: --gpus {n} but {ndev} GPU(s) visible and no launcher environment (WORLD_SIZE): refusing to run fewer ranks under an "
           f"{n}-GPU label (use --host-comm for a rehearsal on fewer GPUs)", file=sys.stderr)
     return 2
-  with socket.socket() as sk:
-    sk.bind(('127.0.0.1', 0))
-    port = sk.getsockname()[1]
+  # MASTER_PORT is only a TAG here: the ranks meet on a Unix-domain socket whose name carries it and this launcher's pid (parallel.default_address);
+  # nothing binds the number, so there is no port to lose between a probe and its use
+  port = 20000 + os.getpid() % 40000
   procs = []
   for r in range(n):
     env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -219,9 +242,23 @@ def spawn_ranks(n):
                                   stdout=None if r == 0 else subprocess.DEVNULL))
   rc = 0
   try:
-    for p_ in procs:
-      r_ = p_.wait()
-      rc = rc or r_
+    live = list(procs)
+    while live and rc == 0:
+      time.sleep(0.05)
+      for p_ in list(live):
+        r_ = p_.poll()
+        if r_ is not None:
+          live.remove(p_)
+          rc = rc or r_
+    if rc:                                              # a rank failed: the others would wait for it in the rendezvous (300 s) or in RCCL
+      for p_ in live:
+        p_.terminate()
+      t_end = time.time() + 10.
+      for p_ in live:
+        try:
+          p_.wait(max(0.1, t_end - time.time()))
+        except subprocess.TimeoutExpired:
+          pass
   finally:
     for p_ in procs:
       if p_.poll() is None:
@@ -396,9 +433,11 @@ def main():
   if pool is None:
     for k in range(args.steps):
       ta = time.perf_counter()
-      vals.append(like.batch(draws[args.warmup + k]))          # synchronous: returns after the HIP stream has drained
+      vals.append(like.batch(draws[args.warmup + k]))          # synchronous: returns when the last kernel has stored the results (completion flags)
       step_s.append(time.perf_counter() - ta)
-      kt += like.last_timing()
+    # [r6] HIP-event times of the LAST step only: reading them waits for the call's final event (an interrupt-driven wait of tens of microseconds
+    # that round 5 paid after every step of the timed region)
+    kt += like.last_timing() * max(args.steps, 1)
   else:
     from collections import deque
     # [r4] step k carries ticket k on every rank: the lanes' all-reduces (one RCCL communicator per lane, one host thread per lane) are handed

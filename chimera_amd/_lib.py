@@ -73,7 +73,8 @@ SYMBOLS = ['chm_version', 'chm_device_count', 'chm_last_error', 'chm_like_create
            'chm_device_synchronize', 'chm_device_pci_bus_id',
            'chm_last_timing', 'chm_like_full_general_pixels', 'chm_pcat_compute', 'chm_kde2d_pixels',
            'chm_kde1d', 'chm_binning1d', 'chm_gkde_nd', 'chm_gkde_nd_log', 'chm_trapz', 'chm_cumtrapz',
-           'chm_like_set_option', 'chm_sel_set_option', 'chm_diag_build', 'chm_has_fused', 'chm_comm_set_ticket', 'chm_comm_ticket_reset', 'chm_comm_ticket_skip']
+           'chm_like_set_option', 'chm_sel_set_option', 'chm_diag_build', 'chm_has_fused', 'chm_comm_set_ticket', 'chm_comm_ticket_reset', 'chm_comm_ticket_skip',
+           'chm_comm_ticket_timeout', 'chm_comm_ticket_wait', 'chm_comm_ticket_done']
 
 # options of a handle (include/chimera_hip.h: CHM_OPT_*); ids >= 100 need a library built with -DCHM_DIAG
 OPTION = {'serial': 1, 'groups': 2, 'fused': 3, 'timing': 4, 'graph_max_nb': 5, 'spin_wait': 6,
@@ -131,6 +132,9 @@ def lib():
   L.chm_comm_set_ticket.argtypes = [vp, i64]
   L.chm_comm_ticket_reset.argtypes = [i64]
   L.chm_comm_ticket_skip.argtypes = [i64]
+  L.chm_comm_ticket_timeout.argtypes = [i64]
+  L.chm_comm_ticket_wait.argtypes = [i64]
+  L.chm_comm_ticket_done.argtypes = [i64]
   L.chm_device_pci_bus_id.argtypes = [i32, C.c_char_p, i32]
   for name in SYMBOLS:
     if name not in ('chm_version', 'chm_last_error'):

@@ -168,6 +168,7 @@ struct Ctx {
   hipEvent_t evb[4] = {};               // fork/join + timing on `stream2`
   double ms[8] = {};
   int t_ngroups = 0; bool t_like = false, t_sel = false, t_valid = false, t_all = false;
+  bool t_pending = false;              // the last call returned through its completion flags: its timing events may not have retired yet (chm_last_timing waits)
   // HIP graph of the few-draw call (the reference-shaped scalar call like(**lambda) is launch-bound: ~10 kernels on three streams):
   // the launch sequence of one configuration is captured once and replayed; `gkey` = everything baked into the captured arguments
   hipGraphExec_t gexec = nullptr;
@@ -389,42 +390,79 @@ struct chm_comm {
 #include <mutex>
 #include <condition_variable>
 #include <chrono>
-#ifndef CHM_TICKET_TIMEOUT_S
-#define CHM_TICKET_TIMEOUT_S 120
-#endif
-static struct CollSeq { std::mutex m; std::condition_variable cv; long long next = 0; } g_seq;
+#include <set>
+#include <atomic>
+// `next`: the lowest ticket that has neither enqueued its collective nor been forfeited.  A served or forfeited ticket k advances `next` only while
+// every ticket below it is served or forfeited too ([r6], ADVICE r5: a skip of ticket k used to set next = k + 1 outright, letting ticket k + 1 pass
+// ticket k - 1 on this rank only -- the very reordering the tickets exist to prevent); tickets closed ahead of their turn wait in `closed`.
+static struct CollSeq {
+  std::mutex m; std::condition_variable cv; long long next = 0; std::set<long long> closed;
+  std::atomic<long long> timeout_ms{120000};
+  void close(long long k) {                                   // (m held) ticket k is served or forfeited
+    if (k < next) return;
+    closed.insert(k);
+    while (!closed.empty() && *closed.begin() == next) { closed.erase(closed.begin()); next++; }
+  }
+} g_seq;
+// wait for the turn of `ticket`: true when every lower ticket is served or forfeited; false after the timeout (chm_comm_ticket_timeout, 120 s by default:
+// a lane whose host thread raised before chm_eval, a call made with collective=False) -- the ticket is then forfeited, so that the lanes behind it go on
+static bool ticket_wait(long long ticket) {
+  std::unique_lock<std::mutex> lk(g_seq.m);
+  const long long ms = g_seq.timeout_ms.load();
+  if (g_seq.cv.wait_for(lk, std::chrono::milliseconds(ms), [&] { return g_seq.next >= ticket; })) return true;
+  g_seq.close(ticket);
+  lk.unlock();
+  g_seq.cv.notify_all();
+  return false;
+}
+static void ticket_close(long long ticket) {
+  { std::lock_guard<std::mutex> lk(g_seq.m); g_seq.close(ticket); }
+  g_seq.cv.notify_all();
+}
 struct TicketTurn {
   chm_comm* c; bool held = false;
   explicit TicketTurn(chm_comm* c_) : c(c_ && c_->ticket >= 0 ? c_ : nullptr) {}
-  // false: the lower tickets did not come within CHM_TICKET_TIMEOUT_S (a lane whose host thread raised before chm_eval, a skipped ticket, a call made
-  // with collective=False): the caller fails with CHM_E_RCCL instead of hanging this lane and its RCCL peers; chm_comm_ticket_skip forfeits a ticket
+  // false: the lower tickets did not come in time: the caller fails with CHM_E_RCCL instead of hanging this lane and its RCCL peers; the turn is given
+  // up for good (the destructor does not wait a second time)
   bool acquire() {
     if (c && !held) {
-      std::unique_lock<std::mutex> lk(g_seq.m);
-      if (!g_seq.cv.wait_for(lk, std::chrono::seconds(CHM_TICKET_TIMEOUT_S), [&] { return g_seq.next >= c->ticket; })) return false;
+      if (!ticket_wait(c->ticket)) { c->ticket = -1; c = nullptr; return false; }
       held = true;
     }
     return true;
   }
-  void release() { if (c && held) { { std::lock_guard<std::mutex> lk(g_seq.m); if (g_seq.next <= c->ticket) g_seq.next = c->ticket + 1; } c->ticket = -1; held = false; c = nullptr; g_seq.cv.notify_all(); } }
-  ~TicketTurn() { if (c) { if (acquire()) release(); else { c->ticket = -1; } } }      // a call that failed before its collective still passes the turn on
+  void release() { if (c && held) { const long long k = c->ticket; c->ticket = -1; held = false; c = nullptr; ticket_close(k); } }
+  // a call that failed BEFORE its collective forfeits its ticket at once (nothing of it will reach the device: waiting for the lower tickets first
+  // would only delay the lanes behind it)
+  ~TicketTurn() { if (c) { const long long k = c->ticket; c->ticket = -1; ticket_close(k); } }
 };
 extern "C" int chm_comm_set_ticket(chm_comm* c, int64_t ticket) {
   if (!c) return fail(CHM_E_ARG, "chm_comm_set_ticket: null communicator");
   c->ticket = (long long)ticket;
   return CHM_OK;
 }
-// forfeit ticket k (a step that will not reach its collective: the lanes behind it go on) -- e.g. from a try / finally around a failed step
-extern "C" int chm_comm_ticket_skip(int64_t ticket) {
-  { std::lock_guard<std::mutex> lk(g_seq.m); if (g_seq.next <= (long long)ticket) g_seq.next = (long long)ticket + 1; }
-  g_seq.cv.notify_all();
-  return CHM_OK;
-}
+// forfeit ticket k (a step that will not reach its collective: the lanes behind it go on once the tickets below k are through) -- e.g. from a
+// try / finally around a failed step
+extern "C" int chm_comm_ticket_skip(int64_t ticket) { ticket_close((long long)ticket); return CHM_OK; }
 extern "C" int chm_comm_ticket_reset(int64_t next) {
-  { std::lock_guard<std::mutex> lk(g_seq.m); g_seq.next = (long long)next; }
+  { std::lock_guard<std::mutex> lk(g_seq.m); g_seq.next = (long long)next; g_seq.closed.clear(); }
   g_seq.cv.notify_all();
   return CHM_OK;
 }
+// how long a ticketed call waits for the lower tickets before it fails with CHM_E_RCCL (milliseconds; default 120 000).  A job whose steps may
+// legitimately take longer (first-call allocations of a large full-mode shard) raises it; tests lower it.
+extern "C" int chm_comm_ticket_timeout(int64_t milliseconds) {
+  if (milliseconds <= 0) return fail(CHM_E_ARG, "chm_comm_ticket_timeout: need a positive number of milliseconds");
+  g_seq.timeout_ms.store((long long)milliseconds);
+  return CHM_OK;
+}
+// the sequencer on its own (host only; what a ticketed chm_eval does around its all-reduce): wait for the turn of `ticket` / pass it on.  For
+// callers that issue collectives of their own between evaluations, and for tests of the ordering rules that need no GPU.
+extern "C" int chm_comm_ticket_wait(int64_t ticket) {
+  if (!ticket_wait((long long)ticket)) return fail(CHM_E_RCCL, "chm_comm_ticket_wait: the calls with lower tickets never passed their turn on (timeout; the ticket is forfeited)");
+  return CHM_OK;
+}
+extern "C" int chm_comm_ticket_done(int64_t ticket) { ticket_close((long long)ticket); return CHM_OK; }
 
 template <class T, class Own>
 static int upload(Own& owned, const T* host, size_t n, const T** dev, hipStream_t s) {
@@ -647,6 +685,14 @@ extern "C" int chm_like_create(const chm_like_desc* d, chm_like** out) {
     if (d->ra_pix) UP(ra_pix, d->ra_pix, P);
     if (d->dec_pix) UP(dec_pix, d->dec_pix, P);
     UP(neff_pixels, d->neff_pixels, 1);
+  }
+  // [r6] the k-range of an event (event_stats_from: verified at its two ends) and the early end of the standard GW kernel's grid loop assume
+  // an ASCENDING event grid -- the reference's (pop_wrapper.py:207: linspace).  A caller-supplied grid with a descending step anywhere (NaNs aside) is
+  // evaluated point by point over the whole grid by the general kernels, as the reference's arithmetic would
+  for (size_t e = 0; e < E && !L.grid_unsorted; e++) {
+    const double* zg = d->z_grids + ((size_t)e0 + e) * Z;
+    double prev = -INFINITY;
+    for (size_t k = 0; k < Z; k++) { const double z = zg[k]; if (z != z) continue; if (z < prev) { L.grid_unsorted = 1; break; } prev = z; }
   }
   {                                                          // NaNs in the per-event inputs of the integrand (see d_ev_bad)
     std::vector<unsigned char> bad(E, 0);
@@ -1018,7 +1064,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   const bool opt_zf_full = o.zf_full || rate_special_call, opt_marg_generic = o.marg_generic || rate_special_call;
   const int graph_max_nb = o.graph_max_nb;
   const bool zc_env = !o.no_zero_copy;
-  const bool zero_copy = zc_env && nb <= 8;               // parameters read from / results written to pinned host memory by the kernels themselves
+  const bool zero_copy = zc_env && nb <= 8;               // few draws: k_tables reads the parameters from pinned host memory itself (no copy node in front of it)
+  // [r6] results of EVERY call size are written to pinned host memory by the last kernel (the trailing D2H copy of 3 nb doubles was ~4 us of copy kernel
+  // + its launch behind every batched call: profiles/r05/timeline_shard125_batched.txt)
+  const bool zc_out = zc_env;
   const bool graph_ok = nb <= graph_max_nb && !tab && !want_dump && !out->log_like_evs && !out->numlike_evs;
   int Tc_host = 0, Tm_host = 0;
   rc = ctx_tables_host(c, params, nb, tab ? tab->fR : nullptr, &Tc_host, &Tm_host); if (rc) return rc;
@@ -1081,7 +1130,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     const int few_nb_f = o.few_nb;
     if (like && like->fused_ok && use_fast && !tab && !want_dump && fmode > 0 && (nb <= few_nb_f || fmode >= 2) &&
         like->L.mode == CHM_MODE_MARG && like->L.binning && like->L.has_cut && (like->L.Z & 1) == 0 && like->L.num_bins == 200 &&
-        !opt_marg_generic && !opt_zf_full && !like->neg_prior) {
+        !opt_marg_generic && !opt_zf_full && !like->neg_prior && !like->L.grid_unsorted) {
       int Tc_call = 0, Tm_call = 0;
       double zmax_min = INFINITY;
       for (int b = 0; b < nb; b++) {
@@ -1166,7 +1215,9 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   if (zc_use && (c.zc_zmax != params[0].z_max || c.zc_Tc != params[0].z_grid_res)) zc_make = true;
   // ---- graph bookkeeping: the key lists everything the captured launch arguments depend on
   // completion through the flags in pinned memory (wait_flags): zero-copy results, spinning wait, nothing copied back behind the last kernel
-  const bool use_flags = zero_copy && o.spin_wait != 0 && nb <= o.few_nb && !out->partials && !out->log_like_evs && !out->numlike_evs && !want_dump && !tab;
+  // [r6] calls of any size (round 5: few-draw calls only): a batched call of a small shard is ~1.3 ms, of which the interrupt-driven wake-up of
+  // hipStreamSynchronize was 20-40 us (profiles/r06/ab_shard_step_r06.txt)
+  const bool use_flags = zc_out && o.spin_wait != 0 && !out->partials && !out->log_like_evs && !out->numlike_evs && !want_dump && !tab;
   std::vector<long long> key;
   bool capturing = false;
   long long zmax_bits = 0; { const double zm = params[0].z_max; memcpy(&zmax_bits, &zm, 8); }
@@ -1190,10 +1241,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         turn.release();
         hipLaunchKernelGGL(k_combine, dim3((nb + 63) / 64), dim3(64), 0, sA, nb, (const DevParams*)c.d_params, (const double*)c.d_partials,
                            comm ? (double)E_total : (like ? (double)like->L.E : 0.), sel ? sel->S.N_inj : 1., sel ? sel->S.N_eff : 0.,
-                           sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, zero_copy ? c.h_out : c.d_out3,
+                           sel ? sel->S.has_neff : 0, like ? 1 : 0, sel ? 1 : 0, zc_out ? c.h_out : c.d_out3,
                            (const long long*)c.h_seq, use_flags ? c.h_seq + 1 : (long long*)nullptr);
         HIPCHK(hipGetLastError());
-        if (!zero_copy) HIPCHK(hipMemcpyAsync(c.h_out, c.d_out3, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
+        if (!zc_out) HIPCHK(hipMemcpyAsync(c.h_out, c.d_out3, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
       }
       const double hp2 = host_prof_on() ? now_us() : 0.;
       if (use_flags) HIPCHK(wait_flags(c.h_seq, nb, c.seq, sA)); else
@@ -1209,15 +1260,15 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       return CHM_OK;
     }
     if (key == c.gwarm) {                                     // second sight of this configuration: capture it
-      if (c.gexec) { (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; c.gkey.clear(); }
+      // (a call that completed through its flags may still be retiring on the stream: drain it before the graph it runs from goes -- ADVICE r5)
+      if (c.gexec) { HIPCHK(hipStreamSynchronize(sA)); (void)hipGraphExecDestroy(c.gexec); c.gexec = nullptr; c.gkey.clear(); }
       HIPCHK(hipStreamBeginCapture(sA, hipStreamCaptureModeThreadLocal));
       capturing = true;
     } else c.gwarm = key;
   }
   const bool timing = timing_env && !capturing;
-  // (an eager call that carries timing events waits for its stream as before: chm_last_timing reads the events; the captured call is launched once at
-  //  the end of its capture and takes the flags, as every replay after it)
-  const bool flags_now = use_flags && !timing;
+  // (an eager call that carries timing events completes through the flags too; chm_last_timing waits for the call's last event before it reads them)
+  const bool flags_now = use_flags;
   if (flags_now) { c.h_seq[0] = ++c.seq; __atomic_thread_fence(__ATOMIC_RELEASE); }
   // with a communicator (multi-GPU shards: short calls) only the whole evaluation and the GW kernel are timed: each event record
   // costs ~3 us of stream time (measured: 35 us per call for the full set); CHM_TIMING_ALL=1 keeps the full set (diagnosing a multi-GPU line)
@@ -1243,7 +1294,8 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     like->zg_zmax = params[0].z_max; like->zg_Tc = params[0].z_grid_res;
   }
   HIPCHK(hipEventRecord(c.ev[1], sA));
-  if (!one_stream) HIPCHK(hipStreamWaitEvent(sB, c.ev[1], 0));               // fork: the other lanes start after the tables
+  bool used_sB = false;                                      // (the fork of lane B is made when its first kernel is about to be enqueued)
+  auto fork_sB = [&]() -> int { if (!one_stream && !used_sB) { HIPCHK(hipStreamWaitEvent(sB, c.ev[1], 0)); used_sB = true; } return CHM_OK; };
 
   const int Tc = c.TcMax, Tm = c.TmMax;
   const DevParams* dp = c.d_params;
@@ -1275,6 +1327,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     if (ngroups > CHM_MAX_GROUPS) return fail(CHM_E_ARG, "chm_eval: more than 128 x 65535 events in one shard");
     for (int g = 0; g < ngroups; g++) {
       hipStream_t sg = (g & 1) ? sB : sA;
+      if (sg == sB && sB != sA) { rc = fork_sB(); if (rc) return rc; }
       LikeDev L = like->L;
       L.tab_pm = td.pm_s; L.tab_rate = td.rate_g; L.tab_bkg = td.bkg_g; L.tab_jac = td.jac_g;
       if (zg_use) { L.zg_i = like->d_zg_i; L.zg_t = like->d_zg_t; L.zg_lz = like->d_zg_lz; }
@@ -1312,9 +1365,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       // 30 % slower: 19 KB of LDS per wave halve the occupancy); anything else, or CHM_MARG_GENERIC=1, -> the general kernel
       // (a negative pe_prior -- negative weights, which the reference's arithmetic takes as they come -- goes to the general kernel: the standard
       //  one bounds its rounding error and skips empty bins on the assumption of weights >= 0; scripts/fuzz_parity.py, round 4)
-      const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && (L.Z & 1) == 0 && !opt_marg_generic && !like->neg_prior;
+      const bool marg_std = L.mode == CHM_MODE_MARG && L.binning && L.has_cut && (L.Z & 1) == 0 && !opt_marg_generic && !like->neg_prior && !L.grid_unsorted;
       const int zf_mode = !zf_ranged ? 0 : (L.mode == CHM_MODE_MARG ? 1 : 2);
       hipStream_t sz = (one_stream || zf_ranged) ? sg : ((g & 1) ? sA : sB);
+      if (sz == sB && sB != sA) { rc = fork_sB(); if (rc) return rc; }
       // ~2048 blocks in all: each stages the draw's (zt, It) tables in LDS once and walks over E_cnt / gridDim.x events
 #ifndef CHM_ZF_TARGET
 #define CHM_ZF_TARGET 2048     // (A/B, profiles/r04/ab_zf_target.txt: 1536 = one full round of 6 blocks per CU, and 1024: -0.3 .. -0.8 % of the step -- inside the run-to-run spread; unchanged)
@@ -1442,7 +1496,9 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       HIPCHK(hipGetLastError());
       if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 3], sg));
     }
-    if (!one_stream) { HIPCHK(hipEventRecord(c.evb[0], sB)); HIPCHK(hipStreamWaitEvent(sA, c.evb[0], 0)); }   // join the two lanes
+    // join the two lanes -- [r6] only when the second one carried anything (one event group with ranged per-z factors runs on lane A alone: the record on
+    // an idle stream + the barrier packet cost ~10 us between the fix-up and the reduction of a small shard)
+    if (!one_stream && used_sB) { HIPCHK(hipEventRecord(c.evb[0], sB)); HIPCHK(hipStreamWaitEvent(sA, c.evb[0], 0)); }
     if (timing_all) HIPCHK(hipEventRecord(c.ev[3], sA));
     // per-event log-likelihoods and their block sums
     nblk_ev = (L0.E + 255) / 256;
@@ -1494,7 +1550,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
                                             // one rank, so that a single GPU exercises the very path the multi-GPU run takes)
   double Etot = comm ? (double)E_total : (like ? (double)like->L.E : 0.);
   const bool one_kernel = !like || like->L.E <= 4096;
-  double* out3 = zero_copy ? c.h_out : c.d_out3;           // zero_copy: the last kernel stores the 3 doubles per draw in pinned host memory
+  double* out3 = zc_out ? c.h_out : c.d_out3;              // zc_out: the last kernel stores the 3 doubles per draw in pinned host memory
   if (like && !one_kernel) {
     hipLaunchKernelGGL(k_reduce_events, dim3(nblk_ev, nb), dim3(256), 0, sA, like->L.E, like->L.P > 0 ? like->L.P : 1,
                        (const double*)like->L.like_pix, c.d_evpart, d_lle, d_nle, ev_from_fixup ? (const double*)like->L.ev_li : nullptr,
@@ -1538,7 +1594,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
                        (const long long*)c.h_seq, flags_now ? c.h_seq + 1 : (long long*)nullptr);
     HIPCHK(hipGetLastError());
   }
-  if (!zero_copy) HIPCHK(hipMemcpyAsync(c.h_out, c.d_out3, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
+  if (!zc_out) HIPCHK(hipMemcpyAsync(c.h_out, c.d_out3, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
   if (timing) HIPCHK(hipEventRecord(c.ev[5], sA));
   if (d_lle) HIPCHK(hipMemcpyAsync(out->log_like_evs, d_lle, sizeof(double) * nb * El, hipMemcpyDeviceToHost, sA));
   if (d_nle) HIPCHK(hipMemcpyAsync(out->numlike_evs, d_nle, sizeof(double) * nb * El, hipMemcpyDeviceToHost, sA));
@@ -1556,7 +1612,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     if (out->N_exp) out->N_exp[b] = c.h_out[b * 3 + 2];
     if (out->partials) for (int k = 0; k < 3; k++) out->partials[b * 3 + k] = c.h_out[3 * nb + b * 3 + k];
   }
-  c.t_ngroups = ngroups; c.t_like = like != nullptr; c.t_sel = sel != nullptr && !fuse_sel; c.t_valid = timing; c.t_all = timing_all;      // (fused: the selection sums have no span of their own)
+  c.t_ngroups = ngroups; c.t_like = like != nullptr; c.t_sel = sel != nullptr && !fuse_sel; c.t_valid = timing; c.t_all = timing_all; c.t_pending = timing && flags_now;      // (fused: the selection sums have no span of their own)
   return CHM_OK;
 }
 
@@ -1579,6 +1635,7 @@ extern "C" int chm_last_timing(chm_like* like, chm_sel* sel, double msout[8]) {
   float ms = 0.f;
   for (int i = 0; i < 8; i++) c.ms[i] = 0.;
   if (c.t_valid) {                                                                      // elapsed times are formed on demand
+    if (c.t_pending) { HIPCHK(hipSetDevice(c.device)); HIPCHK(hipEventSynchronize(c.ev[5])); c.t_pending = false; }
     if (hipEventElapsedTime(&ms, c.ev[0], c.ev[5]) == hipSuccess) c.ms[0] = ms;       // whole evaluation
     if (hipEventElapsedTime(&ms, c.ev[0], c.ev[1]) == hipSuccess) c.ms[1] = ms;       // tables
     for (int g = 0; g < c.t_ngroups; g++) {                                            // summed over the event groups

@@ -68,7 +68,9 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   int *full_todo;                 // (nb,E,P)  full mode: 1 = the pixel is left to the general kernel by k_full_kde_chain
   double *full_ev;                // (nb,E,FULLEV) full mode: k_full_prep's record of every (draw, event)
   double *full_s;                 // (5,nb_alloc,E,S) full mode: whitened coordinates a, y1, y2, normalised weight, step factor U of every sample
-  int nb_alloc, pad_full;         // draws the workspaces are allocated for (the stride of full_s's five planes)
+  int nb_alloc;                   // draws the workspaces are allocated for (the stride of full_s's five planes)
+  int grid_unsorted;              // [r6] some row of z_grids is not non-decreasing (set at upload): the k-range of an event is then the whole grid and the
+                                  // marginalized mode takes the general kernel (the standard one ends its grid loop at the first pass beyond the KDE's support)
   unsigned char *ev_rbad;         // (nb,E) [r5] calls with an infinite rate parameter only: 1 = the rate factor prate/jac is inf or NaN at some point of the event grid
                                   // (k_zfactors, whole-grid launch) -- the reference's trapz then holds a 0 * inf = NaN where p_gw vanishes (event_poisoned)
 };
@@ -1153,7 +1155,7 @@ DEVFN void event_stats_from(const LikeDev& L, int e, const EvStats& st, double* 
   const int Z = L.Z;
   const double* zg = L.z_grids + (size_t)e * Z;
   int k_lo = 0, k_hi = Z - 1;
-  {
+  if (!L.grid_unsorted) {
     const double z0 = zg[0], zl = zg[Z - 1];
     const double inv_dz = (double)(Z - 1) / (zl - z0);
     double fl = floor((lb - z0) * inv_dz) - 1., fh = ceil((ub - z0) * inv_dz) + 1.;
@@ -1439,7 +1441,7 @@ DEVFN void kde_marg_general(const LikeDev& L, const DevParams* params, const int
   // (1) k-range of the event grid that can see a non-zero KDE: z_k in [lb, ub].  Guess from the end points (the grid is
   //     a linspace, pop_wrapper.py:207), verify against the stored grid, fall back to the whole grid otherwise.
   int k_lo = 0, k_hi = Z - 1;
-  if (ok) {
+  if (ok && !L.grid_unsorted) {
     const double z0 = zg[0], zl = zg[Z - 1];
     const double inv_dz = (double)(Z - 1) / (zl - z0);
     double fl = floor((lb - z0) * inv_dz) - 1., fh = ceil((ub - z0) * inv_dz) + 1.;

@@ -217,6 +217,7 @@ class hyperlikelihood(object):
     new = copy.copy(self)
     new._handles = {}
     new._scalar_state = None
+    new.__dict__.pop('_out_blocks', None)                      # (a lane is driven by its own host thread: its own output rows)
     new._options = dict(self._options)
     new.comm = comm
     for mode, (h, _) in self._handles.items():
@@ -255,9 +256,26 @@ class hyperlikelihood(object):
         tab, tab_keep = build_tab(pops, self._plugins, ev=evd, inj=injd)
     h = self._handle(mode)
     El = self._e1 - self._e0
-    res = {'log_hyper': np.empty(nb), 'log_num': np.empty(nb), 'N_exp': np.empty(nb)}
-    out = _lib.chm_out()
-    out.log_hyper, out.log_num, out.N_exp = (_lib.dptr(res[k]) for k in ('log_hyper', 'log_num', 'N_exp'))
+    sel = self.selection_function._handle() if (with_sel and self.selection_function is not None) else None
+    comm = self.comm if (collective and self.scheme in ('data', 'both')) else None      # 'params': replicas, nothing to reduce inside a call
+    comm_h = getattr(comm, 'handle', None) if comm is not None else None                 # RCCL all-reduce inside chm_eval
+    host_reduce = (comm is not None and comm_h is None and comm.nranks > 1 and hasattr(comm, 'allreduce_sum'))
+    if not want and tab is None and not host_reduce:
+      # the plain call (batch, the samplers): its three output rows and the chm_out that points at them are kept per draw count (building them
+      # is ~10 us of ctypes casts per call); the caller gets copies
+      cache = self.__dict__.setdefault('_out_blocks', {})
+      blk = cache.get(nb)
+      if blk is None:
+        buf = np.empty((3, nb))
+        o_ = _lib.chm_out()
+        o_.log_hyper, o_.log_num, o_.N_exp = (_lib.dptr(buf[i]) for i in range(3))
+        blk = cache[nb] = (buf, o_)
+      buf, out = blk
+      res = None
+    else:
+      res = {'log_hyper': np.empty(nb), 'log_num': np.empty(nb), 'N_exp': np.empty(nb)}
+      out = _lib.chm_out()
+      out.log_hyper, out.log_num, out.N_exp = (_lib.dptr(res[k]) for k in ('log_hyper', 'log_num', 'N_exp'))
     if 'log_like_evs' in want:
       res['log_like_evs'] = np.empty((nb, El)); out.log_like_evs = _lib.dptr(res['log_like_evs'])
     if 'numlike_evs' in want:
@@ -268,16 +286,14 @@ class hyperlikelihood(object):
       res['p_gw'] = np.empty(shape); out.p_gw = _lib.dptr(res['p_gw'])
     if 'partials' in want:
       res['partials'] = np.empty((nb, 3)); out.partials = _lib.dptr(res['partials'])
-    sel = self.selection_function._handle() if (with_sel and self.selection_function is not None) else None
-    comm = self.comm if (collective and self.scheme in ('data', 'both')) else None      # 'params': replicas, nothing to reduce inside a call
-    comm_h = getattr(comm, 'handle', None) if comm is not None else None                 # RCCL all-reduce inside chm_eval
-    host_reduce = (comm is not None and comm_h is None and comm.nranks > 1 and hasattr(comm, 'allreduce_sum'))
     if host_reduce and 'partials' not in res:               # HostComm: the partial sums are reduced and combined on the host
       res['partials'] = np.empty((nb, 3)); out.partials = _lib.dptr(res['partials'])
     if tab is not None:
       _lib.check(_lib.lib().chm_eval_tabulated(h, sel, comm_h, params, nb, self.nevents, C.byref(tab), C.byref(out)))
     else:
       _lib.check(_lib.lib().chm_eval(h, sel, comm_h, params, nb, self.nevents, C.byref(out)))
+    if res is None:
+      return {'log_hyper': buf[0].copy(), 'log_num': buf[1].copy(), 'N_exp': buf[2].copy()}
     if host_reduce:
       from .parallel import combine_partials
       tot = self.comm.allreduce_sum(res['partials']).reshape(nb, 3)
@@ -337,8 +353,7 @@ class hyperlikelihood(object):
     n = _vector_length(hyper_lambdas)
     if n is None:
       return self._scalar_call(hyper_lambdas)
-    lams = [{k: (np.asarray(v).reshape(-1)[i] if np.ndim(v) > 0 else v) for k, v in hyper_lambdas.items()} for i in range(n)]
-    return self.batch(lams)
+    return self.batch(hyper_lambdas)
 
   def _scalar_call(self, lam):
     """One draw, nothing but the value wanted -- the reference's ``like(**lambda)``.  The call is ~0.18 ms of which the device needs ~0.15: the
@@ -391,7 +406,8 @@ class hyperlikelihood(object):
   # -- batched draws (the reference's 'params' scheme, CHIMERA/parallel.py:258-278) ----------------------
   def _params_array(self, list_of_hyper_lambdas):
     """One chm_params per draw = population.update(**lambda).to_params(), formed by patching a copy of the base struct
-    (same values: unknown keys are ignored, every model picks the keys it owns -- pop_wrapper.py:56-64)."""
+    (same values: unknown keys are ignored, every model picks the keys it owns -- pop_wrapper.py:56-64).  A dict of arrays (the vectorised
+    dict of the reference's sampler glue, emcee_utils.py:54-64) is packed with one store per hyper-parameter, no per-draw dict."""
     if getattr(self, '_slots', None) is None:
       from .population._base import param_slots
       pop = self.population
@@ -399,6 +415,16 @@ class hyperlikelihood(object):
       self._base_params = pop.to_params()
       self._params_dtype = np.dtype(_lib.chm_params)
       self._base_view = np.frombuffer(self._base_params, dtype=self._params_dtype).copy()
+    if isinstance(list_of_hyper_lambdas, dict):
+      nb = _vector_length(list_of_hyper_lambdas)
+      arr, view = self._params_block(nb)
+      for k, v in list_of_hyper_lambdas.items():
+        for field, idx, is_int in self._slots.get(k, ()):
+          if idx is None:
+            view[field] = v
+          else:
+            view[field][:, idx] = v
+      return arr
     nb = len(list_of_hyper_lambdas)
     arr = (_lib.chm_params * nb)()
     if nb < 8:                                                 # few draws: patch ctypes structs directly
@@ -413,8 +439,7 @@ class hyperlikelihood(object):
             else:
               getattr(p, field)[idx] = float(v)
       return arr
-    view = np.frombuffer(arr, dtype=self._params_dtype)
-    view[:] = self._base_view                                  # every draw starts from the base population
+    arr, view = self._params_block(nb)                         # every draw starts from the base population
     keys = list_of_hyper_lambdas[0].keys()
     if all(lam.keys() == keys for lam in list_of_hyper_lambdas):
       for k in keys:                                           # one vectorised store per hyper-parameter name
@@ -436,12 +461,33 @@ class hyperlikelihood(object):
               view[field][b, idx] = v
     return arr
 
+  def _params_block(self, nb):
+    """nb copies of the base chm_params as a ctypes array + its structured NumPy view (one memmove from a cached image: a broadcast store
+    through the structured dtype costs 10 us for 128 draws)."""
+    img = self._params_images.get(nb) if hasattr(self, '_params_images') else None
+    if img is None:
+      if not hasattr(self, '_params_images'):
+        self._params_images = {}
+      img = self._params_images[nb] = np.tile(self._base_view, nb).tobytes()
+    arr = (_lib.chm_params * nb)()
+    C.memmove(arr, img, len(img))
+    return arr, np.frombuffer(arr, dtype=self._params_dtype)
+
   #: draws evaluated per launch sequence; longer lists are processed in slices (the per-draw workspaces -- source-frame
   #: z and weights of every sample, per-z factors -- take ~16 B x samples per draw: 65 MB per draw at 1000 events x 4096)
   max_draws_per_call = 256
 
   def batch(self, list_of_hyper_lambdas):
-    """log-hyperlikelihood of several draws in one launch sequence: array of len(list)."""
+    """log-hyperlikelihood of several draws in one launch sequence: array of len(list).  Also takes the vectorised form, a dict of
+    hyper-parameter arrays of one length (scalars broadcast) -- what ``compute_log_hyperlike(**arrays)`` hands over."""
+    if isinstance(list_of_hyper_lambdas, dict):
+      n = _vector_length(list_of_hyper_lambdas)
+      if n is None:
+        raise ValueError("hyperlikelihood.batch: a dict of hyper-parameters needs at least one array-valued entry")
+      plain = not any(self._plugins) and self.scheme == 'data' and n <= max(1, int(self.max_draws_per_call))
+      if plain:
+        return self._eval(self._params_array(list_of_hyper_lambdas))['log_hyper']
+      list_of_hyper_lambdas = [{k: (np.asarray(v).reshape(-1)[i] if np.ndim(v) > 0 else v) for k, v in list_of_hyper_lambdas.items()} for i in range(n)]
     lams = list(list_of_hyper_lambdas)
     if self.scheme == 'params' and self.comm is not None and self.comm.nranks > 1:
       return self._batch_over_params(lams)

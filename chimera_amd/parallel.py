@@ -237,6 +237,12 @@ class Comm(object):
     ``finally`` of a failed step so that the other lanes' higher tickets are served instead of waiting for the timeout."""
     _lib.check(_lib.lib().chm_comm_ticket_skip(int(ticket)))
 
+  @staticmethod
+  def ticket_timeout(seconds):
+    """How long a ticketed evaluation waits for the lower tickets before it fails (``chm_comm_ticket_timeout``; default 120 s).  A step that
+    times out raises once and forfeits its ticket."""
+    _lib.check(_lib.lib().chm_comm_ticket_timeout(int(round(1e3 * float(seconds)))))
+
   def close(self):
     if self._h:
       _lib.lib().chm_comm_destroy(self._h)

@@ -271,6 +271,13 @@ int chm_comm_ticket_reset(int64_t next);
 /* forfeit ticket t: a step that will not reach its collective (its host thread failed before chm_eval) lets the higher tickets pass.  A ticketed
  * call whose turn does not come within 120 s fails with CHM_E_RCCL instead of hanging the lane and its RCCL peers.                              */
 int chm_comm_ticket_skip(int64_t ticket);
+/* [r6] The turn passes to ticket t only when EVERY ticket below t has enqueued its collective or been forfeited (a skipped ticket never lets a higher
+ * one overtake a lower one that is still on its way).  chm_comm_ticket_timeout(ms): how long a ticketed call waits for its turn (default 120 000 ms);
+ * on timeout the call fails with CHM_E_RCCL once and its ticket is forfeited.  chm_comm_ticket_wait / _done: the sequencer on its own (host only) --
+ * wait for the turn of ticket t / pass it on -- for callers that place collectives of their own between evaluations.                              */
+int chm_comm_ticket_timeout(int64_t milliseconds);
+int chm_comm_ticket_wait(int64_t ticket);
+int chm_comm_ticket_done(int64_t ticket);
 /* hipDeviceSynchronize on `device`: the barrier bracket of a timed region (chm_eval itself returns after its stream drained). */
 int chm_device_synchronize(int32_t device);
 /* PCI bus id of `device` ("0000:c1:00.0", NUL-terminated; len >= 16): a sharded job (CHIMERA/parallel.py:94-99: one rank per chunk of events) records one per

@@ -1366,3 +1366,26 @@ def test_selection_function_with_hostile_injections(cfg_pix, models):
       with np.errstate(all='ignore'):
         assert np.isclose(np.exp(allp[2]), ref[1], rtol=1e-10, equal_nan=True) or (ref[1] == 0. and allp[2] == -np.inf)
       like_p.close(); sel_p.close()
+
+
+@pytest.mark.parametrize('kind', ['marginalized', 'approximate'])
+def test_an_event_grid_that_does_not_ascend_is_evaluated_point_by_point_like_the_reference(cfg_pix, kind):
+  """[r6] The standard GW kernel ends its grid loop at the first pass beyond the KDE's support and every kernel takes the k-range of an
+  event from the two ends of [lb, ub] -- both assume the reference's ascending linspace grids (pop_wrapper.py:207).  A caller-supplied grid with a
+  descending step inside the support (two neighbouring points swapped; a whole stretch reversed) goes to the kernels that evaluate every grid
+  point, as the reference's arithmetic (pointwise interpolation, jnp.trapezoid with negative steps) does."""
+  cfg, ev, inj = cfg_pix
+  ev = dict(ev)
+  zg = np.array(ev['z_grids'], copy=True)
+  Z = zg.shape[1]
+  like_ref, _, _ = H.build_oracle(ev, inj, kind=kind)
+  zs = like_ref.population.update(H0=70.)
+  # swap two neighbours in the middle of event 0's grid, reverse a stretch of event 1's
+  zg[0, Z // 2], zg[0, Z // 2 + 1] = zg[0, Z // 2 + 1], zg[0, Z // 2]
+  zg[1, Z // 3: Z // 3 + 9] = zg[1, Z // 3: Z // 3 + 9][::-1].copy()
+  ev['z_grids'] = zg
+  like_o, _, _ = H.build_oracle(ev, inj, kind=kind)
+  like_p, _, _ = H.build_product(ev, inj, kind=kind)
+  for lam in (dict(H0=70.), dict(H0=58., alpha=3.0)):
+    _compare(like_p, like_o, lam, cfg['E'], check_pgw=True)
+  np.testing.assert_allclose(like_p.batch([dict(H0=70.), dict(H0=58., alpha=3.0)])[0], like_p(H0=70.), rtol=0, atol=0)

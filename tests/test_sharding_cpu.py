@@ -322,3 +322,68 @@ def test_both_scheme_shards_inside_groups_and_splits_the_draws_over_them(tmp_pat
     g = int(rec['group'][0])
     a, b = draws_of_group(7, ngroups, g)
     assert list(rec['calls']) == ([b - a] if b > a else []) + ([1] if g == 0 else [])
+
+
+# ---- [r6] the collective sequencer of a rank with several evaluation lanes (chm_comm_set_ticket & co.; host code: no GPU needed) ----
+def _ticket_lib():
+  from chimera_amd import _lib
+  L = _lib.lib()
+  L.chm_comm_ticket_reset(0)
+  L.chm_comm_ticket_timeout(120000)
+  return L
+
+
+def test_a_skipped_ticket_never_lets_a_higher_one_overtake_a_lower_one():
+  """chm_comm_ticket_skip(k) used to serve ticket k + 1 at once, in front of a ticket k - 1 still on its way to its collective on this
+  rank only -- the cross-rank order the tickets exist for.  Tickets 0, 1, 2: 1 is forfeited first, 2 must still wait for 0."""
+  import threading
+  import time
+  L = _ticket_lib()
+  order = []
+
+  def lane(ticket, delay):
+    time.sleep(delay)
+    assert L.chm_comm_ticket_wait(ticket) == 0
+    order.append(ticket)
+    assert L.chm_comm_ticket_done(ticket) == 0
+
+  t2 = threading.Thread(target=lane, args=(2, 0.))
+  t2.start()
+  assert L.chm_comm_ticket_skip(1) == 0                     # the step with ticket 1 failed before its call
+  time.sleep(0.3)
+  assert order == [], "ticket 2 was served while ticket 0 had not enqueued its collective"
+  t0 = threading.Thread(target=lane, args=(0, 0.))
+  t0.start()
+  t0.join(10); t2.join(10)
+  assert order == [0, 2]
+  # forfeiting tickets out of order, then the one in front: everything behind it is through at once
+  L.chm_comm_ticket_reset(10)
+  for k in (13, 12, 11):
+    L.chm_comm_ticket_skip(k)
+  t0 = time.time()
+  assert L.chm_comm_ticket_wait(10) == 0 and L.chm_comm_ticket_done(10) == 0
+  assert L.chm_comm_ticket_wait(14) == 0 and L.chm_comm_ticket_done(14) == 0
+  assert time.time() - t0 < 1.0
+  L.chm_comm_ticket_reset(0)
+
+
+def test_a_ticket_whose_turn_never_comes_fails_once_and_forfeits():
+  """The timeout is a run-time setting (chm_comm_ticket_timeout); a ticket that times out fails ONCE with CHM_E_RCCL (round 5: the destructor of the
+  call waited a second time) and is forfeited, so that the tickets behind it are served as soon as the ones in front of it are."""
+  import time
+  from chimera_amd import _lib
+  L = _ticket_lib()
+  assert L.chm_comm_ticket_timeout(0) != 0                   # refused
+  assert L.chm_comm_ticket_timeout(200) == 0
+  t0 = time.time()
+  rc = L.chm_comm_ticket_wait(1)                             # ticket 0 never comes
+  dt = time.time() - t0
+  assert rc == _lib.CHM_E_RCCL and 0.15 < dt < 2.0, (rc, dt)
+  assert b'timeout' in L.chm_last_error()
+  # ticket 1 is forfeited: once ticket 0 is through, ticket 2 does not wait for it
+  assert L.chm_comm_ticket_wait(0) == 0 and L.chm_comm_ticket_done(0) == 0
+  t0 = time.time()
+  assert L.chm_comm_ticket_wait(2) == 0 and L.chm_comm_ticket_done(2) == 0
+  assert time.time() - t0 < 0.15
+  L.chm_comm_ticket_timeout(120000)
+  L.chm_comm_ticket_reset(0)
