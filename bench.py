@@ -286,6 +286,8 @@ def main():
   ap.add_argument('--host-comm', action='store_true', help='reduce the partial sums through the host sockets instead of RCCL (a rehearsal: the line then says so; never a fallback)')
   ap.add_argument('--force-comm', action='store_true', help='build the rendezvous and the RCCL communicator even for one rank (rehearses the N > 1 path)')
   ap.add_argument('--inflight', type=int, default=1, help='evaluations in flight per rank: 2 = two lanes (hyperlikelihood.lane) driven by two host threads, the steps alternate between them')
+  ap.add_argument('--no-inflight2', action='store_true', help='N > 1: skip the second leg with two evaluations in flight per rank (multi_gpu.inflight2)')
+  ap.add_argument('--no-extra', action='store_true', help='N = 1: skip the short legs of the other BASELINE configurations / modes (extra.configs)')
   ap.add_argument('--cpu-events', type=int, default=1000, help='events of the workload the CPU baseline evaluates (1000 = all of C3)')
   ap.add_argument('--cpu-evals', type=int, default=20, help='timed CPU evaluations (median + IQR)')
   args = ap.parse_args()
@@ -394,10 +396,13 @@ def main():
   H0s = np.linspace(55., 95., 4099)          # a different H0 for every draw of every step
   Xi0s = np.linspace(0.6, 3.0, 4099)
 
-  def lambdas(step):
+  def lambdas(step, n=None):
+    """The draws of one step as the sampler hands them over: the vectorised dict of hyper-parameter arrays (emcee_utils.py:54-64)."""
+    n = nb if n is None else n
+    j = step * n + np.arange(n)
     if mg:                                        # a different (Xi0, H0) for every draw
-      return [dict(Xi0=float(Xi0s[(step * nb + j) % len(Xi0s)]), H0=float(H0s[(7 * (step * nb + j)) % len(H0s)])) for j in range(nb)]
-    return [dict(H0=float(H0s[(step * nb + j) % len(H0s)])) for j in range(nb)]
+      return dict(Xi0=Xi0s[j % len(Xi0s)].copy(), H0=H0s[(7 * j) % len(H0s)].copy())
+    return dict(H0=H0s[j % len(H0s)].copy())
 
   def sync():
     _lib.check(L.chm_device_synchronize(device))
@@ -526,6 +531,83 @@ def main():
               # [r4] the whole call against the HBM roofline: SURVEY 8(d)'s algorithmic bytes of one evaluation over the call's wall time
               "algorithmic_bytes": b_alg, "hbm_GBs": b_alg / (med * 1e-3) / 1e9, "hbm_frac": b_alg / (med * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
+  # [r6] N > 1 (or --force-comm): a second leg with TWO evaluations in flight per rank, after the timed region -- a second lane on the same resident
+  # shard with a communicator of its own, one host thread per lane, the steps alternate between the lanes and carry tickets (chm_comm_set_ticket).
+  # The tables, launch path and reduction tail of one call then run under the kernels of the other: what is left of the non-scaling part of a
+  # 125-event shard's step.  `value` stays the inflight-1 figure; the leg is reported as multi_gpu.inflight2.  It runs in a thread of its own under a
+  # deadline: a lane that hangs (a collective that never completes) costs the leg, not the line -- the process then prints and leaves without the
+  # collectives of an orderly shutdown.
+  hard_exit = False
+  if rdzv is not None and comm is not None and args.inflight == 1 and not args.no_inflight2 and multi_info is not None:
+    import threading
+    leg = {}
+
+    def inflight2_leg():
+      from collections import deque
+      from concurrent.futures import ThreadPoolExecutor
+      lc, err = None, None
+      try:
+        lc = HostComm(world, rank, device, rendezvous=rdzv) if isinstance(comm, HostComm) else Comm(world, rank, device, rendezvous=rdzv)
+      except Exception as e:                                  # noqa: BLE001
+        err = e
+      if int(rdzv.allreduce_sum(np.array([0. if lc is not None else 1.]))[0]) > 0:        # every rank takes the same branch
+        leg['error'] = f"second communicator unavailable ({err})"
+        return
+      lane2 = like.lane(comm=lc)
+      lanes2 = [like, lane2]
+      ticketed = hasattr(comm, 'set_ticket')
+      if ticketed:
+        Comm.ticket_timeout(20.)
+        Comm.reset_tickets(0)
+      tk = [0]
+
+      def run_step(ln, k, ticket):
+        if ticketed:
+          ln.comm.set_ticket(ticket)
+        return ln.batch(draws[args.warmup + (k % max(args.steps, 1))])
+      try:
+        for w in range(2):                                    # both lanes allocate their workspaces before the clock starts
+          for ln in lanes2:
+            run_step(ln, w, tk[0]); tk[0] += 1
+        sync()
+        with ThreadPoolExecutor(max_workers=2) as pool2:
+          pending = deque()
+          ta = time.perf_counter()
+          for k in range(args.steps):
+            if len(pending) == 2:
+              pending.popleft().result()
+            pending.append(pool2.submit(run_step, lanes2[k % 2], k, tk[0])); tk[0] += 1
+          last = None
+          while pending:
+            last = pending.popleft().result()
+          sync()
+          dt2 = time.perf_counter() - ta
+        dt2 = float(rdzv.allreduce_max(np.array([dt2]))[0])
+        leg.update({"ms_per_step": 1e3 * dt2 / max(args.steps, 1), "value": args.steps * nb / dt2, "steps": args.steps, "lanes": 2,
+                    "last_log_hyper": float(np.asarray(last).ravel()[-1]) if last is not None else None,
+                    "note": "two evaluations in flight per rank (two lanes, two communicators, ticketed collectives), measured after the timed region; "
+                            "`value` of the line is the inflight-1 figure"})
+      finally:
+        leg['_cleanup'] = (lane2, lc)
+
+    th = threading.Thread(target=inflight2_leg, daemon=True)
+    th.start()
+    th.join(90.)
+    if th.is_alive():
+      leg = {"error": "the leg did not finish within 90 s (a lane or a collective hung); the line is printed without it"}
+      hard_exit = True
+    elif 'ms_per_step' not in leg:
+      leg.setdefault('error', 'the leg raised: see stderr')
+      hard_exit = 'second communicator unavailable' not in leg['error']
+    cl = leg.pop('_cleanup', None)
+    if cl is not None and not hard_exit:
+      ln2, lc2 = cl
+      if ln2.selection_function is not None:
+        ln2.selection_function.close()
+      ln2.close()
+      lane_comms.append(lc2)
+    multi_info["inflight2"] = leg
+
   if rank == 0:
     evals = args.steps * nb
     value = evals / dt
@@ -546,7 +628,8 @@ def main():
       # sample x query pairs of one step (E npix Z_eff S): the masked stretch of every event grid, [min z - c std, max z + c std]
       # (likelihood.py:222-225), from the source-frame z of the last step's draws (z_from_dGW on the device, outside the timed region)
       full_pairs = 0
-      for lam in draws[-1]:
+      for jd in range(nb):
+        lam = {k_: float(v_[jd]) for k_, v_ in draws[-1].items()}
         zz = np.asarray(CH.cosmo.z_from_dGW(cosmo.update(**lam), ev['dL'][like._e0:like._e1]))
         zlo = zz.min(axis=1) - 2. * zz.std(axis=1); zhi = zz.max(axis=1) + 2. * zz.std(axis=1)
         zg = ev['z_grids'][like._e0:like._e1]
@@ -602,6 +685,8 @@ def main():
             "hbm": {"unique_bytes_per_launch": dom["unique_bytes_per_launch"], "achieved": dom["hbm_unique_GBs"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": dom["hbm_unique_frac"], "traffic_frac": dom.get("hbm_traffic_frac")},
             "kernels": kernels,
+            # SURVEY 8(d)'s call-level figure: the algorithmic bytes of ONE evaluation over the scalar call's wall time against 8 TB/s
+            "hbm_call_frac": single["hbm_frac"] if single else None,
             "note": "both dominant kernels are bound by VALU issue.  frac = useful_frac = issue cycles of the launch's fp64 add / mul / fma instructions "
                     "(PMC class counters of the committed passes of this command x 4 cycles, profiles/r03/issue_cost.txt) / (1024 SIMDs x 2.4 GHz x the "
                     "launch's LIVE HIP-event duration): what the kernel achieves.  issue_busy_frac prices EVERY VALU instruction at its measured issue "
@@ -635,6 +720,14 @@ def main():
                           "evaluation afterwards moves ~350 B of parameters per draw host->device and 24 B back"},
       "last_log_hyper": float(np.asarray(vals[-1]).ravel()[-1]),
     }
+    if world == 1 and not args.no_extra and args.config == 'C3' and kind == 'marginalized' and args.events is None and args.inj is None:
+      # [r6] the other BASELINE configurations and call modes in the SAME driver-run line (everything but C3 / marginalized / 128 draws was
+      # builder-run evidence): short legs after the timed region, inputs synthesised at full size (C5's 4.2 GB synthesis is left to the GPU test)
+      t_x = time.time()
+      out["extra"] = {"configs": extra_legs(CH, synth, _lib, L, device, cfg, ev, inj, like, H0s), "note":
+                      "3 warm-up + 10 timed steps each (hyperlikelihood.batch of nbatch draws, different H0 per draw), then 20 scalar calls; "
+                      "one_draw_kernels: HIP-event times of the C3 kernels at ONE draw per call (graph replay off) against the HBM roofline"}
+      out["extra"]["wall_s"] = time.time() - t_x
     if world == 1 and not args.no_cpu_baseline:
       out["cpu_baseline"] = cb = cpu_baseline(cfg, ev, inj, kind, args.cpu_events, n_evals=args.cpu_evals)
       if cb.get("value"):
@@ -645,22 +738,107 @@ def main():
                                    "abs_diff": abs(g - cb["log_hyper_H0_67"]), "tolerance": 1e-7 * float(np.sqrt(E))}
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(out) + '\n').encode())
-  if pool is not None:
-    pool.shutdown()
-  for ln in lanes[1:]:
-    if ln.selection_function is not None:
-      ln.selection_function.close()
-    ln.close()
-  like.close()
-  sel.close()
-  if rdzv is not None:
-    rdzv.barrier()
-  for lc in lane_comms:
-    lc.close()
-  if comm is not None:
-    comm.close()
-  if rdzv is not None:
-    rdzv.close()
+  if hard_exit:                                     # the inflight-2 leg hung or failed on this rank: no collective of an orderly shutdown can be trusted
+    sys.stderr.flush()
+    os._exit(0)
+  try:
+    if pool is not None:
+      pool.shutdown()
+    for ln in lanes[1:]:
+      if ln.selection_function is not None:
+        ln.selection_function.close()
+      ln.close()
+    like.close()
+    sel.close()
+    if rdzv is not None:
+      rdzv.barrier()
+    for lc in lane_comms:
+      lc.close()
+    if comm is not None:
+      comm.close()
+    if rdzv is not None:
+      rdzv.close()
+  except Exception as e:                              # noqa: BLE001
+    if multi_info is not None and 'inflight2' in multi_info:
+      # a peer left without the shutdown collectives (its inflight-2 leg hung): the line is out, nothing is left to measure
+      print(f"[bench] rank {rank}: shutdown after the inflight-2 leg: {e}", file=sys.stderr)
+      sys.stderr.flush()
+      os._exit(0)
+    raise
+
+
+def extra_legs(CH, synth, _lib, L, device, cfg3, ev3, inj3, like3, H0s, steps=10, warmup=3, single_calls=20):
+  """Short legs of the other BASELINE configurations / modes on one GPU (after the timed region of the headline).  Every leg: evals/s and ms per step
+  of `hyperlikelihood.batch` at its draw count, and the median scalar call."""
+  from chimera_amd.catalog import dVdz_completeness, pixelated_catalog
+  pe_fields = ('m1det', 'm2det', 'dL', 'ra', 'dec', 'pe_prior', 'pixels_opt_nsides', 'ra_pix', 'dec_pix', 'gw_loc2d_pdf', 'pixels_pe_opt_nside')
+
+  def build(cfg, ev, inj, kind):
+    if cfg['pixelated']:
+      th = CH.data.theta_pe_det(**{k: ev[k] for k in pe_fields})
+      gal_cat = pixelated_catalog(dVdz_completeness(z_range=[0.073, 1.3]), p_cat=ev['p_cat'], z_grids=ev['z_grids'], neff_pixels=ev['neff_pixels'])
+    else:
+      th = CH.data.theta_pe_det(**{k: ev[k] for k in ('m1det', 'm2det', 'dL', 'pe_prior')})
+      gal_cat, kind = None, None
+    pop = CH.population(CH.cosmo.flrw(H0=70., Om0=0.25, z_max=5.), CH.mass.plp(), CH.rate.madau_dickinson(gamma=2.7, kappa=3., zp=2.), gal_cat=gal_cat, scale_free=True)
+    sel = CH.selection_function(CH.data.theta_inj_det(**{k: inj[k] for k in ('m1det', 'm2det', 'dL', 'p_draw')}), N_inj=inj['N_inj'], N_eff=5.)
+    like = CH.hyperlikelihood(th, ev['z_grids'], pop, sel, kind_p_gw3d=kind, kernel='epan', bw_method=None, cut_grid=2, binning=True, num_bins=200)
+    return like, sel
+
+  def leg(name, cfg, ev, inj, kind, nb_leg):
+    like, sel = build(cfg, ev, inj, kind)
+    try:
+      draws = [dict(H0=H0s[(k * nb_leg + np.arange(nb_leg)) % len(H0s)].copy()) for k in range(warmup + steps)]
+      for k in range(warmup):
+        like.batch(draws[k])
+      _lib.check(L.chm_device_synchronize(device))
+      ta = time.perf_counter()
+      for k in range(steps):
+        v = like.batch(draws[warmup + k])
+      _lib.check(L.chm_device_synchronize(device))
+      dt = time.perf_counter() - ta
+      for j in range(4):
+        like(H0=float(H0s[-1 - j]))
+      ts = []
+      for j in range(single_calls):
+        tb = time.perf_counter()
+        like(H0=float(H0s[-10 - j]))
+        ts.append(1e3 * (time.perf_counter() - tb))
+      return {"workload": f"{name}: {cfg['E']} events x {cfg['P']} pixels x {cfg['Z']} z-bins, {cfg['S']} samples/event, {cfg['I']} injections, {kind or '1d'}",
+              "nbatch": nb_leg, "steps": steps, "evals_per_s": steps * nb_leg / dt, "ms_per_step": 1e3 * dt / steps,
+              "single_call_ms": float(np.median(ts)), "last_log_hyper": float(np.asarray(v).ravel()[-1])}
+    finally:
+      like.close(); sel.close()
+
+  res = {}
+  for name in ('C1', 'C2', 'C4'):
+    t0 = time.time()
+    cfg, ev, inj = synth.make_config(name)
+    t_gen = time.time() - t0
+    res[name] = leg(name, cfg, ev, inj, 'marginalized' if cfg['pixelated'] else None, 128)
+    res[name]["synthetic_s"] = t_gen
+    del ev, inj
+  res['C3_approximate'] = leg('C3', cfg3, ev3, inj3, 'approximate', 128)
+  res['C3_full'] = leg('C3', cfg3, ev3, inj3, 'full', 4)
+  # the C3 kernels at ONE draw per call: HBM is the applicable bound there (graph replay off, so that the call carries its timing events)
+  E, S, P, Z, I = cfg3['E'], cfg3['S'], cfg3['P'], cfg3['Z'], cfg3['I']
+  like3.set_option('graph_max_nb', 0)
+  try:
+    kt = np.zeros(8); n = 0
+    for k in range(14):
+      like3.batch(dict(H0=H0s[k:k + 1].copy()))
+      if k >= 4:
+        kt += like3.last_timing(); n += 1
+    kt /= n
+    ub_s, ub_g = sample_kernel_unique_bytes(E, S, 1), gw_kernel_unique_bytes(E, S, P, Z, 1)
+    res['one_draw_kernels'] = {"samples_us": 1e3 * kt[2], "gw_kernel_us": 1e3 * kt[3], "tables_us": 1e3 * kt[1], "eval_us": 1e3 * kt[0],
+                               "samples_unique_bytes": ub_s, "gw_unique_bytes": ub_g,
+                               "samples_hbm_frac_unique": ub_s / (kt[2] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[2] > 0 else None,
+                               "gw_hbm_frac_unique": ub_g / (kt[3] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[3] > 0 else None,
+                               "note": "eager one-draw calls; gw_kernel_us spans the GW kernel + fix-up (HIP events around both)"}
+  finally:
+    like3.set_option('graph_max_nb', 8)
+  return res
 
 
 def cpu_baseline(cfg, ev, inj, kind, n_ev, threads=None, numpy_events=48, n_evals=20):
