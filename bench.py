@@ -472,6 +472,7 @@ def main():
   kt_timed_eval = kt[0] / max(args.steps, 1)
   if pool is None and world == 1 and nb > 8:             # (calls of few draws are a single chain anyway)
     like.set_option('groups', 1)
+    like.set_option('timing', 2)                         # per-kernel events (the default call carries the whole evaluation's two only)
     kt = np.zeros(8)
     ntot = max(4, min(args.steps, 24))               # as sustained as the timed region (the chip clocks higher in short bursts): the last half counts
     nser = 0
@@ -480,6 +481,7 @@ def main():
       if k >= ntot // 2:
         kt += like.last_timing(); nser += 1
     like.set_option('groups', args.groups)
+    like.set_option('timing', 1)
     kt *= max(args.steps, 1) / nser
     sync()
   dt_rank = dt
@@ -658,11 +660,13 @@ def main():
       o = _lib.chm_out(); o.N_exp = _lib.dptr(nexp)
       ms = np.zeros(8)
       acc = []
+      sel.set_option('timing', 2)
       for j in range(6):
         _lib.check(L.chm_eval(None, sel._handle(), None, pa, nb, 0, C.byref(o)))
         _lib.check(L.chm_last_timing(None, sel._handle(), _lib.dptr(ms)))
         if j >= 2 and ms[4] > 0:
           acc.append(ms[4])
+      sel.set_option('timing', 1)
       if acc:
         sel_ms = float(np.median(acc))
         kernels.append(kernel_roofline("selection function (dN/dtheta per injection, two sums); standalone selection-only call", "k_selection", sel_ms,
@@ -823,6 +827,7 @@ def extra_legs(CH, synth, _lib, L, device, cfg3, ev3, inj3, like3, H0s, steps=10
   # the C3 kernels at ONE draw per call: HBM is the applicable bound there (graph replay off, so that the call carries its timing events)
   E, S, P, Z, I = cfg3['E'], cfg3['S'], cfg3['P'], cfg3['Z'], cfg3['I']
   like3.set_option('graph_max_nb', 0)
+  like3.set_option('timing', 2)
   try:
     kt = np.zeros(8); n = 0
     for k in range(14):
@@ -837,6 +842,7 @@ def extra_legs(CH, synth, _lib, L, device, cfg3, ev3, inj3, like3, H0s, steps=10
                                "gw_hbm_frac_unique": ub_g / (kt[3] * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[3] > 0 else None,
                                "note": "eager one-draw calls; gw_kernel_us spans the GW kernel + fix-up (HIP events around both)"}
   finally:
+    like3.set_option('timing', 1)
     like3.set_option('graph_max_nb', 8)
   return res
 

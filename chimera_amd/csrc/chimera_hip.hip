@@ -50,7 +50,7 @@ struct Opts {
   int serial = 0;            // 1: every kernel of a call on one stream
   int groups = 0;            // event groups alternating between two streams (0: automatic; 1: one group)
   int fused = 0;             // fused event kernel (chm_fused.h): 0 never, 1 few-draw calls, 2 every call
-  int timing = 1;            // 0: no timing events in the streams; 1: default set; 2: per-kernel events also under a communicator / with event groups
+  int timing = 1;            // 0: no timing events in the streams; 1 (default): the whole evaluation only; 2: per-kernel events too (each record costs ~4 us of stream time)
   int graph_max_nb = 8;      // calls of at most this many draws are replayed from a HIP graph (0: never)
   int spin_wait = 1;         // few-draw calls poll the stream for completion instead of sleeping on an interrupt (the wake-up is part of their latency)
   // ---- diagnostics (-DCHM_DIAG builds only)
@@ -309,7 +309,10 @@ static int ctx_tables_enqueue(Ctx& c, int nb, int Tc, int Tm, LutDesc lutA = Lut
   if (tl <= 112 * 1024) {                                   // + 33 KB of static LDS (build_lut scratch, parameter block)
     static size_t tl_allowed = 0;                             // the kernel also holds 33 KB of static LDS: ask as soon as the sum passes 48 KB
     if (tl > 14 * 1024 && tl > tl_allowed) { (void)hipFuncSetAttribute((const void*)k_tables<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl); tl_allowed = tl; }
-    hipLaunchKernelGGL(k_tables<true>, dim3(nb, 3), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt, hsrc, ztc, lzc);
+#ifndef CHM_TABLES_Y_BATCH
+#define CHM_TABLES_Y_BATCH 3      // (A/B, profiles/r06/ab_shard_step_r06.txt) blocks per draw of a call of many draws: 3 = the cosmology tail split over two blocks (the scalar call's form), 2 = one block
+#endif
+    hipLaunchKernelGGL(k_tables<true>, dim3(nb, nb > 8 ? CHM_TABLES_Y_BATCH : 3), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt, hsrc, ztc, lzc);
   } else {
     hipLaunchKernelGGL(k_tables<false>, dim3(nb, 2), dim3(CHM_TABLES_LONG_NT), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt, hsrc, ztc, lzc);
   }
@@ -360,6 +363,9 @@ struct chm_like {
   bool neg_prior = false;    // some pe_prior < 0: negative sample weights -- the standard GW kernel's rounding bound and empty-bin shortcuts assume weights >= 0
   double ev_oct_max = 0.; int ev_nk_max = 0;
   int* d_redo = nullptr;          // (shared with the clones) count of dense redos, diagnostics
+#ifdef CHM_PROBE
+  LutDesc probe_lut = {}; size_t probe_lds_fast = 0;      // direct-index table and LDS size of the last call's fast sample stage (scripts/gw_loop_probe.hip)
+#endif
 };
 struct chm_sel {
   Ctx ctx;
@@ -1102,10 +1108,13 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       cap = (cap + 7) / 8 * 8;
       lutA = like->F.lut;
       lutA.cap = (int)cap; lutA.lut = like->d_lut; lutA.info = like->d_lutinfo;
-      lds_fast = sizeof(double) * (CHM_EXPTAB_N + 4 * (size_t)cap + 2 * (size_t)Tm_call) + ((size_t)(lutA.nk + 1) * 2 + 15) / 16 * 16;
+      lds_fast = sizeof(double) * (CHM_EXPTAB_N + CHM_REC_STRIDE * (size_t)cap + 2 * (size_t)Tm_call) + ((size_t)(lutA.nk + 1) * 2 + 15) / 16 * 16;
       if (lds_fast > 96 * 1024) use_fast = false;
     }
   }
+#ifdef CHM_PROBE
+  if (like) { like->probe_lut = use_fast ? lutA : LutDesc{}; like->probe_lds_fast = use_fast ? lds_fast : 0; }
+#endif
   // k_marg_fused (chm_fused.h): the standard marginalized configuration in ONE kernel per (event, draw) -- few-draw calls by default
   // (CHM_OPT_FUSED 1: few-draw calls, 2: calls of any size; default off).  LDS per block: P histograms of num_bins + 1 doubles, the overlay region
   // (the draw's mass tables + the widest event's slice of the distance tables + NW - 1 boundary rows | 4 NW prefix arrays) and ~2 KB.
@@ -1184,7 +1193,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       cap = (cap + 7) / 8 * 8;
       lutB = sel->lut;
       lutB.cap = (int)cap; lutB.lut = sel->d_lut; lutB.info = sel->d_lutinfo;
-      lds_sel = sizeof(double) * (CHM_EXPTAB_N + 4 * (size_t)cap + 2 * (size_t)Tm_call) + ((size_t)(lutB.nk + 1) * 2 + 15) / 16 * 16;
+      lds_sel = sizeof(double) * (CHM_EXPTAB_N + CHM_REC_STRIDE * (size_t)cap + 2 * (size_t)Tm_call) + ((size_t)(lutB.nk + 1) * 2 + 15) / 16 * 16;
       if (lds_sel > 64 * 1024) sel_fast = false;
     }
   }
@@ -1272,11 +1281,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   if (flags_now) { c.h_seq[0] = ++c.seq; __atomic_thread_fence(__ATOMIC_RELEASE); }
   // with a communicator (multi-GPU shards: short calls) only the whole evaluation and the GW kernel are timed: each event record
   // costs ~3 us of stream time (measured: 35 us per call for the full set); CHM_TIMING_ALL=1 keeps the full set (diagnosing a multi-GPU line)
-  const bool timing_all_env = o.timing >= 2;
-  // (per-kernel events only for calls whose kernels follow each other on one lane: with event groups on two streams the spans overlap and
-  //  the 4 records per group would cost more stream time than they inform -- bench.py times the kernels in a CHM_GROUPS=1 pass)
-  const bool grouped = like && nb > few_nb && o.groups != 1 && !serial && like->L.E >= 500;
-  const bool timing_all = timing && ((!comm && !grouped) || timing_all_env);
+  // [r6] per-kernel events (sample stage, GW kernel, selection, reduction) only on request (CHM_OPT_TIMING 2: bench.py's pass after its timed region,
+  // chm_last_timing's consumers): the default call carries the two events of the whole evaluation -- the full set was ~40 us of a 1.24 ms
+  // step of a 125-event shard (profiles/r06/ab_shard_step_r06.txt: 1.24 ms without a communicator against 1.20 with one, which had the reduced set)
+  const bool timing_all = timing && o.timing >= 2;
   // an error inside a capture must end it before returning
   struct CaptureGuard { hipStream_t s; bool* on; ~CaptureGuard() { if (*on) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(s, &g); if (g) (void)hipGraphDestroy(g); } } } cguard{sA, &capturing};
   if (timing) HIPCHK(hipEventRecord(c.ev[0], sA));
@@ -1342,7 +1350,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         SampFast Fq = like->F; Fq.lut = lutA;
         L.ev_publish = 1;
         if (timing_all) { HIPCHK(hipEventRecord(c.evg[4 * g], sg)); HIPCHK(hipEventRecord(c.evg[4 * g + 1], sg)); }
-        if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
+        if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
 #define LAUNCH_FUSED_(M, NWV, NTL) do { allow_lds((k_marg_fused<M, NWV, 200, NTL>), lds_fused); \
           hipLaunchKernelGGL((k_marg_fused<M, NWV, 200, NTL>), dim3((unsigned)L.E_cnt * nb), dim3(64 * NWV), lds_fused, sg, L, Fq, FDc, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, c.rec, c.TcMax, c.TmMax); } while (0)
 #ifdef CHM_FUSED_NW16
@@ -1355,7 +1363,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
 #undef LAUNCH_FUSED
 #undef LAUNCH_FUSED_
         HIPCHK(hipGetLastError());
-        if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 3], sg));
+        if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g + 3], sg));
         ev_from_fixup = true;
         continue;
       }
@@ -1447,7 +1455,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       // GW kernel + integrand (needs the per-z factors)
       if (sz != sg) HIPCHK(hipStreamWaitEvent(sg, c.evf[g], 0));
       if (L.mode == CHM_MODE_FULL) {
-        if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
+        if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         // [r3] sample-stationary kernel first; the pixels it cannot do (non-uniform stretch of the grid, very coarse grid, > 4096 samples) are
         // flagged in full_todo and done by the general kernel, whose other blocks return at once.  CHM_FULL_CHAIN=0: general kernel only.
         const bool full_chain = o.full_chain != 0 && !rate_special_call;         // (CHM_OPT_DIAG_FULL_CHAIN 0: the general kernel alone; tests compare the two)
@@ -1461,7 +1469,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         else hipLaunchKernelGGL(k_event_prep, dim3((L.E_cnt + 3) / 4, nb), dim3(256), 0, sg, L, 1);
         HIPCHK(hipGetLastError());
         if (zf_ranged) { launch_zfactors(); HIPCHK(hipGetLastError()); }
-        if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
+        if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         const bool fast = marg_std;
         if (fast) {
           // several pixel groups (pairs of pixels) of the same (event, draw) per wave, one after the other: event statistics and segment
@@ -1486,7 +1494,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         }
         else { allow_lds(k_kde_marg, lds_kde); hipLaunchKernelGGL(k_kde_marg, dim3(L.E_cnt * Pd, nb), dim3(64), lds_kde, sg, L, dp); }
       } else {
-        if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
+        if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         allow_lds(k_kde1d, lds_kde);
         hipLaunchKernelGGL(k_kde1d, dim3(L.E_cnt, nb), dim3(256), lds_kde, sg, L, dp);
         HIPCHK(hipGetLastError());
@@ -1494,7 +1502,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         hipLaunchKernelGGL(k_integrate_1d, dim3(L.E_cnt * nb, 1), dim3(256), 0, sg, L, dp);
       }
       HIPCHK(hipGetLastError());
-      if (timing) HIPCHK(hipEventRecord(c.evg[4 * g + 3], sg));
+      if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g + 3], sg));
     }
     // join the two lanes -- [r6] only when the second one carried anything (one event group with ranged per-z factors runs on lane A alone: the record on
     // an idle stream + the barrier packet cost ~10 us between the fix-up and the reduction of a small shard)
@@ -1640,7 +1648,7 @@ extern "C" int chm_last_timing(chm_like* like, chm_sel* sel, double msout[8]) {
     if (hipEventElapsedTime(&ms, c.ev[0], c.ev[1]) == hipSuccess) c.ms[1] = ms;       // tables
     for (int g = 0; g < c.t_ngroups; g++) {                                            // summed over the event groups
       if (c.t_all && hipEventElapsedTime(&ms, c.evg[4 * g], c.evg[4 * g + 1]) == hipSuccess) c.ms[2] += ms;       // sample stage
-      if (hipEventElapsedTime(&ms, c.evg[4 * g + 2], c.evg[4 * g + 3]) == hipSuccess) c.ms[3] += ms;   // GW kernel + integrand
+      if (c.t_all && hipEventElapsedTime(&ms, c.evg[4 * g + 2], c.evg[4 * g + 3]) == hipSuccess) c.ms[3] += ms;   // GW kernel + integrand
     }
     if (c.t_all && c.t_sel && hipEventElapsedTime(&ms, c.evb[1], c.evb[2]) == hipSuccess) c.ms[4] = ms;   // selection (own stream)
     if (c.t_all && hipEventElapsedTime(&ms, c.ev[3], c.ev[5]) == hipSuccess) c.ms[5] = ms;       // reduce + combine (+ all-reduce)
@@ -1993,3 +2001,9 @@ extern "C" int chm_comm_allreduce_sum(chm_comm* c, double* buf, int32_t n) {
   HIPCHK(hipStreamSynchronize(c->stream));
   return CHM_OK;
 }
+
+#ifdef CHM_PROBE
+// measured ceilings of the two hot kernels (diagnostic builds only): the production bodies on a cache-resident workload
+#include "../../scripts/sample_body_probe.hip"
+#include "../../scripts/gw_loop_probe.hip"
+#endif

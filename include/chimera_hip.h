@@ -304,7 +304,7 @@ int chm_like_full_general_pixels(chm_like* like, int32_t nb, int64_t* count);
  *                         to the separate kernels' to rounding, ~1e-15 per event): 0 never (default), 1 calls of <= 8 draws, 2 every call.
  *                         [r5] A VARIANT build only (-DCHM_WITH_FUSED; chm_has_fused() tells): it is slower than the separate kernels at every
  *                         call size measured (profiles/r04/ab_fused_event_kernel.txt), so the release library refuses values > 0
- *   CHM_OPT_TIMING        0 no timing events in the streams, 1 default, 2 per-kernel events also under a communicator / with event groups
+ *   CHM_OPT_TIMING        0 no timing events in the streams, 1 (default) the whole evaluation only (ms[0], ms[1]), 2 per-kernel events too (ms[2..6]; ~4 us of stream time each)
  *   CHM_OPT_GRAPH_MAX_NB  calls of at most this many draws without per-event outputs are replayed from a HIP graph (default 8; 0: never)
  *   CHM_OPT_SPIN_WAIT     1 (default): calls of <= 8 draws poll their stream for completion instead of sleeping on an interrupt
  * Options >= 100 select other kernels for the same quantity, launch geometries or switch a safeguard off (CHM_OPT_DIAG_NO_DENSE_NODE gives

@@ -1,0 +1,58 @@
+// gw_loop_probe.hip -- what do the bodies of the two hot kernels sustain on the card with HBM out of the picture?  (diagnostic, not product)
+//
+// Compiled INTO the library by -DCHM_PROBE builds only (chimera_hip.hip includes this file and scripts/sample_body_probe.hip at its end:
+// scripts/build_variant.sh probe -DCHM_PROBE); driven by scripts/run_probes.py -> profiles/r06/probe_ceilings.json, which bench.py reads for
+// roofline.frac_of_sustained.  Round 5 priced the kernels against MIN_INST, a count made on paper; this replaces it with a measurement.
+//
+// k_probe_gw: every one-wave block runs kde_marg_sub2_body<32, 4, 200, false> -- the production body of k_kde_marg_sub2, not a copy -- `reps`
+// times over the (draw, pixel group, event) items of a SMALL resident workload (a handful of events x draws: (z, w), p_cat rows, per-z factors
+// and event statistics of a preceding chm_eval, a few MB in all), so that after the first touch every load is served by L2 / the memory-side
+// cache: set-up, histogram, prefix sums, bandwidth, grid loop and final scans at the kernel's own occupancy (4 waves per SIMD, 9.6 KB of LDS per
+// wave), with their LDS traffic and bank conflicts, without the HBM round trips.  The launches are repeated for >= 1 s so that the board settles at
+// the clock it holds under this instruction stream.  Results stored by different waves coincide (same item, same value).
+template <int IPW>
+__global__ void __launch_bounds__(64, 4) k_probe_gw(LikeDev L, const DevParams* params, int reps, int ny) {
+  extern __shared__ double lds_all[];
+  for (int r = 0; r < reps; r++) {
+    const unsigned q = blockIdx.x * 7919u + (unsigned)r * 104729u;     // neighbouring waves work on unrelated items, as in a production launch
+    const int bx = (int)(q % (unsigned)L.nb), by = (int)((q / (unsigned)L.nb) % (unsigned)ny), bz = (int)((q / (unsigned)L.nb / (unsigned)ny) % (unsigned)L.E_cnt);
+    kde_marg_sub2_body<32, IPW, 200, false>(L, params, bx, by, bz, lds_all);
+    wave_sync();                                          // the next item reuses the wave's LDS slice
+  }
+}
+
+// which: 0 = GW kernel body (IPW 4), 1 = sample-stage body; `launches` launches of `nblocks` blocks x `reps` body calls each; ms[i] = HIP-event time of launch i
+extern "C" int chm_debug_probe(chm_like* like, int32_t which, int32_t nb, int32_t nblocks, int32_t reps, int32_t launches, double* ms) {
+  if (!like || !ms || nb < 1 || nb > like->nb_ws || nblocks < 1 || reps < 1 || launches < 1) return fail(CHM_E_ARG, "chm_debug_probe: bad argument (nb must not exceed the draws of the preceding chm_eval)");
+  Ctx& c = like->ctx;
+  HIPCHK(hipSetDevice(c.device));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  LikeDev L = like->L;
+  L.e_off = 0; L.E_cnt = L.E; L.nb = nb; L.p_gw_dump = nullptr; L.no_dense = 0; L.ev_publish = 0;
+  L.zg_i = like->d_zg_i; L.zg_t = like->d_zg_t; L.zg_lz = like->d_zg_lz;
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+  for (int i = 0; i < launches; i++) {
+    HIPCHK(hipEventRecord(e0, c.stream));
+    if (which == 0) {
+      if (L.mode != CHM_MODE_MARG || L.num_bins != 200 || !L.binning || !L.has_cut || (L.Z & 1)) return fail(CHM_E_ARG, "chm_debug_probe: the GW probe needs the standard marginalized configuration");
+      const int PG2 = (L.P + 1) / 2, ny = (PG2 + 3) / 4;
+      const size_t lds_sub = sizeof(double) * (3 * (size_t)L.num_bins + 3) * 2;
+      hipLaunchKernelGGL((k_probe_gw<4>), dim3(nblocks), dim3(64), lds_sub, c.stream, L, (const DevParams*)c.d_params, reps, ny);
+    } else {
+      if (!like->probe_lds_fast) return fail(CHM_E_ARG, "chm_debug_probe: the preceding chm_eval did not take the fast sample stage");
+      SampFast F = like->F; F.lut = like->probe_lut;
+      allow_lds((k_probe_samples<2>), like->probe_lds_fast);
+      hipLaunchKernelGGL((k_probe_samples<2>), dim3(nblocks), dim3(64 * CHM_SF_WAVES), like->probe_lds_fast, c.stream, L, F, (const DevParams*)c.d_params,
+                         (const double*)c.zt, (const double*)c.dLt, (const double*)c.mg, (const double*)c.cdf, (const double*)c.rec, c.TcMax, c.TmMax, reps);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, e0, e1));
+    ms[i] = t;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return CHM_OK;
+}

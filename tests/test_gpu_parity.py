@@ -1331,6 +1331,10 @@ def test_last_timing_reports_the_stages_of_an_eager_call(cfg_pix):
   like, _, _ = H.build_product(ev, inj)
   like.batch([dict(H0=60. + i) for i in range(12)])
   ms = like.last_timing()
+  assert ms[0] > 0 and ms[2] == 0 and ms[3] == 0, ms         # [r6] the default call carries the events of the whole evaluation only
+  like.set_option('timing', 2)                                # per-kernel events on request
+  like.batch([dict(H0=60. + i) for i in range(12)])
+  ms = like.last_timing()
   assert ms[0] > 0 and ms[2] > 0 and ms[3] > 0 and ms[4] > 0 and ms[0] >= ms[3], ms
   for _ in range(4):
     like(H0=70.)
@@ -1378,8 +1382,6 @@ def test_an_event_grid_that_does_not_ascend_is_evaluated_point_by_point_like_the
   ev = dict(ev)
   zg = np.array(ev['z_grids'], copy=True)
   Z = zg.shape[1]
-  like_ref, _, _ = H.build_oracle(ev, inj, kind=kind)
-  zs = like_ref.population.update(H0=70.)
   # swap two neighbours in the middle of event 0's grid, reverse a stretch of event 1's
   zg[0, Z // 2], zg[0, Z // 2 + 1] = zg[0, Z // 2 + 1], zg[0, Z // 2]
   zg[1, Z // 3: Z // 3 + 9] = zg[1, Z // 3: Z // 3 + 9][::-1].copy()
