@@ -1480,7 +1480,8 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
           const int ipw_env = o.kde_ipw;                    // diagnostics: 2 or 4 items per wave
           // (few draws per call: two items per wave -- twice the waves, half the serial chain of each: 0.238 -> 0.229 ms for the scalar call at C3)
           const int ipw = ipw_env == 2 || ipw_env == 4 ? ipw_env : ((PG2 >= 4 && nb > 8) ? 4 : 2);
-          const size_t lds_sub = sizeof(double) * (3 * N + 3) * GW_NPW;
+          // (CHM_GW_SPLIT3 builds, compile-time bin count: five slots of QS = B + 1 + 7 + 1 doubles and one of B + 1, see kde_sub_item)
+          const size_t lds_sub = (CHM_GW_SPLIT3 && L.num_bins == 200 && !L.p_gw_dump) ? sizeof(double) * (5 * (200 + 1 + 7 + 1) + 201) : sizeof(double) * (3 * N + 3) * GW_NPW;
 #define LAUNCH_SUB2(I, BN, DU) hipLaunchKernelGGL((k_kde_marg_sub2<GW_SW, I, BN, DU>), dim3(nb, (PG2 + I - 1) / I, L.E_cnt), dim3(64), lds_sub, sg, L, dp)
           if (L.p_gw_dump) { if (ipw == 4) LAUNCH_SUB2(4, 0, true); else LAUNCH_SUB2(2, 0, true); }    // p_gw3d requested (tests, hyperlikelihood.p_gw3d): the instantiation that stores it
           else if (L.num_bins == 200) { if (ipw == 4) LAUNCH_SUB2(4, 200, false); else LAUNCH_SUB2(2, 200, false); }      // the reference's default bin count (likelihood.py:59): compile-time

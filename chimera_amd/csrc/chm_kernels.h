@@ -1800,6 +1800,20 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
 #define CHM_GW_PACK 0
 #endif
   constexpr bool PACK = FAST && !DUMP && (CHM_GW_PACK != 0);
+  // [r6] CHM_GW_SPLIT3: THREE ds_read_b64 per bin index instead of ds_read2_b64 + ds_read_b64.  With the arrays of a pixel B + 1 = 201 doubles apart
+  // the compiler fuses the reads of P0[i] and -2 P1[i] into one ds_read2_b64 (offset1:201) -- which the LDS serves at HALF the rate of two
+  // ds_read_b64 (MI355X_MICROARCH.md, LDS: ds_read2_b64 = two accesses of 4 x 16 lanes, 8 cycles, 128 B/clk, banks mod 32; ds_read_b64 = 2 cycles,
+  // 256 B/clk, banks mod 64): 10 LDS-array cycles per index where 6 do.  The kernel's LDS pipe was 0.67-0.70 busy beside a VALU at 0.73
+  // (profiles/r05 PMC; the same on cache-resident data: profiles/r06/probe_pmc.txt).  Layout of the wave's slice with the three arrays of BOTH
+  // pixels interleaved array-major, slots of QS doubles:  P0 a | P0 b | -2 P1 a | -2 P1 b | P2 a | P2 b  -- a pixel's arrays are 2 QS = 418 doubles
+  // apart: beyond the 255-element reach of ds_read2_b64 and no multiple of 64 (ds_read2st64_b64), so the three reads stay three instructions at ONE
+  // address register and immediate offsets.  QS = B + 1 + PERC + 1: the slot of P0 holds the zero padding the lanes beyond bin B read.
+#ifndef CHM_GW_SPLIT3
+#define CHM_GW_SPLIT3 0
+#endif
+  constexpr bool SPLIT = FAST && (CHM_GW_SPLIT3 != 0);
+  constexpr int QS = BINS > 0 ? BINS + 1 + (BINS + SW - 1) / SW + 1 : 0, QD = 2 * QS;
+  static_assert(!SPLIT || (QD > 255 && QD % 64 != 0 && (2 * QD) % 64 != 0), "the three prefix arrays must be out of reach of the paired LDS reads");
   const int lane = threadIdx.x, sl = lane % SW;
   const int S = L.S, Z = L.Z, B = BINS > 0 ? BINS : L.num_bins, G = L.G;      // BINS > 0: the bin count is a compile-time constant (LDS offsets, loop bounds)
   const double zmin = es[0], norm = es[3], lb = es[6], ub = es[7];
@@ -1854,7 +1868,10 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
     }
     if (nit >= NR) for (int s = s0 + sl + SW * NR; s < s1; s += SW) hi = vmax_f64(hi, wz[s]);
   }
-  double* const Q0 = Q; double* const Q1 = PRE ? Q12 : Q + (B + 1); double* const Q2 = PRE ? Q12 + (B + 1) : Q + 2 * (B + 1);      // P0 | -2 P1 | P2, (B + 1) doubles each
+  // P0 | -2 P1 | P2, (B + 1) doubles each behind one another; SPLIT: Q is the WAVE's slice, the pixel's slots are QS apart and its arrays QD
+  double* const Q0 = SPLIT ? Q + (lane / SW) * QS : Q;
+  double* const Q1 = SPLIT ? Q0 + QD : (PRE ? Q12 : Q + (B + 1));
+  double* const Q2 = SPLIT ? Q0 + 2 * QD : (PRE ? Q12 + (B + 1) : Q + 2 * (B + 1));
   constexpr int PERC = BINS > 0 ? (BINS + SW - 1) / SW : 1;  // bins per lane (compile-time bin count)
   if (!PRE) {
     hi = sg_last_perm<SW>(sg_scan_max0<SW>(hi));       // z >= 0: z_from_dGW interpolates a table that starts at z = 0 (cosmo.py:43-46)
@@ -1863,7 +1880,10 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
       // PERC stores per lane at immediate offsets, no loop, no bound: [0, PERC SW) covers the B counts and runs into the first slots of the
       // -2 P1 array (B + 1 .. PERC SW - 1 of this pixel's slice), which the prefix pass below rewrites -- the lanes whose bins lie beyond B then
       // read zeros there without a test
+      // (SPLIT: the stores beyond the slot of P0 -- indices QS .. PERC SW - 1 -- land in the first entries of the next slot: pixel b's own P0, which its
+      //  lanes zero in the same instruction, or pixel a's -2 P1, rewritten by the prefix pass; the counts are read from at most index B + 1 + PERC - 1)
       static_assert(BINS <= 0 || PERC * SW <= 2 * (BINS + 1), "zero padding must stay inside the pixel's own prefix arrays");
+      static_assert(!SPLIT || (PERC * SW - QS) <= QS, "zeroing must not run past the neighbouring slot");
 #pragma unroll
       for (int i = 0; i < PERC; i++) Q0[sl + SW * i] = 0.;
     } else for (int j = sl; j < B; j += SW) Q0[j] = 0.;
@@ -1889,6 +1909,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   // sums and prefix sums over the bins; every lane of the group owns `per` consecutive bins (a compile-time 7 for 200 bins on 32 lanes)
   const int per = (B + SW - 1) / SW;
   const int j0 = FAST ? sl * per : (sl * per < B ? sl * per : B), j1 = min(j0 + per, B);     // FAST: unclamped -- the lanes beyond B read the zero padding
+  const int j0r = SPLIT ? min(j0, B + 1) : j0;              // SPLIT: ... which ends with the slot of P0: the lanes wholly beyond B read its last PERC entries
 #ifndef CHM_MAXPER
 #define CHM_MAXPER 8
 #endif
@@ -1901,7 +1922,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   const double c_first = ((double)j0 + 0.5) * dbin;
   if (small) {                                              // the lane's bin counts: all loads in flight at once, summed in bin order
 #pragma unroll
-    for (int i = 0; i < MAXPER; i++) wv[i] = FAST ? Q0[j0 + i] : ((j0 + i < j1) ? Q0[j0 + i] : 0.);      // FAST: zeros beyond B (padding above), no test
+    for (int i = 0; i < MAXPER; i++) wv[i] = FAST ? Q0[j0r + i] : ((j0 + i < j1) ? Q0[j0 + i] : 0.);      // FAST: zeros beyond B (padding above), no test
     double cc = c_first;
 #pragma unroll
     for (int i = 0; i < MAXPER; i++) { const double w = wv[i], t = w * cc; s0w += w; s1w += t; s2w = fma(t, cc, s2w); sq = fma(w, w, sq); cc += dbin; }
@@ -2085,7 +2106,7 @@ DEVFN void kde_marg_sub2_body(const LikeDev& L, const DevParams* params, const i
   const int PG = (L.P + NPW - 1) / NPW, H = (PG + IPW - 1) / IPW;   // pixel groups of an event; the wave's items: by + i H
   const int b = bx, e = L.e_off + bz;
   const int Z = L.Z;
-  double* Q = lds_all + (size_t)sub * (3 * L.num_bins + 3);
+  double* Q = (CHM_GW_SPLIT3 && BINS > 0) ? lds_all : lds_all + (size_t)sub * (3 * L.num_bins + 3);      // (CHM_GW_SPLIT3: the wave's slice, see kde_sub_item)
   const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
   const bool ok = es[4] >= L.pe_neff;                       // likelihood.py:199 (same for every pixel of the event)
   const int* so_ = L.seg_off + (size_t)e * (L.P + 1);

@@ -22,6 +22,7 @@ RTOL_L = 1e-9
 HOSTILE_SHARE = float(os.environ.get('FUZZ_HOSTILE', '0.15'))
 EXTREME_SHARE = float(os.environ.get('FUZZ_EXTREME', '0.2'))
 CHECK_PGW = bool(int(os.environ.get('FUZZ_PGW', '0')))      # also compare the p_gw arrays of the API
+PGW_ATOL = float(os.environ.get('FUZZ_PGW_ATOL', '1e-12'))   # [r6] absolute tolerance of the p_gw comparison, in units of the largest density (1e-9 in round 5)
 INF_RATE_SHARE = float(os.environ.get('FUZZ_INF_RATE', '0.03'))      # share of configurations with one infinite rate parameter
 MANY_EVERY = int(os.environ.get('FUZZ_MANY_EVERY', '0'))      # every n-th configuration: 500+ small events (the event-group path of ten-draw batches)
 
@@ -203,10 +204,26 @@ def one(rng, many_events=False):
       ill = (rtol_e > RTOL_L) | dead
       assert np.array_equal(H.neginf_class(rp0)[~dead], H.neginf_class(ro0)[~dead]), f"-inf-class mismatch: got {rp0}, ref {ro0}"
       fin = ~H.neginf_class(ro0) & ~dead
-      bad_e = fin & ~(np.abs(rp0 - ro0) <= rtol_e * np.abs(ro0) + 1e-9)
+      with np.errstate(all='ignore'):
+        bad_e = fin & ~(np.abs(rp0 - ro0) <= rtol_e * np.abs(ro0) + 1e-9)
       assert not bad_e.any(), f"full mode: events {np.flatnonzero(bad_e)}: {rp0[bad_e]} against {ro0[bad_e]} (1 - sum W^2 = {cond[bad_e]}, rtol {rtol_e[bad_e]})"
+      # [r6] a `dead` event is not compared, but it is not a free pass either: the device's log L_i must be NaN, of the -inf class, or a
+      # density no larger than what ONE sample carrying the whole weight can give at the reference's resolution -- never +inf, never a wild positive
+      # value.  Bound: the oracle's own value + 80 (e^80 above a value that is itself rounding noise) when that is finite, +745 (-log of the smallest
+      # subnormal against a density of order one) otherwise.
+      if dead.any():
+        with np.errstate(all='ignore'):
+          cap = np.where(np.isfinite(ro0) & ~H.neginf_class(ro0), ro0 + 80., 745.)
+          wild = dead & ~(np.isnan(rp0) | H.neginf_class(rp0) | (rp0 <= cap))
+        assert not wild.any(), f"full mode: ill-determined events {np.flatnonzero(wild)} came out as {rp0[wild]} (oracle {ro0[wild]}): not even a sane value class"
+        checks.append(f'dead_events={int(dead.sum())}')
       if ill.any():
-        ro = (ro[0], ro[1], ro[2], np.nan)                    # (the total carries the same difference: not compared)
+        # [r6] the total is compared over the well-conditioned events (it used to be dropped whenever one event was ill-conditioned)
+        well = ~ill
+        if well.any() and not H.neginf_class(ro0[well]).any():
+          np.testing.assert_allclose(np.sum(rp0[well]), np.sum(ro0[well]), rtol=1e-12, atol=1e-7 * np.sqrt(E))
+          checks.append('total_over_well_conditioned')
+        ro = (ro[0], ro[1], ro[2], np.nan)                    # (the total over ALL events carries the ill-conditioned ones' differences: not compared)
     else:
       H.assert_loglike_close(rp[0], ro[0], rtol=RTOL_L, atol=1e-9)
     # (every sample of an event at ONE distance: whether the spread comes out as an exact 0 -- KDE 0/0 = NaN -> log L_i = -inf -- or as 1e-16 -- KDE 0,
@@ -245,7 +262,10 @@ def one(rng, many_events=False):
       fin = np.isfinite(go)
       assert np.array_equal(fin, np.isfinite(gp)), f"p_gw: finite where the oracle's is not (or the reverse) in {int(np.sum(fin != np.isfinite(gp)))} of {fin.size} entries"
       if fin.any():
-        np.testing.assert_allclose(gp[fin], go[fin], rtol=1e-9, atol=1e-9 * np.max(np.abs(go[fin])))
+        # [r6] atol 1e-12 of the largest density (round 5: 1e-9, loose in the tails) -- the rows compared are those of events the ORACLE marks
+        # well-conditioned (`valid` above).  Where an Epanechnikov support ends the two sides may differ by one bin's kernel value at |u| = 1 -+ rounding
+        # (< 1e-15 of the peak); a histogram bin flip of a sample moves a density by O(1 / S) and is NOT covered: it fails here and is looked at
+        np.testing.assert_allclose(gp[fin], go[fin], rtol=1e-9, atol=PGW_ATOL * np.max(np.abs(go[fin])))
       checks.append('p_gw')
     if standard and P <= 64 and S % 2 == 0 and HAS_FUSED:     # (a -DCHM_WITH_FUSED variant build: CHIMERA_LIB=.../libchimera_hip_fused.so)
       like_p.set_option('fused', 2)
@@ -274,6 +294,7 @@ def one(rng, many_events=False):
 
 
 def main():
+  """Counts per check and -- [r6] -- how many events fell into the 'not compared' class of full mode (`dead_events=`), so that the exclusion stays visible."""
   n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
   seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
   budget = float(sys.argv[3]) if len(sys.argv) > 3 else 540.
@@ -284,7 +305,11 @@ def main():
     ok, desc, checks = one(np.random.default_rng(77000 + seed0 + i), many_events=(MANY_EVERY > 0 and (seed0 + i) % MANY_EVERY == MANY_EVERY - 1))
     done += 1
     for c in checks:
-      counts[c] = counts.get(c, 0) + 1
+      if c.startswith('dead_events='):
+        counts['configurations with events not compared (1 - sum W^2 < 1e-8)'] = counts.get('configurations with events not compared (1 - sum W^2 < 1e-8)', 0) + 1
+        counts['events not compared (1 - sum W^2 < 1e-8)'] = counts.get('events not compared (1 - sum W^2 < 1e-8)', 0) + int(c.split('=')[1])
+      else:
+        counts[c] = counts.get(c, 0) + 1
     if not ok:
       fails += 1
       kind_of = desc.split(')')[0] if desc.startswith('HOSTILE') else 'plain'
