@@ -118,6 +118,23 @@ def load_pmc(keys, sha=None):
   return best
 
 
+def load_probe_ceilings(sha):
+  """[r6] Measured ceilings of the two hot kernels (scripts/run_probes.py with the -DCHM_PROBE build: the production BODIES of k_kde_marg_sub2 and
+  k_samples_fast replayed for > 1 s on a cache-resident workload -- what their instruction streams sustain on the card, at the clock the board holds,
+  with HBM out of the picture).  Newest profiles/rNN/probe_ceilings.json; (path, json, fresh): fresh = collected beside the loaded release binary."""
+  best = None
+  for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*', 'probe_ceilings.json'))):
+    try:
+      with open(f) as fh:
+        j = json.load(fh)
+    except Exception:                                 # noqa: BLE001
+      continue
+    fresh = bool(sha) and j.get('release_code_object_sha256') == sha
+    if best is None or fresh or not best[2]:
+      best = (os.path.relpath(f, ROOT), j, fresh)
+  return best
+
+
 def pmc_kernel(pmc, prefix):
   if pmc is None:
     return None
@@ -144,8 +161,9 @@ def quartiles(x):
 MIN_INST = {'k_samples': (140., 'sample'), 'k_kde_marg_sub2': (570., 'pair of pixels'), 'k_selection': (224., 'injection')}
 
 
-def kernel_roofline(label, prefix, ms, unique_bytes, pmc, units=None):
-  """One kernel against its ceilings.  ms: live HIP-event duration of one launch; units: units of work per launch in waves (MIN_INST)."""
+def kernel_roofline(label, prefix, ms, unique_bytes, pmc, units=None, probe=None, work=None):
+  """One kernel against its ceilings.  ms: live HIP-event duration of one launch; units: units of work per launch in waves (MIN_INST);
+  probe / work: the measured ceilings (load_probe_ceilings) and the launch's work in the probe's unit (pairs of pixels, samples)."""
   k = pmc_kernel(pmc, prefix)
   fresh = bool(pmc and pmc[2])
   sec = ms * 1e-3
@@ -192,6 +210,16 @@ def kernel_roofline(label, prefix, ms, unique_bytes, pmc, units=None):
       traffic = (2 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024
       out.update({"traffic_bytes_per_launch": traffic, "hbm_traffic_GBs": traffic / sec / 1e9,
                   "hbm_traffic_frac": traffic / sec / 1e9 / HBM_PEAK_GBS})
+  insts_ = k.get('SQ_INSTS_VALU') if (k and fresh) else None
+  pk = next((v for kk, v in ((probe[1].get('kernels') or {}).items() if probe else ()) if prefix.startswith(kk) or kk.startswith(prefix)), None)
+  if pk and work and probe[2] and sec > 0:
+    # [r6] the launch against what the SAME body sustains on a cache-resident workload (scripts/run_probes.py): work per second, and -- where the PMC
+    # pass of this command counted the launch's VALU instructions -- wave-instructions per second against the probe's
+    out["sustained"] = {"unit": pk.get('unit'), "work_per_launch": work, "achieved_per_s": work / sec, "probe_per_s": pk.get('units_per_s'),
+                        "frac_of_sustained": work / sec / pk['units_per_s'] if pk.get('units_per_s') else None,
+                        "valu_winst_per_s": insts_ / sec if insts_ else None, "probe_valu_winst_per_s": pk.get('valu_winst_per_s'),
+                        "valu_rate_over_probe": insts_ / sec / pk['valu_winst_per_s'] if (insts_ and pk.get('valu_winst_per_s')) else None,
+                        "probe_clock_GHz": pk.get('clock_GHz'), "source": probe[0]}
   return out
 
 
@@ -616,6 +644,7 @@ def main():
     El = like._e1 - like._e0
     lib_sha = code_object_sha256(_lib.LIB_PATH)
     pmc = load_pmc(dict(config=args.config, E=El, P=P, Z=Z, S=S, nbatch=nb, mode=kind or '1d', n_gpus=1, fused=args.fused), lib_sha) if world == 1 else None
+    probe = load_probe_ceilings(lib_sha) if world == 1 else None
     kernels = []
     if kind == 'marginalized' and args.fused >= 2:
       # the fused event kernel does the sample stage, the per-z factors and the GW kernel of every (event, draw) in one launch: its span is kt[3]
@@ -623,7 +652,7 @@ def main():
                                      El * S * 49 + El * P * Z * 8 + El * Z * 8 + nb * ((2 * 1500 + 2 * 1000) * 8 + El * Z * 16), pmc))
     elif kind == 'marginalized':
       kernels.append(kernel_roofline("marginalized GW kernel (histogram + KDE + interp + integrand + trapz)", "k_kde_marg_sub2", kt[3],
-                                     gw_kernel_unique_bytes(El, S, P, Z, nb), pmc, units=El * P / 2. * nb))
+                                     gw_kernel_unique_bytes(El, S, P, Z, nb), pmc, units=El * P / 2. * nb, probe=probe, work=El * ((P + 1) // 2) * nb))
     full_pairs = None
     if kind == 'full':
       kernels.append(kernel_roofline("3-D Gaussian KDE + integrand (sample-stationary kernel; the general kernel's share of the stage is its empty blocks)", "k_full_kde_chain", kt[3], El * S * 32 * nb + El * P * Z * 8, pmc))
@@ -649,7 +678,7 @@ def main():
                  "march_alone_Gpairs_s_measured_r05": march_alone, "frac_of_march_alone": full_pairs / sec / 1e9 / march_alone if sec > 0 else None})
     if not (kind == 'marginalized' and args.fused >= 2):        # (the fused event kernel has no sample stage of its own)
       kernels.append(kernel_roofline("sample stage (z(dL), source-frame masses, population weights, event statistics)", "k_samples", kt[2],
-                                     sample_kernel_unique_bytes(El, S, nb), pmc, units=El * S * nb / 64.))
+                                     sample_kernel_unique_bytes(El, S, nb), pmc, units=El * S * nb / 64., probe=probe, work=float(El) * S * nb))
     # the selection kernel runs on its own stream beside the event kernels (its span there is not a kernel duration): timed standalone
     # here, after the timed region, as the selection-only call chm_eval(NULL, sel, ...) of the same draws
     sel_ms = None
@@ -679,6 +708,8 @@ def main():
             "peak": ISSUE_PEAK_TCYC if kind != 'full' else dom.get("peak_Gpairs_s"),
             "unit": "Tcycle/s (issue cycles of fp64 add / mul / fma instructions; peak: the VALU issue cycles of 1024 SIMDs at 2.4 GHz)" if kind != 'full' else "Gpair/s",
             "frac": dom.get("useful_frac") if kind != 'full' else dom.get("pair_frac"),
+            # [r6] the dominant kernel against the MEASURED ceiling of its own body (cache-resident probe): replaces round 5's paper count as the yardstick
+            "frac_of_sustained": (dom.get("sustained") or {}).get("frac_of_sustained"),
             "useful_frac": dom.get("useful_frac"), "issue_busy_frac": dom.get("valu_busy_frac"),
             "issue_busy_frac_at_held_clock": dom.get("valu_busy_frac_at_held_clock"), "min_inst": dom.get("min_inst"),
             "fp64_TFLOPs_real": dom.get("fp64_TFLOPs_real"), "fp64_peak_TFLOPs": FP64_PEAK_TFLOPS,

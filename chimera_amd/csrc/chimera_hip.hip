@@ -310,7 +310,7 @@ static int ctx_tables_enqueue(Ctx& c, int nb, int Tc, int Tm, LutDesc lutA = Lut
     static size_t tl_allowed = 0;                             // the kernel also holds 33 KB of static LDS: ask as soon as the sum passes 48 KB
     if (tl > 14 * 1024 && tl > tl_allowed) { (void)hipFuncSetAttribute((const void*)k_tables<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl); tl_allowed = tl; }
 #ifndef CHM_TABLES_Y_BATCH
-#define CHM_TABLES_Y_BATCH 3      // (A/B, profiles/r06/ab_shard_step_r06.txt) blocks per draw of a call of many draws: 3 = the cosmology tail split over two blocks (the scalar call's form), 2 = one block
+#define CHM_TABLES_Y_BATCH 2      // (A/B, profiles/r06/ab_shard_step_r06.txt) blocks per draw of a call of many draws: 2 = cosmology | mass (256 blocks of 1024 threads at 128 draws: one per CU); 3 = the cosmology tail split over two blocks (the scalar call's form; 384 blocks: -0.5 % of the 125-event shard's step with 2)
 #endif
     hipLaunchKernelGGL(k_tables<true>, dim3(nb, nb > 8 ? CHM_TABLES_Y_BATCH : 3), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt, hsrc, ztc, lzc);
   } else {
@@ -1108,7 +1108,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       cap = (cap + 7) / 8 * 8;
       lutA = like->F.lut;
       lutA.cap = (int)cap; lutA.lut = like->d_lut; lutA.info = like->d_lutinfo;
-      lds_fast = sizeof(double) * (CHM_EXPTAB_N + CHM_REC_STRIDE * (size_t)cap + 2 * (size_t)Tm_call) + ((size_t)(lutA.nk + 1) * 2 + 15) / 16 * 16;
+      lds_fast = sizeof(double) * (CHM_EXPTAB_N + 4 * (size_t)cap + 2 * (size_t)Tm_call) + ((size_t)(lutA.nk + 1) * 2 + 15) / 16 * 16;
       if (lds_fast > 96 * 1024) use_fast = false;
     }
   }
@@ -1193,7 +1193,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       cap = (cap + 7) / 8 * 8;
       lutB = sel->lut;
       lutB.cap = (int)cap; lutB.lut = sel->d_lut; lutB.info = sel->d_lutinfo;
-      lds_sel = sizeof(double) * (CHM_EXPTAB_N + CHM_REC_STRIDE * (size_t)cap + 2 * (size_t)Tm_call) + ((size_t)(lutB.nk + 1) * 2 + 15) / 16 * 16;
+      lds_sel = sizeof(double) * (CHM_EXPTAB_N + 4 * (size_t)cap + 2 * (size_t)Tm_call) + ((size_t)(lutB.nk + 1) * 2 + 15) / 16 * 16;
       if (lds_sel > 64 * 1024) sel_fast = false;
     }
   }
@@ -1311,6 +1311,42 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   const size_t lds_zfac = sizeof(double) * (size_t)2 * Tc;                          // zt, It
   const bool tab_samp = lds_samp <= 64 * 1024, tab_zfac = lds_zfac <= 64 * 1024;
 
+  // ---- selection function on its own stream, forked after the tables.  Enqueued AFTER the event kernels: every API call between the
+  //      table kernel and the sample stage is stream time the GPU idles (k_tables is 19 us; the fork used to cost 23 us there)
+  bool sel_enqueued = false, sel_joined = false;
+  auto enqueue_selection = [&]() -> int {
+    sel_enqueued = true;
+    if (!(sel && !fuse_sel)) return CHM_OK;
+    HIPCHK(hipStreamWaitEvent(sC, c.ev[1], 0));
+    SelDev S = sel->S;
+    S.tab_pm = td.pm_i; S.tab_rate = td.rate_i; S.tab_bkg = td.bkg_i; S.tab_jac = td.jac_i;
+    if (timing_all) HIPCHK(hipEventRecord(c.evb[1], sC));
+    if (sel_fast) {
+#define LAUNCH_SELF_(M, G) do { allow_lds((k_selection_fast<M, G>), lds_sel); \
+        hipLaunchKernelGGL((k_selection_fast<M, G>), dim3(gx, nb), dim3(256), lds_sel, sC, S, lutB, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm); } while (0)
+#define LAUNCH_SELF(M) do { if (params[0].cosmo_model == 1) LAUNCH_SELF_(M, true); else LAUNCH_SELF_(M, false); } while (0)
+      // every block stages the draw's table slice (tens of KB): ~8192 blocks in all, each walking over several tiles of injections
+      const int self_blocks = (sel ? sel->opts.self_blocks : 8192) > 0 ? (sel ? sel->opts.self_blocks : 8192) : 8192;
+      int gx = self_blocks / nb;
+      gx = gx < 1 ? 1 : (gx > S.nblocks ? S.nblocks : gx);
+      const int mm = params[0].mass_model;
+      if (mm == 0) LAUNCH_SELF(0); else if (mm == 1) LAUNCH_SELF(1); else LAUNCH_SELF(2);
+#undef LAUNCH_SELF
+#undef LAUNCH_SELF_
+    } else if (rate_special_call) {                          // a draw with an infinite rate parameter: the reference's own operations for the rate (merger_rate_special)
+      hipLaunchKernelGGL((k_selection<false, true>), dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    } else if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
+      hipLaunchKernelGGL(k_selection<true>, dim3(S.nblocks, nb), dim3(256), lds_samp, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    } else hipLaunchKernelGGL(k_selection<false>, dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c.evb[2], sC));
+    return CHM_OK;
+  };
+  // [r6] ONE event group on one lane (small shards; few groups): the selection kernel is enqueued right behind the sample stage and lane A takes its join
+  // in FRONT of the GW kernel, where the command processor resolves the cross-queue dependency while the per-z-factor kernel runs -- behind the
+  // fix-up it cost ~20 us of an idle lane in every call (profiles/r06/timeline_shard125_rccl.txt: fix-up end 1249 us, reduction start 1270 us).  Only
+  // where the selection sums are the smaller job by far (they share the chip with the sample stage and end with it); a catalogue of few events with
+  // a million injections (C4) keeps the late join, and so does everything that is not the marginalized chain on one lane.
   // ---- events: groups of events alternate between two streams, so that the (VALU-bound) sample stage of one group
   //      overlaps the (latency-bound) GW-kernel stage of the previous one
   int nblk_ev = 0, ngroups = 0;
@@ -1452,6 +1488,12 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       }
       HIPCHK(hipGetLastError());
       if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g + 1], sg));
+#ifndef CHM_SEL_EARLY
+#define CHM_SEL_EARLY 1      // (0: A/B builds -- the join behind the fix-up as in round 5; profiles/r06/ab_shard_step_r06.txt)
+#endif
+      const bool sel_early = CHM_SEL_EARLY && sel && !fuse_sel && ngroups == 1 && sg == sA && L.mode == CHM_MODE_MARG && zf_ranged && !tab &&
+                             (double)sel->S.I * 4. < (double)L.E_cnt * (double)L.S;
+      if (sel_early) { rc = enqueue_selection(); if (rc) return rc; }
       // GW kernel + integrand (needs the per-z factors)
       if (sz != sg) HIPCHK(hipStreamWaitEvent(sg, c.evf[g], 0));
       if (L.mode == CHM_MODE_FULL) {
@@ -1469,6 +1511,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         else hipLaunchKernelGGL(k_event_prep, dim3((L.E_cnt + 3) / 4, nb), dim3(256), 0, sg, L, 1);
         HIPCHK(hipGetLastError());
         if (zf_ranged) { launch_zfactors(); HIPCHK(hipGetLastError()); }
+        if (sel_early) { HIPCHK(hipStreamWaitEvent(sA, c.evb[2], 0)); sel_joined = true; }      // join: selection sums (resolved under the per-z-factor kernel)
         if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         const bool fast = marg_std;
         if (fast) {
@@ -1480,8 +1523,8 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
           const int ipw_env = o.kde_ipw;                    // diagnostics: 2 or 4 items per wave
           // (few draws per call: two items per wave -- twice the waves, half the serial chain of each: 0.238 -> 0.229 ms for the scalar call at C3)
           const int ipw = ipw_env == 2 || ipw_env == 4 ? ipw_env : ((PG2 >= 4 && nb > 8) ? 4 : 2);
-          // (CHM_GW_SPLIT3 builds, compile-time bin count: five slots of QS = B + 1 + 7 + 1 doubles and one of B + 1, see kde_sub_item)
-          const size_t lds_sub = (CHM_GW_SPLIT3 && L.num_bins == 200 && !L.p_gw_dump) ? sizeof(double) * (5 * (200 + 1 + 7 + 1) + 201) : sizeof(double) * (3 * N + 3) * GW_NPW;
+          // (compile-time bin count: five slots of QS = B + 1 + 7 + 1 doubles and one of B + 1 per wave, see kde_sub_item: SPLIT)
+          const size_t lds_sub = (L.num_bins == 200 && !L.p_gw_dump) ? sizeof(double) * (5 * (200 + 1 + 7 + 1) + 201) : sizeof(double) * (3 * N + 3) * GW_NPW;
 #define LAUNCH_SUB2(I, BN, DU) hipLaunchKernelGGL((k_kde_marg_sub2<GW_SW, I, BN, DU>), dim3(nb, (PG2 + I - 1) / I, L.E_cnt), dim3(64), lds_sub, sg, L, dp)
           if (L.p_gw_dump) { if (ipw == 4) LAUNCH_SUB2(4, 0, true); else LAUNCH_SUB2(2, 0, true); }    // p_gw3d requested (tests, hyperlikelihood.p_gw3d): the instantiation that stores it
           else if (L.num_bins == 200) { if (ipw == 4) LAUNCH_SUB2(4, 200, false); else LAUNCH_SUB2(2, 200, false); }      // the reference's default bin count (likelihood.py:59): compile-time
@@ -1514,33 +1557,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   } else {
     if (timing_all) HIPCHK(hipEventRecord(c.ev[3], sA));
   }
-  // ---- selection function on its own stream, forked after the tables.  Enqueued AFTER the event kernels: every API call between the
-  //      table kernel and the sample stage is stream time the GPU idles (k_tables is 19 us; the fork used to cost 23 us there)
-  if (sel && !fuse_sel) {
-    HIPCHK(hipStreamWaitEvent(sC, c.ev[1], 0));
-    SelDev S = sel->S;
-    S.tab_pm = td.pm_i; S.tab_rate = td.rate_i; S.tab_bkg = td.bkg_i; S.tab_jac = td.jac_i;
-    if (timing_all) HIPCHK(hipEventRecord(c.evb[1], sC));
-    if (sel_fast) {
-#define LAUNCH_SELF_(M, G) do { allow_lds((k_selection_fast<M, G>), lds_sel); \
-        hipLaunchKernelGGL((k_selection_fast<M, G>), dim3(gx, nb), dim3(256), lds_sel, sC, S, lutB, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm); } while (0)
-#define LAUNCH_SELF(M) do { if (params[0].cosmo_model == 1) LAUNCH_SELF_(M, true); else LAUNCH_SELF_(M, false); } while (0)
-      // every block stages the draw's table slice (tens of KB): ~8192 blocks in all, each walking over several tiles of injections
-      const int self_blocks = (sel ? sel->opts.self_blocks : 8192) > 0 ? (sel ? sel->opts.self_blocks : 8192) : 8192;
-      int gx = self_blocks / nb;
-      gx = gx < 1 ? 1 : (gx > S.nblocks ? S.nblocks : gx);
-      const int mm = params[0].mass_model;
-      if (mm == 0) LAUNCH_SELF(0); else if (mm == 1) LAUNCH_SELF(1); else LAUNCH_SELF(2);
-#undef LAUNCH_SELF
-#undef LAUNCH_SELF_
-    } else if (rate_special_call) {                          // a draw with an infinite rate parameter: the reference's own operations for the rate (merger_rate_special)
-      hipLaunchKernelGGL((k_selection<false, true>), dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    } else if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
-      hipLaunchKernelGGL(k_selection<true>, dim3(S.nblocks, nb), dim3(256), lds_samp, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    } else hipLaunchKernelGGL(k_selection<false>, dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c.evb[2], sC));
-  }
+  if (!sel_enqueued) { rc = enqueue_selection(); if (rc) return rc; }
 
   double* d_lle = nullptr; double* d_nle = nullptr;
   const size_t El = like ? like->L.E : 0;
@@ -1566,7 +1583,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
                        ev_from_fixup ? (const double*)like->L.ev_ll : nullptr, like->d_ev_bad);
     HIPCHK(hipGetLastError());
   }
-  if (sel && !fuse_sel) HIPCHK(hipStreamWaitEvent(sA, c.evb[2], 0));     // join: selection sums
+  if (sel && !fuse_sel && !sel_joined) HIPCHK(hipStreamWaitEvent(sA, c.evb[2], 0));     // join: selection sums
   if (one_kernel) {
     hipLaunchKernelGGL(k_reduce_final, dim3(nb), dim3(1024), 0, sA, like ? like->L.E : 0, like ? (like->L.P > 0 ? like->L.P : 1) : 1,
                        like ? (const double*)like->L.like_pix : nullptr, sel ? sel->S.nblocks : 0,

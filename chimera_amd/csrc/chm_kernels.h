@@ -706,31 +706,6 @@ DEVFN double log1pz_from_node(double z, double z0, double lz0, double r, double&
 // once per draw (k_tables) -- the reference's z_0 + ((x - x_0)/dx) dz to <= 2e-18 relative (the increment is < 1.7 % of z).
 // rec: LDS slice [i_lo, i_lo + ns) of the node records.  Returns z and the record (z_0, log(1 + z_0)) used; lanes whose key is
 // outside the table (NaN, <= 0, inf) report bad.
-// [r6] CHM_REC_STRIDE (build knob, A/B: profiles/r06/ab_exp_table_size.txt): doubles between the node records of the table slice IN LDS.  4 = the
-// records as k_tables writes them (32-byte rows: a row's bank group is its index mod 4 -- lanes with unrelated rows collide); 5 = rows padded to
-// 40 bytes (an odd multiple of 8: the rows walk through all the banks; the 16-byte loads of a record become 8-byte pairs).
-#ifndef CHM_REC_STRIDE
-#define CHM_REC_STRIDE 4
-#endif
-#if defined(CHM_WITH_FUSED) && CHM_REC_STRIDE != 4
-#error "the fused event kernel stages 32-byte node records"
-#endif
-// the four values of record j of the LDS slice
-DEVFN double4 rec_row(const double* rec, int j) {
-  if (CHM_REC_STRIDE == 4) return *reinterpret_cast<const double4*>(rec + 4 * j);
-  const double* q = rec + CHM_REC_STRIDE * j;
-  return make_double4(q[0], q[1], q[2], q[3]);
-}
-// global records [ns x 4] -> LDS slice (t of nt threads)
-DEVFN void rec_stage(double* rec, const double* grec, int ns, int t, int nt) {
-  if (CHM_REC_STRIDE == 4) {
-    const double2* gr = reinterpret_cast<const double2*>(grec);
-    double2* lr = reinterpret_cast<double2*>(rec);
-    for (int i = t; i < 2 * ns; i += nt) lr[i] = gr[i];
-  } else {
-    for (int i = t; i < 4 * ns; i += nt) rec[(i >> 2) * CHM_REC_STRIDE + (i & 3)] = grec[i];
-  }
-}
 DEVFN void z_from_lut_x2(double xa, double xb, const double* rec, const unsigned short* luts, int key0, int nk,
                          int i_lo, int ns, int lmax, int Tc, double x_last, double z_last,
                          double& za, double& zb, double& z0a, double& z0b, double& lz0a, double& lz0b, bool& bad) {
@@ -742,18 +717,18 @@ DEVFN void z_from_lut_x2(double xa, double xb, const double* rec, const unsigned
   for (int l = lmax; l > 1;) {
     const int half = l >> 1;
     const int ia = pa + half - 1, ib = pb + half - 1;
-    const double va = rec[CHM_REC_STRIDE * ((ia < i_hi ? ia : i_hi) - i_lo)], vb = rec[CHM_REC_STRIDE * ((ib < i_hi ? ib : i_hi) - i_lo)];
+    const double va = rec[4 * ((ia < i_hi ? ia : i_hi) - i_lo)], vb = rec[4 * ((ib < i_hi ? ib : i_hi) - i_lo)];
     pa += (ia <= i_hi && va <= xa) ? half : 0;
     pb += (ib <= i_hi && vb <= xb) ? half : 0;
     l -= half;
   }
   if (lmax > 0) {
-    const double va = rec[CHM_REC_STRIDE * ((pa < i_hi ? pa : i_hi) - i_lo)], vb = rec[CHM_REC_STRIDE * ((pb < i_hi ? pb : i_hi) - i_lo)];
+    const double va = rec[4 * ((pa < i_hi ? pa : i_hi) - i_lo)], vb = rec[4 * ((pb < i_hi ? pb : i_hi) - i_lo)];
     pa += (pa <= i_hi && va <= xa) ? 1 : 0;
     pb += (pb <= i_hi && vb <= xb) ? 1 : 0;
   }
   const int ja = (pa < 1 ? 1 : (pa > Tc - 1 ? Tc - 1 : pa)) - 1 - i_lo, jb = (pb < 1 ? 1 : (pb > Tc - 1 ? Tc - 1 : pb)) - 1 - i_lo;
-  const double4 ra = rec_row(rec, ja), rb = rec_row(rec, jb);
+  const double4 ra = *reinterpret_cast<const double4*>(rec + 4 * ja), rb = *reinterpret_cast<const double4*>(rec + 4 * jb);
   // jnp.interp clamps to fp[-1] beyond the last node (x < xp[0] = dL(z = 0) = 0 cannot occur for a valid key): the table is sorted here
   // (`fits`), so the interpolant of the last interval exceeds z_last exactly for x > x_last -- one v_min_f64 instead of a compare and two selects
   za = vmin_f64(__builtin_fma(xa - ra.x, ra.z, ra.y), z_last);
@@ -811,7 +786,7 @@ DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParam
   // LDS: node records of the table slice [cap x 4], m_grid [Tm], cdf_m2 [Tm], direct-index table [nk + 1] (u16)
   // [r3] + the 256-entry table of the mass model's exps first (chm_exp_tab: 13 instead of 17 VALU instructions per exp, four exps per sample)
   double* etab = lds;
-  double* rec = lds + CHM_EXPTAB_N; double* mg = rec + CHM_REC_STRIDE * (size_t)cap; double* cdf = mg + Tm;
+  double* rec = lds + CHM_EXPTAB_N; double* mg = rec + 4 * (size_t)cap; double* cdf = mg + Tm;
   unsigned short* luts = reinterpret_cast<unsigned short*>(cdf + Tm);
 #if CHM_EXPTAB
   const ExpTab ex = { etab };
@@ -825,7 +800,9 @@ DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParam
     for (int i = t; i < CHM_EXPTAB_N; i += NT_) etab[i] = exp_table_entry(i);
     for (int i = t; i < Tm; i += NT_) { mg[i] = gm[i]; cdf[i] = gc[i]; }
     if (fits) {
-      rec_stage(rec, rec_all + ((size_t)b * TcMax + i_lo) * 4, ns, t, NT_);
+      const double2* gr = reinterpret_cast<const double2*>(rec_all + ((size_t)b * TcMax + i_lo) * 4);
+      double2* lr = reinterpret_cast<double2*>(rec);
+      for (int i = t; i < 2 * ns; i += NT_) lr[i] = gr[i];
       for (int i = t; i <= nk; i += NT_) luts[i] = gl[i];
     }
   }
@@ -846,7 +823,7 @@ DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParam
     {
       const double xlo = L.dl_lo[e];
       const int k = lut_key(xlo, key0);
-      if (fits) { const int q = ((unsigned)k < (unsigned)nk ? (int)luts[k] : i_lo) - i_lo; z_ref = rec[CHM_REC_STRIDE * (q < 0 ? 0 : (q > ns - 1 ? ns - 1 : q)) + 1]; }
+      if (fits) { const int q = ((unsigned)k < (unsigned)nk ? (int)luts[k] : i_lo) - i_lo; z_ref = rec[4 * (q < 0 ? 0 : (q > ns - 1 ? ns - 1 : q)) + 1]; }
       else { const int c_lo = (P.dl_sorted != 0. && xlo == xlo) ? searchsorted_right(g_dLt, Tc, xlo) : 0; z_ref = g_zt[c_lo < Tc ? c_lo : Tc - 1]; }
     }
     const double ra_ref = FULL ? L.ra[eo] : 0., dec_ref = FULL ? L.dec[eo] : 0.;
@@ -1792,15 +1769,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   // [r5] FAST (the production instantiations: compile-time bin count, histogram formed here): the set-up sheds what the compiler had wrapped
   // round its arithmetic -- see the notes at each step (profiles/r05/ab_gw_setup_diet.txt)
   constexpr bool FAST = !PRE && BINS > 0;
-  // [r6] CHM_GW_PACK (A/B builds, profiles/r06/ab_gw_packed_rows.txt): the three prefix values of a bin side by side -- row j = {P0[j], -2 P1[j], P2[j]} at
-  // Q + 3 j -- instead of three arrays of B + 1 doubles: a node's bin index is then ONE row address read with ds_read2_b64 + ds_read_b64 (two LDS
-  // instructions instead of three, the same 24 bytes).  Same LDS footprint; the bin counts keep their contiguous slots [0, B) in front (every lane has
-  // its counts in registers before the first row is stored).
-#ifndef CHM_GW_PACK
-#define CHM_GW_PACK 0
-#endif
-  constexpr bool PACK = FAST && !DUMP && (CHM_GW_PACK != 0);
-  // [r6] CHM_GW_SPLIT3: THREE ds_read_b64 per bin index instead of ds_read2_b64 + ds_read_b64.  With the arrays of a pixel B + 1 = 201 doubles apart
+  // [r6] SPLIT: THREE ds_read_b64 per bin index instead of ds_read2_b64 + ds_read_b64.  With the arrays of a pixel B + 1 = 201 doubles apart
   // the compiler fuses the reads of P0[i] and -2 P1[i] into one ds_read2_b64 (offset1:201) -- which the LDS serves at HALF the rate of two
   // ds_read_b64 (MI355X_MICROARCH.md, LDS: ds_read2_b64 = two accesses of 4 x 16 lanes, 8 cycles, 128 B/clk, banks mod 32; ds_read_b64 = 2 cycles,
   // 256 B/clk, banks mod 64): 10 LDS-array cycles per index where 6 do.  The kernel's LDS pipe was 0.67-0.70 busy beside a VALU at 0.73
@@ -1808,10 +1777,10 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   // pixels interleaved array-major, slots of QS doubles:  P0 a | P0 b | -2 P1 a | -2 P1 b | P2 a | P2 b  -- a pixel's arrays are 2 QS = 418 doubles
   // apart: beyond the 255-element reach of ds_read2_b64 and no multiple of 64 (ds_read2st64_b64), so the three reads stay three instructions at ONE
   // address register and immediate offsets.  QS = B + 1 + PERC + 1: the slot of P0 holds the zero padding the lanes beyond bin B read.
-#ifndef CHM_GW_SPLIT3
-#define CHM_GW_SPLIT3 0
-#endif
-  constexpr bool SPLIT = FAST && (CHM_GW_SPLIT3 != 0);
+  // Same-box A/B with counters (profiles/r06/ab_lds_layouts_counters.txt): SQ_LDS_IDX_ACTIVE 1.471e9 -> 1.127e9 per launch, LDS pipe 0.68 -> 0.53 busy,
+  // kernel 4.27 -> 4.17 ms (rocprofv3 average), 4.64 -> 4.48 ms (HIP events), bit-identical results.  (Packed rows {P0, -2 P1, P2} per bin -- the
+  // layout the round-5 review asked for -- keep the ds_read2_b64 + ds_read_b64 pair and change nothing: same record; docs/history/ab_arms_r06.patch.)
+  constexpr bool SPLIT = FAST;
   constexpr int QS = BINS > 0 ? BINS + 1 + (BINS + SW - 1) / SW + 1 : 0, QD = 2 * QS;
   static_assert(!SPLIT || (QD > 255 && QD % 64 != 0 && (2 * QD) % 64 != 0), "the three prefix arrays must be out of reach of the paired LDS reads");
   const int lane = threadIdx.x, sl = lane % SW;
@@ -1956,8 +1925,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
         // FAST: bin j0 + i exists iff the lane lies below the one that holds bin B (all of its PERC bins) or is that lane and i < B mod PERC:
         // two lane predicates for the PERC stores instead of an add and a compare for each
         const bool st = FAST ? (sl < B / PERC || (sl == B / PERC && i < B % PERC)) : (j0 + i < j1);
-        if (PACK) { if (st) { double* row = Q + 3 * (j0 + i + 1); row[0] = r0; row[1] = -2. * r1; row[2] = r2; } }
-        else if (st) { Q0[j0 + i + 1] = r0; Q1[j0 + i + 1] = -2. * r1; Q2[j0 + i + 1] = r2; }
+        if (st) { Q0[j0 + i + 1] = r0; Q1[j0 + i + 1] = -2. * r1; Q2[j0 + i + 1] = r2; }
       }
     } else {                                                // many bins per lane: the count of bin j+1 shares the slot of P0[j+1]
       double a0 = r0, a1 = r1, a2 = r2;
@@ -1968,12 +1936,9 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
       wave_sync();
       for (int j = j1 - 1; j >= j0; j--) { double w = Q0[j]; Q0[j + 1] = a0; a0 -= w; }
     }
-    if (PACK) { if (sl == 0) { Q[0] = 0.; Q[1] = 0.; Q[2] = 0.; } }      // (row 0 lies on the counts of bins 0-2: lane 0 read them before the barrier above)
-    else {
-      if (sl == 0) { Q1[0] = 0.; Q2[0] = 0.; }
-      wave_sync();
-      if (sl == 0) Q0[0] = 0.;
-    }
+    if (sl == 0) { Q1[0] = 0.; Q2[0] = 0.; }
+    wave_sync();
+    if (sl == 0) Q0[0] = 0.;
     wave_sync();
   }
   PHG(2);                                                   // (phase 2: bin sums, four scans, prefix stores)
@@ -2010,12 +1975,7 @@ DEVFN void kde_sub_item(const LikeDev& L, const DevParams* params, double* Q, co
   auto node = [&](double gp, double xa, double xb) {
     const int ia = med3_i32_0v(cvt_i32_sat(xa), jl1);
     const int ib = med3_i32(cvt_i32_sat(xb), ia, jl1);
-    double S0, S1, S2;
-    if (PACK) {
-      struct Row { double p0, p1, p2; };
-      const Row rb = *reinterpret_cast<const Row*>(Q + 3 * ib), ra = *reinterpret_cast<const Row*>(Q + 3 * ia);
-      S0 = rb.p0 - ra.p0; S1 = rb.p1 - ra.p1; S2 = rb.p2 - ra.p2;
-    } else { S0 = Q0[ib] - Q0[ia]; S1 = Q1[ib] - Q1[ia]; S2 = Q2[ib] - Q2[ia]; }   // S1 = -2 sum W c'
+    const double S0 = Q0[ib] - Q0[ia], S1 = Q1[ib] - Q1[ia], S2 = Q2[ib] - Q2[ia];   // S1 = -2 sum W c'
     const double qq = fma(gp, fma(gp, S0, S1), S2);         // sum W (g' - c')^2 over the support
     return __builtin_fmax(fma(m_inv_bw2, qq, S0), 0.);      // a sum of non-negative kernel values (rounding may leave -1e-14 of the peak)
   };
@@ -2106,7 +2066,7 @@ DEVFN void kde_marg_sub2_body(const LikeDev& L, const DevParams* params, const i
   const int PG = (L.P + NPW - 1) / NPW, H = (PG + IPW - 1) / IPW;   // pixel groups of an event; the wave's items: by + i H
   const int b = bx, e = L.e_off + bz;
   const int Z = L.Z;
-  double* Q = (CHM_GW_SPLIT3 && BINS > 0) ? lds_all : lds_all + (size_t)sub * (3 * L.num_bins + 3);      // (CHM_GW_SPLIT3: the wave's slice, see kde_sub_item)
+  double* Q = BINS > 0 ? lds_all : lds_all + (size_t)sub * (3 * L.num_bins + 3);      // (compile-time bin count: the wave's slice, laid out by kde_sub_item -- SPLIT)
   const double* es = L.evstat + ((size_t)b * L.E + e) * NEVSTAT;
   const bool ok = es[4] >= L.pe_neff;                       // likelihood.py:199 (same for every pixel of the event)
   const int* so_ = L.seg_off + (size_t)e * (L.P + 1);
@@ -3138,7 +3098,7 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
   const bool fits = info[3] != 0;
   const int key0 = lut.key0, nk = lut.nk, cap = lut.cap;
   double* etab = lds;                                        // [r3] the table of the mass model's exps (chm_exp_tab), as in k_samples_fast
-  double* rec = lds + CHM_EXPTAB_N; double* mg = rec + CHM_REC_STRIDE * (size_t)cap; double* cdf = mg + Tm;
+  double* rec = lds + CHM_EXPTAB_N; double* mg = rec + 4 * (size_t)cap; double* cdf = mg + Tm;
   unsigned short* luts = reinterpret_cast<unsigned short*>(cdf + Tm);
 #if CHM_EXPTAB
   const ExpTab ex = { etab };
@@ -3152,7 +3112,9 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
     for (int i = t; i < CHM_EXPTAB_N; i += 256) etab[i] = exp_table_entry(i);
     for (int i = t; i < Tm; i += 256) { mg[i] = gm[i]; cdf[i] = gc[i]; }
     if (fits) {
-      rec_stage(rec, rec_all + ((size_t)b * TcMax + i_lo) * 4, ns, t, 256);
+      const double2* gr = reinterpret_cast<const double2*>(rec_all + ((size_t)b * TcMax + i_lo) * 4);
+      double2* lr = reinterpret_cast<double2*>(rec);
+      for (int i = t; i < 2 * ns; i += 256) lr[i] = gr[i];
       for (int i = t; i <= nk; i += 256) luts[i] = gl[i];
     }
   }

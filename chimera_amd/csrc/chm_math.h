@@ -144,54 +144,23 @@ DEVFN double chm_exp_clamped(double x) {
 // [r3] exp(x) through a table of 2^(j/256) (256 doubles in LDS, exp_table_fill): x = (256 k + j) ln2/256 + r, |r| <= ln2/512, e^r by its degree-4
 // Taylor sum (remainder < 4e-17) -- 13 VALU instructions against the 17 of chm_exp_nb (the table read is an LDS instruction).  Same contract
 // as chm_exp_nb: no range checks (a huge |x| ends in v_ldexp_f64's 0 / inf, NaN propagates through the polynomial); <= 1.8 ulp (4.0e-16 on 2e7 arguments, scripts/check_fastmath.cpp).
-// [r6] CHM_EXPTAB_N (build knob, A/B: profiles/r06/ab_exp_table_size.txt): entries of the table.  256 entries are 2 KB -- 64 lanes with unrelated
-// arguments gather from 16 rows of the LDS banks and collide (63 % of the sample stage's LDS-active cycles were bank conflicts, profiles/r05); a table
-// of 32 entries is two rows (at most two lanes' distinct addresses per bank), of 16 one row (same-address reads are broadcast: no conflict at all)
-// -- at the price of a longer e^r sum: |r| <= ln2 / (2 N) needs degree 4 / 5 / 5 / 6 / 7 for N = 256 / 128 / 64 / 32 / 16 (remainder < 4e-17).
-#ifndef CHM_EXPTAB_N
 #define CHM_EXPTAB_N 256
-#endif
-#if CHM_EXPTAB_N == 256
-#define CHM_EXPTAB_LOG2N 8
-#define CHM_EXPTAB_DEG 4
-#elif CHM_EXPTAB_N == 128
-#define CHM_EXPTAB_LOG2N 7
-#define CHM_EXPTAB_DEG 5
-#elif CHM_EXPTAB_N == 64
-#define CHM_EXPTAB_LOG2N 6
-#define CHM_EXPTAB_DEG 5
-#elif CHM_EXPTAB_N == 32
-#define CHM_EXPTAB_LOG2N 5
-#define CHM_EXPTAB_DEG 6
-#elif CHM_EXPTAB_N == 16
-#define CHM_EXPTAB_LOG2N 4
-#define CHM_EXPTAB_DEG 7
-#else
-#error "CHM_EXPTAB_N must be 16, 32, 64, 128 or 256"
-#endif
 #ifndef CHM_EXPTAB
 #define CHM_EXPTAB 1           // 0: the fast sample / selection kernels keep the polynomial exp (A/B builds)
 #endif
 DEVFN double chm_exp_tab(double x, const double* T) {
-  const double SC = 3.69329930467574632e+02 * (CHM_EXPTAB_N / 256.);               // N / ln 2 (an exact scaling of 256 / ln 2)
-  const double L_HI = 6.93147180369123816490e-01 / CHM_EXPTAB_N, L_LO = 1.90821492927058770002e-10 / CHM_EXPTAB_N;      // ln2/N in two pieces (exact scalings of fdlibm's)
+  const double SC = 3.69329930467574632e+02;               // 256 / ln 2
+  const double L_HI = 6.93147180369123816490e-01 / 256., L_LO = 1.90821492927058770002e-10 / 256.;      // ln2/256 in two pieces (exact scalings of fdlibm's)
   double n = __builtin_rint(x * SC);
   double r = __builtin_fma(-n, L_HI, x);
   r = __builtin_fma(-n, L_LO, r);
   const int ni = (int)n;
   const double tj = T[ni & (CHM_EXPTAB_N - 1)];
-  double p;
-  if (CHM_EXPTAB_DEG == 4) p = FM_FMA(r, 4.16666666666666644e-02, 1.66666666666666657e-01);
-  else {
-    if (CHM_EXPTAB_DEG == 5) p = FM_FMA(r, 8.33333333333333322e-03, 4.16666666666666644e-02);
-    else if (CHM_EXPTAB_DEG == 6) p = FM_FMA(FM_FMA(r, 1.38888888888888894e-03, 8.33333333333333322e-03), r, 4.16666666666666644e-02);
-    else p = FM_FMA(FM_FMA(FM_FMA(r, 1.98412698412698413e-04, 1.38888888888888894e-03), r, 8.33333333333333322e-03), r, 4.16666666666666644e-02);
-    p = FM_FMA(p, r, 1.66666666666666657e-01);
-  }
+  double p = FM_FMA(r, 4.16666666666666644e-02, 1.66666666666666657e-01);
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
-  return __builtin_ldexp(tj * p, ni >> CHM_EXPTAB_LOG2N);
+  return __builtin_ldexp(tj * p, ni >> 8);
 }
 DEVFN double chm_exp_tab_clamped(double x, const double* T) {      // chm_exp_clamped with the table
   double lo, hi;
@@ -199,9 +168,9 @@ DEVFN double chm_exp_tab_clamped(double x, const double* T) {      // chm_exp_cl
   asm("v_min_f64 %0, %1, %2" : "=v"(hi) : "v"(lo), "v"(700.));
   return chm_exp_tab(hi, T);
 }
-// entry j of the table: 2^(j/N) = exp(j ln2/N) with the argument formed in two pieces (as chm_pow10): chm_exp's own 0.63 ulp
+// entry j of the table: 2^(j/256) = exp(j ln2/256) with the argument formed in two pieces (as chm_pow10): chm_exp's own 0.63 ulp
 DEVFN double exp_table_entry(int j) {
-  const double C_HI = 6.93147180369123816490e-01 / CHM_EXPTAB_N, C_LO = 1.90821492927058770002e-10 / CHM_EXPTAB_N;
+  const double C_HI = 6.93147180369123816490e-01 / 256., C_LO = 1.90821492927058770002e-10 / 256.;
   const double a = (double)j * C_HI;                       // exact: j < 2^8, C_HI ends in 20 zero bits
   const double v = chm_exp(a);
   return __builtin_fma(v, (double)j * C_LO, v);

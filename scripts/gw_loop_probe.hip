@@ -37,7 +37,7 @@ extern "C" int chm_debug_probe(chm_like* like, int32_t which, int32_t nb, int32_
     if (which == 0) {
       if (L.mode != CHM_MODE_MARG || L.num_bins != 200 || !L.binning || !L.has_cut || (L.Z & 1)) return fail(CHM_E_ARG, "chm_debug_probe: the GW probe needs the standard marginalized configuration");
       const int PG2 = (L.P + 1) / 2, ny = (PG2 + 3) / 4;
-      const size_t lds_sub = sizeof(double) * (3 * (size_t)L.num_bins + 3) * 2;
+      const size_t lds_sub = sizeof(double) * (5 * (200 + 1 + 7 + 1) + 201);      // (the wave's slice of the production launch: chm_eval)
       hipLaunchKernelGGL((k_probe_gw<4>), dim3(nblocks), dim3(64), lds_sub, c.stream, L, (const DevParams*)c.d_params, reps, ny);
     } else {
       if (!like->probe_lds_fast) return fail(CHM_E_ARG, "chm_debug_probe: the preceding chm_eval did not take the fast sample stage");
