@@ -1311,42 +1311,6 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   const size_t lds_zfac = sizeof(double) * (size_t)2 * Tc;                          // zt, It
   const bool tab_samp = lds_samp <= 64 * 1024, tab_zfac = lds_zfac <= 64 * 1024;
 
-  // ---- selection function on its own stream, forked after the tables.  Enqueued AFTER the event kernels: every API call between the
-  //      table kernel and the sample stage is stream time the GPU idles (k_tables is 19 us; the fork used to cost 23 us there)
-  bool sel_enqueued = false, sel_joined = false;
-  auto enqueue_selection = [&]() -> int {
-    sel_enqueued = true;
-    if (!(sel && !fuse_sel)) return CHM_OK;
-    HIPCHK(hipStreamWaitEvent(sC, c.ev[1], 0));
-    SelDev S = sel->S;
-    S.tab_pm = td.pm_i; S.tab_rate = td.rate_i; S.tab_bkg = td.bkg_i; S.tab_jac = td.jac_i;
-    if (timing_all) HIPCHK(hipEventRecord(c.evb[1], sC));
-    if (sel_fast) {
-#define LAUNCH_SELF_(M, G) do { allow_lds((k_selection_fast<M, G>), lds_sel); \
-        hipLaunchKernelGGL((k_selection_fast<M, G>), dim3(gx, nb), dim3(256), lds_sel, sC, S, lutB, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm); } while (0)
-#define LAUNCH_SELF(M) do { if (params[0].cosmo_model == 1) LAUNCH_SELF_(M, true); else LAUNCH_SELF_(M, false); } while (0)
-      // every block stages the draw's table slice (tens of KB): ~8192 blocks in all, each walking over several tiles of injections
-      const int self_blocks = (sel ? sel->opts.self_blocks : 8192) > 0 ? (sel ? sel->opts.self_blocks : 8192) : 8192;
-      int gx = self_blocks / nb;
-      gx = gx < 1 ? 1 : (gx > S.nblocks ? S.nblocks : gx);
-      const int mm = params[0].mass_model;
-      if (mm == 0) LAUNCH_SELF(0); else if (mm == 1) LAUNCH_SELF(1); else LAUNCH_SELF(2);
-#undef LAUNCH_SELF
-#undef LAUNCH_SELF_
-    } else if (rate_special_call) {                          // a draw with an infinite rate parameter: the reference's own operations for the rate (merger_rate_special)
-      hipLaunchKernelGGL((k_selection<false, true>), dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    } else if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
-      hipLaunchKernelGGL(k_selection<true>, dim3(S.nblocks, nb), dim3(256), lds_samp, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    } else hipLaunchKernelGGL(k_selection<false>, dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c.evb[2], sC));
-    return CHM_OK;
-  };
-  // [r6] ONE event group on one lane (small shards; few groups): the selection kernel is enqueued right behind the sample stage and lane A takes its join
-  // in FRONT of the GW kernel, where the command processor resolves the cross-queue dependency while the per-z-factor kernel runs -- behind the
-  // fix-up it cost ~20 us of an idle lane in every call (profiles/r06/timeline_shard125_rccl.txt: fix-up end 1249 us, reduction start 1270 us).  Only
-  // where the selection sums are the smaller job by far (they share the chip with the sample stage and end with it); a catalogue of few events with
-  // a million injections (C4) keeps the late join, and so does everything that is not the marginalized chain on one lane.
   // ---- events: groups of events alternate between two streams, so that the (VALU-bound) sample stage of one group
   //      overlaps the (latency-bound) GW-kernel stage of the previous one
   int nblk_ev = 0, ngroups = 0;
@@ -1488,12 +1452,6 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       }
       HIPCHK(hipGetLastError());
       if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g + 1], sg));
-#ifndef CHM_SEL_EARLY
-#define CHM_SEL_EARLY 1      // (0: A/B builds -- the join behind the fix-up as in round 5; profiles/r06/ab_shard_step_r06.txt)
-#endif
-      const bool sel_early = CHM_SEL_EARLY && sel && !fuse_sel && ngroups == 1 && sg == sA && L.mode == CHM_MODE_MARG && zf_ranged && !tab &&
-                             (double)sel->S.I * 4. < (double)L.E_cnt * (double)L.S;
-      if (sel_early) { rc = enqueue_selection(); if (rc) return rc; }
       // GW kernel + integrand (needs the per-z factors)
       if (sz != sg) HIPCHK(hipStreamWaitEvent(sg, c.evf[g], 0));
       if (L.mode == CHM_MODE_FULL) {
@@ -1511,7 +1469,6 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         else hipLaunchKernelGGL(k_event_prep, dim3((L.E_cnt + 3) / 4, nb), dim3(256), 0, sg, L, 1);
         HIPCHK(hipGetLastError());
         if (zf_ranged) { launch_zfactors(); HIPCHK(hipGetLastError()); }
-        if (sel_early) { HIPCHK(hipStreamWaitEvent(sA, c.evb[2], 0)); sel_joined = true; }      // join: selection sums (resolved under the per-z-factor kernel)
         if (timing_all) HIPCHK(hipEventRecord(c.evg[4 * g + 2], sg));
         const bool fast = marg_std;
         if (fast) {
@@ -1557,7 +1514,36 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   } else {
     if (timing_all) HIPCHK(hipEventRecord(c.ev[3], sA));
   }
-  if (!sel_enqueued) { rc = enqueue_selection(); if (rc) return rc; }
+  // ---- selection function on its own stream, forked after the tables.  Enqueued AFTER the event kernels: every API call between the
+  //      table kernel and the sample stage is stream time the GPU idles (k_tables is 19 us; the fork used to cost 23 us there).
+  //      ([r6] Enqueued right behind the sample stage and joined in FRONT of the GW kernel for one-group calls -- the kernel trace shows ~20 us between
+  //      the fix-up and the reduction, the cross-queue dependency -- the step of the 125-event shard did not change: 1.1963 against 1.1967 ms, mean of
+  //      three, same box; profiles/r06/ab_shard_step_r06.txt.  Not adopted.)
+  if (sel && !fuse_sel) {
+    HIPCHK(hipStreamWaitEvent(sC, c.ev[1], 0));
+    SelDev S = sel->S;
+    S.tab_pm = td.pm_i; S.tab_rate = td.rate_i; S.tab_bkg = td.bkg_i; S.tab_jac = td.jac_i;
+    if (timing_all) HIPCHK(hipEventRecord(c.evb[1], sC));
+    if (sel_fast) {
+#define LAUNCH_SELF_(M, G) do { allow_lds((k_selection_fast<M, G>), lds_sel); \
+        hipLaunchKernelGGL((k_selection_fast<M, G>), dim3(gx, nb), dim3(256), lds_sel, sC, S, lutB, dp, c.zt, c.dLt, c.mg, c.cdf, c.rec, Tc, Tm); } while (0)
+#define LAUNCH_SELF(M) do { if (params[0].cosmo_model == 1) LAUNCH_SELF_(M, true); else LAUNCH_SELF_(M, false); } while (0)
+      // every block stages the draw's table slice (tens of KB): ~8192 blocks in all, each walking over several tiles of injections
+      const int self_blocks = (sel ? sel->opts.self_blocks : 8192) > 0 ? (sel ? sel->opts.self_blocks : 8192) : 8192;
+      int gx = self_blocks / nb;
+      gx = gx < 1 ? 1 : (gx > S.nblocks ? S.nblocks : gx);
+      const int mm = params[0].mass_model;
+      if (mm == 0) LAUNCH_SELF(0); else if (mm == 1) LAUNCH_SELF(1); else LAUNCH_SELF(2);
+#undef LAUNCH_SELF
+#undef LAUNCH_SELF_
+    } else if (rate_special_call) {                          // a draw with an infinite rate parameter: the reference's own operations for the rate (merger_rate_special)
+      hipLaunchKernelGGL((k_selection<false, true>), dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    } else if (tab_samp) { allow_lds(k_selection<true>, lds_samp);
+      hipLaunchKernelGGL(k_selection<true>, dim3(S.nblocks, nb), dim3(256), lds_samp, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    } else hipLaunchKernelGGL(k_selection<false>, dim3(S.nblocks, nb), dim3(256), 0, sC, S, dp, c.zt, c.It, c.dLt, c.mg, c.cdf, Tc, Tm);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c.evb[2], sC));
+  }
 
   double* d_lle = nullptr; double* d_nle = nullptr;
   const size_t El = like ? like->L.E : 0;
@@ -1583,7 +1569,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
                        ev_from_fixup ? (const double*)like->L.ev_ll : nullptr, like->d_ev_bad);
     HIPCHK(hipGetLastError());
   }
-  if (sel && !fuse_sel && !sel_joined) HIPCHK(hipStreamWaitEvent(sA, c.evb[2], 0));     // join: selection sums
+  if (sel && !fuse_sel) HIPCHK(hipStreamWaitEvent(sA, c.evb[2], 0));     // join: selection sums
   if (one_kernel) {
     hipLaunchKernelGGL(k_reduce_final, dim3(nb), dim3(1024), 0, sA, like ? like->L.E : 0, like ? (like->L.P > 0 ? like->L.P : 1) : 1,
                        like ? (const double*)like->L.like_pix : nullptr, sel ? sel->S.nblocks : 0,
