@@ -444,12 +444,24 @@ def main():
   # --inflight 2: a second lane on the same resident data (chm_like_clone / chm_sel_clone: own streams, tables, workspaces; with a
   # communicator its own RCCL communicator), one host thread per lane, the steps alternate between the lanes
   lanes, lane_comms, pool = [like], [], None
+
+  def lane_comm(i):
+    """The communicator of lane i >= 1.  RCCL: a communicator of its own (the job's rendezvous carries its id once).  Host sockets: a socket star of
+    its OWN as well -- the lanes' host threads reduce concurrently, and two threads on one socket interleave their messages."""
+    if not isinstance(comm, HostComm):
+      return Comm(world, rank, device, rendezvous=rdzv)
+    a = rdzv.address
+    r2 = Rendezvous(world, rank, address=(a + f'.lane{i}') if isinstance(a, str) else (a[0], a[1] + 10 + i))
+    hc = HostComm(world, rank, device, rendezvous=r2)
+    hc._own = True                                          # (closed with the communicator)
+    return hc
+
   if args.inflight > 1:
     from concurrent.futures import ThreadPoolExecutor
     for i in range(1, args.inflight):
       lc = None
       if comm is not None:
-        lc = HostComm(world, rank, device, rendezvous=rdzv) if isinstance(comm, HostComm) else Comm(world, rank, device, rendezvous=rdzv)
+        lc = lane_comm(i)
         lane_comms.append(lc)
       lanes.append(like.lane(comm=lc))
     pool = ThreadPoolExecutor(max_workers=args.inflight)
@@ -577,7 +589,7 @@ def main():
       from concurrent.futures import ThreadPoolExecutor
       lc, err = None, None
       try:
-        lc = HostComm(world, rank, device, rendezvous=rdzv) if isinstance(comm, HostComm) else Comm(world, rank, device, rendezvous=rdzv)
+        lc = lane_comm(args.inflight)
       except Exception as e:                                  # noqa: BLE001
         err = e
       if int(rdzv.allreduce_sum(np.array([0. if lc is not None else 1.]))[0]) > 0:        # every rank takes the same branch

@@ -61,7 +61,7 @@ def main():
   os.environ['TMPDIR'] = '/tmp'
   env = dict(os.environ)
   base = ['python3', 'bench.py'] + bench_args
-  quick = base + ['--no-cpu-baseline', '--no-single-call']
+  quick = base + ['--no-cpu-baseline', '--no-single-call', '--no-extra']
 
   if not skip_trace:
     for serial in (False, True):
@@ -102,7 +102,7 @@ def main():
   # to profiles/<round>/ of THIS copy first so that the line's roofline block is computed from it
   prof_dir = os.path.join(ROOT, 'profiles', rnd)
   os.makedirs(prof_dir, exist_ok=True)
-  probe = subprocess.run(base + ['--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-single-call'], cwd=ROOT, capture_output=True, text=True,
+  probe = subprocess.run(base + ['--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-single-call', '--no-extra'], cwd=ROOT, capture_output=True, text=True,
                          timeout=900)
   line = [l for l in probe.stdout.strip().split('\n') if l.startswith('{')]
   cfg = json.loads(line[-1])['config'] if line else {}

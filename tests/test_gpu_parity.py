@@ -1322,6 +1322,9 @@ def test_bench_starts_its_ranks_itself_without_a_launcher():
   line = json.loads(p.stdout.strip().split('\n')[-1])
   assert line['n_gpus'] == 2 and line['multi_gpu']['world'] == 2 and len(line['multi_gpu']['pci_bus_ids']) == 2
   assert 'rehearsal' in line['multi_gpu']['collective'] and np.isfinite(line['value'])
+  # [r6] the guarded second leg with two evaluations in flight per rank (two lanes, each with a socket star of its own under --host-comm) ran and agrees
+  leg = line['multi_gpu']['inflight2']
+  assert 'error' not in leg and leg['lanes'] == 2 and leg['ms_per_step'] > 0 and leg['last_log_hyper'] == line['last_log_hyper'], leg
 
 
 def test_last_timing_reports_the_stages_of_an_eager_call(cfg_pix):
