@@ -974,21 +974,36 @@ static hipError_t wait_stream(hipStream_t s, bool spin) {
   if (spin) { hipError_t e; while ((e = hipStreamQuery(s)) == hipErrorNotReady) {} return e; }
   return hipStreamSynchronize(s);
 }
-// [r5] Completion of a zero-copy few-draw call through the flags the last kernel stores behind the results (completion_flag, chm_kernels.h): the host spins on
-// pinned memory; every 4096 looks it asks the stream, so that a kernel that faulted (the flags never come) surfaces as an error instead of a hang
-static hipError_t wait_flags(const long long* h_seq, int nb, long long seq, hipStream_t s) {
+// [r5] Completion of a zero-copy call through the flags the last kernel stores behind the results (completion_flag, chm_kernels.h): the host spins on
+// pinned memory; every 4096 looks it asks the stream, so that a kernel that faulted (the flags never come) surfaces as an error instead of a hang.
+// [r6] ... and the RESULTS prove their own arrival: the host fills the result block with CHM_PENDING (a NaN bit pattern no result can have:
+// combine_one stores canonical NaNs) before the launch and, once the flags are there, waits until none of the 3 nb doubles holds it any more.  A
+// fence on the device orders the kernel's stores as it issues them; it does not order their ARRIVAL in host memory -- results and flags live in
+// different allocations and travel as independent posted writes.  Found by the round's fuzz campaign with the flags on every call: 2 of 6648
+// configurations (~20 000 flagged calls) read a result block the flag had overtaken (log_hyper = 0.0 of freshly allocated pages; not reproducible in
+// isolation: profiles/r06/fuzz_r06.txt).
+static const unsigned long long CHM_PENDING = 0x7ff8dead5eedbeefULL;
+static void mark_pending(double* h_out, int nb) {
+  volatile unsigned long long* r = reinterpret_cast<volatile unsigned long long*>(h_out);
+  for (int i = 0; i < 3 * nb; i++) r[i] = CHM_PENDING;
+}
+static hipError_t wait_flags(const long long* h_seq, const double* h_out, int nb, long long seq, hipStream_t s) {
   const volatile long long* f = h_seq + 1;
+  const volatile unsigned long long* r = reinterpret_cast<const volatile unsigned long long*>(h_out);
+  auto arrived = [&]() {
+    for (int b = 0; b < nb; b++) if (f[b] != seq) return false;
+    for (int i = 0; i < 3 * nb; i++) if (r[i] == CHM_PENDING) return false;
+    return true;
+  };
   for (unsigned it = 1;; it++) {
-    bool done = true;
-    for (int b = 0; b < nb; b++) if (f[b] != seq) { done = false; break; }
-    if (done) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return hipSuccess; }
+    if (arrived()) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return hipSuccess; }
     if ((it & 0xFFFu) == 0u) {
       hipError_t e = hipStreamQuery(s);
       if (e == hipErrorNotReady) continue;
       if (e != hipSuccess) return e;
-      for (int b = 0; b < nb; b++) if (f[b] != seq) return hipErrorUnknown;      // the stream drained and the flags are not there
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);
-      return hipSuccess;
+      // the stream drained: what it wrote is on its way at the latest now -- a bounded grace, then an error (never a hang)
+      for (unsigned g = 0; g < 2000000u; g++) if (arrived()) { __atomic_thread_fence(__ATOMIC_ACQUIRE); return hipSuccess; }
+      return hipErrorUnknown;
     }
   }
 }
@@ -1242,7 +1257,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
             zmax_bits, like ? like->opts.epoch : -1, sel ? sel->opts.epoch : -1, params[0].cosmo_model, rate_special_call, use_flags, (long long)(intptr_t)c.h_seq };
     if (c.gexec && key == c.gkey) {                           // replay
       const double hp1 = host_prof_on() ? now_us() : 0.;
-      if (use_flags) { c.h_seq[0] = ++c.seq; __atomic_thread_fence(__ATOMIC_RELEASE); }
+      if (use_flags) { mark_pending(c.h_out, nb); c.h_seq[0] = ++c.seq; __atomic_thread_fence(__ATOMIC_RELEASE); }
       HIPCHK(hipGraphLaunch(c.gexec, sA));
       if (comm) {                                             // the graph ends at the rank's partials: all-reduce + combination behind it
         if (!turn.acquire()) return fail(CHM_E_RCCL, "chm_eval: the calls with lower tickets never enqueued their collectives (chm_comm_set_ticket; timeout)");
@@ -1256,7 +1271,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
         if (!zc_out) HIPCHK(hipMemcpyAsync(c.h_out, c.d_out3, sizeof(double) * nb * 3, hipMemcpyDeviceToHost, sA));
       }
       const double hp2 = host_prof_on() ? now_us() : 0.;
-      if (use_flags) HIPCHK(wait_flags(c.h_seq, nb, c.seq, sA)); else
+      if (use_flags) HIPCHK(wait_flags(c.h_seq, c.h_out, nb, c.seq, sA)); else
       HIPCHK(wait_stream(sA, o.spin_wait != 0));
       if (host_prof_on()) { const double hp3 = now_us(); g_hp.pre.push_back(hp1 - hp0); g_hp.launch.push_back(hp2 - hp1); g_hp.sync.push_back(hp3 - hp2); }
       for (int b = 0; b < nb; b++) {
@@ -1278,7 +1293,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   const bool timing = timing_env && !capturing;
   // (an eager call that carries timing events completes through the flags too; chm_last_timing waits for the call's last event before it reads them)
   const bool flags_now = use_flags;
-  if (flags_now) { c.h_seq[0] = ++c.seq; __atomic_thread_fence(__ATOMIC_RELEASE); }
+  if (flags_now) { mark_pending(c.h_out, nb); c.h_seq[0] = ++c.seq; __atomic_thread_fence(__ATOMIC_RELEASE); }
   // with a communicator (multi-GPU shards: short calls) only the whole evaluation and the GW kernel are timed: each event record
   // costs ~3 us of stream time (measured: 35 us per call for the full set); CHM_TIMING_ALL=1 keeps the full set (diagnosing a multi-GPU line)
   // [r6] per-kernel events (sample stage, GW kernel, selection, reduction) only on request (CHM_OPT_TIMING 2: bench.py's pass after its timed region,
@@ -1616,7 +1631,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
     HIPCHK(hipMemcpyAsync(out->p_gw, src, sizeof(double) * nb * El * Pd * like->L.Z, hipMemcpyDeviceToHost, sA));
   }
   if (capturing) { rc = end_capture(); if (rc) return rc; }
-  if (flags_now) HIPCHK(wait_flags(c.h_seq, nb, c.seq, sA)); else
+  if (flags_now) HIPCHK(wait_flags(c.h_seq, c.h_out, nb, c.seq, sA)); else
   HIPCHK(wait_stream(sA, o.spin_wait != 0 && nb <= few_nb));
   for (int b = 0; b < nb; b++) {
     if (out->log_hyper) out->log_hyper[b] = c.h_out[b * 3];

@@ -3286,7 +3286,9 @@ DEVFN void combine_one(const DevParams& P, double log_num, double s1, double s2,
     if (!P.scale_free) log_num += E_total * log(P.R0 * P.Tobs);
     if (has_sel) log_hyper = P.scale_free ? log_num - E_total * log(Nexp) : log_num - Nexp;
   } else log_num = __builtin_nan("");
-  out[0] = log_hyper; out[1] = log_num; out[2] = Nexp;
+  // (NaNs leave with the canonical bit pattern: the host recognises a result that has not arrived yet by a NaN payload of its own, chm_eval: CHM_PENDING)
+  const double cn = __builtin_nan("");
+  out[0] = log_hyper != log_hyper ? cn : log_hyper; out[1] = log_num != log_num ? cn : log_num; out[2] = Nexp != Nexp ? cn : Nexp;
 }
 
 // k_final: one block per draw: shard partials [sum_i log L_i, nansum dN, sum dN^2] in fixed order; when do_combine, also

@@ -113,6 +113,22 @@ def headline(rnd):
     out.append('| `roofline` of the driver line | bound **%s**, kernel `%s`: achieved %.3f of %.4f Tcycle/s = **frac %.3f** (%.3f at the %.2f GHz held); real fp64 %.1f of 78.6 TFLOP/s; HBM: unique bytes %.2f GB per launch = %.2f of 8 TB/s, PMC traffic %.2f GB = %.2f | `bench.json: roofline` |'
                % (r['bound'], r['kernel'], r['achieved'], r['peak'], r['frac'], r['frac_at_held_clock'] or 0., dk.get('clock_GHz_under_profile') or 0.,
                   r['fp64_TFLOPs_real'] or 0., r['hbm']['unique_bytes_per_launch'] / 1e9, r['hbm']['frac'], (r['traffic'] or 0) / 1e9, r['hbm']['traffic_frac'] or 0.))
+  # [r6] the kernels against the MEASURED ceilings of their own bodies (scripts/run_probes.py -> probe_ceilings.json) and the LDS side of the GW kernel
+  for k in r['kernels']:
+    su = k.get('sustained')
+    if su and su.get('frac_of_sustained'):
+      out.append('| `%s` against the measured ceiling of its body (cache-resident probe) | %.4g %s/s of %.4g sustained = **%.3f**; VALU wave-instructions: %s of %.4g /s (probe clock %.2f GHz) | `roofline.kernels[].sustained`, `%s` |'
+                 % (k['kernel'], su['achieved_per_s'], su['unit'], su['probe_per_s'], su['frac_of_sustained'],
+                    ('%.4g' % su['valu_winst_per_s']) if su.get('valu_winst_per_s') else 'n/a', su.get('probe_valu_winst_per_s') or 0., su.get('probe_clock_GHz') or 0., su.get('source')))
+  pj = pmc(rnd)
+  if pj:
+    n_, gk = find(pj['kernels'], 'k_kde_marg_sub2')
+    if gk and gk.get('SQ_LDS_IDX_ACTIVE') and gk.get('GRBM_GUI_ACTIVE'):
+      cyc = gk['GRBM_GUI_ACTIVE'] / 8 * 256
+      out.append('| LDS pipe of `%s` | `SQ_LDS_IDX_ACTIVE` %.4g of %.4g CU-cycles = **%.2f busy**, of which bank conflicts %.4g = %.0f %%; `SQ_INSTS_LDS` %.4g per launch | `pmc_per_launch.json` |'
+                 % (n_, gk['SQ_LDS_IDX_ACTIVE'], cyc, gk['SQ_LDS_IDX_ACTIVE'] / cyc, gk.get('SQ_LDS_BANK_CONFLICT', 0.), 100. * gk.get('SQ_LDS_BANK_CONFLICT', 0.) / gk['SQ_LDS_IDX_ACTIVE'], gk.get('SQ_INSTS_LDS', 0.)))
+  if r.get('hbm_call_frac') is not None:
+    out.append('| `roofline.hbm_call_frac` (SURVEY 8(d): algorithmic bytes of one evaluation over the scalar call) | **%.3f of 8 TB/s** | `bench.json: roofline` |' % r['hbm_call_frac'])
   for k in r['kernels'][1:]:
     if k.get('valu_busy_frac'):
       mi = k.get('min_inst') or {}
@@ -135,6 +151,18 @@ def headline(rnd):
         k = x['roofline']['kernels'][0]
         extra = '; `%s` %.2f ms per launch = %.2f Tpair/s = %.3f of the power-sum ceiling' % (k['kernel'], k['kernel_ms'], k['Gpairs_s'] / 1e3, k['pair_frac'])
       out.append('| %s | %.0f evals/s (%.3f ms per step; scalar call %.3f ms)%s | `bench%s.json` |' % (label, x['value'], x['ms_per_step'], x.get('single_call_ms') or 0., extra, tag))
+  ex = (b.get('extra') or {}).get('configs') or {}
+  lab = {'C1': 'C1 (10 events, 1-D)', 'C2': 'C2 (100 ev × 16 px × 500 z)', 'C4': 'C4 (69 ev × 16 px × 500 z, 1e6 injections)',
+         'C3_approximate': "C3, `kind_p_gw3d='approximate'`", 'C3_full': "C3, `kind_p_gw3d='full'`"}
+  for key in ('C1', 'C2', 'C4', 'C3_approximate', 'C3_full'):
+    x = ex.get(key)
+    if x:
+      out.append('| %s -- leg of the SAME driver-run line, %d draws per call | %.0f evals/s (%.3f ms per step; scalar call %.3f ms) | `bench.json: extra.configs.%s` |'
+                 % (lab[key], x['nbatch'], x['evals_per_s'], x['ms_per_step'], x['single_call_ms'], key))
+  od = ex.get('one_draw_kernels')
+  if od:
+    out.append('| C3 kernels at ONE draw per call (leg of the driver-run line; HBM is the applicable bound) | sample stage %.1f µs = %.2f of 8 TB/s (unique bytes), GW kernel + fix-up %.1f µs = %.2f; tables %.1f µs; whole eager call %.1f µs | `bench.json: extra.configs.one_draw_kernels` |'
+               % (od['samples_us'], od['samples_hbm_frac_unique'] or 0., od['gw_kernel_us'], od['gw_hbm_frac_unique'] or 0., od['tables_us'], od['eval_us']))
   for tag, label in (('_fused', 'FUSED event kernel (`--fused 2`: off by default), 128 draws per call'), ('_fused_nbatch1', 'FUSED event kernel, one draw per call')):
     x = bench(rnd, tag)
     if x:

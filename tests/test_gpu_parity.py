@@ -1394,3 +1394,29 @@ def test_an_event_grid_that_does_not_ascend_is_evaluated_point_by_point_like_the
   for lam in (dict(H0=70.), dict(H0=58., alpha=3.0)):
     _compare(like_p, like_o, lam, cfg['E'], check_pgw=True)
   np.testing.assert_allclose(like_p.batch([dict(H0=70.), dict(H0=58., alpha=3.0)])[0], like_p(H0=70.), rtol=0, atol=0)
+
+
+def test_results_behind_completion_flags_have_arrived_when_the_call_returns():
+  """[r6] Calls of every size complete through flags the last kernel stores in pinned memory behind the results.  A fuzz campaign (~20 000 flagged calls)
+  caught two calls returning the content of a freshly allocated result block: the flag had overtaken the results on their way to host memory.  The host
+  now marks the block with a NaN payload no result carries and waits until the results have replaced it.  Stress: 20 000 calls of 1-5 draws on one pair
+  of handles, and 200 fresh pairs (first-sight calls right after the allocation of the block) -- every value must be the bits of the first evaluation."""
+  cfg, ev, inj = H.small_config(E=2, S=128, P=2, Z=32, I=300, seed=11)
+  like, _, sel = H.build_product(ev, inj)
+  lams = [dict(H0=60. + 3. * i) for i in range(5)]
+  want = np.array([like(**l) for l in lams])
+  assert np.all(np.isfinite(want))
+  bad = 0
+  for it in range(5000):
+    for n in (1, 2, 3, 5):
+      got = like.batch(lams[:n]) if n > 1 else np.array([like(**lams[0])])
+      bad += int(not np.array_equal(got, want[:n]))
+  assert bad == 0, f"{bad} of 20000 calls returned something else than the first evaluation's bits"
+  like.close(); sel.close()
+  for it in range(200):
+    lk, _, sl = H.build_product(ev, inj)
+    a = lk(**lams[0])
+    b = lk.batch(lams[:2])
+    c = lk.batch(lams[:5] + lams[:5])
+    assert a == want[0] and np.array_equal(b, want[:2]) and np.array_equal(c, np.concatenate([want, want])), (it, a, b, c)
+    lk.close(); sl.close()
