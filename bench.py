@@ -310,7 +310,7 @@ def main():
   ap.add_argument('--no-graph', action='store_true', help='no HIP-graph replay of few-draw calls (keeps the per-kernel HIP-event timings for --nbatch <= 8)')
   ap.add_argument('--serial', action='store_true', help='every kernel of a call on one stream (CHM_OPT_SERIAL; per-kernel durations under a profiler)')
   ap.add_argument('--groups', type=int, default=0, help='event groups alternating between two streams (CHM_OPT_GROUPS; 0 = automatic, 1 = one group)')
-  ap.add_argument('--fused', type=int, default=0, help='fused event kernel (CHM_OPT_FUSED): 0 never, 1 calls of <= 8 draws, 2 every call')
+  ap.add_argument('--fused', type=int, default=0, help='fused event kernel (CHM_OPT_FUSED; a -DCHM_WITH_FUSED variant build only -- the release library refuses values > 0): 0 never, 1 calls of <= 8 draws, 2 every call')
   ap.add_argument('--host-comm', action='store_true', help='reduce the partial sums through the host sockets instead of RCCL (a rehearsal: the line then says so; never a fallback)')
   ap.add_argument('--force-comm', action='store_true', help='build the rendezvous and the RCCL communicator even for one rank (rehearses the N > 1 path)')
   ap.add_argument('--inflight', type=int, default=1, help='evaluations in flight per rank: 2 = two lanes (hyperlikelihood.lane) driven by two host threads, the steps alternate between them')
@@ -767,7 +767,8 @@ def main():
                           "evaluation afterwards moves ~350 B of parameters per draw host->device and 24 B back"},
       "last_log_hyper": float(np.asarray(vals[-1]).ravel()[-1]),
     }
-    if world == 1 and not args.no_extra and args.config == 'C3' and kind == 'marginalized' and args.events is None and args.inj is None:
+    if world == 1 and not args.no_extra and args.config == 'C3' and kind == 'marginalized' and args.events is None and args.inj is None and nb == 128 and args.inflight == 1 \
+       and not (args.serial or args.groups or args.fused or args.no_graph):
       # [r6] the other BASELINE configurations and call modes in the SAME driver-run line (everything but C3 / marginalized / 128 draws was
       # builder-run evidence): short legs after the timed region, inputs synthesised at full size (C5's 4.2 GB synthesis is left to the GPU test)
       t_x = time.time()

@@ -184,7 +184,7 @@ class hyperlikelihood(object):
 
   def set_option(self, name, value):
     """Evaluation option of this object's device handles (include/chimera_hip.h, ``CHM_OPT_*``; names: ``_lib.OPTION``), e.g.
-    ``set_option('groups', 1)``, ``set_option('fused', 1)``.  Also handed to the selection function, whose handle takes part in the
+    ``set_option('groups', 1)``, ``set_option('timing', 2)`` (``'fused'`` > 0 only with a ``-DCHM_WITH_FUSED`` variant build).  Also handed to the selection function, whose handle takes part in the
     same calls.  ``diag_*`` options need a library built with ``-DCHM_DIAG`` (``ValueError`` otherwise).  Returns ``self``."""
     if name not in _lib.OPTION:
       raise ValueError(f"hyperlikelihood.set_option: unknown option {name!r} (known: {sorted(_lib.OPTION)})")

@@ -15,7 +15,7 @@ d = os.path.join(ROOT, 'gpurun_out', 'tl_trace')
 shutil.rmtree(d, ignore_errors=True)
 os.environ['TMPDIR'] = '/tmp'
 cmd = ['rocprofv3', '--kernel-trace', '--output-format', 'csv', '-d', d, '--', 'python3', 'bench.py', '--nbatch', '1', '--steps', '200', '--warmup', '20',
-       '--no-cpu-baseline', '--no-single-call'] + sys.argv[2:]
+       '--no-cpu-baseline', '--no-single-call', '--no-extra'] + sys.argv[2:]
 subprocess.call(cmd, cwd=ROOT, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
 rows = []
 for f in glob.glob(os.path.join(d, '*', '*kernel_trace.csv')):
