@@ -420,6 +420,8 @@ def main():
     like.set_option('fused', args.fused)
   if graph_max_nb is not None:
     like.set_option('graph_max_nb', graph_max_nb)
+  if nb <= 8 and graph_max_nb == 0:
+    like.set_option('timing', 2)                      # --no-graph with few draws: the run exists for its per-kernel HIP-event times (the one-lane pass below is for calls of many draws)
   nb = args.nbatch
   H0s = np.linspace(55., 95., 4099)          # a different H0 for every draw of every step
   Xi0s = np.linspace(0.6, 3.0, 4099)
@@ -480,9 +482,12 @@ def main():
       ta = time.perf_counter()
       vals.append(like.batch(draws[args.warmup + k]))          # synchronous: returns when the last kernel has stored the results (completion flags)
       step_s.append(time.perf_counter() - ta)
+      if nb <= 8 and graph_max_nb == 0:
+        kt += like.last_timing()                               # (the --no-graph run of few draws: per-kernel times of every step)
     # [r6] HIP-event times of the LAST step only: reading them waits for the call's final event (an interrupt-driven wait of tens of microseconds
     # that round 5 paid after every step of the timed region)
-    kt += like.last_timing() * max(args.steps, 1)
+    if not (nb <= 8 and graph_max_nb == 0):
+      kt += like.last_timing() * max(args.steps, 1)
   else:
     from collections import deque
     # [r4] step k carries ticket k on every rank: the lanes' all-reduces (one RCCL communicator per lane, one host thread per lane) are handed

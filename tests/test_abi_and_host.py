@@ -437,3 +437,17 @@ def test_release_library_reads_no_environment_switch(lib):
   hdr = open(os.path.join(ROOT, 'include', 'chimera_hip.h')).read()
   for name, val in lib.OPTION.items():
     assert re.search(r'CHM_OPT_%s\s*=\s*%d\b' % (name.upper(), val), hdr), (name, val)
+
+
+def test_bench_prices_a_launch_against_the_measured_ceiling_of_its_body():
+  """[r6] roofline.frac_of_sustained: work per second of the launch over what the probe measured for the same body; nothing is printed from a
+  ceiling file that belongs to another binary."""
+  import bench
+  probe = ('profiles/rXX/probe_ceilings.json', {'kernels': {'k_kde_marg_sub2': {'unit': 'pairs of pixels', 'units_per_s': 5.0e8, 'valu_winst_per_s': 4.2e11, 'clock_GHz': 2.25}}}, True)
+  k = bench.kernel_roofline('GW kernel', 'k_kde_marg_sub2', 4.096, 1e9, None, units=1., probe=probe, work=2.048e6)
+  assert abs(k['sustained']['frac_of_sustained'] - 1.0) < 1e-12 and k['sustained']['achieved_per_s'] == 2.048e6 / 4.096e-3
+  stale = (probe[0], probe[1], False)
+  assert 'sustained' not in bench.kernel_roofline('GW kernel', 'k_kde_marg_sub2', 4.096, 1e9, None, units=1., probe=stale, work=2.048e6)
+  assert 'sustained' not in bench.kernel_roofline('sample stage', 'k_samples', 3.9, 1e9, None, units=1., probe=probe, work=5e8)      # no ceiling for that body in the file
+  got = bench.load_probe_ceilings('0' * 64)
+  assert got is None or got[2] is False                      # whatever is committed was not measured beside a binary with that hash

@@ -54,3 +54,31 @@ def test_fused_event_kernel_variant_build():
   assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1500:]
   assert ' passed' in p.stdout and 'failed' not in p.stdout, p.stdout[-1500:]
 
+
+
+def test_probe_build_replays_the_production_bodies_and_leaves_the_results_alone():
+  """[r6] -DCHM_PROBE: scripts/gw_loop_probe.hip / sample_body_probe.hip replay the production bodies of k_kde_marg_sub2 and k_samples_fast on a
+  cache-resident workload (the measured ceilings behind bench.py's roofline.frac_of_sustained).  A short run: both bodies report a rate, and the
+  evaluation made AFTER the probes (same handle, same workspaces) gives the value a run without probes gives."""
+  import json
+  lib = _build('probe', ['-DCHM_PROBE'])
+  env = dict(os.environ, CHIMERA_LIB=lib, CHIMERA_NO_REBUILD='1')
+  p = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'run_probes.py'), '--events', '2', '--draws', '2', '--seconds', '0.3'], cwd=ROOT, env=env,
+                     capture_output=True, text=True, timeout=600)
+  assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+  out = json.loads(p.stdout.strip().split('\n')[-1])
+  gw = next(v for k, v in out.items() if k.startswith('k_kde_marg_sub2'))
+  sf = next(v for k, v in out.items() if k.startswith('k_samples_fast'))
+  assert gw['units_per_s'] > 1e7 and sf['units_per_s'] > 1e9, (gw['units_per_s'], sf['units_per_s'])
+  # the same workload on the release library, no probes
+  code = ("import sys, numpy as np; sys.path.insert(0, %r); import chimera_amd as CH; from chimera_amd import synth; "
+          "from chimera_amd.catalog import dVdz_completeness, pixelated_catalog; cfg, ev, inj = synth.make_config('C3', E=2, I=4000); "
+          "pe = ('m1det', 'm2det', 'dL', 'ra', 'dec', 'pe_prior', 'pixels_opt_nsides', 'ra_pix', 'dec_pix', 'gw_loc2d_pdf', 'pixels_pe_opt_nside'); "
+          "th = CH.data.theta_pe_det(**{k: ev[k] for k in pe}); gc = pixelated_catalog(dVdz_completeness(z_range=[0.073, 1.3]), p_cat=ev['p_cat'], z_grids=ev['z_grids'], neff_pixels=ev['neff_pixels']); "
+          "pop = CH.population(CH.cosmo.flrw(H0=70., Om0=0.25, z_max=5.), CH.mass.plp(), CH.rate.madau_dickinson(gamma=2.7, kappa=3., zp=2.), gal_cat=gc, scale_free=True); "
+          "sel = CH.selection_function(CH.data.theta_inj_det(**{k: inj[k] for k in ('m1det', 'm2det', 'dL', 'p_draw')}), N_inj=inj['N_inj'], N_eff=5.); "
+          "like = CH.hyperlikelihood(th, ev['z_grids'], pop, sel, kind_p_gw3d='marginalized', kernel='epan', bw_method=None, cut_grid=2, binning=True, num_bins=200); "
+          "print(repr(float(like(H0=70.))))") % ROOT
+  q = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=dict(os.environ, CHIMERA_NO_REBUILD='1'), capture_output=True, text=True, timeout=600)
+  assert q.returncode == 0, q.stderr[-2000:]
+  assert float(q.stdout.strip().split('\n')[-1]) == out['log_hyper_after'], (q.stdout, out['log_hyper_after'])
