@@ -420,9 +420,9 @@ def main():
     like.set_option('fused', args.fused)
   if graph_max_nb is not None:
     like.set_option('graph_max_nb', graph_max_nb)
+  nb = args.nbatch
   if nb <= 8 and graph_max_nb == 0:
     like.set_option('timing', 2)                      # --no-graph with few draws: the run exists for its per-kernel HIP-event times (the one-lane pass below is for calls of many draws)
-  nb = args.nbatch
   H0s = np.linspace(55., 95., 4099)          # a different H0 for every draw of every step
   Xi0s = np.linspace(0.6, 3.0, 4099)
 

@@ -451,3 +451,48 @@ def test_bench_prices_a_launch_against_the_measured_ceiling_of_its_body():
   assert 'sustained' not in bench.kernel_roofline('sample stage', 'k_samples', 3.9, 1e9, None, units=1., probe=probe, work=5e8)      # no ceiling for that body in the file
   got = bench.load_probe_ceilings('0' * 64)
   assert got is None or got[2] is False                      # whatever is committed was not measured beside a binary with that hash
+
+
+def test_bench_binds_every_local_before_it_reads_it():
+  """bench.py's main() runs only on a GPU box; a line moved above the assignment it depends on (round 6: `nb`) costs a GPU session to find.  A plain
+  source-order check of every function of bench.py: no local name is read on a line in front of its first binding (nested functions are deferred)."""
+  import ast
+  tree = ast.parse(open(os.path.join(ROOT, 'bench.py')).read())
+  for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+    stores, loads = {}, []
+
+    class V(ast.NodeVisitor):
+      def visit_FunctionDef(self, n):
+        if n is fn:
+          for a in n.args.args + n.args.kwonlyargs:
+            stores.setdefault(a.arg, 0)
+          self.generic_visit(n)
+        else:
+          stores.setdefault(n.name, n.lineno)
+
+      def visit_Lambda(self, n):
+        return None
+
+      def visit_Name(self, n):
+        if isinstance(n.ctx, ast.Store):
+          stores.setdefault(n.id, n.lineno)
+        elif isinstance(n.ctx, ast.Load):
+          loads.append((n.id, n.lineno))
+
+      def visit_Import(self, n):
+        for a in n.names:
+          stores.setdefault((a.asname or a.name).split('.')[0], n.lineno)
+      visit_ImportFrom = visit_Import
+
+      def visit_ExceptHandler(self, n):
+        if n.name:
+          stores.setdefault(n.name, n.lineno)
+        self.generic_visit(n)
+    for node in ast.walk(fn):
+      if isinstance(node, ast.comprehension):
+        for t in ast.walk(node.target):
+          if isinstance(t, ast.Name):
+            stores.setdefault(t.id, 0)
+    V().visit(fn)
+    early = sorted({(n, l) for n, l in loads if n in stores and stores[n] > l})
+    assert not early, f"bench.py: {fn.name} reads {early} before binding them"
