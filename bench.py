@@ -421,8 +421,8 @@ def main():
   if graph_max_nb is not None:
     like.set_option('graph_max_nb', graph_max_nb)
   nb = args.nbatch
-  if nb <= 8 and graph_max_nb == 0:
-    like.set_option('timing', 2)                      # --no-graph with few draws: the run exists for its per-kernel HIP-event times (the one-lane pass below is for calls of many draws)
+  if nb <= 8 and graph_max_nb is not None:
+    like.set_option('timing', 2)                      # few draws per call with the graph replay off (--no-graph, or 1 < nbatch <= 8: the timed calls stay eager): per-kernel HIP-event times of every step (the one-lane pass below is for calls of many draws)
   H0s = np.linspace(55., 95., 4099)          # a different H0 for every draw of every step
   Xi0s = np.linspace(0.6, 3.0, 4099)
 
@@ -482,11 +482,11 @@ def main():
       ta = time.perf_counter()
       vals.append(like.batch(draws[args.warmup + k]))          # synchronous: returns when the last kernel has stored the results (completion flags)
       step_s.append(time.perf_counter() - ta)
-      if nb <= 8 and graph_max_nb == 0:
+      if nb <= 8 and graph_max_nb is not None:
         kt += like.last_timing()                               # (the --no-graph run of few draws: per-kernel times of every step)
     # [r6] HIP-event times of the LAST step only: reading them waits for the call's final event (an interrupt-driven wait of tens of microseconds
     # that round 5 paid after every step of the timed region)
-    if not (nb <= 8 and graph_max_nb == 0):
+    if not (nb <= 8 and graph_max_nb is not None):
       kt += like.last_timing() * max(args.steps, 1)
   else:
     from collections import deque

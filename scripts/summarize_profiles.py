@@ -149,7 +149,7 @@ def headline(rnd):
       extra = ''
       if tag == '_full':
         k = x['roofline']['kernels'][0]
-        extra = '; `%s` %.2f ms per launch = %.2f Tpair/s = %.3f of the power-sum ceiling' % (k['kernel'], k['kernel_ms'], k['Gpairs_s'] / 1e3, k['pair_frac'])
+        extra = ('; `%s` %.2f ms per launch = %.2f Tpair/s = %.3f of the power-sum ceiling' % (k['kernel'], k['kernel_ms'], k['Gpairs_s'] / 1e3, k['pair_frac'])) if k.get('Gpairs_s') else ''
       out.append('| %s | %.0f evals/s (%.3f ms per step; scalar call %.3f ms)%s | `bench%s.json` |' % (label, x['value'], x['ms_per_step'], x.get('single_call_ms') or 0., extra, tag))
   ex = (b.get('extra') or {}).get('configs') or {}
   lab = {'C1': 'C1 (10 events, 1-D)', 'C2': 'C2 (100 ev × 16 px × 500 z)', 'C4': 'C4 (69 ev × 16 px × 500 z, 1e6 injections)',
