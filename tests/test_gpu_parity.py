@@ -1412,6 +1412,20 @@ def test_results_behind_completion_flags_have_arrived_when_the_call_returns():
       got = like.batch(lams[:n]) if n > 1 else np.array([like(**lams[0])])
       bad += int(not np.array_equal(got, want[:n]))
   assert bad == 0, f"{bad} of 20000 calls returned something else than the first evaluation's bits"
+  # two lanes on the same resident data, each driven by its own host thread (its own result block and flags)
+  import threading
+  lane2 = like.lane()
+  errs = []
+
+  def drive(ln, n):
+    for it in range(3000):
+      got = ln.batch(lams[:n])
+      if not np.array_equal(got, want[:n]):
+        errs.append((n, it, got))
+  ts = [threading.Thread(target=drive, args=(like, 2)), threading.Thread(target=drive, args=(lane2, 5))]
+  [t.start() for t in ts]; [t.join() for t in ts]
+  assert not errs, errs[:3]
+  lane2.selection_function.close(); lane2.close()
   like.close(); sel.close()
   for it in range(200):
     lk, _, sl = H.build_product(ev, inj)
