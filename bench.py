@@ -161,10 +161,12 @@ def quartiles(x):
 MIN_INST = {'k_samples': (140., 'sample'), 'k_kde_marg_sub2': (570., 'pair of pixels'), 'k_selection': (224., 'injection')}
 
 
-def kernel_roofline(label, prefix, ms, unique_bytes, pmc, units=None, probe=None, work=None):
+def kernel_roofline(label, prefix, ms, unique_bytes, pmc, units=None, probe=None, work=None, scale=None):
   """One kernel against its ceilings.  ms: live HIP-event duration of one launch; units: units of work per launch in waves (MIN_INST);
   probe / work: the measured ceilings (load_probe_ceilings) and the launch's work in the probe's unit (pairs of pixels, samples)."""
   k = pmc_kernel(pmc, prefix)
+  if k and scale:                                     # counters of a launch over the whole workload -> this shard's launch (cycle counts and times of the profiled launch stay: the clock)
+    k = {kk: (v * scale if (isinstance(v, (int, float)) and (kk.startswith(('SQ_INSTS', 'SQ_WAVES', 'FETCH_SIZE', 'WRITE_SIZE', 'TCC_')))) else v) for kk, v in k.items()}
   fresh = bool(pmc and pmc[2])
   sec = ms * 1e-3
   out = {"kernel": k['name'] if k else prefix, "stage": label, "kernel_ms": ms, "bound": "valu-issue",
@@ -172,6 +174,8 @@ def kernel_roofline(label, prefix, ms, unique_bytes, pmc, units=None, probe=None
          "hbm_unique_GBs": unique_bytes / sec / 1e9 if sec > 0 else None,
          "hbm_unique_frac": unique_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else None,
          "pmc_matches_loaded_code_object": fresh}
+  if scale:
+    out["pmc_counters_scaled_by"] = scale
   if k and sec > 0 and fresh:
     insts = k.get('SQ_INSTS_VALU')
     if insts:
@@ -204,7 +208,7 @@ def kernel_roofline(label, prefix, ms, unique_bytes, pmc, units=None, probe=None
       if k.get('GRBM_GUI_ACTIVE') and k.get('profiled_ms'):
         clk = k['GRBM_GUI_ACTIVE'] / 8 / (k['profiled_ms'] * 1e-3)         # 8 XCDs count the launch's cycles
         out["clock_GHz_under_profile"] = clk / 1e9
-        out["valu_busy_frac_at_held_clock"] = cycles / (N_SIMD * clk * k['profiled_ms'] * 1e-3)
+        out["valu_busy_frac_at_held_clock"] = (cycles / scale if scale else cycles) / (N_SIMD * clk * k['profiled_ms'] * 1e-3)      # (of the profiled launch)
     if k.get('FETCH_SIZE') is not None and k.get('WRITE_SIZE') is not None:
       # gfx950: FETCH_SIZE tallies 64 B per 128-B request of wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM)
       traffic = (2 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024
@@ -515,7 +519,8 @@ def main():
   # for large shards overlaps the sample stage of one event group with the GW kernel of the previous one on two streams, where a kernel's
   # HIP-event span is not its duration) -- outside the timed region, same draws
   kt_timed_eval = kt[0] / max(args.steps, 1)
-  if pool is None and world == 1 and nb > 8:             # (calls of few draws are a single chain anyway)
+  # [r6] also for N > 1 (every rank runs the same collective calls on its shard): the N > 1 line then carries the roofline block of rank 0's shard
+  if pool is None and nb > 8:                            # (calls of few draws are a single chain anyway)
     like.set_option('groups', 1)
     like.set_option('timing', 2)                         # per-kernel events (the default call carries the whole evaluation's two only)
     kt = np.zeros(8)
@@ -660,8 +665,14 @@ def main():
     value = evals / dt
     El = like._e1 - like._e0
     lib_sha = code_object_sha256(_lib.LIB_PATH)
-    pmc = load_pmc(dict(config=args.config, E=El, P=P, Z=Z, S=S, nbatch=nb, mode=kind or '1d', n_gpus=1, fused=args.fused), lib_sha) if world == 1 else None
-    probe = load_probe_ceilings(lib_sha) if world == 1 else None
+    pmc = load_pmc(dict(config=args.config, E=El, P=P, Z=Z, S=S, nbatch=nb, mode=kind or '1d', n_gpus=1, fused=args.fused), lib_sha)
+    pmc_scale = None
+    if pmc is None and world > 1:
+      # [r6] a shard of an N-GPU run: the PMC passes of the WHOLE workload on one GPU, per-launch counters scaled by the shard's share of the events (the
+      # counts per pair of pixels / per sample do not depend on how many events a launch holds); labelled in the line
+      pmc = load_pmc(dict(config=args.config, E=E, P=P, Z=Z, S=S, nbatch=nb, mode=kind or '1d', n_gpus=1, fused=args.fused), lib_sha)
+      pmc_scale = El / float(E) if pmc is not None else None
+    probe = load_probe_ceilings(lib_sha)
     kernels = []
     if kind == 'marginalized' and args.fused >= 2:
       # the fused event kernel does the sample stage, the per-z factors and the GW kernel of every (event, draw) in one launch: its span is kt[3]
@@ -669,7 +680,7 @@ def main():
                                      El * S * 49 + El * P * Z * 8 + El * Z * 8 + nb * ((2 * 1500 + 2 * 1000) * 8 + El * Z * 16), pmc))
     elif kind == 'marginalized':
       kernels.append(kernel_roofline("marginalized GW kernel (histogram + KDE + interp + integrand + trapz)", "k_kde_marg_sub2", kt[3],
-                                     gw_kernel_unique_bytes(El, S, P, Z, nb), pmc, units=El * P / 2. * nb, probe=probe, work=El * ((P + 1) // 2) * nb))
+                                     gw_kernel_unique_bytes(El, S, P, Z, nb), pmc, units=El * P / 2. * nb, probe=probe, work=El * ((P + 1) // 2) * nb, scale=pmc_scale))
     full_pairs = None
     if kind == 'full':
       kernels.append(kernel_roofline("3-D Gaussian KDE + integrand (sample-stationary kernel; the general kernel's share of the stage is its empty blocks)", "k_full_kde_chain", kt[3], El * S * 32 * nb + El * P * Z * 8, pmc))
@@ -695,7 +706,7 @@ def main():
                  "march_alone_Gpairs_s_measured_r05": march_alone, "frac_of_march_alone": full_pairs / sec / 1e9 / march_alone if sec > 0 else None})
     if not (kind == 'marginalized' and args.fused >= 2):        # (the fused event kernel has no sample stage of its own)
       kernels.append(kernel_roofline("sample stage (z(dL), source-frame masses, population weights, event statistics)", "k_samples", kt[2],
-                                     sample_kernel_unique_bytes(El, S, nb), pmc, units=El * S * nb / 64., probe=probe, work=float(El) * S * nb))
+                                     sample_kernel_unique_bytes(El, S, nb), pmc, units=El * S * nb / 64., probe=probe, work=float(El) * S * nb, scale=pmc_scale))
     # the selection kernel runs on its own stream beside the event kernels (its span there is not a kernel duration): timed standalone
     # here, after the timed region, as the selection-only call chm_eval(NULL, sel, ...) of the same draws
     sel_ms = None
@@ -731,7 +742,8 @@ def main():
             "issue_busy_frac_at_held_clock": dom.get("valu_busy_frac_at_held_clock"), "min_inst": dom.get("min_inst"),
             "fp64_TFLOPs_real": dom.get("fp64_TFLOPs_real"), "fp64_peak_TFLOPs": FP64_PEAK_TFLOPS,
             "traffic": dom.get("traffic_bytes_per_launch"),
-            "traffic_source": (pmc[0] + " (separate rocprofv3 --pmc passes of this command)") if pmc else None,
+            "traffic_source": (pmc[0] + (" (separate rocprofv3 --pmc passes of this command)" if not pmc_scale else
+                                         f" (PMC passes of the WHOLE workload on one GPU; per-launch counters scaled by this rank's share of the events, {pmc_scale:.4f})")) if pmc else None,
             "code_object_sha256": lib_sha, "pmc_matches_loaded_code_object": bool(pmc and pmc[2]),
             "kernel_ms": dom["kernel_ms"],
             "hbm": {"unique_bytes_per_launch": dom["unique_bytes_per_launch"], "achieved": dom["hbm_unique_GBs"], "peak": HBM_PEAK_GBS,
