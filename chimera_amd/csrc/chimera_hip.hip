@@ -276,7 +276,14 @@ static void fill_dev_params(const chm_params* p, DevParams* d) {
   // `m_low <= m <= m_high` test of tpl_notnorm (mass.py:240-245) decides if the first / last trapezoid node of cdf_m2 and
   // norm_p_m1 counts -- an O(1e-3) effect hanging on the last bit of pow().  The host's libm forms them (as NumPy / the CPU
   // back-end of the reference does), so the decision is the CPU reference's for every (m_low, m_high), not only the defaults.
-  d->mg_first = pow(10., log10(p->mass[CHM_M_MLOW])); d->mg_last = pow(10., log10(p->mass[CHM_M_MHIGH]));
+  // ([r6] memoised per host thread: the draws of a scan or of a chain's batch mostly share m_low / m_high, and the four libm calls per draw were ~15 us of
+  //  host time in front of the first kernel of a 128-draw call)
+  static thread_local double memo_in[2] = { -1., -1. }, memo_out[2] = { 0., 0. };
+  const double in[2] = { p->mass[CHM_M_MLOW], p->mass[CHM_M_MHIGH] };
+  for (int i = 0; i < 2; i++) {
+    if (memcmp(&in[i], &memo_in[i], sizeof(double)) != 0) { memo_out[i] = pow(10., log10(in[i])); memo_in[i] = in[i]; }
+  }
+  d->mg_first = memo_out[0]; d->mg_last = memo_out[1];
 }
 
 // host part of the per-draw tables: parameter checks, buffers, the draws packed into the pinned staging block
@@ -1085,7 +1092,12 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   const bool opt_zf_full = o.zf_full || rate_special_call, opt_marg_generic = o.marg_generic || rate_special_call;
   const int graph_max_nb = o.graph_max_nb;
   const bool zc_env = !o.no_zero_copy;
-  const bool zero_copy = zc_env && nb <= 8;               // few draws: k_tables reads the parameters from pinned host memory itself (no copy node in front of it)
+#ifndef CHM_ZC_PARAMS_MAX_NB
+#define CHM_ZC_PARAMS_MAX_NB (1 << 30)     // (8: A/B builds -- calls of more draws copy the parameter block to the device in front of k_tables, as until round 5)
+#endif
+  // k_tables reads the draws from pinned host memory itself (no copy node in front of it): [r6] calls of every size (each block fetches its draw's 400 bytes;
+  // the H2D copy of a 128-draw block was ~8 us of stream time + its enqueue in front of the first kernel of every call)
+  const bool zero_copy = zc_env && nb <= CHM_ZC_PARAMS_MAX_NB;
   // [r6] results of EVERY call size are written to pinned host memory by the last kernel (the trailing D2H copy of 3 nb doubles was ~4 us of copy kernel
   // + its launch behind every batched call: profiles/r05/timeline_shard125_batched.txt)
   const bool zc_out = zc_env;
