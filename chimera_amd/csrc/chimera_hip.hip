@@ -1092,12 +1092,10 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
   const bool opt_zf_full = o.zf_full || rate_special_call, opt_marg_generic = o.marg_generic || rate_special_call;
   const int graph_max_nb = o.graph_max_nb;
   const bool zc_env = !o.no_zero_copy;
-#ifndef CHM_ZC_PARAMS_MAX_NB
-#define CHM_ZC_PARAMS_MAX_NB (1 << 30)     // (8: A/B builds -- calls of more draws copy the parameter block to the device in front of k_tables, as until round 5)
-#endif
-  // k_tables reads the draws from pinned host memory itself (no copy node in front of it): [r6] calls of every size (each block fetches its draw's 400 bytes;
-  // the H2D copy of a 128-draw block was ~8 us of stream time + its enqueue in front of the first kernel of every call)
-  const bool zero_copy = zc_env && nb <= CHM_ZC_PARAMS_MAX_NB;
+  // k_tables reads the draws from pinned host memory itself (no copy node in front of it): [r6] calls of every size -- each block fetches its draw's 400 bytes;
+  // the H2D copy of a 128-draw block in front of the first kernel was 15 us of the 125-event shard's step (same-box A/B, four repetitions: 1.1800 -> 1.1630 ms,
+  // profiles/r06/ab_shard_step_r06.txt; until round 5 only calls of <= 8 draws took this path)
+  const bool zero_copy = zc_env;
   // [r6] results of EVERY call size are written to pinned host memory by the last kernel (the trailing D2H copy of 3 nb doubles was ~4 us of copy kernel
   // + its launch behind every batched call: profiles/r05/timeline_shard125_batched.txt)
   const bool zc_out = zc_env;
