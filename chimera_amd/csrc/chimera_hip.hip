@@ -316,10 +316,9 @@ static int ctx_tables_enqueue(Ctx& c, int nb, int Tc, int Tm, LutDesc lutA = Lut
   if (tl <= 112 * 1024) {                                   // + 33 KB of static LDS (build_lut scratch, parameter block)
     static size_t tl_allowed = 0;                             // the kernel also holds 33 KB of static LDS: ask as soon as the sum passes 48 KB
     if (tl > 14 * 1024 && tl > tl_allowed) { (void)hipFuncSetAttribute((const void*)k_tables<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl); tl_allowed = tl; }
-#ifndef CHM_TABLES_Y_BATCH
-#define CHM_TABLES_Y_BATCH 2      // (A/B, profiles/r06/ab_shard_step_r06.txt) blocks per draw of a call of many draws: 2 = cosmology | mass (256 blocks of 1024 threads at 128 draws: one per CU); 3 = the cosmology tail split over two blocks (the scalar call's form; 384 blocks: -0.5 % of the 125-event shard's step with 2)
-#endif
-    hipLaunchKernelGGL(k_tables<true>, dim3(nb, nb > 8 ? CHM_TABLES_Y_BATCH : 3), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt, hsrc, ztc, lzc);
+    // blocks per draw: the scalar call's form splits the cosmology tail over two blocks (grid (nb, 3)); a call of many draws runs cosmology | mass (grid (nb, 2):
+    // 256 blocks of 1024 threads at 128 draws, one per CU -- 26 -> 21 us, -0.5 % of the 125-event shard's step: profiles/r06/ab_shard_step_r06.txt)
+    hipLaunchKernelGGL(k_tables<true>, dim3(nb, nb > 8 ? 2 : 3), dim3(1024), tl, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt, hsrc, ztc, lzc);
   } else {
     hipLaunchKernelGGL(k_tables<false>, dim3(nb, 2), dim3(CHM_TABLES_LONG_NT), 0, c.stream, c.d_params, c.zt, c.It, c.dLt, c.mg, c.cdf, c.tmp, c.TcMax, c.TmMax, lutA, lutB, (lutA.nk > 0 || lutB.nk > 0) ? c.rec : nullptr, tab_zt, tab_dLt, hsrc, ztc, lzc);
   }

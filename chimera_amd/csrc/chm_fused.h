@@ -69,11 +69,7 @@ k_marg_fused(LikeDev L, SampFast F, FusedDesc D, const DevParams* params, const 
   double* const rec = cdf + D.cap_m;
   unsigned short* const luts = reinterpret_cast<unsigned short*>(rec + 4 * (size_t)D.cap_rec);
   double* const Hb = rec + 4 * (size_t)D.cap_rec + (D.cap_keys + 3) / 4;      // [NW - 1][HS] boundary rows
-#if CHM_EXPTAB
   const ExpTab ex = { etab };
-#else
-  const ExpPoly ex = {};
-#endif
   const double* g_zt = zt_all + (size_t)b * TcMax;
   const double* g_It = It_all + (size_t)b * TcMax;
   const double* g_dLt = dLt_all + (size_t)b * TcMax;

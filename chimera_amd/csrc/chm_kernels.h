@@ -788,11 +788,7 @@ DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParam
   double* etab = lds;
   double* rec = lds + CHM_EXPTAB_N; double* mg = rec + 4 * (size_t)cap; double* cdf = mg + Tm;
   unsigned short* luts = reinterpret_cast<unsigned short*>(cdf + Tm);
-#if CHM_EXPTAB
   const ExpTab ex = { etab };
-#else
-  const ExpPoly ex = {};
-#endif
   {
     const double* gm = mg_all + (size_t)b * TmMax;
     const double* gc = cdf_all + (size_t)b * TmMax;
@@ -1298,19 +1294,15 @@ DEVFN void zfactors_body(const LikeDev& L, const DevParams* params, const double
   const DevParams P = params[b];      // by value: uniform loads at kernel start -> scalar registers, nothing re-read in the loops
   const double* zt = zt_all + (size_t)b * TcMax;
   const double* It = It_all + (size_t)b * TcMax;
-#if CHM_EXPTAB
   __shared__ double etab[CHM_EXPTAB_N];             // [r3] the two powers of the merger rate through the table exp (chm_exp_tab)
   for (int i = t; i < CHM_EXPTAB_N; i += nt) etab[i] = exp_table_entry(i);
   const ExpTab ex = { etab };
-#else
-  const ExpPoly ex = {};
-#endif
   if (LDS_TAB) {                                    // staged once per block; the block then walks over its events
     double* a = lds; double* c = lds + P.Tc;
     for (int i = t; i < P.Tc; i += nt) { a[i] = zt[i]; c[i] = It[i]; }
     zt = a; It = c;
   }
-  if (LDS_TAB || CHM_EXPTAB) __syncthreads();
+  __syncthreads();
   const int Z = L.Z;
   // ranged: a WAVE per event (the support of an event's KDE is ~Z/3 points: 64-lane passes waste less than 256-thread ones);
   // whole grids: the block walks over the events
@@ -2582,15 +2574,8 @@ __global__ void __launch_bounds__(256, FULL_MINW) k_full_kde(LikeDev L, const De
 #ifndef FULLC_PB
 #define FULLC_PB 4            // samples of a thread whose values are requested together at the block's start, two such sets at a time (divides FULLC_SPT)
 #endif
-#ifndef FULLC_QPIPE
-#define FULLC_QPIPE 0
-#endif
-#ifndef FULLC_DIAG_NOEXCH
-#define FULLC_DIAG_NOEXCH 0
-#endif
-#ifndef FULLC_REDUCE16
-#define FULLC_REDUCE16 0       // sixteen points x one half of the wave per exchange (44 instead of 68 VALU per chunk): measured 8.41-8.53 against 8.26-8.30 ms -- off
-#endif
+// (measured in round 5 and dropped, profiles/r05/ab_full_mode_r05.txt; text: docs/history/ab_arms_r06.patch -- the running product one group ahead (equal), sixteen
+//  points x one half of the wave per exchange (44 instead of 68 VALU per chunk: 8.41-8.53 against 8.26-8.30 ms), the march without its exchange (a timing diagnostic))
 #define FULLC_ROW 72          // doubles per grid point in the exchange buffer: 64 lanes + 8 (the eight points a wave reads fall in distinct banks)
 // per (draw, event) record of k_full_prep (doubles): what the pixels of an event share
 enum { FE_L00 = 0, FE_L10, FE_L11, FE_L20, FE_L21, FE_L22, FE_LOGNORM, FE_ZLO, FE_ZHI, FE_NORM, FE_OK, FE_KFIRST, FE_KLAST, FE_CHAIN, FE_D, FE_K1, FE_K2,
@@ -2826,10 +2811,6 @@ __global__ void __launch_bounds__(64 * FULLC_NW, FULLC_MINW) k_full_kde_chain(Li
           const double u2 = u * u, u3 = u2 * u, u4 = u2 * u2;
 #pragma unroll
           for (int i = 0; i < LK; i += 4) {
-#if FULLC_QPIPE
-            double qn = q * u4;                            // the next group's running product before this group's sums: nothing waits on it
-            asm volatile("" : "+v"(qn));
-#endif
             if (j == 0) {                                  // [r5] the first sample sets the accumulators (0 + q, fma(q, u, 0): the same roundings) -- no reset
               acc[i] = q; acc[i + 1] = q * u; acc[i + 2] = q * u2; acc[i + 3] = q * u3;
             } else {
@@ -2838,12 +2819,7 @@ __global__ void __launch_bounds__(64 * FULLC_NW, FULLC_MINW) k_full_kde_chain(Li
               acc[i + 2] = __builtin_fma(q, u2, acc[i + 2]);
               acc[i + 3] = __builtin_fma(q, u3, acc[i + 3]);
             }
-#if FULLC_QPIPE
-            asm volatile("" : "+v"(acc[i + 3]));
-            q = qn;
-#else
             q *= u4;
-#endif
           }
           pw[j] = q * K1; uu[j] = u * K2;
         }
@@ -2873,36 +2849,6 @@ __global__ void __launch_bounds__(64 * FULLC_NW, FULLC_MINW) k_full_kde_chain(Li
       }
     }
     PH(1);                                                  // (phase 1: the march of a chunk)
-#if FULLC_REDUCE16
-    // sixteen grid points at a time, the two halves of the wave one after the other: the 32 lanes of a half write their sixteen sums, lane l
-    // adds lanes l%4, l%4 + 4, ... of point l/4 to its running sum (both halves), two DPP steps complete the point in lane 4 (l/4) + 3
-    // (44 instead of 68 VALU instructions per chunk; rows of 32 + 4 doubles: the eight points a half-wave reads fall in distinct banks)
-#pragma unroll
-    for (int h = 0; h < LK; h += 16) {
-      if (h < ng) {
-        double v = 0.;
-#pragma unroll
-        for (int lh = 0; lh < 2; lh++) {
-          if ((lane >> 5) == lh) {
-#pragma unroll
-            for (int i = 0; i < 16; i++) xb[i * 36 + (lane & 31)] = acc[h + i];
-          }
-          wave_sync();                                       // the lanes read each other's sums: no access moves across (LDS itself runs in issue order)
-          const double* src = xb + (lane >> 2) * 36 + (lane & 3);
-#pragma unroll
-          for (int q = 0; q < 8; q++) v += src[4 * q];
-          wave_sync();
-        }
-        v += dpp_move<0x111, 0xf, true>(v); v += dpp_move<0x112, 0xf, true>(v);
-        if ((lane & 3) == 3) { double* o = vrow + c * LK + h + (lane >> 2); *o = sb == 0 ? v : *o + v; }
-      }
-    }
-#elif FULLC_DIAG_NOEXCH      // timing diagnostic only (WRONG results): no cross-lane exchange, one sum per chunk keeps the march alive
-    { double v = 0.;
-#pragma unroll
-      for (int i = 0; i < LK; i++) v += acc[i];
-      if (v == 1.2345e-300) vrow[c * LK] = v; }
-#else
 #pragma unroll
     for (int h = 0; h < LK; h += 8) {
       if (h < ng) {
@@ -2918,7 +2864,6 @@ __global__ void __launch_bounds__(64 * FULLC_NW, FULLC_MINW) k_full_kde_chain(Li
         if ((lane & 7) == 7) { double* o = vrow + c * LK + h + (lane >> 3); *o = sb == 0 ? v : *o + v; }
       }
     }
-#endif
     PH(2);                                                  // (phase 2: the chunk's sums across the lanes)
   }
   if (sb + nt * FULLC_SPT < S) { FULLC_LOADB(bA, sb + nt * FULLC_SPT, 0) }
@@ -3078,18 +3023,11 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
                                const int b, const int bx, const int nbx, double* lds, double* red) {
 #pragma clang fp contract(fast)
   const int t = threadIdx.x;
-#ifdef CHM_SELF_PLDS
-  __shared__ DevParams Ps;
-  if (t == 0) Ps = params[b];
-  __syncthreads();
-  const DevParams& P = Ps;
-#else
   DevParams P = params[b];
 #ifndef CHM_SELF_NPV
 #define CHM_SELF_NPV 11       // 127 VGPRs: four waves per SIMD (one more: three waves; C4 step 2.47 -> 2.42 ms on one box)
 #endif
   mass_params_to_vgpr<MASS, CHM_SELF_NPV>(P);
-#endif
   const double* g_zt = zt_all + (size_t)b * TcMax;
   const double* g_dLt = dLt_all + (size_t)b * TcMax;
   const int Tc = P.Tc, Tm = P.Tm;
@@ -3100,11 +3038,7 @@ DEVFN void selection_fast_body(const SelDev& Sd, const LutDesc& lut, const DevPa
   double* etab = lds;                                        // [r3] the table of the mass model's exps (chm_exp_tab), as in k_samples_fast
   double* rec = lds + CHM_EXPTAB_N; double* mg = rec + 4 * (size_t)cap; double* cdf = mg + Tm;
   unsigned short* luts = reinterpret_cast<unsigned short*>(cdf + Tm);
-#if CHM_EXPTAB
   const ExpTab ex = { etab };
-#else
-  const ExpPoly ex = {};
-#endif
   {
     const double* gm = mg_all + (size_t)b * TmMax;
     const double* gc = cdf_all + (size_t)b * TmMax;

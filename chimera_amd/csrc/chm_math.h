@@ -22,8 +22,7 @@
 // v_fma_f64 that reads it as its one scalar operand.  The ~20 coefficients of exp / log then occupy no registers at all -- in VGPRs they
 // took 40 registers or two v_mov_b32 (2 cycles each) per use, in allocated SGPRs the register allocator spilled them to VGPR lanes
 // (v_readlane: 4 cycles) -- and the s_mov_b32 issue on the scalar unit beside the VALU stream (v_fma_f64 + SALU pairs: 4.8 against
-// 4.4 cycles, profiles/r03/issue_cost.txt).  CHM_FMA_COEF_VGPR restores the round-2 form for A/B runs.
-#ifndef CHM_FMA_COEF_VGPR
+// 4.4 cycles, profiles/r03/issue_cost.txt).
 template <unsigned LO, unsigned HI>
 DEVFN double fm_fma_k(double a, double b) {
   double d;
@@ -32,13 +31,6 @@ DEVFN double fm_fma_k(double a, double b) {
 }
 #define FM_BITS(c) __builtin_bit_cast(unsigned long long, (double)(c))
 #define FM_FMA(a, b, c) fm_fma_k<(unsigned)(FM_BITS(c) & 0xffffffffull), (unsigned)(FM_BITS(c) >> 32)>((a), (b))
-#else
-DEVFN double FM_FMA(double a, double b, double c) {
-  double d;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
-#endif
 
 // Single instructions the compiler does not emit on its own: v_max_f64 / v_min_f64 without the canonicalising v_max_f64 x, x that
 // llvm.maxnum / minnum put in front of every loaded operand (IEEE maxNum / minNum: a quiet NaN operand yields the other one);
@@ -145,9 +137,6 @@ DEVFN double chm_exp_clamped(double x) {
 // Taylor sum (remainder < 4e-17) -- 13 VALU instructions against the 17 of chm_exp_nb (the table read is an LDS instruction).  Same contract
 // as chm_exp_nb: no range checks (a huge |x| ends in v_ldexp_f64's 0 / inf, NaN propagates through the polynomial); <= 1.8 ulp (4.0e-16 on 2e7 arguments, scripts/check_fastmath.cpp).
 #define CHM_EXPTAB_N 256
-#ifndef CHM_EXPTAB
-#define CHM_EXPTAB 1           // 0: the fast sample / selection kernels keep the polynomial exp (A/B builds)
-#endif
 DEVFN double chm_exp_tab(double x, const double* T) {
   const double SC = 3.69329930467574632e+02;               // 256 / ln 2
   const double L_HI = 6.93147180369123816490e-01 / 256., L_LO = 1.90821492927058770002e-10 / 256.;      // ln2/256 in two pieces (exact scalings of fdlibm's)

@@ -424,11 +424,7 @@ DEVFN double p_m1m2(const DevParams& p, double m1, double m2, A1 mg, A2 cdf) {
 // pointers and the exec-mask stack in 102 SGPRs: the allocator spilled half of them to VGPR lanes and re-read them with v_readlane inside
 // the loops (84 of 860 VALU instructions per pass of k_selection_fast), while -- with the polynomial coefficients out of the VGPRs -- a
 // quarter of the vector registers stood empty.
-#ifndef CHM_NO_PARAM_VGPR
 #define CHM_TO_VGPR(x) asm volatile("" : "+v"(x))
-#else
-#define CHM_TO_VGPR(x)
-#endif
 // N: how many of them (in the order of their use count in p_m1m2_fused<MASS>) -- as many as the kernel's vector registers take without spilling
 template <int MASS, int N>
 DEVFN void mass_params_to_vgpr(DevParams& p) {
@@ -451,18 +447,9 @@ DEVFN double tab_first(const TabSlice& a) { return a.first; }
 DEVFN double tab_last(const TabSlice& a, int) { return a.last; }
 // [r5] the end nodes of the mass grid and the last value of cdf_m2 travel with the draw (DevParams: k_tables stores exactly these values in mg[0], mg[Tm - 1],
 // cdf[Tm - 1]): the per-sample loops compare against scalars instead of reading the table ends from LDS for every sample
-#ifndef CHM_MGRID_ENDS_SCALAR
-#define CHM_MGRID_ENDS_SCALAR 1
-#endif
-#if CHM_MGRID_ENDS_SCALAR
 template <class A> DEVFN double mgrid_first(const DevParams& p, A) { return p.mg_first; }
 template <class A> DEVFN double mgrid_last(const DevParams& p, A, int) { return p.mg_last; }
 template <class A> DEVFN double cdf_last_of(const DevParams& p, A, int) { return p.cdf_last; }
-#else
-template <class A> DEVFN double mgrid_first(const DevParams&, A a) { return tab_first(a); }
-template <class A> DEVFN double mgrid_last(const DevParams&, A a, int n) { return tab_last(a, n); }
-template <class A> DEVFN double cdf_last_of(const DevParams&, A a, int n) { return tab_last(a, n); }
-#endif
 DEVFN double mgrid_first(const DevParams&, const TabSlice& a) { return a.first; }
 DEVFN double mgrid_last(const DevParams&, const TabSlice& a, int) { return a.last; }
 DEVFN double cdf_last_of(const DevParams&, const TabSlice& a, int) { return a.last; }
