@@ -13,7 +13,10 @@ the latency of the reference-shaped scalar call (one draw per call) is reported 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 N > 1: events and injections are sharded across ranks (strong scaling: the total workload is fixed), one RCCL
-all-reduce of 3 * nbatch doubles per step inside chm_eval.  Rank 0 prints ONE JSON line.  No PyTorch anywhere: the
+all-reduce of 3 * nbatch doubles per step inside chm_eval.  Rank 0 prints ONE JSON line.  [r6] After the timed region an N > 1 run adds
+a guarded leg with two evaluations in flight per rank (multi_gpu.inflight2: a hang costs the leg, not the line) and its line carries the
+roofline block of rank 0's shard (PMC counters of the whole workload scaled by the shard's share, the probe ceilings); an N = 1 run adds
+short legs of the other BASELINE configurations and call modes (extra.configs: C1, C2, C4, approximate, full, one-draw kernel times).  No PyTorch anywhere: the
 launcher only provides RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT; the ranks meet over chimera_amd.parallel.Rendezvous
 (a Unix-domain socket) for the RCCL unique id, the barriers and the max-over-ranks of the wall time.
 
@@ -31,6 +34,9 @@ profiles/rNN/pmc_per_launch*.json) x those costs, with the share of 2-cycle opco
 same at the clock the chip held under the profile, and the real fp64 flops (FMA = 2, add / mul = 1: SQ_INSTS_VALU_FLOPS_FP64) against
 78.6 TFLOP/s are printed beside it.  The PMC file carries the sha256 of the gfx950 code object it was collected from: when the loaded
 library's differs, no fraction is printed.  The HBM view (unique bytes of the launch and PMC fabric traffic against 8 TB/s) is kept.
+[r6] roofline.frac_of_sustained = the launch's work per second over what the SAME kernel body sustains on a cache-resident workload
+(profiles/rNN/probe_ceilings.json, scripts/run_probes.py: the production bodies replayed for > 1 s at the kernels' own occupancy) -- a measured
+ceiling in the place of round 5's paper count; roofline.hbm_call_frac = the algorithmic bytes of one evaluation over the scalar call's wall time.
 """
 import argparse
 import ctypes as C_
