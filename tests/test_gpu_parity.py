@@ -1412,6 +1412,15 @@ def test_results_behind_completion_flags_have_arrived_when_the_call_returns():
       got = like.batch(lams[:n]) if n > 1 else np.array([like(**lams[0])])
       bad += int(not np.array_equal(got, want[:n]))
   assert bad == 0, f"{bad} of 20000 calls returned something else than the first evaluation's bits"
+  # calls of many draws (128: the bench's shape; the draws read from pinned memory by k_tables, 384 results + 128 flags written back)
+  big = dict(H0=np.linspace(58., 82., 128))
+  want_big = like.batch(big)
+  assert np.array_equal(want_big[::32], np.array([like(H0=float(h)) for h in big['H0'][::32]]))
+  for it in range(3000):
+    got = like.batch(big)
+    if not np.array_equal(got, want_big):
+      bad += 1
+  assert bad == 0, f"{bad} of 3000 128-draw calls differ from the first"
   # two lanes on the same resident data, each driven by its own host thread (its own result block and flags)
   import threading
   lane2 = like.lane()
