@@ -537,6 +537,18 @@ DEVFN void block_reduce_stats(double* v, double* scratch /* 4 x (NS+2) */) {
 
 // CHM_PHASE_PROF (diagnostic builds only, scripts/phase_prof.py): shader-clock cycles between phase marks of k_kde_marg_sub (g_phase) and
 // k_samples (g_phase_s), summed over every 64th block's first wave ([7] counts them)
+// CHM_CLOCK_STAMP builds (with CHM_PROBE): the shader clock INSIDE the two hot kernels -- every 64th block's first lane adds the core-clock cycles
+// (s_memtime) and the 10 ns ticks of the constant 100 MHz counter (s_memrealtime) between the start and the end of its body call
+// (scripts/clock_under_load.py).  The four scalar registers held across the body cost the kernels spilled registers (2 / 21 vector registers):
+// such a build tells the clock, not the time -- the ceilings come from the plain CHM_PROBE build.
+#ifdef CHM_CLOCK_STAMP
+__device__ unsigned long long g_clk[4];                    // GW kernel: cycles, ticks; sample stage: cycles, ticks
+#define CLK_BEGIN const unsigned long long clk_c0 = clock64(), clk_r0 = wall_clock64()
+#define CLK_END(i) do { if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) { atomicAdd(&g_clk[i], clock64() - clk_c0); atomicAdd(&g_clk[i + 1], wall_clock64() - clk_r0); } } while (0)
+#else
+#define CLK_BEGIN
+#define CLK_END(i)
+#endif
 #ifdef CHM_PHASE_PROF
 __device__ unsigned long long g_phase[8], g_phase_s[8];
 #define PH_INIT unsigned long long ph_prev = clock64(); const bool ph_on = threadIdx.x == 0 && (blockIdx.x & 63) == 0; if (ph_on) atomicAdd(&g_phase[7], 1ull)
@@ -882,8 +894,19 @@ DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParam
         }
       }
       if ((S & 1) == 0) {                             // s even, S even: s + 1 < s_end, 16-byte aligned
-        *reinterpret_cast<double2*>(wz + s) = make_double2(zz[0], zz[1]);
-        *reinterpret_cast<double2*>(ww + s) = make_double2(wv[0], wv[1]);
+        if (!NT) {
+          // [r6] many draws per call: the (z, w) of the call -- 8.4 GB at C3, read once by the GW kernel -- are stored with the streaming hint, so
+          // that they do not displace the tiles and tables the draws' blocks share in L2 (stage -2.5 %, step -1.7 %; `sc1` / `sc0 sc1`
+          // write-through: no gain; profiles/r06/ab_memory_path_r06.txt).  Few draws per call: plain stores, the GW kernel finds them in the
+          // memory-side cache.
+          typedef double d2_t __attribute__((ext_vector_type(2)));
+          const d2_t vz = { zz[0], zz[1] }, vw = { wv[0], wv[1] };
+          __builtin_nontemporal_store(vz, reinterpret_cast<d2_t*>(wz + s));
+          __builtin_nontemporal_store(vw, reinterpret_cast<d2_t*>(ww + s));
+        } else {
+          *reinterpret_cast<double2*>(wz + s) = make_double2(zz[0], zz[1]);
+          *reinterpret_cast<double2*>(ww + s) = make_double2(wv[0], wv[1]);
+        }
       } else {
         wz[s] = zz[0]; ww[s] = wv[0];
         if (s + 1 < s_end) { wz[s + 1] = zz[1]; ww[s + 1] = wv[1]; }
@@ -917,7 +940,9 @@ __global__ void __launch_bounds__(64 * CHM_SF_WAVES, CHM_SF_MINW) k_samples_fast
                                                                     const double* dLt_all, const double* mg_all, const double* cdf_all,
                                                                     const double* rec_all, int TcMax, int TmMax) {
   extern __shared__ double lds[];
+  CLK_BEGIN;
   samples_fast_body<MASS, FULL, NT>(L, F, params, zt_all, dLt_all, mg_all, cdf_all, rec_all, TcMax, TmMax, blockIdx.x % L.nb, blockIdx.x / L.nb, gridDim.x / L.nb, lds);
+  CLK_END(2);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -2126,7 +2151,9 @@ DEVFN void kde_marg_sub2_body(const LikeDev& L, const DevParams* params, const i
 template <int SW, int IPW, int BINS, bool DUMP>
 __global__ void __launch_bounds__(64, 4) k_kde_marg_sub2(LikeDev L, const DevParams* params) {
   extern __shared__ double lds_all[];
+  CLK_BEGIN;
   kde_marg_sub2_body<SW, IPW, BINS, DUMP>(L, params, blockIdx.x, blockIdx.y, blockIdx.z, lds_all);
+  CLK_END(0);
 }
 
 // ------------------------------------------------------------------------------------------------------

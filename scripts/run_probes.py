@@ -54,14 +54,14 @@ def main():
     ms = (C.c_double * 64)()
     reps = 40 if which == 0 else 4
     _lib.check(L.chm_debug_probe(h, which, nb, nblocks, reps, 1, ms))               # calibration launch (also the first touch of the data)
-    reps = max(1, int(reps * 150. / ms[0]))                                          # ~0.15 s per launch
+    reps = min(65535, max(1, int(reps * 150. / ms[0])))                                          # ~0.15 s per launch
     nl = min(64, max(4, int(np.ceil(args.seconds / 0.15))))
     _lib.check(L.chm_debug_probe(h, which, nb, nblocks, reps, nl, ms))
     t = np.array(ms[:nl])
     units = nblocks * reps * per_call
     tail = t[nl // 2:]                                                               # the second half: the clock has settled
     rate = units / (np.median(tail) * 1e-3)
-    out[name] = {"unit": "pairs of pixels" if which == 0 else "samples", "units_per_launch": units, "blocks": nblocks, "body_calls_per_block": reps,
+    out[name] = {"unit": "pairs of pixels" if which == 0 else "samples", "units_per_launch": units, "blocks": nblocks * reps, "body_calls_per_block": 1,
                  "launches": nl, "launch_ms": [float(x) for x in t], "launch_ms_median_second_half": float(np.median(tail)),
                  "units_per_s": rate, "total_s": float(t.sum() * 1e-3)}
     print(f"{name}: {nl} launches x {np.median(tail):.1f} ms, {rate / 1e6:.1f} M {out[name]['unit']}/s sustained ({t.sum() * 1e-3:.2f} s in all)", flush=True)

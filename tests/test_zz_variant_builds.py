@@ -61,7 +61,22 @@ def test_probe_build_replays_the_production_bodies_and_leaves_the_results_alone(
   cache-resident workload (the measured ceilings behind bench.py's roofline.frac_of_sustained).  A short run: both bodies report a rate, and the
   evaluation made AFTER the probes (same handle, same workspaces) gives the value a run without probes gives."""
   import json
-  lib = _build('probe', ['-DCHM_PROBE'])
+  import re
+  # the probe kernels must BE the production code: same registers, nothing spilled to scratch (the first form of the probes looped the bodies inside
+  # a block and carried 12-48 spilled vector registers through the replayed stream -- the ceilings it gave were 17-29 % too low)
+  b = subprocess.run(['bash', os.path.join(ROOT, 'scripts', 'build_variant.sh'), 'probe', '-DCHM_PROBE', '-Rpass-analysis=kernel-resource-usage'], cwd=ROOT,
+                     capture_output=True, text=True, timeout=900)
+  assert b.returncode == 0, b.stderr[-2000:]
+  lib = os.path.join(ROOT, 'chimera_amd', 'lib', 'variants', 'libchimera_hip_probe.so')
+  res = {}
+  for m in re.finditer(r'Function Name: (\S+).*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?VGPRs Spill: (\d+)', b.stderr, re.S):
+    res[m.group(1)] = tuple(int(x) for x in m.group(2, 3, 4))
+  probe = {k: v for k, v in res.items() if 'k_probe_gw' in k or 'k_probe_samples' in k}
+  assert len(probe) == 2, sorted(res)[:5]
+  prod = {'gw': next(v for k, v in res.items() if 'k_kde_marg_sub2ILi32ELi4ELi200ELb0' in k), 'sf': next(v for k, v in res.items() if 'k_samples_fastILi2ELb0ELb0' in k)}
+  for k, v in probe.items():
+    assert v[1] == 0 and v[2] == 0, (k, v)
+    assert v[0] <= prod['gw' if 'k_probe_gw' in k else 'sf'][0] + 2, (k, v, prod)
   env = dict(os.environ, CHIMERA_LIB=lib, CHIMERA_NO_REBUILD='1')
   p = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'run_probes.py'), '--events', '2', '--draws', '2', '--seconds', '0.3'], cwd=ROOT, env=env,
                      capture_output=True, text=True, timeout=600)
