@@ -1367,6 +1367,7 @@ static int eval_impl(chm_like* like, chm_sel* sel, chm_comm* comm, const chm_par
       if (!want_dump) L.p_gw_dump = nullptr;
       const int eb = (int)((long long)L0.E * g / ngroups), ee = (int)((long long)L0.E * (g + 1) / ngroups);
       L.e_off = eb; L.E_cnt = ee - eb; L.nb = nb;
+      L.zw_stream = (size_t)nb * (size_t)(ee - eb) * (size_t)L.S * 16 > ((size_t)256 << 20) ? 1 : 0;      // (256 MB: the memory-side cache)
       // per-z factors of the group's events: on the other lane, concurrently with the sample stage -- except in marginalized
       // mode, where they follow k_event_prep on the group's own lane and cover only the support of each event's KDE
 #ifdef CHM_WITH_FUSED

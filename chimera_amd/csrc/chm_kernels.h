@@ -71,6 +71,7 @@ struct LikeDev {                  // device-resident shard of events (see chm_li
   int nb_alloc;                   // draws the workspaces are allocated for (the stride of full_s's five planes)
   int grid_unsorted;              // [r6] some row of z_grids is not non-decreasing (set at upload): the k-range of an event is then the whole grid and the
                                   // marginalized mode takes the general kernel (the standard one ends its grid loop at the first pass beyond the KDE's support)
+  int zw_stream;                  // [r6] the (z, w) of this launch exceed what the memory-side cache holds (set per launch): the fast sample stage stores them with the streaming hint
   unsigned char *ev_rbad;         // (nb,E) [r5] calls with an infinite rate parameter only: 1 = the rate factor prate/jac is inf or NaN at some point of the event grid
                                   // (k_zfactors, whole-grid launch) -- the reference's trapz then holds a 0 * inf = NaN where p_gw vanishes (event_poisoned)
 };
@@ -894,11 +895,11 @@ DEVFN void samples_fast_body(const LikeDev& L, const SampFast& F, const DevParam
         }
       }
       if ((S & 1) == 0) {                             // s even, S even: s + 1 < s_end, 16-byte aligned
-        if (!NT) {
-          // [r6] many draws per call: the (z, w) of the call -- 8.4 GB at C3, read once by the GW kernel -- are stored with the streaming hint, so
+        if (!NT && L.zw_stream) {
+          // [r6] many draws per call: the (z, w) of the launch -- 8.4 GB at C3, read once by the GW kernel -- are stored with the streaming hint, so
           // that they do not displace the tiles and tables the draws' blocks share in L2 (stage -2.5 %, step -1.7 %; `sc1` / `sc0 sc1`
-          // write-through: no gain; profiles/r06/ab_memory_path_r06.txt).  Few draws per call: plain stores, the GW kernel finds them in the
-          // memory-side cache.
+          // write-through: no gain; profiles/r06/ab_memory_path_r06.txt).  Few draws per call, or a launch whose (z, w) fit the memory-side
+          // cache: plain stores, the GW kernel finds them there.
           typedef double d2_t __attribute__((ext_vector_type(2)));
           const d2_t vz = { zz[0], zz[1] }, vw = { wv[0], wv[1] };
           __builtin_nontemporal_store(vz, reinterpret_cast<d2_t*>(wz + s));
