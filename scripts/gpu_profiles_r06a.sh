@@ -8,6 +8,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/profiles_r06; mkdir -p $O profiles/r06
 CHIMERA_LIB=$GRAFT_REPO_ROOT/chimera_amd/lib/variants/libchimera_hip_probe.so timeout -k 10 240 python3 scripts/run_probes.py --events 4 --draws 4 --seconds 1.5 --out $O/probe_E4_nb4.json > $O/probe_E4_nb4.txt 2> $O/probe.err || { tail -20 $O/probe.err; exit 1; }
 grep sustained $O/probe_E4_nb4.txt
+CHIMERA_LIB=$GRAFT_REPO_ROOT/chimera_amd/lib/variants/libchimera_hip_probe.so timeout -k 10 240 python3 scripts/run_probes.py --events 16 --draws 8 --seconds 1.5 --out $O/probe_E16_nb8.json > $O/probe_E16_nb8.txt 2>> $O/probe.err || { tail -20 $O/probe.err; exit 1; }
+grep sustained $O/probe_E16_nb8.txt
 rm -rf $O/pp; CHIMERA_LIB=$GRAFT_REPO_ROOT/chimera_amd/lib/variants/libchimera_hip_probe.so timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d $O/pp -- python3 scripts/run_probes.py --events 4 --draws 4 --seconds 1.5 > $O/probe_pmc.log 2>&1 || { tail -20 $O/probe_pmc.log; exit 1; }
 python3 - <<PY | tee $O/probe_pmc.txt
 import csv, glob, collections

@@ -32,7 +32,7 @@ extern "C" int chm_debug_probe(chm_like* like, int32_t which, int32_t nb, int32_
   HIPCHK(hipStreamSynchronize(c.stream));
   LikeDev L = like->L;
   L.e_off = 0; L.E_cnt = L.E; L.nb = nb; L.p_gw_dump = nullptr; L.no_dense = 0; L.ev_publish = 0;
-  L.zw_stream = 1;                                          // (the store flavour of a C3-sized launch)
+  L.zw_stream = 0;                                          // (plain stores: with the streaming hint of a C3-sized launch the probe's few MB would be written out to HBM over and over)
   L.zg_i = like->d_zg_i; L.zg_t = like->d_zg_t; L.zg_lz = like->d_zg_lz;
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
