@@ -83,3 +83,31 @@ def test_full_mode_at_baseline_shape_against_the_c_oracle():
     H.assert_loglike_close(rp[0], rc[0], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(rp[3], rc[3], rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
   like_p.close()
+
+
+@pytest.mark.timeout(600)
+def test_streaming_and_plain_workspace_stores_give_the_same_bits():
+  """[r6] A many-draw launch whose (z, w) workspaces exceed the 256 MB of the memory-side cache stores them with the streaming hint
+  (LikeDev.zw_stream, k_samples_fast); smaller launches store plainly.  40 events x 4096 samples x 128 draws = 335 MB in one call against the same
+  draws in two calls of 64 (168 MB each) and against scalar calls: every value bit for bit, and the C restatement within the stated tolerance."""
+  from chimera_amd import synth
+  from oracle import oracle_c as OC
+  cfg, ev, inj = synth.make_config('C3', E=40, I=20_000)
+  like_p, _, _ = H.build_product(ev, inj)
+  like_p.set_option('groups', 1)                              # one event group: the whole call is one launch of the sample stage
+  rng = np.random.default_rng(606)
+  draws = dict(H0=rng.uniform(55., 90., 128), gamma=rng.uniform(1.5, 3.5, 128), lambda_peak=rng.uniform(0.01, 0.1, 128))
+  assert 40 * 4096 * 128 * 16 > 256 << 20 > 40 * 4096 * 64 * 16
+  whole = like_p.batch(draws)
+  halves = np.concatenate([like_p.batch({k: v[:64] for k, v in draws.items()}), like_p.batch({k: v[64:] for k, v in draws.items()})])
+  assert np.all(np.isfinite(whole))
+  assert np.array_equal(whole, halves)
+  for i in (0, 63, 64, 127):
+    assert like_p(**{k: float(v[i]) for k, v in draws.items()}) == whole[i]
+  like_o, _, _ = H.build_oracle(ev, inj)
+  for i in (5, 100):
+    rc = OC.compute_all(like_o, {k: float(v[i]) for k, v in draws.items()}, nthreads=_nthreads())
+    np.testing.assert_allclose(whole[i], rc[3], rtol=0, atol=1e-7 * np.sqrt(cfg['E']))
+  like_p.close()
+  del like_p, like_o, ev, inj
+  gc.collect()
