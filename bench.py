@@ -48,6 +48,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# ranks of one node share device memory handles through dmabuf only on this image's driver (RCCL's intra-node transports): the launcher's environment
+# normally carries this; a rank started without it would fail in ncclCommInitRank with hipIpcGetMemHandle: invalid argument.  Read at HSA start-up,
+# i.e. at the first HIP call of the process -- nothing has loaded the library yet.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 import numpy as np
 
